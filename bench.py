@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- LF-steps/s of batched path extraction on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over the whole batch: extract every forward sequence of the
+rank's index (what gbunzip extracts, src/bin/gbunzip.rs:447-532) into a device-resident CSR.
+Workload at N = 1: the headline config, bubble chain 333,334 sites x 5,000 haplotypes
+(1,000,002 nodes, 3.33 G forward LF-steps, seed 42, mosaic).  At N > 1 every rank holds its own
+contig of the same shape (seed 42 + rank): the path set shards by contig, no collective inside the
+timed region, weak scaling.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sites", type=int, default=333334)
+    ap.add_argument("--haplotypes", type=int, default=5000)
+    ap.add_argument("--model", choices=["mosaic", "iid"], default="mosaic")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--bytes-sample", type=int, default=16, help="paths used for the algorithmic-bytes pass")
+    return ap.parse_args()
+
+
+def cpu_baseline(index_path, n_paths, target_seconds):
+    """The oracle (a port of the reference algorithm with its per-step costs), timed on this host's cores.
+    Only this leg of bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import subprocess
+    import oracle_lib as O
+    kind_note = "generic x86-64 build"
+    if O._lib is None:
+        try:  # the reference builds with target-cpu=native (.cargo/config.toml:1-2): rebuild for this host
+            subprocess.check_call(["make", "-C", O.ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            native = os.path.join(O.ORACLE_DIR, "_native", "liboracle.so")
+            if os.path.exists(native):
+                O.LIB_OVERRIDE, kind_note = native, "-O3 -march=native build"
+        except Exception:
+            pass
+    threads = min(os.cpu_count() or 1, 64)  # gbunzip caps its pool at 64 (src/bin/gbunzip.rs:94-95)
+    oracle = O.OracleGBZ(index_path).gbwt()
+    # calibration: one path per thread
+    ids = np.arange(0, 2 * min(threads, n_paths), 2, dtype=np.uint64)
+    t0 = time.perf_counter()
+    steps = oracle.extract_timed(ids, threads)
+    dt = time.perf_counter() - t0
+    rate = steps / dt
+    per_path = steps / len(ids)
+    want = int(max(len(ids), min(n_paths, target_seconds * rate / per_path)))
+    ids = np.arange(0, 2 * want, 2, dtype=np.uint64)
+    t0 = time.perf_counter()
+    steps = oracle.extract_timed(ids, threads)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{want} of {n_paths} forward paths ({steps} LF-steps, {dt:.1f} s wall, {kind_note}, "
+                      f"pthread pool pulling path ids like gbunzip's rayon par_iter)"}
+
+
+def algorithmic_bytes(index_path, n_paths, sample):
+    """Exact algorithmic bytes W = sum(H + P + 4) over a sample of paths (untimed oracle pass)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    oracle = O.OracleGBZ(index_path).gbwt()
+    ids = np.arange(0, 2 * min(sample, n_paths), 2, dtype=np.uint64)
+    total, steps = oracle.algorithmic_bytes(ids)
+    return total / steps, int(steps)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: gbwt_rs_amd has no CPU fallback")
+
+    import gbwt_rs_amd as G
+    from gbwt_rs_amd import synth as S
+
+    model = S.MOSAIC if args.model == "mosaic" else S.IID
+    t0 = time.perf_counter()
+    s = S.Synth.chain(sites=args.sites, haplotypes=args.haplotypes, alleles=2, model=model, founders=32, switch_rate=2e-3,
+                      seed=args.seed + rank)
+    gen_s = time.perf_counter() - t0
+    tmpdir = tempfile.mkdtemp(prefix=f"gbwt_bench_r{rank}_")
+    index_path = os.path.join(tmpdir, "bench.gbz")
+    s.save(index_path, as_gbz=True)  # same .gbz for the GPU path and the CPU baseline
+    index = G.GBZ.load(index_path, device=local_rank)
+    n_paths = index.paths()
+    ids = np.arange(0, 2 * n_paths, 2, dtype=np.uint64)
+    expected_steps = (index.len() - index.sequences()) // 2
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        index.extract_device(ids)
+    barrier()
+    walk_ms, total_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = index.extract_device(ids)
+        w, t = index.last_kernel_ms()
+        walk_ms.append(w)
+        total_ms.append(t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    steps_done = int(out.total)
+    assert steps_done == expected_steps, (steps_done, expected_steps)
+
+    # untimed: full-size check of the last extraction against the generator's ground truth
+    sums = index.path_sums(n_paths)
+    truth = np.array([s.path_checksum(h) for h in range(n_paths)], dtype=np.uint64)
+    assert np.array_equal(sums, truth), "extracted paths differ from the generator's ground truth"
+    for h in (0, n_paths // 2, n_paths - 1):
+        assert np.array_equal(index.copy_path(h), s.path(h))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([steps_done], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        all_steps = float(tot.item())
+    else:
+        all_steps = float(steps_done)
+
+    if rank == 0:
+        cpu = None if args.no_cpu_baseline else cpu_baseline(index_path, n_paths, args.cpu_seconds)
+        b_per_step, sampled_steps = algorithmic_bytes(index_path, n_paths, args.bytes_sample)
+        walk_avg_ms = float(np.mean(walk_ms))
+        achieved = b_per_step * steps_done / (walk_avg_ms * 1e-3) / 1e9
+        result = {
+            "metric": "LF-steps/sec (batched path extract)",
+            "value": all_steps * args.steps / elapsed,
+            "unit": "LF-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"bubble-chain GBZ, {args.haplotypes} paths x {3 * args.sites} nodes per GPU "
+                            f"({args.sites} sites, {args.model}, seed {args.seed}+rank), all forward sequences -> device CSR",
+                "paths_per_gpu": int(n_paths),
+                "lf_steps_per_gpu": steps_done,
+                "index_bytes": int(index.stats.data_bytes),
+                "records": int(index.stats.records),
+                "sharding": "one contig (index + path set) per rank, no data-path collective",
+                "generator_seconds": round(gen_s, 1),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_walk",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_step": b_per_step,
+                "bytes_sample": f"exact H+P+4 over {sampled_steps} LF-steps of {min(args.bytes_sample, n_paths)} paths, scaled to {steps_done}",
+                "kernel_ms": walk_avg_ms,
+                "extract_ms": float(np.mean(total_ms)),
+            },
+        }
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    try:
+        os.remove(index_path)
+        os.rmdir(tmpdir)
+    except OSError:
+        pass
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""Loader + ctypes signatures of libgbwt_hip.so (the C ABI declared in include/gbwt_hip.h).
+
+The shared library is built in-tree by `make -C gbwt_rs_amd/csrc` (see __graft_entry__.build).
+There is no Python or CPU fallback: if the library is missing, importing this module's `lib()`
+raises, and on a box without a HIP device every compute call returns GBWT_HIP_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgbwt_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "gbwt_hip.h")
+
+OK, INVALID_DATA, IO_ERROR, BAD_ARGUMENT, NO_DEVICE, DEVICE_ERROR, CAPACITY, UNSUPPORTED = range(8)
+STATUS_NAMES = ["OK", "INVALID_DATA", "IO_ERROR", "BAD_ARGUMENT", "NO_DEVICE", "DEVICE_ERROR", "CAPACITY", "UNSUPPORTED"]
+
+
+class Pos(C.Structure):
+    _fields_ = [("node", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class State(C.Structure):
+    _fields_ = [("node", C.c_uint64), ("start", C.c_uint64), ("end", C.c_uint64)]
+
+
+class BdState(C.Structure):
+    _fields_ = [("forward", State), ("reverse", State)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("size", C.c_uint64), ("sequences", C.c_uint64), ("alphabet_size", C.c_uint64),
+                ("alphabet_offset", C.c_uint64), ("records", C.c_uint64), ("data_bytes", C.c_uint64),
+                ("paths", C.c_uint64), ("bidirectional", C.c_uint32), ("has_metadata", C.c_uint32),
+                ("is_gbz", C.c_uint32), ("has_translation", C.c_uint32), ("max_record_len", C.c_uint64),
+                ("max_outdegree", C.c_uint64)]
+
+
+class Paths(C.Structure):
+    _fields_ = [("d_offsets", C.c_void_p), ("d_nodes", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
+
+
+_p, _u64, _int = C.c_void_p, C.c_uint64, C.c_int
+
+SIGNATURES = {
+    "gbwt_hip_last_error": (C.c_char_p, []),
+    "gbwt_hip_device_count": (_int, []),
+    "gbwt_hip_open_file": (_int, [C.c_char_p, _int, C.POINTER(_p)]),
+    "gbwt_hip_parse_file": (_int, [C.c_char_p, C.POINTER(Stats)]),
+    "gbwt_hip_open_records": (_int, [_p, _u64, _p, _u64, _u64, _u64, _u64, _u64, _int, _int, C.POINTER(_p)]),
+    "gbwt_hip_close": (None, [_p]),
+    "gbwt_hip_get_stats": (_int, [_p, C.POINTER(Stats)]),
+    "gbwt_hip_workspace_create": (_int, [_p, C.POINTER(_p)]),
+    "gbwt_hip_workspace_destroy": (None, [_p]),
+    "gbwt_hip_workspace_stream": (_p, [_p]),
+    "gbwt_hip_extract": (_int, [_p, _p, _p, _u64, _p, _p, _u64, C.POINTER(_u64)]),
+    "gbwt_hip_extract_device": (_int, [_p, _p, _p, _u64, C.POINTER(Paths)]),
+    "gbwt_hip_extract_paths": (_int, [_p, _p, _p, _u64, _int, _p, _p, _u64, C.POINTER(_u64)]),
+    "gbwt_hip_start": (_int, [_p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_forward": (_int, [_p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_find": (_int, [_p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_extend": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_bd_find": (_int, [_p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_extend_forward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_extend_backward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_search": (_int, [_p, _p, _p, _u64, _u64, _p, _p]),
+    "gbwt_hip_path_sums": (_int, [_p, _p, _p, _u64]),
+    "gbwt_hip_copy_path": (_int, [_p, _p, _u64, _p, _u64, C.POINTER(_u64)]),
+    "gbwt_hip_last_kernel_ms": (_int, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C {CSRC}` (or __graft_entry__.build()); "
+                              "gbwt_rs_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class GbwtHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES[status] if 0 <= status < len(STATUS_NAMES) else status}: {message}")
+        self.status = status
+
+
+def check(status):
+    if status != OK:
+        raise GbwtHipError(status, lib().gbwt_hip_last_error().decode(errors="replace"))

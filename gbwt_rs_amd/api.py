@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's GBWT / GBZ interface for the hot path, batched, on MI355X.
+
+Method names, argument meaning and None-behaviour follow the Rust API (file:line into the reference):
+
+  GBWT.len / sequences / alphabet_size / alphabet_offset / first_node / is_bidirectional   src/gbwt.rs:108-174
+  GBWT.start(ids)            GBWT::start            src/gbwt.rs:213-219
+  GBWT.forward(positions)    GBWT::forward          src/gbwt.rs:222-229
+  GBWT.sequence(id)          GBWT::sequence         src/gbwt.rs:253-261   (None for id >= sequences)
+  GBWT.sequences_csr(ids)    the batched form of sequence(): CSR arrays
+  GBWT.find / extend / bd_find / extend_forward / extend_backward     src/gbwt.rs:269-367
+  GBZ.path(path_id, orientation)   GBZ::path        src/gbz.rs:461-466
+
+Every call goes through the C ABI of libgbwt_hip.so (hand-written HIP); "not found" is reported as
+None / a False entry of the validity mask, never as an exception.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import BdState, GbwtHipError, Paths, Pos, State, Stats, check
+
+FORWARD, REVERSE = 0, 1  # support::Orientation, src/support.rs:30-47
+
+POS_DTYPE = np.dtype([("node", "<u8"), ("offset", "<u8")])
+STATE_DTYPE = np.dtype([("node", "<u8"), ("start", "<u8"), ("end", "<u8")])
+BD_DTYPE = np.dtype([("forward", STATE_DTYPE), ("reverse", STATE_DTYPE)])
+
+
+def encode_node(node_id, orientation):  # support::encode_node, src/support.rs:155-157
+    return 2 * node_id + orientation
+
+
+def decode_node(node):  # support::decode_node, src/support.rs:180-182
+    return node // 2, node & 1
+
+
+def flip_node(node):  # support::flip_node, src/support.rs:188-190
+    return node ^ 1
+
+
+def encode_path(path_id, orientation):  # support::encode_path, src/support.rs:229-231
+    return 2 * path_id + orientation
+
+
+def device_count():
+    return _lib.lib().gbwt_hip_device_count()
+
+
+def parse_file(path):
+    """Host-only parse + validation (no GPU): the statistics serialize::load_from would yield."""
+    st = Stats()
+    check(_lib.lib().gbwt_hip_parse_file(os.fsencode(path), C.byref(st)))
+    return st
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class GBWT:
+    """A GBWT index resident in HBM.  Mirrors gbwt::GBWT (src/gbwt.rs:95-385) for the hot path."""
+
+    def __init__(self, handle):
+        self._L = _lib.lib()
+        self._h = handle
+        self._ws = C.c_void_p()
+        check(self._L.gbwt_hip_workspace_create(self._h, C.byref(self._ws)))
+        self._stats = Stats()
+        check(self._L.gbwt_hip_get_stats(self._h, C.byref(self._stats)))
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def load(cls, path, device=0):
+        """serialize::load_from::<GBWT | GBZ>(path) (src/gbwt.rs:402-438, src/gbz.rs:674-717)."""
+        h = C.c_void_p()
+        check(_lib.lib().gbwt_hip_open_file(os.fsencode(path), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_records(cls, data, starts, alphabet_offset, alphabet_size, sequences, size, bidirectional=True, device=0):
+        """From the raw record stream of a bwt::BWT (compressed_record, src/bwt.rs:134-143) + header fields."""
+        d = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        s = np.ascontiguousarray(starts, dtype=np.uint64)
+        h = C.c_void_p()
+        check(_lib.lib().gbwt_hip_open_records(_ptr(d), d.size, _ptr(s), s.size, alphabet_offset, alphabet_size,
+                                               sequences, size, int(bidirectional), device, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_ws", None):
+            self._L.gbwt_hip_workspace_destroy(self._ws)
+            self._ws = None
+        if getattr(self, "_h", None):
+            self._L.gbwt_hip_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- statistics (src/gbwt.rs:105-175) -----------------------------------------------------
+    def len(self):
+        return self._stats.size
+
+    def is_empty(self):
+        return self.len() == 0
+
+    def sequences(self):
+        return self._stats.sequences
+
+    def alphabet_size(self):
+        return self._stats.alphabet_size
+
+    def alphabet_offset(self):
+        return self._stats.alphabet_offset
+
+    def effective_size(self):
+        return self.alphabet_size() - self.alphabet_offset()
+
+    def first_node(self):
+        return self.alphabet_offset() + 1
+
+    def has_node(self, node):
+        return self.alphabet_offset() < node < self.alphabet_size()
+
+    def is_bidirectional(self):
+        return bool(self._stats.bidirectional)
+
+    def has_metadata(self):
+        return bool(self._stats.has_metadata)
+
+    @property
+    def stats(self):
+        return self._stats
+
+    # ---- navigation ---------------------------------------------------------------------------
+    def start(self, ids):
+        """GBWT::start for an array of sequence ids -> (positions[POS_DTYPE], valid[bool])."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = np.zeros(ids.size, dtype=POS_DTYPE)
+        valid = np.zeros(ids.size, dtype=np.uint8)
+        check(self._L.gbwt_hip_start(self._h, self._ws, _ptr(ids), ids.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def forward(self, positions):
+        """GBWT::forward for an array of positions -> (positions, valid)."""
+        pos = np.ascontiguousarray(positions, dtype=POS_DTYPE)
+        out = np.zeros(pos.size, dtype=POS_DTYPE)
+        valid = np.zeros(pos.size, dtype=np.uint8)
+        check(self._L.gbwt_hip_forward(self._h, self._ws, _ptr(pos), pos.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def sequences_csr(self, ids):
+        """GBWT::sequence(id).collect() for every id -> (offsets[u64, n+1], nodes[u32])."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        offsets = np.zeros(ids.size + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(self._L.gbwt_hip_extract(self._h, self._ws, _ptr(ids), ids.size, _ptr(offsets), None, 0, C.byref(total)))
+        nodes = np.zeros(max(1, total.value), dtype=np.uint32)
+        check(self._L.gbwt_hip_extract(self._h, self._ws, _ptr(ids), ids.size, _ptr(offsets), _ptr(nodes), nodes.size,
+                                       C.byref(total)))
+        return offsets, nodes[: total.value]
+
+    def sequence(self, seq_id):
+        """GBWT::sequence(id): list of GBWT nodes, or None if there is no such sequence."""
+        if seq_id >= self.sequences():
+            return None
+        offsets, nodes = self.sequences_csr([seq_id])
+        return [int(x) for x in nodes]
+
+    def extract_device(self, ids):
+        """Device-resident extraction (what bench.py times): returns a Paths struct with device pointers."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = Paths()
+        check(self._L.gbwt_hip_extract_device(self._h, self._ws, _ptr(ids), ids.size, C.byref(out)))
+        return out
+
+    def path_sums(self, n):
+        """Per-path sums of node ids of the last extract_device() (device-side reduction)."""
+        out = np.zeros(n, dtype=np.uint64)
+        check(self._L.gbwt_hip_path_sums(self._h, self._ws, _ptr(out), n))
+        return out
+
+    def copy_path(self, k):
+        """Row k of the last extract_device() as a host array."""
+        ln = C.c_uint64(0)
+        check(self._L.gbwt_hip_copy_path(self._h, self._ws, k, None, 0, C.byref(ln)))
+        out = np.zeros(max(1, ln.value), dtype=np.uint32)
+        check(self._L.gbwt_hip_copy_path(self._h, self._ws, k, _ptr(out), out.size, C.byref(ln)))
+        return out[: ln.value]
+
+    def last_kernel_ms(self):
+        walk, total = C.c_float(0), C.c_float(0)
+        check(self._L.gbwt_hip_last_kernel_ms(self._ws, C.byref(walk), C.byref(total)))
+        return walk.value, total.value
+
+    def stream(self):
+        return self._L.gbwt_hip_workspace_stream(self._ws)
+
+    # ---- search -------------------------------------------------------------------------------
+    def find(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = np.zeros(nodes.size, dtype=STATE_DTYPE)
+        valid = np.zeros(nodes.size, dtype=np.uint8)
+        check(self._L.gbwt_hip_find(self._h, self._ws, _ptr(nodes), nodes.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def extend(self, states, nodes):
+        states = np.ascontiguousarray(states, dtype=STATE_DTYPE)
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        assert states.size == nodes.size
+        out = np.zeros(nodes.size, dtype=STATE_DTYPE)
+        valid = np.zeros(nodes.size, dtype=np.uint8)
+        check(self._L.gbwt_hip_extend(self._h, self._ws, _ptr(states), _ptr(nodes), nodes.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def bd_find(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = np.zeros(nodes.size, dtype=BD_DTYPE)
+        valid = np.zeros(nodes.size, dtype=np.uint8)
+        check(self._L.gbwt_hip_bd_find(self._h, self._ws, _ptr(nodes), nodes.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def _bd_extend(self, fn, states, nodes):
+        states = np.ascontiguousarray(states, dtype=BD_DTYPE)
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        assert states.size == nodes.size
+        out = np.zeros(nodes.size, dtype=BD_DTYPE)
+        valid = np.zeros(nodes.size, dtype=np.uint8)
+        check(fn(self._h, self._ws, _ptr(states), _ptr(nodes), nodes.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def extend_forward(self, states, nodes):
+        return self._bd_extend(self._L.gbwt_hip_extend_forward, states, nodes)
+
+    def extend_backward(self, states, nodes):
+        return self._bd_extend(self._L.gbwt_hip_extend_backward, states, nodes)
+
+    def search(self, queries):
+        """find(q[0]) + extend over q[1:] for every row of the (n, len) query matrix (src/bin/benchmark.rs:155-169)."""
+        q = np.ascontiguousarray(queries, dtype=np.uint64)
+        assert q.ndim == 2
+        out = np.zeros(q.shape[0], dtype=STATE_DTYPE)
+        valid = np.zeros(q.shape[0], dtype=np.uint8)
+        check(self._L.gbwt_hip_search(self._h, self._ws, _ptr(q), q.shape[0], q.shape[1], _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+
+class GBZ(GBWT):
+    """gbz::GBZ for the hot path: GBZ::path / paths (src/gbz.rs:446-466)."""
+
+    def paths(self):
+        return self.sequences() // 2
+
+    def path(self, path_id, orientation=FORWARD):
+        """GBZ::path(path_id, orientation): list of (node_id, orientation), or None (src/gbz.rs:461-466)."""
+        seq = self.sequence(encode_path(path_id, orientation))
+        return None if seq is None else [decode_node(x) for x in seq]
+
+    def paths_csr(self, path_ids, orientation=FORWARD):
+        ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
+        offsets = np.zeros(ids.size + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(self._L.gbwt_hip_extract_paths(self._h, self._ws, _ptr(ids), ids.size, orientation, _ptr(offsets), None, 0,
+                                             C.byref(total)))
+        nodes = np.zeros(max(1, total.value), dtype=np.uint32)
+        check(self._L.gbwt_hip_extract_paths(self._h, self._ws, _ptr(ids), ids.size, orientation, _ptr(offsets), _ptr(nodes),
+                                             nodes.size, C.byref(total)))
+        return offsets, nodes[: total.value]
+
+
+__all__ = ["GBWT", "GBZ", "GbwtHipError", "FORWARD", "REVERSE", "POS_DTYPE", "STATE_DTYPE", "BD_DTYPE", "encode_node",
+           "decode_node", "flip_node", "encode_path", "device_count", "parse_file", "Pos", "State", "BdState"]

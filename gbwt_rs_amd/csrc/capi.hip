@@ -1,0 +1,486 @@
+// capi.hip -- the C ABI of libgbwt_hip.so (include/gbwt_hip.h): handles, workspaces, host<->device
+// plumbing around the kernels.  There is deliberately no CPU implementation of any compute entry
+// point in this library: without a HIP device they fail with GBWT_HIP_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gbwt_hip.h"
+#include "device_index.hpp"
+#include "host_index.hpp"
+#include "kernels.hpp"
+
+using namespace gbwt_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+gbwt_hip_status fail(gbwt_hip_status st, const std::string &msg) {
+    g_last_error = msg;
+    return st;
+}
+
+struct HipError { hipError_t err; const char *what; };
+
+#define HIP_CHECK(expr)                                            \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) throw HipError{e_, #expr};           \
+    } while (0)
+
+// Grow-only device buffer.
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void reserve(size_t need) {
+        if (need <= bytes) return;
+        if (ptr) { HIP_CHECK(hipFree(ptr)); ptr = nullptr; bytes = 0; }
+        size_t want = std::max<size_t>(need, 256);
+        HIP_CHECK(hipMalloc(&ptr, want));
+        bytes = want;
+    }
+    template <class T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+gbwt_hip_status status_of(const HipError &e) {
+    std::string msg = std::string(e.what) + ": " + hipGetErrorString(e.err);
+    if (e.err == hipErrorNoDevice || e.err == hipErrorInvalidDevice) return fail(GBWT_HIP_NO_DEVICE, msg);
+    return fail(GBWT_HIP_DEVICE_ERROR, msg);
+}
+
+}  // namespace
+
+struct gbwt_hip_index {
+    HostIndex host;
+    int device = 0;
+    DeviceBuffer data, starts, endmarker;
+    DeviceIndex dev{};
+    gbwt_hip_stats stats{};
+};
+
+struct gbwt_hip_workspace {
+    const gbwt_hip_index *index = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
+    DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
+    DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
+    ~gbwt_hip_workspace() {
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+void fill_stats(gbwt_hip_index &ix) {
+    const HostIndex &h = ix.host;
+    gbwt_hip_stats &s = ix.stats;
+    s.size = h.size; s.sequences = h.sequences; s.alphabet_size = h.alphabet_size; s.alphabet_offset = h.alphabet_offset;
+    s.records = h.records(); s.data_bytes = h.data.size(); s.paths = h.path_names.size();
+    s.bidirectional = h.bidirectional; s.has_metadata = h.has_metadata; s.is_gbz = h.is_gbz; s.has_translation = h.has_translation;
+}
+
+// Uploads the host image and runs the load-time device passes.
+void upload(gbwt_hip_index &ix) {
+    HostIndex &h = ix.host;
+    if (h.alphabet_size > (uint64_t(1) << 32)) throw InvalidData("alphabet_size > 2^32 is not supported (u32 node ids on device)");
+    HIP_CHECK(hipSetDevice(ix.device));
+    const uint64_t n_records = h.records();
+    ix.data.reserve(h.data.size() + DATA_PAD);
+    HIP_CHECK(hipMemset(ix.data.ptr, 0, h.data.size() + DATA_PAD));
+    if (!h.data.empty()) HIP_CHECK(hipMemcpy(ix.data.ptr, h.data.data(), h.data.size(), hipMemcpyHostToDevice));
+    DeviceIndex &d = ix.dev;
+    d = DeviceIndex{};
+    d.data = ix.data.as<uint8_t>();
+    d.data_len = h.data.size();
+    d.n_records = n_records;
+    d.n_sequences = h.sequences;
+    d.alphabet_offset = static_cast<uint32_t>(h.alphabet_offset);
+    d.first_node = static_cast<uint32_t>(h.alphabet_offset + 1);
+    if (h.data.size() < (uint64_t(1) << 32)) {
+        std::vector<uint32_t> s32(h.starts.begin(), h.starts.end());
+        if (s32.empty()) s32.push_back(0);
+        ix.starts.reserve(s32.size() * sizeof(uint32_t));
+        HIP_CHECK(hipMemcpy(ix.starts.ptr, s32.data(), s32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d.starts32 = ix.starts.as<uint32_t>();
+    } else {
+        ix.starts.reserve(h.starts.size() * sizeof(uint64_t));
+        HIP_CHECK(hipMemcpy(ix.starts.ptr, h.starts.data(), h.starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        d.starts64 = ix.starts.as<uint64_t>();
+    }
+
+    // Load-time device passes: record statistics, then the endmarker (src/gbwt.rs:413-414).
+    DeviceBuffer tmp;
+    tmp.reserve(8 * sizeof(uint64_t));
+    HIP_CHECK(hipMemset(tmp.ptr, 0, 8 * sizeof(uint64_t)));
+    uint64_t *d_stats = tmp.as<uint64_t>();
+    launch_record_stats(d, d_stats, nullptr);
+    launch_endmarker_sigma(d, d_stats + 4, nullptr);
+    uint64_t hs[8];
+    HIP_CHECK(hipMemcpy(hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    ix.stats.max_record_len = hs[0];
+    ix.stats.max_outdegree = hs[1];
+    if (hs[2] != 0) throw InvalidData("BWT: record without a readable outdegree");
+    if (hs[0] >= (uint64_t(1) << 32)) throw InvalidData("record longer than 2^32 positions is not supported");
+    const uint64_t end_len = hs[4], end_sigma = hs[5];
+    ix.endmarker.reserve(std::max<uint64_t>(end_len, 1) * sizeof(uint2));
+    if (end_len > 0) {
+        DeviceBuffer scratch;
+        scratch.reserve(2 * end_sigma * sizeof(uint64_t));
+        launch_endmarker_decompress(d, ix.endmarker.as<uint2>(), end_len, scratch.as<uint64_t>(), d_stats + 6, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipGetLastError());
+    }
+    d.endmarker = ix.endmarker.as<uint2>();
+    d.n_endmarker = end_len;
+}
+
+gbwt_hip_status open_common(gbwt_hip_index *ix, gbwt_hip_index **out) {
+    try {
+        fill_stats(*ix);
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+            delete ix;
+            return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
+        }
+        upload(*ix);
+        *out = ix;
+        return GBWT_HIP_OK;
+    } catch (const InvalidData &e) {
+        delete ix; return fail(GBWT_HIP_INVALID_DATA, e.what());
+    } catch (const HipError &e) {
+        delete ix; return status_of(e);
+    } catch (const std::bad_alloc &) {
+        delete ix; return fail(GBWT_HIP_DEVICE_ERROR, "out of host memory");
+    }
+}
+
+// Staging helper for the one-lane-per-query entry points.
+template <class Launch>
+gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *in_a, size_t a_bytes,
+                          const void *in_b, size_t b_bytes, void *out, size_t out_bytes, uint8_t *valid, uint64_t n,
+                          Launch launch) {
+    if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (n == 0) return GBWT_HIP_OK;
+    if (!in_a || !out || !valid) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        ws->in_a.reserve(a_bytes);
+        ws->out_a.reserve(out_bytes);
+        ws->out_valid.reserve(n);
+        HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, a_bytes, hipMemcpyHostToDevice, ws->stream));
+        if (in_b) {
+            ws->in_b.reserve(b_bytes);
+            HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, b_bytes, hipMemcpyHostToDevice, ws->stream));
+        }
+        launch();
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, ws->out_a.ptr, out_bytes, hipMemcpyDeviceToHost, ws->stream));
+        HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, ws->stream));
+        HIP_CHECK(hipStreamSynchronize(ws->stream));
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gbwt_hip_last_error(void) { return g_last_error.c_str(); }
+
+int gbwt_hip_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+gbwt_hip_status gbwt_hip_parse_file(const char *path, gbwt_hip_stats *out) {
+    if (!path || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    try {
+        gbwt_hip_index tmp;
+        tmp.host = load_index_file(path);
+        fill_stats(tmp);
+        *out = tmp.stats;
+        return GBWT_HIP_OK;
+    } catch (const InvalidData &e) {
+        return fail(GBWT_HIP_INVALID_DATA, e.what());
+    } catch (const IoError &e) {
+        return fail(GBWT_HIP_IO_ERROR, e.what());
+    }
+}
+
+gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index **out) {
+    if (!path || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    *out = nullptr;
+    gbwt_hip_index *ix = new gbwt_hip_index;
+    ix->device = device;
+    try {
+        ix->host = load_index_file(path);
+    } catch (const InvalidData &e) {
+        delete ix; return fail(GBWT_HIP_INVALID_DATA, e.what());
+    } catch (const IoError &e) {
+        delete ix; return fail(GBWT_HIP_IO_ERROR, e.what());
+    }
+    return open_common(ix, out);
+}
+
+gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
+                                      uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,
+                                      int bidirectional, int device, gbwt_hip_index **out) {
+    if (!out || (data_len && !data) || (n_records && !starts)) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    *out = nullptr;
+    gbwt_hip_index *ix = new gbwt_hip_index;
+    ix->device = device;
+    try {
+        ix->host = index_from_records(data, data_len, starts, n_records, alphabet_offset, alphabet_size, n_sequences, size,
+                                      bidirectional != 0);
+    } catch (const InvalidData &e) {
+        delete ix; return fail(GBWT_HIP_INVALID_DATA, e.what());
+    }
+    return open_common(ix, out);
+}
+
+void gbwt_hip_close(gbwt_hip_index *index) { delete index; }
+
+gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *out) {
+    if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    *out = index->stats;
+    return GBWT_HIP_OK;
+}
+
+gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_workspace **out) {
+    if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    *out = nullptr;
+    gbwt_hip_workspace *ws = new gbwt_hip_workspace;
+    ws->index = index;
+    try {
+        HIP_CHECK(hipSetDevice(index->device));
+        HIP_CHECK(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+        for (auto &e : ws->ev) HIP_CHECK(hipEventCreate(&e));
+        ws->counters.reserve(4 * sizeof(uint32_t));
+    } catch (const HipError &e) {
+        delete ws; return status_of(e);
+    }
+    *out = ws;
+    return GBWT_HIP_OK;
+}
+
+void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws) { delete ws; }
+
+void *gbwt_hip_workspace_stream(gbwt_hip_workspace *ws) { return ws ? static_cast<void *>(ws->stream) : nullptr; }
+
+gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
+                                        gbwt_hip_paths *out) {
+    if (!ix || !ws || ws->index != ix || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (n && !seq_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null seq_ids");
+    // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256)
+    for (uint64_t k = 0; k < n; k++)
+        if (seq_ids[k] >= ix->host.sequences) return fail(GBWT_HIP_BAD_ARGUMENT, "sequence id " + std::to_string(seq_ids[k]) + " >= sequences");
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        hipStream_t s = ws->stream;
+        ws->seq_ids.reserve(std::max<uint64_t>(n, 1) * sizeof(uint64_t));
+        ws->lengths.reserve(std::max<uint64_t>(n, 1) * sizeof(uint64_t));
+        ws->offsets.reserve((n + 1) * sizeof(uint64_t));
+        ws->head.reserve(std::max<uint64_t>(n, 1) * sizeof(uint32_t));
+        size_t temp_bytes = n ? scan_temp_bytes(n) : 0;
+        ws->scan_temp.reserve(std::max<size_t>(temp_bytes, 16));
+        // Pool bound for distinct ids: all sequences together hold size - sequences nodes
+        // (src/gbwt.rs:108-122), and every path wastes less than one block.
+        const uint64_t all_nodes = ix->host.size >= ix->host.sequences ? ix->host.size - ix->host.sequences : 0;
+        uint64_t pool_blocks = all_nodes / POOL_BLOCK_NODES + n + 1;
+        if (n) HIP_CHECK(hipMemcpyAsync(ws->seq_ids.ptr, seq_ids, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        uint32_t flags = 0;
+        WalkArgs a{};
+        for (int attempt = 0; attempt < 8; attempt++) {
+            if (pool_blocks >= POOL_NONE) return fail(GBWT_HIP_UNSUPPORTED, "path pool would exceed 2^32 blocks");
+            ws->pool.reserve(pool_blocks * POOL_BLOCK_NODES * sizeof(uint32_t));
+            ws->next.reserve(pool_blocks * sizeof(uint32_t));
+            a.seq_ids = ws->seq_ids.as<uint64_t>(); a.n = n;
+            a.pool = ws->pool.as<uint32_t>(); a.next = ws->next.as<uint32_t>(); a.pool_blocks = static_cast<uint32_t>(pool_blocks);
+            a.counter = ws->counters.as<uint32_t>(); a.flags = ws->counters.as<uint32_t>() + 1;
+            a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
+            HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
+            HIP_CHECK(hipEventRecord(ws->ev[0], s));
+            launch_walk(ix->dev, a, s);
+            HIP_CHECK(hipEventRecord(ws->ev[1], s));
+            HIP_CHECK(hipMemcpyAsync(&flags, a.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            launch_scan(a.lengths, ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipGetLastError());
+            if (!(flags & FLAG_POOL_OVERFLOW)) break;
+            pool_blocks *= 2;  // duplicate ids can exceed the distinct-id bound: grow and walk again
+        }
+        if (flags & FLAG_POOL_OVERFLOW) return fail(GBWT_HIP_DEVICE_ERROR, "path pool overflow");
+        uint64_t total = 0;
+        HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        ws->nodes.reserve(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
+        launch_compact(a, ws->offsets.as<uint64_t>(), ws->nodes.as<uint32_t>(), s);
+        HIP_CHECK(hipEventRecord(ws->ev[2], s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipGetLastError());
+        ws->timed = true;
+        ws->last_n = n; ws->last_total = total;
+        out->d_offsets = ws->offsets.as<uint64_t>();
+        out->d_nodes = ws->nodes.as<uint32_t>();
+        out->total = total;
+        out->n = n;
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
+                                 uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity, uint64_t *total) {
+    if (!out_offsets || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
+    gbwt_hip_paths p{};
+    gbwt_hip_status st = gbwt_hip_extract_device(ix, ws, seq_ids, n, &p);
+    if (st != GBWT_HIP_OK) return st;
+    try {
+        HIP_CHECK(hipMemcpy(out_offsets, p.d_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        *total = p.total;
+        if (!out_nodes) return GBWT_HIP_OK;
+        if (capacity < p.total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(p.total));
+        if (p.total) HIP_CHECK(hipMemcpy(out_nodes, p.d_nodes, p.total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+gbwt_hip_status gbwt_hip_extract_paths(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n,
+                                       int reverse, uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity,
+                                       uint64_t *total) {
+    if (n && !path_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null path_ids");
+    std::vector<uint64_t> ids(n);
+    for (uint64_t k = 0; k < n; k++) ids[k] = 2 * path_ids[k] + (reverse ? 1 : 0);  // support::encode_path
+    return gbwt_hip_extract(ix, ws, ids.data(), n, out_offsets, out_nodes, capacity, total);
+}
+
+gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n) {
+    if (!ix || !ws || ws->index != ix || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident extraction on this workspace");
+    if (n != ws->last_n || (n && !out_sums)) return fail(GBWT_HIP_BAD_ARGUMENT, "n does not match the last extraction");
+    if (n == 0) return GBWT_HIP_OK;
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        ws->out_a.reserve(n * sizeof(uint64_t));
+        launch_path_sums(ws->offsets.as<uint64_t>(), ws->nodes.as<uint32_t>(), n, ws->out_a.as<uint64_t>(), ws->stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out_sums, ws->out_a.ptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
+        HIP_CHECK(hipStreamSynchronize(ws->stream));
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t k, uint32_t *out_nodes,
+                                   uint64_t capacity, uint64_t *len) {
+    if (!ix || !ws || ws->index != ix || !ws->timed || !len) return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident extraction on this workspace");
+    if (k >= ws->last_n) return fail(GBWT_HIP_BAD_ARGUMENT, "row out of range");
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        uint64_t range[2];
+        HIP_CHECK(hipMemcpy(range, ws->offsets.as<uint64_t>() + k, sizeof(range), hipMemcpyDeviceToHost));
+        *len = range[1] - range[0];
+        uint64_t count = std::min(*len, capacity);
+        if (count && out_nodes) HIP_CHECK(hipMemcpy(out_nodes, ws->nodes.as<uint32_t>() + range[0], count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms) {
+    if (!ws || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no timed extraction on this workspace");
+    float a = 0, b = 0;
+    if (hipEventElapsedTime(&a, ws->ev[0], ws->ev[1]) != hipSuccess || hipEventElapsedTime(&b, ws->ev[0], ws->ev[2]) != hipSuccess)
+        return fail(GBWT_HIP_DEVICE_ERROR, "hipEventElapsedTime failed");
+    if (walk_ms) *walk_ms = a;
+    if (total_ms) *total_ms = b;
+    return GBWT_HIP_OK;
+}
+
+gbwt_hip_status gbwt_hip_start(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
+                               gbwt_hip_pos *out, uint8_t *valid) {
+    return run_query(ix, ws, seq_ids, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
+        launch_start(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+gbwt_hip_status gbwt_hip_forward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
+                                 gbwt_hip_pos *out, uint8_t *valid) {
+    return run_query(ix, ws, in, n * sizeof(gbwt_hip_pos), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
+        launch_forward(ix->dev, ws->in_a.as<gbwt_hip_pos>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+gbwt_hip_status gbwt_hip_find(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
+                              gbwt_hip_state *out, uint8_t *valid) {
+    return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {
+        launch_find(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+gbwt_hip_status gbwt_hip_extend(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_state *states,
+                                const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid) {
+    if (n && !nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null nodes");
+    return run_query(ix, ws, states, n * sizeof(gbwt_hip_state), nodes, n * sizeof(uint64_t), out, n * sizeof(gbwt_hip_state), valid, n, [&] {
+        launch_extend(ix->dev, ws->in_a.as<gbwt_hip_state>(), ws->in_b.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_state>(),
+                      ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+gbwt_hip_status gbwt_hip_bd_find(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
+                                 gbwt_hip_bd_state *out, uint8_t *valid) {
+    // the reference asserts here (src/gbwt.rs:312)
+    if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
+    return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
+        launch_bd_find(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+static gbwt_hip_status bd_extend(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states,
+                                 const uint64_t *nodes, uint64_t n, bool backward, gbwt_hip_bd_state *out, uint8_t *valid) {
+    if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
+    if (n && !nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null nodes");
+    return run_query(ix, ws, states, n * sizeof(gbwt_hip_bd_state), nodes, n * sizeof(uint64_t), out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
+        launch_bd_extend(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), ws->in_b.as<uint64_t>(), n, backward,
+                         ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+gbwt_hip_status gbwt_hip_extend_forward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states,
+                                        const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid) {
+    return bd_extend(ix, ws, states, nodes, n, false, out, valid);
+}
+
+gbwt_hip_status gbwt_hip_extend_backward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states,
+                                         const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid) {
+    return bd_extend(ix, ws, states, nodes, n, true, out, valid);
+}
+
+gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *queries, uint64_t n,
+                                uint64_t len, gbwt_hip_state *out, uint8_t *valid) {
+    return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {
+        launch_search(ix->dev, ws->in_a.as<uint64_t>(), n, len, ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// host_index.hpp -- host-side image of a GBWT / GBZ file (product code).
+//
+// Reads the simple-sds serialization the reference loads with serialize::load_from
+// (src/gbwt.rs:402-438, src/gbz.rs:674-717, src/graph.rs:296-338, src/headers.rs) and flattens it
+// into the arrays the device needs: the record byte stream, a dense record-start array decoded
+// from the Elias-Fano index (the device never runs select), and -- for the GFA rows -- path names,
+// node label lengths and the node->segment translation.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace gbwt_hip {
+
+// Raised for anything the reference reports as io::ErrorKind::InvalidData.
+struct InvalidData : std::runtime_error { using std::runtime_error::runtime_error; };
+struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// gbwt::PathName, src/gbwt.rs:912-926
+struct PathName { uint32_t sample, contig, phase, fragment; };
+
+// support::StringArray flattened: offsets[n+1] into bytes
+struct Strings {
+    std::vector<uint64_t> offsets{0};
+    std::vector<uint8_t> bytes;
+    size_t size() const { return offsets.size() - 1; }
+    std::string str(size_t i) const { return std::string(bytes.begin() + offsets[i], bytes.begin() + offsets[i + 1]); }
+    size_t len(size_t i) const { return offsets[i + 1] - offsets[i]; }
+    bool find(const std::string &s, uint64_t &id) const;
+};
+
+struct HostIndex {
+    // Header<GBWTPayload>, src/headers.rs:190-234
+    uint64_t sequences = 0, size = 0, alphabet_offset = 0, alphabet_size = 0;
+    bool bidirectional = false;
+    // BWT, src/bwt.rs:97-100: data + record starts (n_records + 1 entries, last = data.size())
+    std::vector<uint8_t> data;
+    std::vector<uint64_t> starts;
+    uint64_t records() const { return starts.empty() ? 0 : starts.size() - 1; }
+
+    // tags of the GBWT (key -> value, lower-cased keys), src/support.rs:915-1020
+    std::vector<std::pair<std::string, std::string>> tags;
+    // tags of the GBZ container (src/gbz.rs:124-130) and the opaque document-array samples
+    // (src/gbwt.rs:100,417); kept only so that a loaded file can be written back unchanged
+    std::vector<std::pair<std::string, std::string>> gbz_tags;
+    std::vector<uint64_t> da_samples;
+    const std::string *tag(const std::string &key) const;
+
+    // Metadata, src/gbwt.rs:623-896
+    bool has_metadata = false;
+    uint64_t metadata_flags = 0, sample_count = 0, haplotype_count = 0, contig_count = 0;
+    std::vector<PathName> path_names;
+    Strings sample_names, contig_names;
+    // generic paths were stored with phase GENERIC_HAPLOTYPE (vg convention) and converted to 0 at load
+    // (src/gbwt.rs:879-886); older files store 0 directly.  Remembered so write-back is unchanged.
+    bool generic_phase_on_disk = true;
+
+    // Graph (GBZ only), src/graph.rs:84-89
+    bool is_gbz = false, has_translation = false;
+    uint64_t graph_nodes = 0;              // Header<GraphPayload>.nodes
+    Strings sequences_labels;   // node labels, one per potential node
+    Strings segment_names;
+    std::vector<uint64_t> segment_starts;  // node id of the first node of each segment (mapping ones)
+    uint64_t mapping_len = 0;              // universe of the node-to-segment mapping
+};
+
+// Parses a .gbwt or .gbz (detected by the header tag).  Throws InvalidData / IoError.
+HostIndex load_index_file(const std::string &path);
+
+// Writes the index back in the simple-sds format (GBWT v5; GBZ v1 container with an uncompressed
+// graph, version 3), following the Serialize impls src/gbwt.rs:389-400, src/gbz.rs:662-672,
+// src/graph.rs:284-294.  Used by the synthetic generator and by the writer round-trip tests.
+void save_index_file(const HostIndex &index, const std::string &path, bool as_gbz);
+
+// Builds the host image from raw parts (gbwt_hip_open_records).
+HostIndex index_from_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
+                             uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,
+                             bool bidirectional);
+
+}  // namespace gbwt_hip

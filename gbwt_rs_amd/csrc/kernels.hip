@@ -1,0 +1,332 @@
+// kernels.hip -- gfx950 kernels of the GBWT LF-step path (hand-written HIP, no MFMA: this is
+// integer pointer-chasing over a byte stream).  Launch wrappers are declared in kernels.hpp.
+#include "kernels.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include "lf_device.hpp"
+
+namespace gbwt_hip {
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------
+// Load-time passes
+
+// One lane per record: Record::len and outdegree maxima (sizes u32 offsets on device, feeds stats).
+__global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *stats) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    uint64_t start, limit;
+    record_bounds(ix, rec, start, limit);
+    if (start >= limit) return;
+    ByteCursor c(ix.data, start, limit);
+    uint64_t sigma;
+    if (!c.varint(sigma)) { atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), 1ull); return; }
+    if (sigma == 0) return;
+    uint64_t len = record_len(c, sigma);
+    atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(len));
+    atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
+}
+
+// Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
+__global__ void k_endmarker_sigma(DeviceIndex ix, uint64_t *result) {
+    result[0] = 0; result[1] = 0;
+    if (ix.n_records == 0) return;
+    uint64_t start, limit;
+    record_bounds(ix, 0, start, limit);
+    if (start >= limit) return;
+    ByteCursor c(ix.data, start, limit);
+    uint64_t sigma;
+    if (!c.varint(sigma) || sigma == 0) return;
+    result[1] = sigma;
+    result[0] = record_len(c, sigma);
+}
+
+// Record::decompress (src/bwt.rs:465-475) of the endmarker record, done once at open.  Single
+// lane: the record has one run per sequence in the worst case and this is load-time work.
+__global__ void k_endmarker_decompress(DeviceIndex ix, uint2 *out, uint64_t n_out, uint64_t *scratch, uint64_t *result) {
+    uint64_t start, limit;
+    record_bounds(ix, 0, start, limit);
+    ByteCursor c(ix.data, start, limit);
+    uint64_t sigma = 0;
+    c.varint(sigma);
+    uint64_t *nodes = scratch, *offsets = scratch + sigma;
+    uint64_t node = 0;
+    for (uint64_t e = 0; e < sigma; e++) {
+        uint64_t delta = 0, off = 0;
+        c.varint(delta); c.varint(off);
+        node += delta;
+        nodes[e] = node; offsets[e] = off;
+    }
+    RunDecoder rd(sigma);
+    uint64_t produced = 0, value, len;
+    while (rd.next(c, value, len)) {
+        if (value >= sigma) break;  // malformed
+        for (uint64_t k = 0; k < len && produced < n_out; k++) {
+            out[produced++] = make_uint2(static_cast<uint32_t>(nodes[value]), static_cast<uint32_t>(offsets[value]));
+            offsets[value]++;
+        }
+    }
+    result[0] = produced;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Path extraction: one lane per sequence (GBWT::sequence + SequenceIter::next, src/gbwt.rs:253-261,
+// 557-568).  Lengths are unknown until a sequence ends, so every lane appends the nodes it visits
+// to a chain of 1 KiB blocks drawn from a shared pool; a second, bandwidth-bound kernel lays the
+// chains out as CSR once the lengths (and their prefix sums) exist.
+
+__global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(WAVE) + threadIdx.x;
+    if (k >= a.n) return;
+    const uint64_t id = a.seq_ids[k];
+    uint64_t node = 0, offset = 0;
+    bool valid = false;
+    if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+        uint2 e = ix.endmarker[id];
+        node = e.x; offset = e.y;
+        valid = node != 0;
+    }
+    uint32_t cur = POOL_NONE, fill = POOL_BLOCK_NODES, head = POOL_NONE;
+    uint64_t len = 0;
+    while (valid) {
+        if (fill == POOL_BLOCK_NODES) {
+            uint32_t nb = atomicAdd(a.counter, 1u);
+            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); break; }
+            a.next[nb] = POOL_NONE;
+            if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
+            cur = nb; fill = 0;
+        }
+        a.pool[static_cast<uint64_t>(cur) * POOL_BLOCK_NODES + fill] = static_cast<uint32_t>(node);
+        fill++; len++;
+        uint64_t nn, no;
+        valid = gbwt_forward(ix, node, offset, nn, no);
+        node = nn; offset = no;
+    }
+    a.head[k] = head;
+    a.lengths[k] = len;
+}
+
+// One wave per path: follow the block chain and copy it to its CSR row.
+__global__ void __launch_bounds__(256) k_compact(WalkArgs a, const uint64_t *offsets, uint32_t *nodes) {
+    const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (path >= a.n) return;
+    uint64_t remaining = offsets[path + 1] - offsets[path];
+    uint32_t *dst = nodes + offsets[path];
+    uint32_t b = a.head[path];
+    while (remaining > 0 && b != POOL_NONE) {
+        const uint32_t cnt = remaining < POOL_BLOCK_NODES ? static_cast<uint32_t>(remaining) : POOL_BLOCK_NODES;
+        const uint32_t *src = a.pool + static_cast<uint64_t>(b) * POOL_BLOCK_NODES;
+        const uint32_t nb = a.next[b];
+#pragma unroll
+        for (uint32_t j = 0; j < POOL_BLOCK_NODES / WAVE; j++) {
+            uint32_t idx = j * WAVE + lane;
+            if (idx < cnt) dst[idx] = src[idx];
+        }
+        dst += cnt;
+        remaining -= cnt;
+        b = nb;
+    }
+}
+
+// One wave per CSR row: sum of the node ids (checking hook for device-resident results).
+__global__ void __launch_bounds__(256) k_path_sums(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, uint64_t *sums) {
+    const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (path >= n) return;
+    uint64_t acc = 0;
+    for (uint64_t k = offsets[path] + lane; k < offsets[path + 1]; k += WAVE) acc += nodes[k];
+    for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, WAVE);
+    if (lane == 0) sums[path] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Navigation and search: one lane per query.
+
+__global__ void __launch_bounds__(256) k_start(DeviceIndex ix, const uint64_t *ids, uint64_t n, gbwt_hip_pos *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    gbwt_hip_pos p{0, 0};
+    uint8_t ok = 0;
+    uint64_t id = ids[k];
+    if (id < ix.n_endmarker) {
+        uint2 e = ix.endmarker[id];
+        if (e.x != 0) { p.node = e.x; p.offset = e.y; ok = 1; }
+    }
+    out[k] = p; valid[k] = ok;
+}
+
+__global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    gbwt_hip_pos p = in[k], r{0, 0};
+    uint8_t ok = gbwt_forward(ix, p.node, p.offset, r.node, r.offset) ? 1 : 0;
+    if (!ok) { r.node = 0; r.offset = 0; }
+    out[k] = r; valid[k] = ok;
+}
+
+// GBWT::find, src/gbwt.rs:269-281
+__device__ __forceinline__ bool dev_find(const DeviceIndex &ix, uint64_t node, gbwt_hip_state &st) {
+    ByteCursor c(ix.data, 0, 0);
+    uint64_t sigma;
+    if (!open_record(ix, node, c, sigma)) return false;
+    st.node = node; st.start = 0; st.end = record_len(c, sigma);
+    return true;
+}
+
+// GBWT::extend, src/gbwt.rs:292-304
+__device__ __forceinline__ bool dev_extend(const DeviceIndex &ix, const gbwt_hip_state &st, uint64_t node, gbwt_hip_state &out) {
+    if (node < ix.first_node) return false;
+    ByteCursor c(ix.data, 0, 0);
+    uint64_t sigma, rs, re, count;
+    if (!open_record(ix, st.node, c, sigma)) return false;
+    if (!record_follow<false>(c, sigma, st.start, st.end, node, rs, re, count)) return false;
+    out.node = node; out.start = rs; out.end = re;
+    return true;
+}
+
+// GBWT::extend_forward + bd_internal, src/gbwt.rs:339-347, 371-384
+__device__ __forceinline__ bool dev_extend_forward(const DeviceIndex &ix, const gbwt_hip_bd_state &st, uint64_t node, gbwt_hip_bd_state &out) {
+    if (node < ix.first_node) return false;
+    ByteCursor c(ix.data, 0, 0);
+    uint64_t sigma, rs, re, count;
+    if (!open_record(ix, st.forward.node, c, sigma)) return false;
+    if (!record_follow<true>(c, sigma, st.forward.start, st.forward.end, node, rs, re, count)) return false;
+    out.forward.node = node; out.forward.start = rs; out.forward.end = re;
+    uint64_t pos = st.reverse.start + count;
+    out.reverse.node = st.reverse.node; out.reverse.start = pos; out.reverse.end = pos + (re - rs);
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_find(DeviceIndex ix, const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    gbwt_hip_state st{0, 0, 0};
+    uint8_t ok = dev_find(ix, nodes[k], st) ? 1 : 0;
+    out[k] = st; valid[k] = ok;
+}
+
+__global__ void __launch_bounds__(256) k_extend(DeviceIndex ix, const gbwt_hip_state *states, const uint64_t *nodes, uint64_t n,
+                                                 gbwt_hip_state *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    gbwt_hip_state st = states[k], r{0, 0, 0};
+    uint8_t ok = dev_extend(ix, st, nodes[k], r) ? 1 : 0;
+    out[k] = r; valid[k] = ok;
+}
+
+// GBWT::bd_find, src/gbwt.rs:311-324
+__global__ void __launch_bounds__(256) k_bd_find(DeviceIndex ix, const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    gbwt_hip_bd_state r{{0, 0, 0}, {0, 0, 0}};
+    gbwt_hip_state st{0, 0, 0};
+    uint8_t ok = dev_find(ix, nodes[k], st) ? 1 : 0;
+    if (ok) { r.forward = st; r.reverse.node = st.node ^ 1; r.reverse.start = st.start; r.reverse.end = st.end; }
+    out[k] = r; valid[k] = ok;
+}
+
+// extend_forward, or extend_backward = flip(extend_forward(flip(state), node ^ 1)) (src/gbwt.rs:362-367, 506-511)
+__global__ void __launch_bounds__(256) k_bd_extend(DeviceIndex ix, const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
+                                                    bool backward, gbwt_hip_bd_state *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    gbwt_hip_bd_state st = states[k], r{{0, 0, 0}, {0, 0, 0}}, zero{{0, 0, 0}, {0, 0, 0}};
+    uint64_t node = nodes[k];
+    if (backward) { gbwt_hip_state t = st.forward; st.forward = st.reverse; st.reverse = t; node ^= 1; }
+    uint8_t ok = dev_extend_forward(ix, st, node, r) ? 1 : 0;
+    if (ok && backward) { gbwt_hip_state t = r.forward; r.forward = r.reverse; r.reverse = t; }
+    out[k] = ok ? r : zero; valid[k] = ok;
+}
+
+// find(q[0]) then extend over q[1..len) in one launch (src/bin/benchmark.rs:155-169)
+__global__ void __launch_bounds__(256) k_search(DeviceIndex ix, const uint64_t *queries, uint64_t n, uint64_t len,
+                                                 gbwt_hip_state *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t *q = queries + k * len;
+    gbwt_hip_state st{0, 0, 0}, zero{0, 0, 0};
+    bool ok = len > 0 && dev_find(ix, q[0], st);
+    for (uint64_t j = 1; ok && j < len; j++) {
+        gbwt_hip_state nx;
+        ok = dev_extend(ix, st, q[j], nx);
+        st = nx;
+    }
+    out[k] = ok ? st : zero; valid[k] = ok ? 1 : 0;
+}
+
+inline unsigned grid_for(uint64_t n, unsigned block) { return static_cast<unsigned>((n + block - 1) / block); }
+
+}  // namespace
+
+void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_record_stats, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_stats);
+}
+
+void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream) {
+    hipLaunchKernelGGL(k_endmarker_sigma, dim3(1), dim3(1), 0, stream, ix, d_result);
+}
+
+void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
+                                 uint64_t *d_result, hipStream_t stream) {
+    hipLaunchKernelGGL(k_endmarker_decompress, dim3(1), dim3(1), 0, stream, ix, d_out, n_out, d_scratch, d_result);
+}
+
+void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream) {
+    if (args.n == 0) return;
+    hipLaunchKernelGGL(k_walk, dim3(grid_for(args.n, WAVE)), dim3(WAVE), 0, stream, ix, args);
+}
+
+void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {
+    if (args.n == 0) return;
+    hipLaunchKernelGGL(k_compact, dim3(grid_for(args.n, 256 / WAVE)), dim3(256), 0, stream, args, d_offsets, d_nodes);
+}
+
+void launch_path_sums(const uint64_t *d_offsets, const uint32_t *d_nodes, uint64_t n, uint64_t *d_sums, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_path_sums, dim3(grid_for(n, 256 / WAVE)), dim3(256), 0, stream, d_offsets, d_nodes, n, d_sums);
+}
+
+void launch_start(const DeviceIndex &ix, const uint64_t *ids, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_start, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, ids, n, out, valid);
+}
+void launch_forward(const DeviceIndex &ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_forward, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, in, n, out, valid);
+}
+void launch_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_find, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, nodes, n, out, valid);
+}
+void launch_extend(const DeviceIndex &ix, const gbwt_hip_state *states, const uint64_t *nodes, uint64_t n,
+                   gbwt_hip_state *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_extend, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, states, nodes, n, out, valid);
+}
+void launch_bd_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bd_find, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, nodes, n, out, valid);
+}
+void launch_bd_extend(const DeviceIndex &ix, const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
+                      bool backward, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bd_extend, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, states, nodes, n, backward, out, valid);
+}
+void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, gbwt_hip_state *out,
+                   uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_search, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, queries, n, len, out, valid);
+}
+
+size_t scan_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, static_cast<const uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr),
+                                     static_cast<int>(n));
+    return bytes;
+}
+
+void launch_scan(const uint64_t *d_lengths, uint64_t *d_offsets, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t s) {
+    (void)hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s);
+    if (n == 0) return;
+    (void)hipcub::DeviceScan::InclusiveSum(d_temp, temp_bytes, d_lengths, d_offsets + 1, static_cast<int>(n), s);
+}
+
+}  // namespace gbwt_hip

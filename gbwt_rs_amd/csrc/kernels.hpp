@@ -1,0 +1,61 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (implemented in kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/gbwt_hip.h"
+#include "device_index.hpp"
+
+namespace gbwt_hip {
+
+constexpr uint32_t POOL_BLOCK_NODES = 256;        // node ids per pool block (1 KiB)
+constexpr uint32_t POOL_NONE = 0xFFFFFFFFu;
+
+constexpr uint32_t FLAG_POOL_OVERFLOW = 1u;
+
+// ---- load-time passes -------------------------------------------------------------------------
+// stats[0] = max Record::len, stats[1] = max outdegree, stats[2] = number of malformed records
+void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream);
+// Record::decompress of record 0 into d_out[n_out] (src/gbwt.rs:413-414); d_scratch: 2 * sigma u64.
+// d_result[0] = number of positions produced, d_result[1] = outdegree of record 0 (first call sizes scratch)
+void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream);
+void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
+                                 uint64_t *d_result, hipStream_t stream);
+
+// ---- extraction -------------------------------------------------------------------------------
+struct WalkArgs {
+    const uint64_t *seq_ids;   // [n]
+    uint64_t n;
+    uint32_t *pool;            // [pool_blocks * POOL_BLOCK_NODES]
+    uint32_t *next;            // [pool_blocks] chain links
+    uint32_t pool_blocks;
+    uint32_t *counter;         // [1] next free block
+    uint32_t *head;            // [n] first block of each path
+    uint64_t *lengths;         // [n]
+    uint32_t *flags;           // [1]
+};
+void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);
+void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
+
+// per-path sum of node ids over CSR rows (checking hook)
+void launch_path_sums(const uint64_t *d_offsets, const uint32_t *d_nodes, uint64_t n, uint64_t *d_sums, hipStream_t stream);
+
+// ---- navigation / search ----------------------------------------------------------------------
+void launch_start(const DeviceIndex &ix, const uint64_t *ids, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s);
+void launch_forward(const DeviceIndex &ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s);
+void launch_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid, hipStream_t s);
+void launch_extend(const DeviceIndex &ix, const gbwt_hip_state *states, const uint64_t *nodes, uint64_t n,
+                   gbwt_hip_state *out, uint8_t *valid, hipStream_t s);
+void launch_bd_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s);
+void launch_bd_extend(const DeviceIndex &ix, const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
+                      bool backward, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s);
+void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, gbwt_hip_state *out,
+                   uint8_t *valid, hipStream_t s);
+
+// inclusive scan of lengths[n] into offsets[1..n], offsets[0] = 0 (hipcub); temp storage managed by caller
+size_t scan_temp_bytes(uint64_t n);
+void launch_scan(const uint64_t *d_lengths, uint64_t *d_offsets, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t s);
+
+}  // namespace gbwt_hip

@@ -1,0 +1,106 @@
+"""ctypes wrapper of libgbwt_synth.so: synthetic GBWT/GBZ generator (host-only; see gbwt_synth.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgbwt_synth.so")
+
+MOSAIC, IID = 0, 1
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C {HERE}` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        p, u64 = C.c_void_p, C.c_uint64
+        L.gbwt_synth_chain.restype = p
+        L.gbwt_synth_chain.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64]
+        L.gbwt_synth_from_paths.restype = p
+        L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
+        L.gbwt_synth_from_file.restype = p
+        L.gbwt_synth_from_file.argtypes = [C.c_char_p, C.c_char_p, u64]
+        L.gbwt_synth_free.restype = None
+        L.gbwt_synth_free.argtypes = [p]
+        L.gbwt_synth_data.restype = p
+        L.gbwt_synth_data.argtypes = [p, C.POINTER(u64)]
+        L.gbwt_synth_starts.restype = p
+        L.gbwt_synth_starts.argtypes = [p, C.POINTER(u64)]
+        L.gbwt_synth_header.restype = None
+        L.gbwt_synth_header.argtypes = [p, u64 * 8]
+        L.gbwt_synth_save.restype = C.c_int
+        L.gbwt_synth_save.argtypes = [p, C.c_char_p, C.c_int]
+        L.gbwt_synth_path.restype = u64
+        L.gbwt_synth_path.argtypes = [p, u64, p, u64]
+        L.gbwt_synth_path_checksum.restype = u64
+        L.gbwt_synth_path_checksum.argtypes = [p, u64]
+        _lib = L
+    return _lib
+
+
+class Synth:
+    """A generated (or loaded) index held on the host: record stream, starts, header, ground-truth paths."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("generator returned NULL (bad parameters)")
+        self._L = lib()
+        self._h = handle
+        hdr = (C.c_uint64 * 8)()
+        self._L.gbwt_synth_header(self._h, hdr)
+        (self.sequences, self.size, self.alphabet_offset, self.alphabet_size, bd, self.paths, self.sites,
+         self.alleles) = [int(x) for x in hdr]
+        self.bidirectional = bool(bd)
+
+    @classmethod
+    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42):
+        return cls(lib().gbwt_synth_chain(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed))
+
+    @classmethod
+    def from_paths(cls, paths, bidirectional=True):
+        """paths: list of lists of GBWT-encoded nodes (2 * id + orientation)."""
+        offsets = np.zeros(len(paths) + 1, dtype=np.uint64)
+        np.cumsum([len(p) for p in paths], out=offsets[1:])
+        flat = np.array([x for p in paths for x in p] or [0], dtype=np.uint64)
+        return cls(lib().gbwt_synth_from_paths(offsets.ctypes.data, flat.ctypes.data, len(paths), int(bidirectional)))
+
+    @classmethod
+    def from_file(cls, path):
+        err = C.create_string_buffer(256)
+        h = lib().gbwt_synth_from_file(os.fsencode(path), err, 256)
+        if not h:
+            raise ValueError(err.value.decode())
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.gbwt_synth_free(self._h)
+            self._h = None
+
+    def data(self):
+        n = C.c_uint64(0)
+        p = self._L.gbwt_synth_data(self._h, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+
+    def starts(self):
+        n = C.c_uint64(0)
+        p = self._L.gbwt_synth_starts(self._h, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+
+    def save(self, path, as_gbz=False):
+        if self._L.gbwt_synth_save(self._h, os.fsencode(path), int(as_gbz)) != 0:
+            raise IOError(f"cannot write {path}")
+
+    def path(self, path_id):
+        n = self._L.gbwt_synth_path(self._h, path_id, None, 0)
+        out = np.zeros(max(1, n), dtype=np.uint32)
+        self._L.gbwt_synth_path(self._h, path_id, out.ctypes.data, n)
+        return out[:n]
+
+    def path_checksum(self, path_id):
+        return int(self._L.gbwt_synth_path_checksum(self._h, path_id))

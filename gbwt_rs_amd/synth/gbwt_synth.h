@@ -1,0 +1,60 @@
+/*
+ * gbwt_synth.h -- synthetic GBWT / GBZ generator (host-only C API of libgbwt_synth.so).
+ *
+ * The reference cannot build a GBWT ("no BWT construction algorithms have been implemented",
+ * src/bwt.rs:209; README.md:27), so every synthetic config of BASELINE.json needs a constructor.
+ * Two are provided:
+ *   - gbwt_synth_chain: "bubble chain" / "star chain" pangenome: S sites, each an
+ *     anchor node followed by one of A allele nodes; bidirectional GBWT built by a PBWT-style
+ *     sweep, O(haplotypes) per site.  The generator keeps the allele
+ *     matrix, i.e. the ground-truth paths, so extraction can be checked at full size.
+ *   - gbwt_synth_from_paths: any path set (cycles, both orientations) by brute-force sorting of
+ *     reverse prefixes; for small test inputs.
+ * Files are written in the simple-sds format the reference loads (GBWT v5, GBZ v1 container).
+ */
+#ifndef GBWT_SYNTH_H
+#define GBWT_SYNTH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gbwt_synth gbwt_synth;
+
+enum { GBWT_SYNTH_MOSAIC = 0, GBWT_SYNTH_IID = 1 };
+
+/* alleles == 2: allele 1 ~ Bernoulli(p_site), p_site ~ U(0.05, 0.95); alleles > 2: Zipf(zipf) over the alleles.
+ * MOSAIC: `founders` founder haplotypes carry the per-site draws and every haplotype copies a founder,
+ * switching founder with probability switch_rate per site.  IID: every haplotype draws independently.
+ * Node ids: site s has anchor s*(alleles+1)+1 and allele nodes s*(alleles+1)+2+a; 1 bp labels.
+ * Path 0 is a generic path (sample _gbwt_ref, contig chr1); path h >= 1 is sample s{(h-1)/2}, phase (h-1)%2+1. */
+gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                             double switch_rate, double zipf, uint64_t seed);
+
+/* Paths as CSR over GBWT-encoded nodes (2 * id + orientation, id >= 1).  bidirectional != 0 adds the
+ * reverse sequence of every path (src/support.rs:310-314).  No metadata, no graph. */
+gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, int bidirectional);
+
+/* Loads a .gbwt / .gbz with the product loader (for writer round-trip tests). */
+gbwt_synth *gbwt_synth_from_file(const char *path, char *err, uint64_t errlen);
+
+void gbwt_synth_free(gbwt_synth *s);
+
+const uint8_t *gbwt_synth_data(const gbwt_synth *s, uint64_t *len);
+const uint64_t *gbwt_synth_starts(const gbwt_synth *s, uint64_t *n_records);
+/* out = {sequences, size, alphabet_offset, alphabet_size, bidirectional, paths, sites, alleles} */
+void gbwt_synth_header(const gbwt_synth *s, uint64_t out[8]);
+int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz);
+
+/* Ground truth of chain generators: GBWT-encoded nodes of path `path_id` (forward orientation).
+ * Returns the path length; writes at most `cap` nodes. */
+uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, uint64_t cap);
+/* Sum over the path of its GBWT-encoded node values (cheap full-size checksum), computed from the allele matrix. */
+uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,517 @@
+// synth.cpp -- synthetic GBWT / GBZ generator (host-only; see gbwt_synth.h).
+//
+// Construction rule: the record of node v lists, for every visit of v, the
+// successor on that sequence (0 = ENDMARKER at the end).  Visits inside a record are ordered by
+// (predecessor node, position of the visit in the predecessor's record), visits that start a
+// sequence come first in sequence-id order.  Edge (v -> w) stores the number of visits in record w
+// whose predecessor is smaller than v.  Runs are maximal equal-successor stretches, written with
+// the reference's codecs (ByteCode src/support.rs:1063-1070, RLE src/support.rs:1238-1248,
+// BWTBuilder::append src/bwt.rs:241-253).
+#include "gbwt_synth.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../csrc/host_index.hpp"
+
+using gbwt_hip::HostIndex;
+using gbwt_hip::PathName;
+
+namespace {
+
+// ---- codecs (encoder side) ------------------------------------------------------------------
+inline void put_varint(std::vector<uint8_t> &out, uint64_t v) {
+    while (v > 0x7F) { out.push_back(static_cast<uint8_t>((v & 0x7F) | 0x80)); v >>= 7; }
+    out.push_back(static_cast<uint8_t>(v));
+}
+
+inline void put_run(std::vector<uint8_t> &out, uint64_t sigma, uint64_t value, uint64_t len) {
+    if (sigma >= 255) { put_varint(out, value); put_varint(out, len - 1); return; }
+    uint64_t threshold = 256 / sigma;
+    if (len < threshold) out.push_back(static_cast<uint8_t>(value + sigma * (len - 1)));
+    else { out.push_back(static_cast<uint8_t>(value + sigma * (threshold - 1))); put_varint(out, len - threshold); }
+}
+
+// Appends one record: edges (node ascending) + body given as successor ranks with run merging.
+struct RecordWriter {
+    std::vector<uint8_t> &out;
+    uint64_t sigma = 0, run_value = 0, run_len = 0;
+    explicit RecordWriter(std::vector<uint8_t> &o) : out(o) {}
+    void begin(const std::vector<std::pair<uint64_t, uint64_t>> &edges) {
+        sigma = edges.size();
+        put_varint(out, sigma);
+        uint64_t prev = 0;
+        for (auto &e : edges) { put_varint(out, e.first - prev); put_varint(out, e.second); prev = e.first; }
+        run_len = 0;
+    }
+    inline void push(uint64_t rank, uint64_t count = 1) {
+        if (run_len && rank == run_value) { run_len += count; return; }
+        if (run_len) put_run(out, sigma, run_value, run_len);
+        run_value = rank; run_len = count;
+    }
+    void end() { if (run_len) put_run(out, sigma, run_value, run_len); run_len = 0; }
+};
+
+// ---- deterministic RNG (xoshiro256** seeded by splitmix64) -------------------------------------
+struct Rng {
+    uint64_t s[4];
+    explicit Rng(uint64_t seed) {
+        for (auto &x : s) { seed += 0x9E3779B97F4A7C15ull; uint64_t z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; x = z ^ (z >> 31); }
+    }
+    static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    inline uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    inline double uniform() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+    inline uint64_t below(uint64_t n) { return static_cast<uint64_t>((static_cast<unsigned __int128>(next()) * n) >> 64); }
+};
+
+}  // namespace
+
+struct gbwt_synth {
+    HostIndex index;
+    // chain truth
+    uint64_t sites = 0, haplotypes = 0, alleles = 0;
+    std::vector<uint64_t> bits;     // alleles == 2: site-major bit rows
+    uint64_t row_words = 0;
+    std::vector<uint16_t> choices;  // alleles > 2: site-major
+    // explicit truth (from_paths)
+    std::vector<uint64_t> path_offsets;
+    std::vector<uint32_t> path_nodes;
+
+    inline uint32_t allele(uint64_t s, uint64_t h) const {
+        if (alleles == 2) return static_cast<uint32_t>((bits[s * row_words + (h >> 6)] >> (h & 63)) & 1);
+        return choices[s * haplotypes + h];
+    }
+    inline void set_allele(uint64_t s, uint64_t h, uint32_t a) {
+        if (alleles == 2) { if (a) bits[s * row_words + (h >> 6)] |= uint64_t(1) << (h & 63); }
+        else choices[s * haplotypes + h] = static_cast<uint16_t>(a);
+    }
+    inline uint64_t anchor_id(uint64_t s) const { return s * (alleles + 1) + 1; }
+    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * (alleles + 1) + 2 + a; }
+};
+
+namespace {
+
+void draw_alleles(gbwt_synth &g, uint32_t model, uint32_t founders, double rho, double zipf, uint64_t seed) {
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
+    Rng rng(seed);
+    std::vector<double> cdf;
+    if (A > 2) {
+        cdf.resize(A);
+        double total = 0;
+        for (uint64_t a = 0; a < A; a++) { total += 1.0 / std::pow(static_cast<double>(a + 1), zipf); cdf[a] = total; }
+        for (auto &x : cdf) x /= total;
+    }
+    auto draw = [&](double p_site) -> uint32_t {
+        if (A == 2) return rng.uniform() < p_site ? 1u : 0u;
+        double u = rng.uniform();
+        uint32_t a = static_cast<uint32_t>(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+        return a >= A ? static_cast<uint32_t>(A - 1) : a;
+    };
+    if (model == GBWT_SYNTH_IID) {
+        for (uint64_t s = 0; s < S; s++) {
+            double p = 0.05 + 0.9 * rng.uniform();
+            for (uint64_t h = 0; h < n; h++) g.set_allele(s, h, draw(p));
+        }
+        return;
+    }
+    if (founders == 0) founders = 1;
+    std::vector<uint32_t> founder(n), founder_allele(founders);
+    std::vector<uint64_t> next_switch(n);
+    const double log1m = rho > 0 && rho < 1 ? std::log(1.0 - rho) : 0.0;
+    auto gap = [&]() -> uint64_t {  // sites until the next founder switch (geometric)
+        if (rho <= 0) return UINT64_MAX / 2;
+        if (rho >= 1) return 1;
+        double u = rng.uniform();
+        if (u <= 0) u = 1e-300;
+        return 1 + static_cast<uint64_t>(std::log(u) / log1m);
+    };
+    for (uint64_t h = 0; h < n; h++) { founder[h] = static_cast<uint32_t>(rng.below(founders)); next_switch[h] = gap(); }
+    for (uint64_t s = 0; s < S; s++) {
+        double p = 0.05 + 0.9 * rng.uniform();
+        for (uint32_t f = 0; f < founders; f++) founder_allele[f] = draw(p);
+        for (uint64_t h = 0; h < n; h++) {
+            if (next_switch[h] == s) { founder[h] = static_cast<uint32_t>(rng.below(founders)); next_switch[h] = s + gap(); }
+            g.set_allele(s, h, founder_allele[founder[h]]);
+        }
+    }
+}
+
+// Per-site allele counts and rank among the alleles that occur.
+struct SiteStats {
+    std::vector<uint32_t> cnt, rank;
+    uint32_t present = 0;
+    void compute(const gbwt_synth &g, uint64_t s) {
+        const uint64_t A = g.alleles, n = g.haplotypes;
+        cnt.assign(A, 0); rank.assign(A, 0);
+        if (A == 2) {
+            uint64_t ones = 0;
+            const uint64_t *row = g.bits.data() + s * g.row_words;
+            for (uint64_t w = 0; w < g.row_words; w++) ones += static_cast<uint64_t>(__builtin_popcountll(row[w]));
+            cnt[1] = static_cast<uint32_t>(ones); cnt[0] = static_cast<uint32_t>(n - ones);
+        } else {
+            const uint16_t *row = g.choices.data() + s * n;
+            for (uint64_t h = 0; h < n; h++) cnt[row[h]]++;
+        }
+        present = 0;
+        for (uint64_t a = 0; a < A; a++) if (cnt[a]) rank[a] = present++;
+    }
+};
+
+// Stable counting sort of `ord` by the allele at site s.
+void partition(const gbwt_synth &g, uint64_t s, const SiteStats &st, const std::vector<uint32_t> &ord, std::vector<uint32_t> &out,
+               std::vector<uint32_t> &cursor) {
+    const uint64_t A = g.alleles;
+    cursor.assign(A, 0);
+    uint32_t acc = 0;
+    for (uint64_t a = 0; a < A; a++) { cursor[a] = acc; acc += st.cnt[a]; }
+    out.resize(ord.size());
+    for (uint32_t h : ord) out[cursor[g.allele(s, h)]++] = h;
+}
+
+// Pool of records produced by one sweep: slot (s, k) with k = 0 anchor, 1 + a = allele a.
+struct Pool {
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> start;  // (S * (A + 1) + 1) entries, in generation order
+};
+
+void forward_sweep(const gbwt_synth &g, Pool &pool) {
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
+    pool.start.assign(S * (A + 1) + 1, 0);
+    pool.bytes.reserve(S * 24);
+    std::vector<uint32_t> ord(n), nxt, cursor;
+    for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
+    SiteStats st;
+    std::vector<std::pair<uint64_t, uint64_t>> edges;
+    RecordWriter rw(pool.bytes);
+    for (uint64_t s = 0; s < S; s++) {
+        st.compute(g, s);
+        const uint64_t base = s * (A + 1);
+        // anchor, forward orientation: successors are the allele nodes of this site
+        pool.start[base] = pool.bytes.size();
+        edges.clear();
+        for (uint64_t a = 0; a < A; a++) if (st.cnt[a]) edges.emplace_back(2 * g.allele_id(s, static_cast<uint32_t>(a)), 0);
+        rw.begin(edges);
+        for (uint32_t h : ord) rw.push(st.rank[g.allele(s, h)]);
+        rw.end();
+        partition(g, s, st, ord, nxt, cursor);
+        ord.swap(nxt);
+        // allele nodes, forward: one edge to the next anchor (or the ENDMARKER at the last site)
+        uint64_t before = 0;
+        for (uint64_t a = 0; a < A; a++) {
+            pool.start[base + 1 + a] = pool.bytes.size();
+            if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
+            edges.clear();
+            if (s + 1 < S) edges.emplace_back(2 * g.anchor_id(s + 1), before); else edges.emplace_back(0, 0);
+            rw.begin(edges);
+            rw.push(0, st.cnt[a]);
+            rw.end();
+            before += st.cnt[a];
+        }
+    }
+    pool.start[S * (A + 1)] = pool.bytes.size();
+}
+
+// Reverse orientation, generated from the last site down; slots are stored in generation order:
+// slot index for site s = (S - 1 - s) * (A + 1) + k.
+void reverse_sweep(const gbwt_synth &g, Pool &pool) {
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
+    pool.start.assign(S * (A + 1) + 1, 0);
+    pool.bytes.reserve(S * 24);
+    std::vector<uint32_t> ord(n), nxt, cursor;
+    for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
+    SiteStats st, prev;
+    std::vector<std::pair<uint64_t, uint64_t>> edges;
+    RecordWriter rw(pool.bytes);
+    for (uint64_t s = S; s-- > 0;) {
+        st.compute(g, s);
+        const uint64_t base = (S - 1 - s) * (A + 1);
+        partition(g, s, st, ord, nxt, cursor);
+        ord.swap(nxt);  // order of the visits in the reverse anchor record
+        // anchor, reverse orientation: successors are the reverse allele nodes of site s - 1
+        pool.start[base] = pool.bytes.size();
+        edges.clear();
+        if (s > 0) {
+            prev.compute(g, s - 1);
+            for (uint64_t a = 0; a < A; a++) if (prev.cnt[a]) edges.emplace_back(2 * g.allele_id(s - 1, static_cast<uint32_t>(a)) + 1, 0);
+            rw.begin(edges);
+            for (uint32_t h : ord) rw.push(prev.rank[g.allele(s - 1, h)]);
+            rw.end();
+        } else {
+            edges.emplace_back(0, 0);
+            rw.begin(edges);
+            rw.push(0, n);
+            rw.end();
+        }
+        // allele nodes, reverse: one edge to the reverse anchor of this site
+        uint64_t before = 0;
+        for (uint64_t a = 0; a < A; a++) {
+            pool.start[base + 1 + a] = pool.bytes.size();
+            if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
+            edges.clear();
+            edges.emplace_back(2 * g.anchor_id(s) + 1, before);
+            rw.begin(edges);
+            rw.push(0, st.cnt[a]);
+            rw.end();
+            before += st.cnt[a];
+        }
+    }
+    pool.start[S * (A + 1)] = pool.bytes.size();
+}
+
+void add_string(gbwt_hip::Strings &s, const std::string &x) {
+    s.bytes.insert(s.bytes.end(), x.begin(), x.end());
+    s.offsets.push_back(s.bytes.size());
+}
+
+void build_chain(gbwt_synth &g, uint64_t seed) {
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
+    HostIndex &ix = g.index;
+    Pool fwd, rev;
+    std::thread t([&] { reverse_sweep(g, rev); });
+    forward_sweep(g, fwd);
+    t.join();
+
+    // endmarker record: sequence 2h starts at the first anchor, sequence 2h + 1 at the reverse of the last allele
+    SiteStats last;
+    last.compute(g, S - 1);
+    std::vector<std::pair<uint64_t, uint64_t>> edges;
+    edges.emplace_back(2 * g.anchor_id(0), 0);
+    for (uint64_t a = 0; a < A; a++) if (last.cnt[a]) edges.emplace_back(2 * g.allele_id(S - 1, static_cast<uint32_t>(a)) + 1, 0);
+    ix.data.clear();
+    ix.data.reserve(fwd.bytes.size() + rev.bytes.size() + 4 * n + 64);
+    ix.starts.clear();
+    ix.starts.reserve(2 * S * (A + 1) + 2);
+    ix.starts.push_back(0);
+    {
+        RecordWriter rw(ix.data);
+        rw.begin(edges);
+        for (uint64_t h = 0; h < n; h++) { rw.push(0); rw.push(1 + last.rank[g.allele(S - 1, h)]); }
+        rw.end();
+    }
+    // interleave: node id ascending, forward record then reverse record
+    for (uint64_t s = 0; s < S; s++) {
+        for (uint64_t k = 0; k <= A; k++) {
+            uint64_t fs = s * (A + 1) + k, rs = (S - 1 - s) * (A + 1) + k;
+            ix.starts.push_back(ix.data.size());
+            ix.data.insert(ix.data.end(), fwd.bytes.begin() + fwd.start[fs], fwd.bytes.begin() + fwd.start[fs + 1]);
+            ix.starts.push_back(ix.data.size());
+            ix.data.insert(ix.data.end(), rev.bytes.begin() + rev.start[rs], rev.bytes.begin() + rev.start[rs + 1]);
+        }
+    }
+    // alphabet_size = largest visited GBWT node + 1: drop the records of unused trailing allele nodes
+    uint32_t top = 0;
+    for (uint64_t a = 0; a < A; a++) if (last.cnt[a]) top = static_cast<uint32_t>(a);
+    const uint64_t max_node = 2 * g.allele_id(S - 1, top) + 1;
+    if (max_node < ix.starts.size()) {   // records 0 .. max_node - 1 (record r <-> node r + 1)
+        ix.data.resize(ix.starts[max_node]);
+        ix.starts.resize(max_node);
+    }
+    ix.starts.push_back(ix.data.size());
+    ix.sequences = 2 * n;
+    ix.size = 2 * n * (2 * S) + 2 * n;
+    ix.alphabet_offset = 1;
+    ix.alphabet_size = max_node + 1;
+    ix.bidirectional = true;
+    ix.tags.emplace_back("source", "gbwt_rs_amd/synth");
+    ix.gbz_tags.emplace_back("source", "gbwt_rs_amd/synth");
+
+    // metadata: path 0 generic, the rest haplotypes of samples s0, s1, ...
+    ix.has_metadata = true;
+    ix.metadata_flags = 7;
+    const uint64_t n_samples = (n > 1 ? (n - 1 + 1) / 2 : 0);
+    for (uint64_t k = 0; k < n_samples; k++) add_string(ix.sample_names, "s" + std::to_string(k));
+    add_string(ix.sample_names, "_gbwt_ref");
+    add_string(ix.contig_names, "chr1");
+    ix.sample_count = n_samples + 1; ix.haplotype_count = n; ix.contig_count = 1;
+    ix.path_names.resize(n);
+    ix.path_names[0] = PathName{static_cast<uint32_t>(n_samples), 0, 0, 0};
+    for (uint64_t h = 1; h < n; h++) ix.path_names[h] = PathName{static_cast<uint32_t>((h - 1) / 2), 0, static_cast<uint32_t>((h - 1) % 2 + 1), 0};
+
+    // graph: 1 bp labels for nodes that occur, empty labels for allele nodes nobody uses
+    ix.is_gbz = true; ix.has_translation = false;
+    Rng rng(seed ^ 0xACDCACDCull);
+    SiteStats st;
+    uint64_t real = 0;
+    ix.sequences_labels.bytes.reserve(S * (A + 1));
+    ix.sequences_labels.offsets.reserve(S * (A + 1) + 1);
+    for (uint64_t s = 0; s < S; s++) {
+        st.compute(g, s);
+        for (uint64_t k = 0; k <= A; k++) {
+            if (s * (A + 1) + k + 1 > g.allele_id(S - 1, top)) break;  // ids past the largest visited node
+            if (k == 0 || st.cnt[k - 1]) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
+            ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
+        }
+    }
+    ix.graph_nodes = real;
+}
+
+// ---- general path sets: brute-force reverse-prefix sort ------------------------------------------
+void build_from_paths(gbwt_synth &g, const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, bool bidirectional) {
+    std::vector<std::vector<uint64_t>> seqs;
+    for (uint64_t p = 0; p < n_paths; p++) {
+        std::vector<uint64_t> f(nodes + offsets[p], nodes + offsets[p + 1]);
+        seqs.push_back(f);
+        if (bidirectional) {
+            std::vector<uint64_t> r(f.rbegin(), f.rend());
+            for (auto &x : r) x ^= 1;
+            seqs.push_back(r);
+        }
+    }
+    g.path_offsets.assign(1, 0);
+    for (uint64_t p = 0; p < n_paths; p++) {
+        for (uint64_t k = offsets[p]; k < offsets[p + 1]; k++) g.path_nodes.push_back(static_cast<uint32_t>(nodes[k]));
+        g.path_offsets.push_back(g.path_nodes.size());
+    }
+    HostIndex &ix = g.index;
+    uint64_t min_node = UINT64_MAX, max_node = 0, total = 0;
+    for (auto &s : seqs) for (uint64_t v : s) { min_node = std::min(min_node, v); max_node = std::max(max_node, v); total++; }
+    ix.sequences = seqs.size();
+    ix.size = total + seqs.size();
+    ix.bidirectional = bidirectional;
+    if (total == 0) {  // only empty sequences: endmarker record alone
+        ix.alphabet_offset = 0; ix.alphabet_size = 1;
+    } else {
+        ix.alphabet_offset = min_node - 1; ix.alphabet_size = max_node + 1;
+    }
+    struct Visit { uint32_t seq, pos; };
+    const uint64_t n_records = ix.alphabet_size - ix.alphabet_offset;
+    std::vector<std::vector<Visit>> visits(n_records);
+    for (uint32_t i = 0; i < seqs.size(); i++)
+        for (uint32_t j = 0; j < seqs[i].size(); j++) visits[seqs[i][j] - ix.alphabet_offset].push_back(Visit{i, j});
+    auto less = [&](const Visit &a, const Visit &b) {  // compare reverse prefixes, ENDMARKER < every node, ties by sequence id
+        uint32_t ja = a.pos, jb = b.pos;
+        while (ja > 0 && jb > 0) {
+            uint64_t x = seqs[a.seq][ja - 1], y = seqs[b.seq][jb - 1];
+            if (x != y) return x < y;
+            ja--; jb--;
+        }
+        if (ja == 0 && jb == 0) return a.seq < b.seq;
+        return ja == 0;
+    };
+    for (auto &v : visits) std::stable_sort(v.begin(), v.end(), less);
+    auto pred_of = [&](const Visit &v) -> uint64_t { return v.pos == 0 ? 0 : seqs[v.seq][v.pos - 1]; };
+    auto count_smaller_preds = [&](uint64_t w, uint64_t v) -> uint64_t {  // visits of w whose predecessor < v
+        uint64_t c = 0;
+        for (auto &x : visits[w - ix.alphabet_offset]) if (pred_of(x) < v) c++;
+        return c;
+    };
+    ix.data.clear(); ix.starts.clear();
+    RecordWriter rw(ix.data);
+    for (uint64_t r = 0; r < n_records; r++) {
+        ix.starts.push_back(ix.data.size());
+        std::vector<uint64_t> succ;
+        uint64_t v = r == 0 ? 0 : r + ix.alphabet_offset;
+        if (r == 0) {
+            for (auto &s : seqs) succ.push_back(s.empty() ? 0 : s[0]);
+        } else {
+            for (auto &x : visits[r]) succ.push_back(x.pos + 1 < seqs[x.seq].size() ? seqs[x.seq][x.pos + 1] : 0);
+        }
+        if (succ.empty()) { ix.data.push_back(0); continue; }
+        std::vector<uint64_t> distinct(succ);
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        std::vector<std::pair<uint64_t, uint64_t>> edges;
+        for (uint64_t w : distinct) edges.emplace_back(w, (w == 0 || r == 0) ? 0 : count_smaller_preds(w, v));
+        rw.begin(edges);
+        for (uint64_t w : succ) rw.push(static_cast<uint64_t>(std::lower_bound(distinct.begin(), distinct.end(), w) - distinct.begin()));
+        rw.end();
+    }
+    ix.starts.push_back(ix.data.size());
+    ix.tags.emplace_back("source", "gbwt_rs_amd/synth");
+}
+
+}  // namespace
+
+extern "C" {
+
+gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                             double switch_rate, double zipf, uint64_t seed) {
+    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000) return nullptr;
+    gbwt_synth *g = new gbwt_synth;
+    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles;
+    if (alleles == 2) { g->row_words = (haplotypes + 63) / 64; g->bits.assign(sites * g->row_words, 0); }
+    else g->choices.assign(sites * haplotypes, 0);
+    draw_alleles(*g, model, founders, switch_rate, zipf, seed);
+    build_chain(*g, seed);
+    return g;
+}
+
+gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, int bidirectional) {
+    gbwt_synth *g = new gbwt_synth;
+    build_from_paths(*g, offsets, nodes, n_paths, bidirectional != 0);
+    return g;
+}
+
+gbwt_synth *gbwt_synth_from_file(const char *path, char *err, uint64_t errlen) {
+    gbwt_synth *g = new gbwt_synth;
+    try {
+        g->index = gbwt_hip::load_index_file(path);
+    } catch (const std::exception &e) {
+        if (err && errlen) snprintf(err, errlen, "%s", e.what());
+        delete g;
+        return nullptr;
+    }
+    return g;
+}
+
+void gbwt_synth_free(gbwt_synth *s) { delete s; }
+
+const uint8_t *gbwt_synth_data(const gbwt_synth *s, uint64_t *len) { *len = s->index.data.size(); return s->index.data.data(); }
+
+const uint64_t *gbwt_synth_starts(const gbwt_synth *s, uint64_t *n_records) { *n_records = s->index.records(); return s->index.starts.data(); }
+
+void gbwt_synth_header(const gbwt_synth *s, uint64_t out[8]) {
+    out[0] = s->index.sequences; out[1] = s->index.size; out[2] = s->index.alphabet_offset; out[3] = s->index.alphabet_size;
+    out[4] = s->index.bidirectional; out[5] = s->index.bidirectional ? s->index.sequences / 2 : s->index.sequences;
+    out[6] = s->sites; out[7] = s->alleles;
+}
+
+int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz) {
+    try {
+        gbwt_hip::save_index_file(s->index, path, as_gbz != 0);
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "gbwt_synth_save: %s\n", e.what());
+        return 1;
+    }
+}
+
+uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, uint64_t cap) {
+    if (s->sites) {
+        if (path_id >= s->haplotypes) return 0;
+        uint64_t len = 2 * s->sites;
+        for (uint64_t site = 0; site < s->sites && 2 * site < cap; site++) {
+            out[2 * site] = static_cast<uint32_t>(2 * s->anchor_id(site));
+            if (2 * site + 1 < cap) out[2 * site + 1] = static_cast<uint32_t>(2 * s->allele_id(site, s->allele(site, path_id)));
+        }
+        return len;
+    }
+    if (path_id + 1 >= s->path_offsets.size()) return 0;
+    uint64_t a = s->path_offsets[path_id], b = s->path_offsets[path_id + 1];
+    for (uint64_t k = a; k < b && k - a < cap; k++) out[k - a] = s->path_nodes[k];
+    return b - a;
+}
+
+uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id) {
+    uint64_t sum = 0;
+    if (s->sites) {
+        if (path_id >= s->haplotypes) return 0;
+        for (uint64_t site = 0; site < s->sites; site++)
+            sum += 2 * s->anchor_id(site) + 2 * s->allele_id(site, s->allele(site, path_id));
+        return sum;
+    }
+    if (path_id + 1 >= s->path_offsets.size()) return 0;
+    for (uint64_t k = s->path_offsets[path_id]; k < s->path_offsets[path_id + 1]; k++) sum += s->path_nodes[k];
+    return sum;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+/*
+ * gbwt_hip.h -- C ABI of libgbwt_hip.so: the MI355X (gfx950) drop-in for the GBWT LF-step hot path
+ * of jltsiren/gbwt-rs (crate `gbz` 0.5.1).
+ *
+ * The reference has no FFI of its own (no `extern`, no build.rs); every entry point below names the
+ * Rust interface it replaces (file:line into the reference repository) and mirrors its semantics in
+ * batched form.  Plain pointers and sizes only; no torch / HIP types in any signature (streams and
+ * device buffers are passed as `void *`).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions:
+ *   - every function returns a gbwt_hip_status; 0 = success.  "Not found" is a value
+ *     (Option::None <-> valid[i] = 0), never an error.
+ *   - a handle is immutable after open and safe for concurrent read-only calls from several host
+ *     threads as long as each thread uses its own gbwt_hip_workspace (the reference shares &GBZ across
+ *     rayon workers, src/bin/gbunzip.rs:421-434).
+ *   - malformed *files* -> GBWT_HIP_INVALID_DATA (io::ErrorKind::InvalidData in the reference);
+ *     where the reference asserts/panics (non-bidirectional index in bd_* calls) -> GBWT_HIP_BAD_ARGUMENT.
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     GBWT_HIP_NO_DEVICE / GBWT_HIP_DEVICE_ERROR.
+ */
+#ifndef GBWT_HIP_H
+#define GBWT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GBWT_HIP_OK = 0,
+    GBWT_HIP_INVALID_DATA = 1, /* io::ErrorKind::InvalidData: bad tag/version/flags, length mismatch, ... */
+    GBWT_HIP_IO_ERROR = 2,     /* file cannot be opened / read */
+    GBWT_HIP_BAD_ARGUMENT = 3, /* id out of range, index not bidirectional, null pointer, ... */
+    GBWT_HIP_NO_DEVICE = 4,    /* no HIP device available */
+    GBWT_HIP_DEVICE_ERROR = 5, /* a HIP runtime call failed */
+    GBWT_HIP_CAPACITY = 6,     /* caller-provided output capacity too small (total is still reported) */
+    GBWT_HIP_UNSUPPORTED = 7   /* e.g. alphabet_size > 2^32 (u32 node ids on device) */
+} gbwt_hip_status;
+
+/* bwt::Pos, src/bwt.rs:63-69 */
+typedef struct { uint64_t node, offset; } gbwt_hip_pos;
+/* gbwt::SearchState, src/gbwt.rs:455-460 (range = start..end) */
+typedef struct { uint64_t node, start, end; } gbwt_hip_state;
+/* gbwt::BidirectionalState, src/gbwt.rs:485-490 */
+typedef struct { gbwt_hip_state forward, reverse; } gbwt_hip_bd_state;
+
+/* GBWT statistics: len/sequences/alphabet_size/alphabet_offset/is_bidirectional/has_metadata,
+ * src/gbwt.rs:108-182; records = BWT::len (src/bwt.rs:105-107). */
+typedef struct {
+    uint64_t size;            /* GBWT::len */
+    uint64_t sequences;       /* GBWT::sequences */
+    uint64_t alphabet_size;   /* GBWT::alphabet_size */
+    uint64_t alphabet_offset; /* GBWT::alphabet_offset */
+    uint64_t records;         /* BWT::len */
+    uint64_t data_bytes;      /* length of the record byte stream */
+    uint64_t paths;           /* metadata path names (0 if none) */
+    uint32_t bidirectional;   /* GBWT::is_bidirectional */
+    uint32_t has_metadata;    /* GBWT::has_metadata */
+    uint32_t is_gbz;          /* file was a GBZ container (graph + translation available) */
+    uint32_t has_translation; /* Graph::has_translation, src/graph.rs:158-160 */
+    uint64_t max_record_len;  /* largest Record::len over all records (device pass at open) */
+    uint64_t max_outdegree;   /* largest Record::outdegree */
+} gbwt_hip_stats;
+
+typedef struct gbwt_hip_index gbwt_hip_index;         /* opaque: host + device copies of one index */
+typedef struct gbwt_hip_workspace gbwt_hip_workspace; /* opaque: per-caller device scratch + stream */
+
+/* Message for the last failing call on this thread. */
+const char *gbwt_hip_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only box; never fails). */
+int gbwt_hip_device_count(void);
+
+/* ---- load --------------------------------------------------------------------------------------
+ * Replaces simple_sds::serialize::load_from::<GBWT | GBZ> (src/gbwt.rs:402-438, src/gbz.rs:674-717).
+ * Detects GBWT vs GBZ by the header tag, rejects what the reference rejects (src/headers.rs:101-115,
+ * 229-231; src/bwt.rs:179-181; src/gbz.rs:684-692) and uploads the record stream, the dense record
+ * start array (decoded from the Elias-Fano index) and the decompressed endmarker (src/gbwt.rs:413-414)
+ * to `device`. */
+gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index **out);
+
+/* Host-only parse + validation of a .gbwt/.gbz (no device needed): what load_from would accept. */
+gbwt_hip_status gbwt_hip_parse_file(const char *path, gbwt_hip_stats *out);
+
+/* Replaces constructing a GBWT from an in-memory BWT: the thin Rust shim passes the raw record stream
+ * it already owns -- base pointer from BWT::compressed_record(0) (src/bwt.rs:134-143), record starts
+ * recovered per record -- plus the header fields (src/gbwt.rs:108-174).  `starts` has n_records
+ * entries; record i spans [starts[i], starts[i+1]) and the last one ends at data_len
+ * (BWT::record_bytes, src/bwt.rs:116-121).  Inputs are borrowed only for the call. */
+gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts,
+                                      uint64_t n_records, uint64_t alphabet_offset, uint64_t alphabet_size,
+                                      uint64_t n_sequences, uint64_t size, int bidirectional, int device,
+                                      gbwt_hip_index **out);
+void gbwt_hip_close(gbwt_hip_index *index);
+gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *out);
+
+/* Workspaces own a HIP stream and reusable device scratch (path pool, CSR outputs). */
+gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_workspace **out);
+void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws);
+/* The hipStream_t the workspace launches on (for event timing by the caller). */
+void *gbwt_hip_workspace_stream(gbwt_hip_workspace *ws);
+
+/* ---- path extraction ---------------------------------------------------------------------------
+ * gbwt_hip_extract: GBWT::sequence(id).collect::<Vec<_>>() for every id (src/gbwt.rs:253-261,
+ * SequenceIter::next 557-568).  CSR output: out_offsets[n+1], nodes of sequence k at
+ * out_nodes[out_offsets[k] .. out_offsets[k+1]).  id >= sequences -> GBWT_HIP_BAD_ARGUMENT (the
+ * reference returns no iterator); an empty sequence gives a zero-length row.  `*total` always receives
+ * the number of nodes (= LF steps); with out_nodes == NULL it is a size query; if capacity < total the
+ * call returns GBWT_HIP_CAPACITY.  Host buffers. */
+gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *seq_ids,
+                                 uint64_t n, uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity,
+                                 uint64_t *total);
+
+/* Device-resident form: results stay in HBM inside the workspace (valid until the next call on it).
+ * d_offsets: uint64_t[n+1], d_nodes: uint32_t[total] (device pointers).  This is what bench.py times. */
+typedef struct { const uint64_t *d_offsets; const uint32_t *d_nodes; uint64_t total; uint64_t n; } gbwt_hip_paths;
+gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws,
+                                        const uint64_t *seq_ids, uint64_t n, gbwt_hip_paths *out);
+
+/* GBZ::path(path_id, orientation) (src/gbz.rs:461-466, PathIter 1053-1059): sequence id =
+ * 2*path_id + orientation (support::encode_path, src/support.rs:229-231); output nodes stay GBWT-encoded
+ * (node_id = v / 2, orientation = v & 1: support::decode_node, src/support.rs:180-182). */
+gbwt_hip_status gbwt_hip_extract_paths(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *path_ids,
+                                       uint64_t n, int reverse, uint64_t *out_offsets, uint32_t *out_nodes,
+                                       uint64_t capacity, uint64_t *total);
+
+/* ---- navigation --------------------------------------------------------------------------------
+ * GBWT::start (src/gbwt.rs:213-219) and GBWT::forward (222-229) for n independent inputs. */
+gbwt_hip_status gbwt_hip_start(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
+                               gbwt_hip_pos *out, uint8_t *valid);
+gbwt_hip_status gbwt_hip_forward(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
+                                 gbwt_hip_pos *out, uint8_t *valid);
+
+/* ---- search ------------------------------------------------------------------------------------
+ * GBWT::find (src/gbwt.rs:269-281), GBWT::extend (292-304). */
+gbwt_hip_status gbwt_hip_find(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
+                              gbwt_hip_state *out, uint8_t *valid);
+gbwt_hip_status gbwt_hip_extend(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const gbwt_hip_state *states,
+                                const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid);
+/* GBWT::bd_find (311-324), extend_forward (339-347), extend_backward (362-367).  The reference asserts a
+ * bidirectional index; here a unidirectional one returns GBWT_HIP_BAD_ARGUMENT. */
+gbwt_hip_status gbwt_hip_bd_find(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
+                                 gbwt_hip_bd_state *out, uint8_t *valid);
+gbwt_hip_status gbwt_hip_extend_forward(const gbwt_hip_index *index, gbwt_hip_workspace *ws,
+                                        const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
+                                        gbwt_hip_bd_state *out, uint8_t *valid);
+gbwt_hip_status gbwt_hip_extend_backward(const gbwt_hip_index *index, gbwt_hip_workspace *ws,
+                                         const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
+                                         gbwt_hip_bd_state *out, uint8_t *valid);
+/* Whole query in one launch, the shape of src/bin/benchmark.rs:155-169: for query q (row q of the
+ * n x len matrix `queries`), find(q[0]) then extend by q[1..]; out/valid describe the final state
+ * (valid = 0 as soon as any step returns None). */
+gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *queries,
+                                uint64_t n, uint64_t len, gbwt_hip_state *out, uint8_t *valid);
+
+/* ---- checking hooks for device-resident results -------------------------------------------------
+ * Per-path sums of the node ids of the last gbwt_hip_extract_device call on `ws` (a wave-per-path
+ * reduction on the device), copied to out_sums[n]: a cheap full-size checksum of the extraction. */
+gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *index, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n);
+/* Copies row k of the last device-resident extraction to host: out_nodes[min(len, capacity)], *len = row length. */
+gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *index, gbwt_hip_workspace *ws, uint64_t k, uint32_t *out_nodes,
+                                   uint64_t capacity, uint64_t *len);
+
+/* ---- measurement hooks -------------------------------------------------------------------------
+ * Name and average duration (ms, from HIP events on the workspace stream) of the dominant kernel of
+ * the last gbwt_hip_extract_device call, for bench.py's roofline object. */
+gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -66,6 +66,7 @@ class Builder(C.Structure):
 
 
 _lib = None
+LIB_OVERRIDE = None  # bench.py's cpu_baseline leg points this at the -march=native build before first use
 
 
 def build(target="all"):
@@ -76,7 +77,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(ORACLE_DIR, "liboracle.so")
+    path = LIB_OVERRIDE or os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

@@ -1,0 +1,375 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's known answers.
+
+Bit-exact for everything (integer/index work).  Mirrors the reference's own tests:
+src/bwt/tests.rs:159-237 (lf / follow over every offset and range), src/gbwt/tests.rs:164-462
+(extract, sequence, find, extend, bidirectional search), src/gbz/tests.rs:85-98,371-381 (GBZ::path).
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import gbwt_rs_amd as G
+import kat
+import oracle_lib as O
+from gbwt_rs_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = O.GOLDEN
+
+
+def states(rows):
+    return np.array(rows, dtype=G.STATE_DTYPE)
+
+
+def bd_states(rows):
+    return np.array(rows, dtype=G.BD_DTYPE)
+
+
+def bd_tuple(x):
+    return (tuple(int(v) for v in x["forward"]), tuple(int(v) for v in x["reverse"]))
+
+
+def open_synth(s):
+    return G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, s.bidirectional)
+
+
+def oracle_of(s):
+    bwt = O.OracleBWT.from_parts(bytes(s.data()), s.starts())
+    return O.OracleGBWT.from_bwt(bwt, s.sequences, s.size, s.alphabet_offset, s.alphabet_size, s.bidirectional)
+
+
+def check_all_positions(dev, oracle):
+    """start + forward for every position of every record, find/extend/bd for every state the oracle can reach."""
+    n_seq = oracle.sequences()
+    pos, ok = dev.start(np.arange(n_seq + 2))
+    for i in range(n_seq + 2):
+        exp = oracle.start(i)
+        assert bool(ok[i]) == (exp is not None)
+        if exp is not None:
+            assert tuple(int(v) for v in pos[i]) == exp
+    # every (node, offset) incl. one past the end of each record and nodes outside the alphabet
+    queries = []
+    for node in range(0, oracle.alphabet_size() + 2):
+        st = oracle.find(node)
+        ln = (st[2] - st[1]) if st else 0
+        for off in range(ln + 2):
+            queries.append((node, off))
+    out, ok = dev.forward(np.array(queries, dtype=G.POS_DTYPE))
+    for q, r, v in zip(queries, out, ok):
+        exp = oracle.forward(q)
+        assert bool(v) == (exp is not None), q
+        if exp is not None:
+            assert tuple(int(x) for x in r) == exp, q
+
+
+def check_search(dev, oracle, nodes_of_interest):
+    nodes = np.arange(0, oracle.alphabet_size() + 2, dtype=np.uint64)
+    st, ok = dev.find(nodes)
+    for node, s, v in zip(nodes, st, ok):
+        exp = oracle.find(int(node))
+        assert bool(v) == (exp is not None)
+        if exp:
+            assert tuple(int(x) for x in s) == exp
+    # extend: every sub-range of every record x every destination
+    q_states, q_nodes = [], []
+    for node in nodes_of_interest:
+        f = oracle.find(node)
+        if f is None:
+            continue
+        ln = f[2]
+        ranges = [(a, b) for a in range(ln + 1) for b in range(a, ln + 2)] if ln <= 6 else \
+                 [(0, ln), (0, 1), (ln - 1, ln), (1, ln - 1), (ln // 2, ln // 2), (ln, ln + 3)]
+        for (a, b) in ranges:
+            for dest in range(0, oracle.alphabet_size() + 2):
+                q_states.append((node, a, b))
+                q_nodes.append(dest)
+    out, ok = dev.extend(states(q_states), q_nodes)
+    for s, d, r, v in zip(q_states, q_nodes, out, ok):
+        exp = oracle.extend(s, d)
+        assert bool(v) == (exp is not None), (s, d)
+        if exp:
+            assert tuple(int(x) for x in r) == exp, (s, d)
+    if not oracle.is_bidirectional():
+        return
+    bst, ok = dev.bd_find(nodes)
+    for node, s, v in zip(nodes, bst, ok):
+        exp = oracle.bd_find(int(node))
+        assert bool(v) == (exp is not None)
+        if exp:
+            assert bd_tuple(s) == exp
+    # bidirectional extension: forward range from the extend cases, arbitrary reverse range of the same length
+    q_bd = []
+    for (node, a, b) in q_states[::2]:
+        for rev_start in (0, 2):
+            q_bd.append(((node, a, b), (node ^ 1, rev_start, rev_start + max(0, b - a))))
+    dests = list(range(0, oracle.alphabet_size() + 2))
+    rng = random.Random(7)
+    q_nodes = [rng.choice(dests) for _ in q_bd]
+    for fn, ofn in ((dev.extend_forward, oracle.extend_forward), (dev.extend_backward, oracle.extend_backward)):
+        out, ok = fn(bd_states(q_bd), q_nodes)
+        for s, d, r, v in zip(q_bd, q_nodes, out, ok):
+            exp = ofn(s, d)
+            assert bool(v) == (exp is not None), (s, d)
+            if exp:
+                assert bd_tuple(r) == exp, (s, d)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference fixtures
+
+
+@pytest.mark.parametrize("name,with_empty", [("example.gbwt", False), ("with-empty.gbwt", True)])
+def test_fixture_extract(name, with_empty):
+    """src/gbwt/tests.rs:164-189, 216-238: all sequences vs the known paths, both orientations."""
+    dev = G.GBWT.load(os.path.join(GOLDEN, name))
+    truth = kat.true_paths(with_empty)
+    assert dev.sequences() == 2 * len(truth)
+    offsets, nodes = dev.sequences_csr(np.arange(dev.sequences()))
+    assert int(offsets[-1]) == dev.len() - dev.sequences()
+    for i, t in enumerate(truth):
+        assert list(nodes[offsets[2 * i]:offsets[2 * i + 1]]) == t
+        assert list(nodes[offsets[2 * i + 1]:offsets[2 * i + 2]]) == kat.reverse_path(t)
+        assert dev.sequence(2 * i) == t
+    assert dev.sequence(dev.sequences()) is None
+    with pytest.raises(G.GbwtHipError):
+        dev.sequences_csr([dev.sequences()])
+    if with_empty:
+        assert dev.sequence(8) == [] and dev.sequence(9) == []
+
+
+def test_fixture_statistics():
+    dev = G.GBWT.load(os.path.join(GOLDEN, "example.gbwt"))
+    assert (dev.len(), dev.sequences(), dev.alphabet_size(), dev.alphabet_offset()) == (68, 12, 52, 21)
+    assert dev.is_bidirectional() and dev.first_node() == 22 and dev.has_metadata()
+    assert dev.stats.max_record_len == 12 and dev.stats.max_outdegree == 4
+
+
+@pytest.mark.parametrize("name", ["example.gbwt", "with-empty.gbwt"])
+def test_fixture_navigation_and_search(name):
+    path = os.path.join(GOLDEN, name)
+    dev, oracle = G.GBWT.load(path), O.OracleGBWT.load(path)
+    check_all_positions(dev, oracle)
+    check_search(dev, oracle, sorted(kat.true_nodes()))
+
+
+def test_fixture_search_known_answers():
+    """doc-test src/gbwt.rs:70-83 and the brute-force counts of src/gbwt/tests.rs:294-350 / 393-462."""
+    dev = G.GBWT.load(os.path.join(GOLDEN, "example.gbwt"))
+    st, ok = dev.search([[24, 28, 30]])
+    assert ok[0] and int(st[0]["node"]) == 30 and int(st[0]["end"] - st[0]["start"]) == 2
+    bd, ok = dev.bd_find([28])
+    bd, ok = dev.extend_backward(bd, [24])
+    bd, ok = dev.extend_forward(bd, [30])
+    assert ok[0] and bd_tuple(bd[0]) == ((30, 0, 2), (25, 0, 2))
+    paths = kat.true_paths(False)
+    queries, expected = [], []
+    for p in paths:
+        for p2 in (p, kat.reverse_path(p)):
+            for j in range(len(p2)):
+                for k in range(j + 1, len(p2) + 1):
+                    queries.append(p2[j:k])
+                    expected.append(kat.count_occurrences(paths, p2[j:k]))
+    for ln in sorted({len(q) for q in queries}):
+        qs = [q for q in queries if len(q) == ln]
+        ex = [e for q, e in zip(queries, expected) if len(q) == ln]
+        st, ok = dev.search(qs)
+        assert ok.all()
+        assert [int(s["end"] - s["start"]) for s in st] == ex
+    st, ok = dev.search([[24, 30], [0, 22], [22, 0], [60, 22]])
+    assert not ok.any()
+
+
+@pytest.mark.parametrize("name", ["example.gbz", "example-v1.gbz", "translation.gbz", "translation-v1.gbz"])
+def test_fixture_gbz_paths(name):
+    """src/gbz/tests.rs:85-98, 279-292, 371-381: GBZ::path in both orientations."""
+    path = os.path.join(GOLDEN, name)
+    dev, oracle = G.GBZ.load(path), O.OracleGBZ(path)
+    truth = kat.true_paths(False) if name.startswith("example") else [[2 * x for x in p] for p in kat.TRANSLATION_PATHS]
+    assert dev.paths() == len(truth) == oracle.paths()
+    for i, t in enumerate(truth):
+        assert dev.path(i) == [(x // 2, x & 1) for x in t] == oracle.path(i)
+        assert dev.path(i, G.REVERSE) == [(x // 2, x & 1) for x in kat.reverse_path(t)]
+    assert dev.path(dev.paths()) is None
+    offsets, nodes = dev.paths_csr(np.arange(dev.paths()))
+    o_off, o_nodes = oracle.gbwt().extract(np.arange(0, 2 * dev.paths(), 2))
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+
+
+def test_unidirectional_index_rejects_bd_calls():
+    """Where the reference asserts (src/gbwt.rs:312,340), the C ABI returns an error status."""
+    bwt = O.OracleBWT(kat.PAPER_EDGES, kat.PAPER_RUNS)
+    dev = G.GBWT.from_records(bwt.data(), bwt.starts(), 0, 8, 3, 17, bidirectional=False)
+    with pytest.raises(G.GbwtHipError):
+        dev.bd_find([1])
+    st, ok = dev.find([1, 2, 7, 8, 0])
+    assert list(ok) == [True, True, True, False, False]
+
+
+# ---------------------------------------------------------------------------------------------
+# paper examples through gbwt_hip_open_records (src/bwt/tests.rs:10-87)
+
+
+@pytest.mark.parametrize("edges,runs,n_seq,bidirectional", [(kat.PAPER_EDGES, kat.PAPER_RUNS, 3, False),
+                                                            (kat.BD_EDGES, kat.BD_RUNS, 6, True)])
+def test_paper_examples(edges, runs, n_seq, bidirectional):
+    bwt = O.OracleBWT(edges, runs)
+    size = sum(l for r in runs for _, l in r)
+    data, starts = bwt.data(), bwt.starts()
+    # unidirectional example: node v <-> record v; bidirectional: GBWT nodes 2..15 <-> records 1..14 (offset 1)
+    offset = 1 if bidirectional else 0
+    alphabet = len(edges) + offset
+    dev = G.GBWT.from_records(data, starts, offset, alphabet, n_seq, size, bidirectional=bidirectional)
+    oracle = O.OracleGBWT.from_bwt(O.OracleBWT.from_parts(data, starts), n_seq, size, offset, alphabet, bidirectional)
+    check_all_positions(dev, oracle)
+    check_search(dev, oracle, list(range(offset + 1, alphabet)))
+    offsets, nodes = dev.sequences_csr(np.arange(n_seq))
+    o_off, o_nodes = oracle.extract(np.arange(n_seq))
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+
+
+def test_empty_records():
+    """src/bwt/tests.rs:314-329: records 2 and 6 are the single byte 0x00."""
+    edges = [list(e) for e in kat.PAPER_EDGES]
+    runs = [list(r) for r in kat.PAPER_RUNS]
+    for k in (2, 6):
+        edges[k], runs[k] = [], []
+    bwt = O.OracleBWT(edges, runs)
+    dev = G.GBWT.from_records(bwt.data(), bwt.starts(), 0, 8, 3, 17, bidirectional=False)
+    oracle = O.OracleGBWT.from_bwt(O.OracleBWT.from_parts(bwt.data(), bwt.starts()), 3, 17, 0, 8, False)
+    check_all_positions(dev, oracle)
+    st, ok = dev.find([2, 6])
+    assert not ok.any()
+
+
+# ---------------------------------------------------------------------------------------------
+# generated indexes
+
+
+@pytest.mark.parametrize("seed,cyclic", [(11, False), (12, True), (13, True)])
+def test_random_path_sets(seed, cyclic):
+    rng = random.Random(seed)
+    paths = []
+    for _ in range(40):
+        ln = rng.randint(0, 30)
+        if cyclic:
+            paths.append([2 * rng.randint(1, 12) + rng.randint(0, 1) for _ in range(ln)])
+        else:
+            paths.append([2 * i for i in sorted(rng.sample(range(1, 41), ln))])
+    paths[0] = [2, 4, 6]
+    s = S.Synth.from_paths(paths, bidirectional=True)
+    dev, oracle = open_synth(s), oracle_of(s)
+    ids = list(range(s.sequences)) + [3, 3, 0]   # duplicates are allowed
+    offsets, nodes = dev.sequences_csr(ids)
+    for k, i in enumerate(ids):
+        exp = paths[i // 2] if i % 2 == 0 else kat.reverse_path(paths[i // 2])
+        assert list(nodes[offsets[k]:offsets[k + 1]]) == exp
+    check_all_positions(dev, oracle)
+    nodes_used = sorted({x for p in paths for x in p} | {x ^ 1 for p in paths for x in p})
+    check_search(dev, oracle, nodes_used[:24])
+
+
+@pytest.mark.parametrize("alleles,model,zipf", [(2, S.MOSAIC, 1.2), (2, S.IID, 1.2), (7, S.IID, 1.0), (300, S.IID, 0.2), (400, S.IID, 0.0)])
+def test_chain_indexes(alleles, model, zipf):
+    """Bubble / star chains incl. the sigma >= 255 two-varint regime and runs longer than one byte can hold."""
+    s = S.Synth.chain(sites=40, haplotypes=1500 if alleles > 100 else 700, alleles=alleles, model=model, founders=6,
+                      switch_rate=0.05, zipf=zipf, seed=alleles)
+    dev, oracle = open_synth(s), oracle_of(s)
+    if alleles >= 300:
+        assert dev.stats.max_outdegree >= 255
+    ids = np.arange(s.sequences, dtype=np.uint64)
+    offsets, nodes = dev.sequences_csr(ids)
+    o_off, o_nodes = oracle.extract(ids, threads=4)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    for h in (0, 1, s.paths - 1):
+        assert np.array_equal(nodes[offsets[2 * h]:offsets[2 * h + 1]], s.path(h))
+    # random positions / searches against the oracle
+    rng = random.Random(alleles)
+    first = s.alphabet_offset + 1
+    qs = []
+    for _ in range(300):
+        node = rng.randrange(first, s.alphabet_size)
+        f = oracle.find(node)
+        qs.append((node, rng.randrange(0, (f[2] if f else 1) + 1)))
+    out, ok = dev.forward(np.array(qs, dtype=G.POS_DTYPE))
+    for q, r, v in zip(qs, out, ok):
+        exp = oracle.forward(q)
+        assert bool(v) == (exp is not None) and (exp is None or tuple(int(x) for x in r) == exp)
+    # queries of length 6 cut out of true paths (all must be found) + corrupted ones
+    queries = []
+    for _ in range(200):
+        p = s.path(rng.randrange(s.paths))
+        a = rng.randrange(0, len(p) - 6)
+        q = [int(x) for x in p[a:a + 6]]
+        if rng.random() < 0.3:
+            q[rng.randrange(6)] ^= 2
+        if rng.random() < 0.3:
+            q = kat.reverse_path(q)
+        queries.append(q)
+    st, ok = dev.search(queries)
+    for q, r, v in zip(queries, st, ok):
+        exp = oracle.find(q[0])
+        for x in q[1:]:
+            exp = oracle.extend(exp, x) if exp else None
+        assert bool(v) == (exp is not None), q
+        if exp:
+            assert tuple(int(x) for x in r) == exp
+    # bidirectional walk: bd_find(q[2]) -> forward over q[3:], backward over q[1], q[0]
+    mid, ok = dev.bd_find([q[2] for q in queries])
+    exp = [oracle.bd_find(q[2]) for q in queries]
+    cur, cur_ok = mid, ok
+    for step, (fn, ofn, col) in enumerate([(dev.extend_forward, oracle.extend_forward, 3), (dev.extend_forward, oracle.extend_forward, 4),
+                                           (dev.extend_backward, oracle.extend_backward, 1), (dev.extend_backward, oracle.extend_backward, 0)]):
+        nodes_col = [q[col] for q in queries]
+        nxt, nxt_ok = fn(cur, nodes_col)
+        for k in range(len(queries)):
+            e = ofn(exp[k], nodes_col[k]) if (exp[k] is not None) else None
+            if exp[k] is not None:
+                assert bool(nxt_ok[k]) == (e is not None), (queries[k], step)
+                if e:
+                    assert bd_tuple(nxt[k]) == e
+            exp[k] = e
+            if e is None:
+                nxt[k] = bd_states([((0, 0, 0), (0, 0, 0))])[0]
+        cur, cur_ok = nxt, nxt_ok
+
+
+def test_config_c2_bit_exact(tmp_path):
+    """BASELINE config 2: synthetic 1k paths x 10k nodes (3,333 sites, seed 42), both models, via a .gbz file."""
+    for model in (S.MOSAIC, S.IID):
+        s = S.Synth.chain(sites=3333, haplotypes=1000, alleles=2, model=model, founders=32, switch_rate=2e-3, seed=42)
+        path = tmp_path / f"c2-{model}.gbz"
+        s.save(str(path), as_gbz=True)
+        dev = G.GBZ.load(str(path))
+        oracle = O.OracleGBZ(str(path)).gbwt()
+        ids = np.arange(0, 2000, 2, dtype=np.uint64)       # forward sequences = what gbunzip extracts
+        offsets, nodes = dev.sequences_csr(ids)
+        o_off, o_nodes = oracle.extract(ids, threads=8)
+        assert int(offsets[-1]) == 1000 * 6666
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+        ids = np.arange(1, 2000, 2, dtype=np.uint64)       # reverse sequences
+        offsets, nodes = dev.sequences_csr(ids)
+        o_off, o_nodes = oracle.extract(ids, threads=8)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+
+
+def test_headline_scale_properties():
+    """Size-independent checks at a large size (paths x sites well beyond what the oracle finishes quickly):
+    every extracted path equals the generator's ground truth, lengths are uniform, the total equals
+    (size - sequences) / 2, and reverse extraction is the flipped reversal of forward extraction."""
+    s = S.Synth.chain(sites=40000, haplotypes=2048, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=7)
+    dev = open_synth(s)
+    ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
+    offsets, nodes = dev.sequences_csr(ids)
+    assert int(offsets[-1]) == (s.size - s.sequences) // 2
+    assert np.all(np.diff(offsets) == 2 * s.sites)
+    sums = np.add.reduceat(nodes.astype(np.uint64), offsets[:-1].astype(np.int64))
+    for h in range(s.paths):
+        assert int(sums[h]) == s.path_checksum(h)
+    for h in (0, 1, 777, 2047):
+        assert np.array_equal(nodes[offsets[h]:offsets[h + 1]], s.path(h))
+    r_off, r_nodes = dev.sequences_csr([2 * 777 + 1, 1])
+    assert np.array_equal(r_nodes[r_off[0]:r_off[1]], (s.path(777) ^ 1)[::-1])
+    assert np.array_equal(r_nodes[r_off[1]:r_off[2]], (s.path(0) ^ 1)[::-1])
