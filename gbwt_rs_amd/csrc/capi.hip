@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -73,6 +74,7 @@ struct gbwt_hip_workspace {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
+    uint32_t walk_mode = WALK_COOP, paths_per_wave = 64, small_record = 16;
     DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
     ~gbwt_hip_workspace() {
@@ -275,11 +277,21 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
     } catch (const HipError &e) {
         delete ws; return status_of(e);
     }
+    // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
+    if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) ws->walk_mode = std::atoi(v) == 1 ? WALK_LANE_SERIAL : WALK_COOP;
+    if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 1 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
+    if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
     *out = ws;
     return GBWT_HIP_OK;
 }
 
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws) { delete ws; }
+
+gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record) {
+    if (!ws || walk_mode > WALK_LANE_SERIAL || paths_per_wave < 1 || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
+    ws->walk_mode = walk_mode; ws->paths_per_wave = paths_per_wave; ws->small_record = small_record;
+    return GBWT_HIP_OK;
+}
 
 void *gbwt_hip_workspace_stream(gbwt_hip_workspace *ws) { return ws ? static_cast<void *>(ws->stream) : nullptr; }
 
@@ -314,6 +326,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.pool = ws->pool.as<uint32_t>(); a.next = ws->next.as<uint32_t>(); a.pool_blocks = static_cast<uint32_t>(pool_blocks);
             a.counter = ws->counters.as<uint32_t>(); a.flags = ws->counters.as<uint32_t>() + 1;
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
+            a.mode = ws->walk_mode; a.paths_per_wave = ws->paths_per_wave; a.small_record = ws->small_record;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);

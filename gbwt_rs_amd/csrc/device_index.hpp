@@ -13,7 +13,7 @@
 
 namespace gbwt_hip {
 
-constexpr uint32_t DATA_PAD = 64;
+constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start
 
 struct DeviceIndex {
     const uint8_t *data;

@@ -4,6 +4,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include "coop_device.hpp"
 #include "lf_device.hpp"
 
 namespace gbwt_hip {
@@ -108,6 +109,90 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
     }
     a.head[k] = head;
     a.lengths[k] = len;
+}
+
+// Appends `node` to the lane's block chain (shared by both walk kernels).  Returns false on pool overflow.
+struct PathSink {
+    uint32_t cur = POOL_NONE, fill = POOL_BLOCK_NODES, head = POOL_NONE;
+    uint64_t len = 0;
+    __device__ __forceinline__ bool push(const WalkArgs &a, uint32_t node) {
+        if (fill == POOL_BLOCK_NODES) {
+            uint32_t nb = atomicAdd(a.counter, 1u);
+            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); return false; }
+            a.next[nb] = POOL_NONE;
+            if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
+            cur = nb; fill = 0;
+        }
+        a.pool[static_cast<uint64_t>(cur) * POOL_BLOCK_NODES + fill] = node;
+        fill++; len++;
+        return true;
+    }
+};
+
+// Wave-cooperative walk: lanes 0..P-1 of each wave own one sequence each.  Per step every owner
+// looks up its record; short records are decoded by their own lane (lf_device.hpp), long ones are
+// handled one distinct record at a time by the whole wave (coop_device.hpp), so sequences that sit in
+// the same record -- the common case for the high-coverage records of a pangenome -- share one decode.
+__global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
+    const bool owner = lane < a.paths_per_wave && k < a.n;
+    uint32_t node = 0, offset = 0;
+    bool active = false;
+    if (owner) {
+        const uint64_t id = a.seq_ids[k];
+        if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+            uint2 e = ix.endmarker[id];
+            node = e.x; offset = e.y;
+            active = node != 0;
+        }
+    }
+    PathSink sink;
+    while (__ballot(active) != 0) {
+        // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
+        if (active && !sink.push(a, node)) active = false;
+        // GBWT::forward guards + BWT::record_bytes (src/gbwt.rs:222-229, src/bwt.rs:116-130)
+        uint64_t start = 0, limit = 0;
+        bool has_record = false;
+        if (active && node >= ix.first_node) {
+            const uint64_t rec = node - ix.alphabet_offset;
+            if (rec < ix.n_records) { record_bounds(ix, rec, start, limit); has_record = limit > start; }
+        }
+        bool ok = false;
+        uint32_t next_node = 0, next_offset = 0;
+        const bool big = has_record && (limit - start) > a.small_record;
+        if (has_record && !big) {
+            ByteCursor c(ix.data, start, limit);
+            uint64_t sigma, nn, no;
+            if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
+                ok = true; next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
+            }
+        }
+        uint64_t todo = __ballot(big);
+        while (todo != 0) {
+            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(todo));
+            const uint64_t gs = read_lane64(start, leader), ge = read_lane64(limit, leader);
+            const bool member = big && start == gs;
+            const int status = coop_record_lf(ix, gs, ge, member, offset, ok, next_node, next_offset);
+            if (status != COOP_DONE && member) {
+                ByteCursor c(ix.data, start, limit);
+                uint64_t sigma, nn, no;
+                ok = false;
+                if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
+                    ok = true; next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
+                }
+            }
+            todo &= ~__ballot(member);
+        }
+        if (active) {
+            active = ok;
+            node = next_node; offset = next_offset;
+        }
+    }
+    if (owner) {
+        a.head[k] = sink.head;
+        a.lengths[k] = sink.len;
+    }
 }
 
 // One wave per path: follow the block chain and copy it to its CSR row.
@@ -279,7 +364,12 @@ void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n
 
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream) {
     if (args.n == 0) return;
-    hipLaunchKernelGGL(k_walk, dim3(grid_for(args.n, WAVE)), dim3(WAVE), 0, stream, ix, args);
+    if (args.mode == WALK_LANE_SERIAL) {
+        hipLaunchKernelGGL(k_walk, dim3(grid_for(args.n, WAVE)), dim3(WAVE), 0, stream, ix, args);
+        return;
+    }
+    const unsigned p = args.paths_per_wave ? args.paths_per_wave : WAVE;
+    hipLaunchKernelGGL(k_walk_coop, dim3(grid_for(args.n, p)), dim3(WAVE), 0, stream, ix, args);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

@@ -35,7 +35,12 @@ struct WalkArgs {
     uint32_t *head;            // [n] first block of each path
     uint64_t *lengths;         // [n]
     uint32_t *flags;           // [1]
+    // tuning (gbwt_hip_workspace_tune)
+    uint32_t mode;             // WALK_COOP or WALK_LANE_SERIAL
+    uint32_t paths_per_wave;   // WALK_COOP: lanes of a wave that own a path (1..64); all 64 lanes decode
+    uint32_t small_record;     // WALK_COOP: records of at most this many bytes are decoded lane-serially
 };
+constexpr uint32_t WALK_COOP = 0, WALK_LANE_SERIAL = 1;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 
