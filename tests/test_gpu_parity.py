@@ -373,3 +373,62 @@ def test_headline_scale_properties():
     r_off, r_nodes = dev.sequences_csr([2 * 777 + 1, 1])
     assert np.array_equal(r_nodes[r_off[0]:r_off[1]], (s.path(777) ^ 1)[::-1])
     assert np.array_equal(r_nodes[r_off[1]:r_off[2]], (s.path(0) ^ 1)[::-1])
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel variants: results never depend on the tuning
+
+TUNINGS = [dict(walk_mode=0, paths_per_wave=64, small_record=16),   # default: cooperative for long records
+           dict(walk_mode=0, paths_per_wave=64, small_record=0),    # every record through the cooperative path
+           dict(walk_mode=0, paths_per_wave=5, small_record=0),     # few owners per wave
+           dict(walk_mode=0, paths_per_wave=17, small_record=40),
+           dict(walk_mode=1, paths_per_wave=64, small_record=16)]   # lane-serial kernel
+
+
+def variant_cases():
+    yield "fixture", None
+    yield "mosaic-long-runs", dict(sites=60, haplotypes=3000, alleles=2, model=S.MOSAIC, founders=2, switch_rate=0.01, seed=3)
+    yield "iid-many-runs", dict(sites=30, haplotypes=3000, alleles=2, model=S.IID, seed=4)
+    yield "single-allele-sites", dict(sites=50, haplotypes=700, alleles=2, model=S.MOSAIC, founders=1, switch_rate=0.0, seed=5)
+    yield "multi-allelic", dict(sites=40, haplotypes=900, alleles=4, model=S.IID, zipf=0.5, seed=6)
+
+
+@pytest.mark.parametrize("name,params", list(variant_cases()))
+def test_walk_variants_agree_with_oracle(name, params):
+    if params is None:
+        path = os.path.join(GOLDEN, "with-empty.gbwt")
+        dev, oracle = G.GBWT.load(path), O.OracleGBWT.load(path)
+        n_seq = oracle.sequences()
+    else:
+        s = S.Synth.chain(**params)
+        dev, oracle = open_synth(s), oracle_of(s)
+        n_seq = s.sequences
+    ids = np.arange(n_seq, dtype=np.uint64)
+    o_off, o_nodes = oracle.extract(ids, threads=8)
+    for t in TUNINGS:
+        dev.tune(**t)
+        offsets, nodes = dev.sequences_csr(ids)
+        assert np.array_equal(offsets, o_off), (name, t)
+        assert np.array_equal(nodes, o_nodes), (name, t)
+    # ragged batch: a few sequences, repeated ids, odd count
+    rng = random.Random(1)
+    some = [rng.randrange(n_seq) for _ in range(37)]
+    o_off, o_nodes = oracle.extract(some)
+    for t in TUNINGS:
+        dev.tune(**t)
+        offsets, nodes = dev.sequences_csr(some)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes), (name, t)
+
+
+def test_random_paths_all_variants():
+    rng = random.Random(99)
+    paths = [[2 * rng.randint(1, 6) + rng.randint(0, 1) for _ in range(rng.randint(0, 300))] for _ in range(150)]
+    s = S.Synth.from_paths(paths, bidirectional=True)
+    dev = open_synth(s)
+    ids = np.arange(s.sequences, dtype=np.uint64)
+    for t in TUNINGS:
+        dev.tune(**t)
+        offsets, nodes = dev.sequences_csr(ids)
+        for i, p in enumerate(paths):
+            assert list(nodes[offsets[2 * i]:offsets[2 * i + 1]]) == p, t
+            assert list(nodes[offsets[2 * i + 1]:offsets[2 * i + 2]]) == kat.reverse_path(p), t
