@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -63,7 +64,7 @@ gbwt_hip_status status_of(const HipError &e) {
 struct gbwt_hip_index {
     HostIndex host;
     int device = 0;
-    DeviceBuffer data, starts, endmarker;
+    DeviceBuffer data, starts, endmarker, desc;
     DeviceIndex dev{};
     gbwt_hip_stats stats{};
 };
@@ -75,6 +76,8 @@ struct gbwt_hip_workspace {
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
     uint32_t walk_mode = WALK_COOP, paths_per_wave = 64, small_record = 16;
+    bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
+    DeviceBuffer prof;
     DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
     ~gbwt_hip_workspace() {
@@ -122,7 +125,10 @@ void upload(gbwt_hip_index &ix) {
         d.starts64 = ix.starts.as<uint64_t>();
     }
 
-    // Load-time device passes: record statistics, then the endmarker (src/gbwt.rs:413-414).
+    // Load-time device passes: per-record descriptors, record statistics, then the endmarker (src/gbwt.rs:413-414).
+    ix.desc.reserve(std::max<uint64_t>(n_records, 1) * sizeof(uint4));
+    launch_build_desc(d, ix.desc.as<uint4>(), nullptr);
+    d.desc = ix.desc.as<uint4>();
     DeviceBuffer tmp;
     tmp.reserve(8 * sizeof(uint64_t));
     HIP_CHECK(hipMemset(tmp.ptr, 0, 8 * sizeof(uint64_t)));
@@ -278,6 +284,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
         delete ws; return status_of(e);
     }
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
+    if (const char *v = std::getenv("GBWT_HIP_PROFILE")) ws->profile = std::atoi(v) != 0;
     if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) ws->walk_mode = std::atoi(v) == 1 ? WALK_LANE_SERIAL : WALK_COOP;
     if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 1 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
     if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
@@ -327,6 +334,12 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.counter = ws->counters.as<uint32_t>(); a.flags = ws->counters.as<uint32_t>() + 1;
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
             a.mode = ws->walk_mode; a.paths_per_wave = ws->paths_per_wave; a.small_record = ws->small_record;
+            a.prof = nullptr;
+            if (ws->profile) {
+                ws->prof.reserve(16 * sizeof(uint64_t));
+                HIP_CHECK(hipMemsetAsync(ws->prof.ptr, 0, 16 * sizeof(uint64_t), s));
+                a.prof = ws->prof.as<uint64_t>();
+            }
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);
@@ -339,6 +352,13 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             pool_blocks *= 2;  // duplicate ids can exceed the distinct-id bound: grow and walk again
         }
         if (flags & FLAG_POOL_OVERFLOW) return fail(GBWT_HIP_DEVICE_ERROR, "path pool overflow");
+        if (ws->profile && a.prof) {
+            uint64_t c[6];
+            HIP_CHECK(hipMemcpy(c, a.prof, sizeof(c), hipMemcpyDeviceToHost));
+            double st = c[0] ? static_cast<double>(c[0]) : 1.0;
+            fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu groups %llu | cycles/step (s_memtime): push %.0f bounds %.0f small %.0f coop %.0f\n",
+                    (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st);
+        }
         uint64_t total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));

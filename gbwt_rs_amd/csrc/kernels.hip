@@ -32,6 +32,32 @@ __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *
     atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
 }
 
+// One lane per record: the 16-byte descriptor the walk kernels read instead of starts[] (device_index.hpp).
+__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    uint64_t start, limit;
+    record_bounds(ix, rec, start, limit);
+    uint4 d = make_uint4(0, 0, 0, 0);
+    if (limit > start) {
+        ByteCursor c(ix.data, start, limit);
+        uint64_t sigma = 0;
+        if (c.varint(sigma) && sigma != 0) {
+            d.x = static_cast<uint32_t>(start); d.y = static_cast<uint32_t>(limit - start);
+            d.z = static_cast<uint32_t>(start >> 32); d.w = sigma > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(sigma);
+            if (sigma == 1) {
+                uint64_t node, off, value, len;
+                RunDecoder rd(1);
+                if (c.varint(node) && c.varint(off) && rd.next(c, value, len) && c.at_end() && len < 0xFFFFFFFFull) {
+                    d.x = static_cast<uint32_t>(len); d.y = DESC_UNARY;
+                    d.z = static_cast<uint32_t>(node); d.w = static_cast<uint32_t>(off);
+                }
+            }
+        }
+    }
+    desc[rec] = d;
+}
+
 // Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
 __global__ void k_endmarker_sigma(DeviceIndex ix, uint64_t *result) {
     result[0] = 0; result[1] = 0;
@@ -80,6 +106,28 @@ __global__ void k_endmarker_decompress(DeviceIndex ix, uint2 *out, uint64_t n_ou
 // to a chain of 1 KiB blocks drawn from a shared pool; a second, bandwidth-bound kernel lays the
 // chains out as CSR once the lengths (and their prefix sums) exist.
 
+// Appends `node` to the lane's block chain (shared by both walk kernels).  Returns false on pool overflow.
+struct PathSink {
+    uint32_t *wp = nullptr;      // next slot in the current block
+    uint32_t left = 0;           // free slots in the current block
+    uint32_t cur = POOL_NONE, head = POOL_NONE, blocks = 0;
+    __device__ __forceinline__ bool push(const WalkArgs &a, uint32_t node) {
+        if (left == 0) {
+            uint32_t nb = atomicAdd(a.counter, 1u);
+            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); return false; }
+            a.next[nb] = POOL_NONE;
+            if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
+            cur = nb; blocks++;
+            wp = a.pool + static_cast<uint64_t>(nb) * POOL_BLOCK_NODES;
+            left = POOL_BLOCK_NODES;
+        }
+        *wp++ = node;
+        left--;
+        return true;
+    }
+    __device__ __forceinline__ uint64_t length() const { return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left; }
+};
+
 __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
     uint64_t k = blockIdx.x * static_cast<uint64_t>(WAVE) + threadIdx.x;
     if (k >= a.n) return;
@@ -91,49 +139,26 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
         node = e.x; offset = e.y;
         valid = node != 0;
     }
-    uint32_t cur = POOL_NONE, fill = POOL_BLOCK_NODES, head = POOL_NONE;
-    uint64_t len = 0;
+    PathSink sink;
     while (valid) {
-        if (fill == POOL_BLOCK_NODES) {
-            uint32_t nb = atomicAdd(a.counter, 1u);
-            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); break; }
-            a.next[nb] = POOL_NONE;
-            if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
-            cur = nb; fill = 0;
-        }
-        a.pool[static_cast<uint64_t>(cur) * POOL_BLOCK_NODES + fill] = static_cast<uint32_t>(node);
-        fill++; len++;
+        if (!sink.push(a, static_cast<uint32_t>(node))) break;
         uint64_t nn, no;
         valid = gbwt_forward(ix, node, offset, nn, no);
         node = nn; offset = no;
     }
-    a.head[k] = head;
-    a.lengths[k] = len;
+    a.head[k] = sink.head;
+    a.lengths[k] = sink.length();
 }
-
-// Appends `node` to the lane's block chain (shared by both walk kernels).  Returns false on pool overflow.
-struct PathSink {
-    uint32_t cur = POOL_NONE, fill = POOL_BLOCK_NODES, head = POOL_NONE;
-    uint64_t len = 0;
-    __device__ __forceinline__ bool push(const WalkArgs &a, uint32_t node) {
-        if (fill == POOL_BLOCK_NODES) {
-            uint32_t nb = atomicAdd(a.counter, 1u);
-            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); return false; }
-            a.next[nb] = POOL_NONE;
-            if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
-            cur = nb; fill = 0;
-        }
-        a.pool[static_cast<uint64_t>(cur) * POOL_BLOCK_NODES + fill] = node;
-        fill++; len++;
-        return true;
-    }
-};
 
 // Wave-cooperative walk: lanes 0..P-1 of each wave own one sequence each.  Per step every owner
 // looks up its record; short records are decoded by their own lane (lf_device.hpp), long ones are
 // handled one distinct record at a time by the whole wave (coop_device.hpp), so sequences that sit in
 // the same record -- the common case for the high-coverage records of a pangenome -- share one decode.
+template <bool PROF>
 __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
+    // PROF: per-phase cycle counters (s_memtime) of wave 0, to see where a step's latency goes
+    uint64_t t_push = 0, t_bounds = 0, t_small = 0, t_coop = 0, n_steps = 0, n_groups = 0, t0 = 0, t1 = 0;
+#define PROF_MARK(acc) do { if (PROF) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } } while (0)
     const uint32_t lane = threadIdx.x;
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
@@ -148,18 +173,31 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         }
     }
     PathSink sink;
+    if (PROF) t0 = __builtin_amdgcn_s_memtime();
     while (__ballot(active) != 0) {
         // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
         if (active && !sink.push(a, node)) active = false;
-        // GBWT::forward guards + BWT::record_bytes (src/gbwt.rs:222-229, src/bwt.rs:116-130)
+        PROF_MARK(t_push);
+        // GBWT::forward guards + BWT::record_bytes (src/gbwt.rs:222-229, src/bwt.rs:116-130) via the descriptor
         uint64_t start = 0, limit = 0;
-        bool has_record = false;
+        bool has_record = false, ok = false;
+        uint32_t next_node = 0, next_offset = 0;
         if (active && node >= ix.first_node) {
             const uint64_t rec = node - ix.alphabet_offset;
-            if (rec < ix.n_records) { record_bounds(ix, rec, start, limit); has_record = limit > start; }
+            if (rec < ix.n_records) {
+                const uint4 d = ix.desc[rec];
+                if (d.y == DESC_UNARY) {             // one run, one successor: lf(i) = (z, w + i) for i < len
+                    ok = offset < d.x && d.z != 0;
+                    next_node = d.z; next_offset = d.w + offset;
+                } else if (d.y != 0) {
+                    start = (static_cast<uint64_t>(d.z) << 32) | d.x;
+                    limit = start + d.y;
+                    has_record = true;
+                }
+            }
         }
-        bool ok = false;
-        uint32_t next_node = 0, next_offset = 0;
+        if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        PROF_MARK(t_bounds);
         const bool big = has_record && (limit - start) > a.small_record;
         if (has_record && !big) {
             ByteCursor c(ix.data, start, limit);
@@ -168,8 +206,10 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
                 ok = true; next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
             }
         }
+        PROF_MARK(t_small);
         uint64_t todo = __ballot(big);
         while (todo != 0) {
+            if (PROF) n_groups++;
             const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(todo));
             const uint64_t gs = read_lane64(start, leader), ge = read_lane64(limit, leader);
             const bool member = big && start == gs;
@@ -184,6 +224,8 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
             }
             todo &= ~__ballot(member);
         }
+        PROF_MARK(t_coop);
+        if (PROF) n_steps++;
         if (active) {
             active = ok;
             node = next_node; offset = next_offset;
@@ -191,8 +233,12 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
     }
     if (owner) {
         a.head[k] = sink.head;
-        a.lengths[k] = sink.len;
+        a.lengths[k] = sink.length();
     }
+    if (PROF && a.prof && blockIdx.x == 0 && lane == 0) {
+        a.prof[0] = n_steps; a.prof[1] = n_groups; a.prof[2] = t_push; a.prof[3] = t_bounds; a.prof[4] = t_small; a.prof[5] = t_coop;
+    }
+#undef PROF_MARK
 }
 
 // One wave per path: follow the block chain and copy it to its CSR row.
@@ -353,6 +399,11 @@ void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t s
     hipLaunchKernelGGL(k_record_stats, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_stats);
 }
 
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc);
+}
+
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream) {
     hipLaunchKernelGGL(k_endmarker_sigma, dim3(1), dim3(1), 0, stream, ix, d_result);
 }
@@ -369,7 +420,8 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         return;
     }
     const unsigned p = args.paths_per_wave ? args.paths_per_wave : WAVE;
-    hipLaunchKernelGGL(k_walk_coop, dim3(grid_for(args.n, p)), dim3(WAVE), 0, stream, ix, args);
+    if (args.prof) hipLaunchKernelGGL(k_walk_coop<true>, dim3(grid_for(args.n, p)), dim3(WAVE), 0, stream, ix, args);
+    else hipLaunchKernelGGL(k_walk_coop<false>, dim3(grid_for(args.n, p)), dim3(WAVE), 0, stream, ix, args);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {
