@@ -126,7 +126,7 @@ void upload(gbwt_hip_index &ix) {
     }
 
     // Load-time device passes: per-record descriptors, record statistics, then the endmarker (src/gbwt.rs:413-414).
-    ix.desc.reserve(std::max<uint64_t>(n_records, 1) * sizeof(uint4));
+    ix.desc.reserve(std::max<uint64_t>(n_records, 1) * 2 * sizeof(uint4));
     launch_build_desc(d, ix.desc.as<uint4>(), nullptr);
     d.desc = ix.desc.as<uint4>();
     DeviceBuffer tmp;
@@ -334,6 +334,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.counter = ws->counters.as<uint32_t>(); a.flags = ws->counters.as<uint32_t>() + 1;
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
             a.mode = ws->walk_mode; a.paths_per_wave = ws->paths_per_wave; a.small_record = ws->small_record;
+            a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
             a.prof = nullptr;
             if (ws->profile) {
                 ws->prof.reserve(16 * sizeof(uint64_t));

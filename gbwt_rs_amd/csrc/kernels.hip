@@ -32,30 +32,41 @@ __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *
     atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
 }
 
-// One lane per record: the 16-byte descriptor the walk kernels read instead of starts[] (device_index.hpp).
+// One lane per record: the 32-byte descriptor the walk kernels read instead of starts[] (device_index.hpp).
 __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
-    uint4 d = make_uint4(0, 0, 0, 0);
+    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
     if (limit > start) {
         ByteCursor c(ix.data, start, limit);
         uint64_t sigma = 0;
         if (c.varint(sigma) && sigma != 0) {
-            d.x = static_cast<uint32_t>(start); d.y = static_cast<uint32_t>(limit - start);
-            d.z = static_cast<uint32_t>(start >> 32); d.w = sigma > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(sigma);
-            if (sigma == 1) {
-                uint64_t node, off, value, len;
-                RunDecoder rd(1);
-                if (c.varint(node) && c.varint(off) && rd.next(c, value, len) && c.at_end() && len < 0xFFFFFFFFull) {
-                    d.x = static_cast<uint32_t>(len); d.y = DESC_UNARY;
-                    d.z = static_cast<uint32_t>(node); d.w = static_cast<uint32_t>(off);
+            A.x = static_cast<uint32_t>(start); A.y = static_cast<uint32_t>(limit - start);
+            B.w = static_cast<uint32_t>(start >> 32);
+            if (sigma <= 2) {
+                uint64_t n0 = 0, o0 = 0, d1 = 0, o1 = 0;
+                bool good = c.varint(n0) && c.varint(o0);
+                if (good && sigma == 2) good = c.varint(d1) && c.varint(o1);
+                const uint64_t body = c.pos - start;
+                if (good && body <= 0xFFFF && n0 + d1 <= 0xFFFFFFFFull && o0 <= 0xFFFFFFFFull && o1 <= 0xFFFFFFFFull) {
+                    A.z = static_cast<uint32_t>(n0); A.w = static_cast<uint32_t>(o0);
+                    B.x = static_cast<uint32_t>(n0 + d1); B.y = static_cast<uint32_t>(o1);
+                    B.z = static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
+                    if (sigma == 1) {
+                        uint64_t value, len;
+                        RunDecoder rd(1);
+                        if (rd.next(c, value, len) && c.at_end() && len < 0xFFFFFFFFull) {
+                            A.x = static_cast<uint32_t>(len); A.y = DESC_UNARY;
+                        }
+                    }
                 }
             }
         }
     }
-    desc[rec] = d;
+    desc[2 * rec] = A;
+    desc[2 * rec + 1] = B;
 }
 
 // Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
@@ -154,7 +165,7 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
 // looks up its record; short records are decoded by their own lane (lf_device.hpp), long ones are
 // handled one distinct record at a time by the whole wave (coop_device.hpp), so sequences that sit in
 // the same record -- the common case for the high-coverage records of a pangenome -- share one decode.
-template <bool PROF>
+template <bool PROF, bool PACK16>
 __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
     // PROF: per-phase cycle counters (s_memtime) of wave 0, to see where a step's latency goes
     uint64_t t_push = 0, t_bounds = 0, t_small = 0, t_coop = 0, n_steps = 0, n_groups = 0, t0 = 0, t1 = 0;
@@ -179,52 +190,53 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         if (active && !sink.push(a, node)) active = false;
         PROF_MARK(t_push);
         // GBWT::forward guards + BWT::record_bytes (src/gbwt.rs:222-229, src/bwt.rs:116-130) via the descriptor
-        uint64_t start = 0, limit = 0;
+        uint64_t start = 0;
+        uint32_t bytes = 0, meta = 0, n0 = 0, o0 = 0, n1 = 0, o1 = 0;
         bool has_record = false, ok = false;
         uint32_t next_node = 0, next_offset = 0;
         if (active && node >= ix.first_node) {
             const uint64_t rec = node - ix.alphabet_offset;
             if (rec < ix.n_records) {
-                const uint4 d = ix.desc[rec];
-                if (d.y == DESC_UNARY) {             // one run, one successor: lf(i) = (z, w + i) for i < len
-                    ok = offset < d.x && d.z != 0;
-                    next_node = d.z; next_offset = d.w + offset;
-                } else if (d.y != 0) {
-                    start = (static_cast<uint64_t>(d.z) << 32) | d.x;
-                    limit = start + d.y;
+                const uint4 A = ix.desc[2 * rec], B = ix.desc[2 * rec + 1];
+                if (A.y == DESC_UNARY) {             // one run, one successor: lf(i) = (z, w + i) for i < len
+                    ok = offset < A.x && A.z != 0;
+                    next_node = A.z; next_offset = A.w + offset;
+                } else if (A.y != 0) {
+                    start = (static_cast<uint64_t>(B.w) << 32) | A.x;
+                    bytes = A.y; meta = B.z;
+                    n0 = A.z; o0 = A.w; n1 = B.x; o1 = B.y;
                     has_record = true;
                 }
             }
         }
         if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         PROF_MARK(t_bounds);
-        const bool big = has_record && (limit - start) > a.small_record;
-        if (has_record && !big) {
-            ByteCursor c(ix.data, start, limit);
+        // long records with outdegree <= 2 go through the cooperative scan, everything else is decoded by its own lane
+        const bool big = has_record && bytes > a.small_record && (meta >> 16) != 0;
+        bool serial = has_record && !big;
+        uint64_t todo = __ballot(big);
+        while (todo != 0) {
+            if (PROF) n_groups++;
+            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(todo));
+            const uint64_t gs = read_lane64(start, leader);
+            const uint32_t gbytes = read_lane(bytes, leader), gmeta = read_lane(meta, leader);
+            const bool member = big && start == gs;
+            const uint32_t body_off = gmeta & 0xFFFFu;
+            const int status = coop_runs_lf<PACK16>(ix.data + gs + body_off, gbytes - body_off, (gmeta >> 16) == 2, member, offset,
+                                                    n0, o0, n1, o1, ok, next_node, next_offset);
+            if (status != COOP_DONE && member) serial = true;
+            todo &= ~__ballot(member);
+        }
+        PROF_MARK(t_coop);
+        if (serial) {
+            ByteCursor c(ix.data, start, start + bytes);
             uint64_t sigma, nn, no;
+            ok = false;
             if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
                 ok = true; next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
             }
         }
         PROF_MARK(t_small);
-        uint64_t todo = __ballot(big);
-        while (todo != 0) {
-            if (PROF) n_groups++;
-            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(todo));
-            const uint64_t gs = read_lane64(start, leader), ge = read_lane64(limit, leader);
-            const bool member = big && start == gs;
-            const int status = coop_record_lf(ix, gs, ge, member, offset, ok, next_node, next_offset);
-            if (status != COOP_DONE && member) {
-                ByteCursor c(ix.data, start, limit);
-                uint64_t sigma, nn, no;
-                ok = false;
-                if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
-                    ok = true; next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
-                }
-            }
-            todo &= ~__ballot(member);
-        }
-        PROF_MARK(t_coop);
         if (PROF) n_steps++;
         if (active) {
             active = ok;
@@ -420,8 +432,14 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         return;
     }
     const unsigned p = args.paths_per_wave ? args.paths_per_wave : WAVE;
-    if (args.prof) hipLaunchKernelGGL(k_walk_coop<true>, dim3(grid_for(args.n, p)), dim3(WAVE), 0, stream, ix, args);
-    else hipLaunchKernelGGL(k_walk_coop<false>, dim3(grid_for(args.n, p)), dim3(WAVE), 0, stream, ix, args);
+    const dim3 grid(grid_for(args.n, p)), block(WAVE);
+    if (args.prof) {
+        if (args.pack16) hipLaunchKernelGGL((k_walk_coop<true, true>), grid, block, 0, stream, ix, args);
+        else hipLaunchKernelGGL((k_walk_coop<true, false>), grid, block, 0, stream, ix, args);
+    } else {
+        if (args.pack16) hipLaunchKernelGGL((k_walk_coop<false, true>), grid, block, 0, stream, ix, args);
+        else hipLaunchKernelGGL((k_walk_coop<false, false>), grid, block, 0, stream, ix, args);
+    }
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

@@ -20,7 +20,7 @@ constexpr uint32_t FLAG_POOL_OVERFLOW = 1u;
 void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream);
 // Record::decompress of record 0 into d_out[n_out] (src/gbwt.rs:413-414); d_scratch: 2 * sigma u64.
 // d_result[0] = number of positions produced, d_result[1] = outdegree of record 0 (first call sizes scratch)
-// per-record descriptors (device_index.hpp); d_desc has n_records entries
+// per-record descriptors (device_index.hpp); d_desc has 2 * n_records entries
 void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream);
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream);
 void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
@@ -41,6 +41,7 @@ struct WalkArgs {
     uint32_t mode;             // WALK_COOP or WALK_LANE_SERIAL
     uint32_t paths_per_wave;   // WALK_COOP: lanes of a wave that own a path (1..64); all 64 lanes decode
     uint32_t small_record;     // WALK_COOP: records of at most this many bytes are decoded lane-serially
+    uint32_t pack16;           // WALK_COOP: every record is shorter than 2^16 (stats.max_record_len): one packed scan
     uint64_t *prof;            // optional [16] cycle counters of wave 0 (GBWT_HIP_PROFILE=1), else null
 };
 constexpr uint32_t WALK_COOP = 0, WALK_LANE_SERIAL = 1;
