@@ -75,7 +75,8 @@ struct gbwt_hip_workspace {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
-    uint32_t walk_mode = WALK_COOP, paths_per_wave = 64, small_record = 16;
+    uint32_t walk_mode = WALK_COOP, paths_per_wave = 4, small_record = 16;
+    uint32_t touch_ahead = 1;
     bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
     DeviceBuffer prof;
     DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
@@ -284,6 +285,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
         delete ws; return status_of(e);
     }
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
+    if (const char *v = std::getenv("GBWT_HIP_TOUCH_AHEAD")) ws->touch_ahead = std::atoi(v) != 0;
     if (const char *v = std::getenv("GBWT_HIP_PROFILE")) ws->profile = std::atoi(v) != 0;
     if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) ws->walk_mode = std::atoi(v) == 1 ? WALK_LANE_SERIAL : WALK_COOP;
     if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 1 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
@@ -335,6 +337,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
             a.mode = ws->walk_mode; a.paths_per_wave = ws->paths_per_wave; a.small_record = ws->small_record;
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
+            a.touch_ahead = ws->touch_ahead;
+            a.debug_nostore = std::getenv("GBWT_HIP_DEBUG_NOSTORE") ? 1u : 0u;
             a.prof = nullptr;
             if (ws->profile) {
                 ws->prof.reserve(16 * sizeof(uint64_t));
@@ -354,11 +358,13 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         }
         if (flags & FLAG_POOL_OVERFLOW) return fail(GBWT_HIP_DEVICE_ERROR, "path pool overflow");
         if (ws->profile && a.prof) {
-            uint64_t c[6];
+            uint64_t c[9];
             HIP_CHECK(hipMemcpy(c, a.prof, sizeof(c), hipMemcpyDeviceToHost));
             double st = c[0] ? static_cast<double>(c[0]) : 1.0;
-            fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu groups %llu | cycles/step (s_memtime): push %.0f bounds %.0f small %.0f coop %.0f\n",
-                    (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st);
+            double gr = c[1] ? static_cast<double>(c[1]) : 1.0;
+            fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu groups %llu | cycles/step (s_memtime): push %.0f bounds %.0f small %.0f coop %.0f"
+                            " | cycles/group: window-load %.0f classify+scan %.0f search %.0f\n",
+                    (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st, c[6] / gr, c[7] / gr, c[8] / gr);
         }
         uint64_t total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));

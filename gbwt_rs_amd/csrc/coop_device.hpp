@@ -14,7 +14,8 @@
 //     generate = O and propagate = C)
 //   * run ends and the per-value rank come from one DPP inclusive scan across the wave (both sums
 //     packed into one register when every record is shorter than 2^16, else two scans)
-//   * each member finds its run with a 6-round binary search over ds_bpermute
+//   * each member finds its run: small groups one member at a time with readlane / ballot broadcasts,
+//     large groups with a 6-round binary search over ds_bpermute
 //
 // The edge list is not parsed here: the per-record descriptor built at open (device_index.hpp) carries
 // the decoded edges of every record with outdegree <= 2 and the offset of its run stream.
@@ -30,6 +31,7 @@ namespace gbwt_hip {
 
 constexpr int COOP_DONE = 0;         // results for all members are final
 constexpr int COOP_UNSUPPORTED = 1;  // over-long run-length varint: caller must use the lane-serial path
+constexpr int SERIAL_MEMBERS = 8;    // groups up to this size are resolved member by member instead of by ds_bpermute search
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -67,10 +69,15 @@ __device__ __forceinline__ uint32_t window_varint32(uint32_t w, uint32_t &nbytes
 // Called by all 64 lanes with identical body / body_len / two; `member` marks the lanes whose path stands
 // in this record at offset i, and (n0, o0, n1, o1) are that record's decoded edges (from the descriptor).
 // PACK16: every record of the index is shorter than 2^16, so run ends and value-0 counts share one scan.
-template <bool PACK16>
+struct CoopProf { uint64_t load = 0, scan = 0, search = 0, t = 0; };  // cycle counters for GBWT_HIP_PROFILE runs
+
+template <bool PACK16, bool PROF = false>
 __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_len, bool two, bool member, uint32_t i,
                                             uint32_t n0, uint32_t o0, uint32_t n1, uint32_t o1,
-                                            bool &ok, uint32_t &out_node, uint32_t &out_offset) {
+                                            bool &ok, uint32_t &out_node, uint32_t &out_offset, CoopProf *prof = nullptr,
+                                            const uint32_t *touch_a = nullptr, const uint32_t *touch_b = nullptr, uint32_t *touched = nullptr) {
+#define COOP_MARK(field) do { if (PROF) { uint64_t now_ = __builtin_amdgcn_s_memtime(); prof->field += now_ - prof->t; prof->t = now_; } } while (0)
+    if (PROF) prof->t = __builtin_amdgcn_s_memtime();
     const uint32_t lane = lane_id();
     const uint32_t threshold = two ? 128u : 256u;  // RLE::sanitize: 256 / sigma
     const uint32_t saturated = two ? 254u : 255u;  // head bytes >= this have len == threshold and a varint follows
@@ -80,7 +87,12 @@ __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_l
     for (;;) {
         const uint32_t rem = body_len - done;
         const uint64_t w = load_u64_unaligned(body + done + lane);
+        if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        COOP_MARK(load);
         const uint32_t b = static_cast<uint32_t>(w) & 0xFFu;
+        // touch-ahead (see k_walk_coop): issued once the window has arrived, so that these loads overlap the
+        // scan below instead of delaying the window (vector loads return in order)
+        if (touch_a && done == 0) { touched[0] = *touch_a; touched[1] = *touch_b; }
         const uint64_t in_body = rem >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rem) - 1);
         const uint64_t C = __ballot(b >= 0x80u) & in_body;
         const uint64_t O = __ballot(b >= saturated) & in_body;
@@ -113,19 +125,37 @@ __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_l
             c0 = base_c0 + wave_inclusive_sum((is_head && value == 0) ? len : 0u);
             total = read_lane(cum, 63); total0 = read_lane(c0, 63);
         }
+        COOP_MARK(scan);
         // members whose offset falls into this chunk: first lane with cum > i (cum is non-decreasing over the lanes)
         const bool hit = pending && i < total;
-        uint32_t j = 0;
-#pragma unroll
-        for (uint32_t s = 32; s >= 1; s >>= 1) {
-            const uint32_t probe = __shfl(cum, static_cast<int>(j + s - 1));
-            if (probe <= i) j += s;
-        }
-        j &= 63u;
         const uint32_t packed = PACK16 ? ((c0 << 16) | cum) : cum;
         const uint32_t lv = (len << 1) | value;
-        const uint32_t packed_j = __shfl(packed, static_cast<int>(j)), lv_j = __shfl(lv, static_cast<int>(j));
-        const uint32_t c0_wide = PACK16 ? 0u : __shfl(c0, static_cast<int>(j));
+        uint32_t packed_j = 0, lv_j = 0, c0_wide = 0;
+        uint64_t hits = __ballot(hit);
+        if (__builtin_popcountll(hits) <= SERIAL_MEMBERS) {
+            // few members: resolve them one by one with scalar broadcasts (readlane / ballot / writelane, no LDS round trips)
+            while (hits != 0) {
+                const uint32_t p = static_cast<uint32_t>(__builtin_ctzll(hits));
+                hits &= hits - 1;
+                const uint32_t target = read_lane(i, p);
+                const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(__ballot(cum > target)));
+                const bool mine = lane == p;
+                packed_j = mine ? read_lane(packed, j) : packed_j;
+                lv_j = mine ? read_lane(lv, j) : lv_j;
+                if (!PACK16) c0_wide = mine ? read_lane(c0, j) : c0_wide;
+            }
+        } else {
+            // many members: every lane binary-searches the scanned run ends through the LDS crossbar
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t s = 32; s >= 1; s >>= 1) {
+                const uint32_t probe = __shfl(cum, static_cast<int>(j + s - 1));
+                if (probe <= i) j += s;
+            }
+            j &= 63u;
+            packed_j = __shfl(packed, static_cast<int>(j)); lv_j = __shfl(lv, static_cast<int>(j));
+            if (!PACK16) c0_wide = __shfl(c0, static_cast<int>(j));
+        }
         if (hit) {
             const uint32_t cum_j = PACK16 ? (packed_j & 0xFFFFu) : packed_j, c0_j = PACK16 ? (packed_j >> 16) : c0_wide;
             const uint32_t len_j = lv_j >> 1, val_j = lv_j & 1u;
@@ -137,6 +167,7 @@ __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_l
             out_offset = (val_j ? o1 : o0) + rank + (i - before);
             pending = false;
         }
+        COOP_MARK(search);
         if (__ballot(pending) == 0) return COOP_DONE;
         if (heads == 0 || exhausted) return COOP_DONE;  // stream exhausted: the remaining members are past the end (None)
         // the next chunk starts right after the last complete run of this one
@@ -145,6 +176,7 @@ __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_l
         if (done >= body_len) return COOP_DONE;
         base_cum = total; base_c0 = total0;
     }
+#undef COOP_MARK
 }
 
 }  // namespace gbwt_hip

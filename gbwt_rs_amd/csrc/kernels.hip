@@ -132,7 +132,8 @@ struct PathSink {
             wp = a.pool + static_cast<uint64_t>(nb) * POOL_BLOCK_NODES;
             left = POOL_BLOCK_NODES;
         }
-        *wp++ = node;
+        if (!a.debug_nostore) *wp = node;
+        wp++;
         left--;
         return true;
     }
@@ -169,6 +170,7 @@ template <bool PROF, bool PACK16>
 __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
     // PROF: per-phase cycle counters (s_memtime) of wave 0, to see where a step's latency goes
     uint64_t t_push = 0, t_bounds = 0, t_small = 0, t_coop = 0, n_steps = 0, n_groups = 0, t0 = 0, t1 = 0;
+    CoopProf cprof;
 #define PROF_MARK(acc) do { if (PROF) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } } while (0)
     const uint32_t lane = threadIdx.x;
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
@@ -184,20 +186,29 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         }
     }
     PathSink sink;
+    // Touch-ahead: records of neighbouring nodes sit next to each other in the descriptor table and in the
+    // byte stream, and walks move to nearby node ids, so every cooperative step also requests the cache lines
+    // AHEAD bytes further on in both.  The values are only folded into `touched` (never used), but the lines
+    // are then resident when the following steps need them.
+    constexpr uint32_t AHEAD = 256;
+    const uint64_t desc_bytes = ix.n_records * 2 * sizeof(uint4);
+    uint32_t touched = 0, pf[2] = {0, 0};
     if (PROF) t0 = __builtin_amdgcn_s_memtime();
     while (__ballot(active) != 0) {
+        touched ^= pf[0] ^ pf[1];
         // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
         if (active && !sink.push(a, node)) active = false;
         PROF_MARK(t_push);
         // GBWT::forward guards + BWT::record_bytes (src/gbwt.rs:222-229, src/bwt.rs:116-130) via the descriptor
         uint64_t start = 0;
-        uint32_t bytes = 0, meta = 0, n0 = 0, o0 = 0, n1 = 0, o1 = 0;
+        uint32_t bytes = 0, meta = 0, n0 = 0, o0 = 0, n1 = 0, o1 = 0, rec32 = 0;
         bool has_record = false, ok = false;
         uint32_t next_node = 0, next_offset = 0;
         if (active && node >= ix.first_node) {
             const uint64_t rec = node - ix.alphabet_offset;
             if (rec < ix.n_records) {
                 const uint4 A = ix.desc[2 * rec], B = ix.desc[2 * rec + 1];
+                rec32 = static_cast<uint32_t>(rec);
                 if (A.y == DESC_UNARY) {             // one run, one successor: lf(i) = (z, w + i) for i < len
                     ok = offset < A.x && A.z != 0;
                     next_node = A.z; next_offset = A.w + offset;
@@ -222,8 +233,15 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
             const uint32_t gbytes = read_lane(bytes, leader), gmeta = read_lane(meta, leader);
             const bool member = big && start == gs;
             const uint32_t body_off = gmeta & 0xFFFFu;
-            const int status = coop_runs_lf<PACK16>(ix.data + gs + body_off, gbytes - body_off, (gmeta >> 16) == 2, member, offset,
-                                                    n0, o0, n1, o1, ok, next_node, next_offset);
+            const uint32_t *touch_a = nullptr, *touch_b = nullptr;
+            if (a.touch_ahead) {
+                const uint64_t da = static_cast<uint64_t>(read_lane(rec32, leader)) * 2 * sizeof(uint4) + AHEAD;
+                const uint64_t db = (gs + AHEAD) & ~uint64_t(3);
+                touch_a = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(ix.desc) + (da < desc_bytes ? da : 0));
+                touch_b = reinterpret_cast<const uint32_t *>(ix.data + (db < ix.data_len ? db : 0));
+            }
+            const int status = coop_runs_lf<PACK16, PROF>(ix.data + gs + body_off, gbytes - body_off, (gmeta >> 16) == 2, member, offset,
+                                                          n0, o0, n1, o1, ok, next_node, next_offset, &cprof, touch_a, touch_b, pf);
             if (status != COOP_DONE && member) serial = true;
             todo &= ~__ballot(member);
         }
@@ -247,8 +265,10 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         a.head[k] = sink.head;
         a.lengths[k] = sink.length();
     }
+    if (touched == 0x9E3779B9u && a.flags) atomicOr(a.flags, 0u);  // keeps the touch-ahead loads alive; changes nothing
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0) {
         a.prof[0] = n_steps; a.prof[1] = n_groups; a.prof[2] = t_push; a.prof[3] = t_bounds; a.prof[4] = t_small; a.prof[5] = t_coop;
+        a.prof[6] = cprof.load; a.prof[7] = cprof.scan; a.prof[8] = cprof.search;
     }
 #undef PROF_MARK
 }
