@@ -64,7 +64,8 @@ gbwt_hip_status status_of(const HipError &e) {
 struct gbwt_hip_index {
     HostIndex host;
     int device = 0;
-    DeviceBuffer data, starts, endmarker, desc;
+    DeviceBuffer data, starts, endmarker, desc, sbase, samples;
+    uint32_t sample_shift = 6;   // rank sample every 64 offsets (GBWT_HIP_SAMPLE_SHIFT)
     DeviceIndex dev{};
     gbwt_hip_stats stats{};
 };
@@ -75,8 +76,7 @@ struct gbwt_hip_workspace {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
-    uint32_t walk_mode = WALK_COOP, paths_per_wave = 4, small_record = 16;
-    uint32_t touch_ahead = 1;
+    uint32_t walk_mode = WALK_SAMPLED, paths_per_wave = 64, small_record = 16;
     bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
     DeviceBuffer prof;
     DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
@@ -126,10 +126,39 @@ void upload(gbwt_hip_index &ix) {
         d.starts64 = ix.starts.as<uint64_t>();
     }
 
-    // Load-time device passes: per-record descriptors, record statistics, then the endmarker (src/gbwt.rs:413-414).
-    ix.desc.reserve(std::max<uint64_t>(n_records, 1) * 2 * sizeof(uint4));
-    launch_build_desc(d, ix.desc.as<uint4>(), nullptr);
-    d.desc = ix.desc.as<uint4>();
+    // Load-time device passes: per-record descriptors + rank samples, record statistics, then the endmarker
+    // (src/gbwt.rs:413-414).
+    if (const char *v = std::getenv("GBWT_HIP_SAMPLE_SHIFT")) { int sh = std::atoi(v); if (sh >= 3 && sh <= 20) ix.sample_shift = static_cast<uint32_t>(sh); }
+    d.sample_shift = ix.sample_shift;
+    {
+        const uint64_t nr = std::max<uint64_t>(n_records, 1);
+        ix.desc.reserve(nr * 2 * sizeof(uint4));
+        ix.sbase.reserve(nr * sizeof(uint32_t));
+        DeviceBuffer counts, scan_tmp;
+        counts.reserve(nr * sizeof(uint32_t));
+        launch_build_desc(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), nullptr);
+        d.desc = ix.desc.as<uint4>();
+        uint64_t n_samples = 0;
+        if (n_records > 0) {
+            if (n_records >= (uint64_t(1) << 31)) throw InvalidData("more than 2^31 records are not supported");
+            size_t tb = sample_scan_temp_bytes(n_records);
+            scan_tmp.reserve(std::max<size_t>(tb, 16));
+            launch_sample_scan(counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), n_records, scan_tmp.ptr, tb, nullptr);
+            uint32_t last_base = 0, last_count = 0;
+            HIP_CHECK(hipMemcpy(&last_base, ix.sbase.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(&last_count, counts.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+            n_samples = static_cast<uint64_t>(last_base) + last_count;
+            if (h.size / (uint64_t(1) << ix.sample_shift) + n_records >= 0xFFFFFFF0ull) throw InvalidData("index too large for 32-bit sample indices: raise GBWT_HIP_SAMPLE_SHIFT");
+            launch_mark_unsampled(counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), n_records, nullptr);
+        }
+        ix.samples.reserve(std::max<uint64_t>(n_samples, 1) * sizeof(uint4));
+        d.sbase = ix.sbase.as<uint32_t>();
+        d.samples = ix.samples.as<uint4>();
+        d.n_samples = n_samples;
+        if (n_samples > 0) launch_fill_samples(d, counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), ix.samples.as<uint4>(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipGetLastError());
+    }
     DeviceBuffer tmp;
     tmp.reserve(8 * sizeof(uint64_t));
     HIP_CHECK(hipMemset(tmp.ptr, 0, 8 * sizeof(uint64_t)));
@@ -285,9 +314,8 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
         delete ws; return status_of(e);
     }
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
-    if (const char *v = std::getenv("GBWT_HIP_TOUCH_AHEAD")) ws->touch_ahead = std::atoi(v) != 0;
     if (const char *v = std::getenv("GBWT_HIP_PROFILE")) ws->profile = std::atoi(v) != 0;
-    if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) ws->walk_mode = std::atoi(v) == 1 ? WALK_LANE_SERIAL : WALK_COOP;
+    if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ws->walk_mode = static_cast<uint32_t>(m); }
     if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 1 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
     if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
     *out = ws;
@@ -297,7 +325,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws) { delete ws; }
 
 gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record) {
-    if (!ws || walk_mode > WALK_LANE_SERIAL || paths_per_wave < 1 || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
+    if (!ws || walk_mode > WALK_COOP || paths_per_wave < 1 || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
     ws->walk_mode = walk_mode; ws->paths_per_wave = paths_per_wave; ws->small_record = small_record;
     return GBWT_HIP_OK;
 }
@@ -337,7 +365,6 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
             a.mode = ws->walk_mode; a.paths_per_wave = ws->paths_per_wave; a.small_record = ws->small_record;
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
-            a.touch_ahead = ws->touch_ahead;
             a.debug_nostore = std::getenv("GBWT_HIP_DEBUG_NOSTORE") ? 1u : 0u;
             a.prof = nullptr;
             if (ws->profile) {
@@ -362,9 +389,10 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             HIP_CHECK(hipMemcpy(c, a.prof, sizeof(c), hipMemcpyDeviceToHost));
             double st = c[0] ? static_cast<double>(c[0]) : 1.0;
             double gr = c[1] ? static_cast<double>(c[1]) : 1.0;
-            fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu groups %llu | cycles/step (s_memtime): push %.0f bounds %.0f small %.0f coop %.0f"
-                            " | cycles/group: window-load %.0f classify+scan %.0f search %.0f\n",
-                    (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st, c[6] / gr, c[7] / gr, c[8] / gr);
+            (void)gr;
+            fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu run-scans %llu | cycles/step (s_memtime, loads drained at each mark): "
+                            "push %.0f descriptor %.0f sample %.0f scan %.0f\n",
+                    (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st);
         }
         uint64_t total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));

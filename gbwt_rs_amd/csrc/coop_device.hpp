@@ -74,8 +74,7 @@ struct CoopProf { uint64_t load = 0, scan = 0, search = 0, t = 0; };  // cycle c
 template <bool PACK16, bool PROF = false>
 __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_len, bool two, bool member, uint32_t i,
                                             uint32_t n0, uint32_t o0, uint32_t n1, uint32_t o1,
-                                            bool &ok, uint32_t &out_node, uint32_t &out_offset, CoopProf *prof = nullptr,
-                                            const uint32_t *touch_a = nullptr, const uint32_t *touch_b = nullptr, uint32_t *touched = nullptr) {
+                                            bool &ok, uint32_t &out_node, uint32_t &out_offset, CoopProf *prof = nullptr) {
 #define COOP_MARK(field) do { if (PROF) { uint64_t now_ = __builtin_amdgcn_s_memtime(); prof->field += now_ - prof->t; prof->t = now_; } } while (0)
     if (PROF) prof->t = __builtin_amdgcn_s_memtime();
     const uint32_t lane = lane_id();
@@ -90,9 +89,6 @@ __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_l
         if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         COOP_MARK(load);
         const uint32_t b = static_cast<uint32_t>(w) & 0xFFu;
-        // touch-ahead (see k_walk_coop): issued once the window has arrived, so that these loads overlap the
-        // scan below instead of delaying the window (vector loads return in order)
-        if (touch_a && done == 0) { touched[0] = *touch_a; touched[1] = *touch_b; }
         const uint64_t in_body = rem >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rem) - 1);
         const uint64_t C = __ballot(b >= 0x80u) & in_body;
         const uint64_t O = __ballot(b >= saturated) & in_body;

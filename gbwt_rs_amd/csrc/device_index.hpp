@@ -2,21 +2,30 @@
 //
 // HBM layout (DESIGN.md "Data layout"):
 //   data      : the record byte stream of bwt::BWT (src/bwt.rs:97-100), verbatim, followed by
-//               DATA_PAD zero bytes so that unaligned 8/16-byte window loads never leave the buffer
+//               DATA_PAD zero bytes so that unaligned 8-byte window loads never leave the buffer
 //   starts    : dense record starts, n_records + 1 entries (sentinel = data_len); u32 when the stream
 //               is < 4 GiB, else u64.  Replaces the Elias-Fano select of BWT::record_bytes
-//               (src/bwt.rs:116-121): one 8-byte load gives [start, limit)
+//               (src/bwt.rs:116-121); used by the search kernels
 //   endmarker : record 0 fully decompressed at open (src/gbwt.rs:413-414), one (node, offset) per sequence
-//   desc      : one 32-byte descriptor per record (two uint4: A = desc[2 * rec], B = desc[2 * rec + 1]), built on the
-//               device at open and read by the walk kernels with two aligned dwordx4 loads:
-//                 ordinary record : A = {start low 32, length in bytes, successor 0, offset 0}
-//                                   B = {successor 1, offset 1, body offset | class << 16, start high 32}
-//                                   class 1 / 2 = outdegree 1 / 2 with the edge list decoded into A.z, A.w, B.x, B.y and
-//                                   "body offset" = where the run stream starts inside the record; class 0 = anything else
-//                 empty / None    : A.y = 0
-//                 unary record    : A = {Record::len, DESC_UNARY, successor node, successor offset}
-//               "unary" = outdegree 1 and a body that is exactly one run (every node on a linear stretch of
-//               the graph): Record::lf(i) is then (A.z, A.w + i) for i < A.x, so a step costs one load and one add.
+//
+// Built on the device at open and read by the walk kernels:
+//   desc      : one 32-byte descriptor per record, two uint4 (A = desc[2 * rec], B = desc[2 * rec + 1]):
+//                 A = {successor 0, offset 0, successor 1, offset 1}         decoded edge list (class 1 / 2 only)
+//                 B = {start (low 32 bits), length in bytes, meta, Record::len}
+//                 meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
+//                 class 1 / 2 = outdegree 1 / 2 with the edges in A and "body offset" = where the run stream starts
+//                 inside the record; class 0 = any other non-empty record (walked by the generic lane-serial code)
+//               empty / None record : B.y = 0
+//               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 and a body that is exactly one run
+//                 (every node on a linear stretch of the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w,
+//                 so a step through it costs one descriptor load and one add.
+//   sbase     : per record, index of its first rank sample or SAMPLE_NONE
+//   samples   : rank samples ("superblocks") of the long class 1 / 2 records: sample k of a record describes the
+//               run that contains offset k << sample_shift: {byte position of that run relative to the record
+//               start, offsets before the run, value-0 offsets before the run, 0}.  A lane jumps to the sample of
+//               its offset and scans at most (1 << sample_shift) offsets worth of runs, so the cost of a step does
+//               not grow with the length of the record (the reference scans from the start of the record,
+//               src/bwt.rs:483-494).  Like simple-sds's rank/select supports these are rebuilt at load, never stored.
 #pragma once
 
 #include <cstdint>
@@ -24,6 +33,7 @@
 namespace gbwt_hip {
 
 constexpr uint32_t DESC_UNARY = 0xFFFFFFFFu;
+constexpr uint32_t SAMPLE_NONE = 0xFFFFFFFFu;
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start
 
 struct DeviceIndex {
@@ -31,13 +41,21 @@ struct DeviceIndex {
     const uint32_t *starts32;  // exactly one of starts32 / starts64 is non-null
     const uint64_t *starts64;
     const uint2 *endmarker;    // .x = node, .y = offset
-    const uint4 *desc;         // 2 * n_records entries (see above)
+    const uint4 *desc;         // 2 * n_records entries
+    const uint32_t *sbase;     // n_records entries
+    const uint4 *samples;      // n_samples entries
     uint64_t data_len;
     uint64_t n_records;
     uint64_t n_sequences;      // header.sequences
     uint64_t n_endmarker;      // decompressed endmarker length
+    uint64_t n_samples;
     uint32_t alphabet_offset;
     uint32_t first_node;       // alphabet_offset + 1
+    uint32_t sample_shift;     // log2 of the sampling interval (in record offsets)
 };
+
+__host__ __device__ inline uint32_t desc_body_offset(uint32_t meta) { return meta & 0xFFFFu; }
+__host__ __device__ inline uint32_t desc_class(uint32_t meta) { return (meta >> 16) & 3u; }
+__host__ __device__ inline uint64_t desc_start(uint32_t start_lo, uint32_t meta) { return (static_cast<uint64_t>(meta >> 24) << 32) | start_lo; }
 
 }  // namespace gbwt_hip

@@ -32,41 +32,79 @@ __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *
     atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
 }
 
-// One lane per record: the 32-byte descriptor the walk kernels read instead of starts[] (device_index.hpp).
-__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc) {
+// One lane per record: the 32-byte descriptor (device_index.hpp) and the number of rank samples the record gets.
+__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *sample_counts) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
     uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
+    uint32_t n_samples = 0;
     if (limit > start) {
         ByteCursor c(ix.data, start, limit);
         uint64_t sigma = 0;
         if (c.varint(sigma) && sigma != 0) {
-            A.x = static_cast<uint32_t>(start); A.y = static_cast<uint32_t>(limit - start);
-            B.w = static_cast<uint32_t>(start >> 32);
-            if (sigma <= 2) {
+            B.x = static_cast<uint32_t>(start); B.y = static_cast<uint32_t>(limit - start);
+            B.z = static_cast<uint32_t>((start >> 32) & 0xFF) << 24;
+            bool classed = false;
+            if (sigma <= 2 && (start >> 40) == 0) {
                 uint64_t n0 = 0, o0 = 0, d1 = 0, o1 = 0;
                 bool good = c.varint(n0) && c.varint(o0);
                 if (good && sigma == 2) good = c.varint(d1) && c.varint(o1);
                 const uint64_t body = c.pos - start;
                 if (good && body <= 0xFFFF && n0 + d1 <= 0xFFFFFFFFull && o0 <= 0xFFFFFFFFull && o1 <= 0xFFFFFFFFull) {
-                    A.z = static_cast<uint32_t>(n0); A.w = static_cast<uint32_t>(o0);
-                    B.x = static_cast<uint32_t>(n0 + d1); B.y = static_cast<uint32_t>(o1);
-                    B.z = static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
-                    if (sigma == 1) {
-                        uint64_t value, len;
-                        RunDecoder rd(1);
-                        if (rd.next(c, value, len) && c.at_end() && len < 0xFFFFFFFFull) {
-                            A.x = static_cast<uint32_t>(len); A.y = DESC_UNARY;
-                        }
+                    // Record::len and the shape of the run stream
+                    RunDecoder rd(sigma);
+                    uint64_t total = 0, runs = 0, value, len;
+                    while (rd.next(c, value, len)) { total += len; runs++; }
+                    if (total < 0xFFFFFFFFull) {
+                        classed = true;
+                        A.x = static_cast<uint32_t>(n0); A.y = static_cast<uint32_t>(o0);
+                        A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
+                        B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
+                        B.w = static_cast<uint32_t>(total);
+                        if (sigma == 1 && runs == 1 && c.at_end()) B.y = DESC_UNARY;
+                        else if (total > (uint64_t(1) << ix.sample_shift)) n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);
                     }
                 }
+            }
+            if (!classed) {  // class 0: Record::len for the statistics only
+                ByteCursor c2(ix.data, start, limit);
+                uint64_t s2 = 0;
+                c2.varint(s2);
+                uint64_t total = record_len(c2, s2);
+                B.w = total < 0xFFFFFFFFull ? static_cast<uint32_t>(total) : 0xFFFFFFFFu;
             }
         }
     }
     desc[2 * rec] = A;
     desc[2 * rec + 1] = B;
+    sample_counts[rec] = n_samples;
+}
+
+// One lane per sampled record: sample k = the run containing offset k << sample_shift (device_index.hpp).
+__global__ void __launch_bounds__(256) k_fill_samples(DeviceIndex ix, const uint32_t *sample_counts, const uint32_t *sbase, uint4 *samples) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint32_t count = sample_counts[rec];
+    if (count == 0) return;
+    const uint4 B = ix.desc[2 * rec + 1];
+    const uint64_t start = desc_start(B.x, B.z);
+    ByteCursor c(ix.data, start + desc_body_offset(B.z), start + B.y);
+    RunDecoder rd(desc_class(B.z));
+    uint4 *out = samples + sbase[rec];
+    uint64_t cum = 0, c0 = 0, value, len;
+    uint32_t k = 0;
+    while (k < count) {
+        const uint64_t run_pos = c.pos - start;
+        if (!rd.next(c, value, len)) break;
+        while (k < count && (static_cast<uint64_t>(k) << ix.sample_shift) < cum + len) {
+            out[k] = make_uint4(static_cast<uint32_t>(run_pos), static_cast<uint32_t>(cum), static_cast<uint32_t>(c0), 0u);
+            k++;
+        }
+        cum += len;
+        if (value == 0) c0 += len;
+    }
 }
 
 // Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
@@ -162,16 +200,57 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
     a.lengths[k] = sink.length();
 }
 
-// Wave-cooperative walk: lanes 0..P-1 of each wave own one sequence each.  Per step every owner
-// looks up its record; short records are decoded by their own lane (lf_device.hpp), long ones are
-// handled one distinct record at a time by the whole wave (coop_device.hpp), so sequences that sit in
-// the same record -- the common case for the high-coverage records of a pangenome -- share one decode.
-template <bool PROF, bool PACK16>
-__global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
-    // PROF: per-phase cycle counters (s_memtime) of wave 0, to see where a step's latency goes
-    uint64_t t_push = 0, t_bounds = 0, t_small = 0, t_coop = 0, n_steps = 0, n_groups = 0, t0 = 0, t1 = 0;
-    CoopProf cprof;
-#define PROF_MARK(acc) do { if (PROF) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } } while (0)
+// Run scan of a class 1 / 2 record by one lane: starting at byte `pos` with `cum` offsets and `c0` value-0 offsets
+// already passed, finds the run containing offset i (RLEIter::next src/support.rs:1413-1430 for sigma <= 2, the
+// loop of Record::lf src/bwt.rs:483-494).  Returns 1 on a hit, 0 when the stream ends first (lf -> None) and
+// -1 when a run-length varint is too long for the 4-byte fast decoder (caller falls back to the generic code).
+__device__ __forceinline__ int scan_runs(const uint8_t *data, uint64_t pos, uint64_t limit, bool two, uint32_t cum, uint32_t c0,
+                                         uint32_t i, uint32_t &value, uint32_t &rank, uint32_t &delta) {
+    const uint32_t threshold = two ? 128u : 256u, saturated = two ? 254u : 255u;
+    uint64_t w = 0;
+    uint32_t avail = 0;
+    for (;;) {
+        if (pos >= limit) return 0;
+        if (avail < 5) { w = load_u64_unaligned(data + pos); avail = 8; }  // a run is at most 1 + 4 bytes here
+        const uint32_t b = static_cast<uint32_t>(w) & 0xFFu;
+        const uint32_t v = two ? (b & 1u) : 0u;
+        uint32_t len = (two ? (b >> 1) : b) + 1, nb = 1;
+        if (b >= saturated) {
+            uint32_t n;
+            const uint32_t extra = window_varint32(static_cast<uint32_t>(w >> 8), n);
+            if (n == 0) return -1;
+            len = threshold + extra; nb = 1 + n;
+        }
+        if (pos + nb > limit) return 0;  // run cut off by the end of the record
+        if (cum + len > i) {
+            value = v; delta = i - cum;
+            rank = v ? (cum - c0) : c0;
+            return 1;
+        }
+        cum += len;
+        if (!v) c0 += len;
+        pos += nb; w >>= 8 * nb; avail -= nb;
+    }
+}
+
+// Generic lane-serial Record::lf for the record of the current descriptor (class 0, or fallback).
+__device__ __forceinline__ bool serial_record_lf(const DeviceIndex &ix, uint64_t start, uint32_t bytes, uint32_t offset,
+                                                 uint32_t &next_node, uint32_t &next_offset) {
+    ByteCursor c(ix.data, start, start + bytes);
+    uint64_t sigma, nn, no;
+    if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
+        next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
+        return true;
+    }
+    return false;
+}
+
+// Default walk: one lane per sequence, no cross-lane work.  Per step: descriptor (two 16-byte loads + sbase),
+// for long records the rank sample of the current offset, then a short run scan.
+template <bool PROF>
+__global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs a) {
+    uint64_t t_push = 0, t_desc = 0, t_sample = 0, t_scan = 0, n_steps = 0, n_scans = 0, t0 = 0, t1 = 0;
+#define PROF_MARK(acc) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } } while (0)
     const uint32_t lane = threadIdx.x;
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
@@ -186,75 +265,53 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         }
     }
     PathSink sink;
-    // Touch-ahead: records of neighbouring nodes sit next to each other in the descriptor table and in the
-    // byte stream, and walks move to nearby node ids, so every cooperative step also requests the cache lines
-    // AHEAD bytes further on in both.  The values are only folded into `touched` (never used), but the lines
-    // are then resident when the following steps need them.
-    constexpr uint32_t AHEAD = 256;
-    const uint64_t desc_bytes = ix.n_records * 2 * sizeof(uint4);
-    uint32_t touched = 0, pf[2] = {0, 0};
     if (PROF) t0 = __builtin_amdgcn_s_memtime();
     while (__ballot(active) != 0) {
-        touched ^= pf[0] ^ pf[1];
         // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
         if (active && !sink.push(a, node)) active = false;
         PROF_MARK(t_push);
-        // GBWT::forward guards + BWT::record_bytes (src/gbwt.rs:222-229, src/bwt.rs:116-130) via the descriptor
-        uint64_t start = 0;
-        uint32_t bytes = 0, meta = 0, n0 = 0, o0 = 0, n1 = 0, o1 = 0, rec32 = 0;
-        bool has_record = false, ok = false;
+        bool ok = false;
         uint32_t next_node = 0, next_offset = 0;
-        if (active && node >= ix.first_node) {
+        uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
+        uint32_t sb = SAMPLE_NONE;
+        // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130) via the descriptor
+        if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
             const uint64_t rec = node - ix.alphabet_offset;
-            if (rec < ix.n_records) {
-                const uint4 A = ix.desc[2 * rec], B = ix.desc[2 * rec + 1];
-                rec32 = static_cast<uint32_t>(rec);
-                if (A.y == DESC_UNARY) {             // one run, one successor: lf(i) = (z, w + i) for i < len
-                    ok = offset < A.x && A.z != 0;
-                    next_node = A.z; next_offset = A.w + offset;
-                } else if (A.y != 0) {
-                    start = (static_cast<uint64_t>(B.w) << 32) | A.x;
-                    bytes = A.y; meta = B.z;
-                    n0 = A.z; o0 = A.w; n1 = B.x; o1 = B.y;
-                    has_record = true;
+            A = ix.desc[2 * rec]; B = ix.desc[2 * rec + 1]; sb = ix.sbase[rec];
+        }
+        PROF_MARK(t_desc);
+        const uint32_t cls = desc_class(B.z);
+        int state = 0;  // 0 = resolved, 1 = scan runs, 2 = generic lane-serial decode
+        uint64_t start = 0, pos = 0;
+        uint32_t cum = 0, c0 = 0;
+        if (B.y == DESC_UNARY) {                    // one run, one successor: lf(i) = (A.x, A.y + i) for i < len
+            ok = offset < B.w && A.x != 0;
+            next_node = A.x; next_offset = A.y + offset;
+        } else if (B.y != 0) {
+            start = desc_start(B.x, B.z);
+            if (cls == 0) state = 2;
+            else if (offset < B.w) {                // i >= Record::len -> None
+                state = 1;
+                pos = start + desc_body_offset(B.z);
+                if (sb != SAMPLE_NONE) {
+                    const uint4 S = ix.samples[sb + (offset >> ix.sample_shift)];
+                    pos = start + S.x; cum = S.y; c0 = S.z;
                 }
             }
         }
-        if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        PROF_MARK(t_bounds);
-        // long records with outdegree <= 2 go through the cooperative scan, everything else is decoded by its own lane
-        const bool big = has_record && bytes > a.small_record && (meta >> 16) != 0;
-        bool serial = has_record && !big;
-        uint64_t todo = __ballot(big);
-        while (todo != 0) {
-            if (PROF) n_groups++;
-            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(todo));
-            const uint64_t gs = read_lane64(start, leader);
-            const uint32_t gbytes = read_lane(bytes, leader), gmeta = read_lane(meta, leader);
-            const bool member = big && start == gs;
-            const uint32_t body_off = gmeta & 0xFFFFu;
-            const uint32_t *touch_a = nullptr, *touch_b = nullptr;
-            if (a.touch_ahead) {
-                const uint64_t da = static_cast<uint64_t>(read_lane(rec32, leader)) * 2 * sizeof(uint4) + AHEAD;
-                const uint64_t db = (gs + AHEAD) & ~uint64_t(3);
-                touch_a = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(ix.desc) + (da < desc_bytes ? da : 0));
-                touch_b = reinterpret_cast<const uint32_t *>(ix.data + (db < ix.data_len ? db : 0));
-            }
-            const int status = coop_runs_lf<PACK16, PROF>(ix.data + gs + body_off, gbytes - body_off, (gmeta >> 16) == 2, member, offset,
-                                                          n0, o0, n1, o1, ok, next_node, next_offset, &cprof, touch_a, touch_b, pf);
-            if (status != COOP_DONE && member) serial = true;
-            todo &= ~__ballot(member);
+        PROF_MARK(t_sample);
+        if (state == 1) {
+            uint32_t value = 0, rank = 0, delta = 0;
+            const int r = scan_runs(ix.data, pos, start + B.y, cls == 2, cum, c0, offset, value, rank, delta);
+            if (r == 1) {
+                next_node = value ? A.z : A.x;
+                next_offset = (value ? A.w : A.y) + rank + delta;
+                ok = next_node != 0;             // ENDMARKER successor: the sequence ends
+            } else if (r < 0) state = 2;
+            if (PROF) n_scans++;
         }
-        PROF_MARK(t_coop);
-        if (serial) {
-            ByteCursor c(ix.data, start, start + bytes);
-            uint64_t sigma, nn, no;
-            ok = false;
-            if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
-                ok = true; next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
-            }
-        }
-        PROF_MARK(t_small);
+        if (state == 2) ok = serial_record_lf(ix, start, B.y, offset, next_node, next_offset);
+        PROF_MARK(t_scan);
         if (PROF) n_steps++;
         if (active) {
             active = ok;
@@ -265,12 +322,74 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         a.head[k] = sink.head;
         a.lengths[k] = sink.length();
     }
-    if (touched == 0x9E3779B9u && a.flags) atomicOr(a.flags, 0u);  // keeps the touch-ahead loads alive; changes nothing
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0) {
-        a.prof[0] = n_steps; a.prof[1] = n_groups; a.prof[2] = t_push; a.prof[3] = t_bounds; a.prof[4] = t_small; a.prof[5] = t_coop;
-        a.prof[6] = cprof.load; a.prof[7] = cprof.scan; a.prof[8] = cprof.search;
+        a.prof[0] = n_steps; a.prof[1] = n_scans; a.prof[2] = t_push; a.prof[3] = t_desc; a.prof[4] = t_sample; a.prof[5] = t_scan;
     }
 #undef PROF_MARK
+}
+
+// Wave-cooperative walk (WALK_COOP): lanes 0..P-1 of each wave own one sequence each; long class 1 / 2 records are
+// decoded one distinct record at a time by the whole wave (coop_device.hpp), so sequences that sit in the same record
+// share one decode.  Kept as an alternative to the sampled walk: it needs no rank samples.
+template <bool PACK16>
+__global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
+    const bool owner = lane < a.paths_per_wave && k < a.n;
+    uint32_t node = 0, offset = 0;
+    bool active = false;
+    if (owner) {
+        const uint64_t id = a.seq_ids[k];
+        if (id < ix.n_endmarker) {
+            uint2 e = ix.endmarker[id];
+            node = e.x; offset = e.y;
+            active = node != 0;
+        }
+    }
+    PathSink sink;
+    while (__ballot(active) != 0) {
+        if (active && !sink.push(a, node)) active = false;
+        uint64_t start = 0;
+        uint32_t bytes = 0, meta = 0, n0 = 0, o0 = 0, n1 = 0, o1 = 0;
+        bool has_record = false, ok = false;
+        uint32_t next_node = 0, next_offset = 0;
+        if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
+            const uint64_t rec = node - ix.alphabet_offset;
+            const uint4 A = ix.desc[2 * rec], B = ix.desc[2 * rec + 1];
+            if (B.y == DESC_UNARY) {
+                ok = offset < B.w && A.x != 0;
+                next_node = A.x; next_offset = A.y + offset;
+            } else if (B.y != 0) {
+                start = desc_start(B.x, B.z);
+                bytes = B.y; meta = B.z;
+                n0 = A.x; o0 = A.y; n1 = A.z; o1 = A.w;
+                has_record = true;
+            }
+        }
+        const bool big = has_record && bytes > a.small_record && desc_class(meta) != 0;
+        bool serial = has_record && !big;
+        uint64_t todo = __ballot(big);
+        while (todo != 0) {
+            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(todo));
+            const uint64_t gs = read_lane64(start, leader);
+            const uint32_t gbytes = read_lane(bytes, leader), gmeta = read_lane(meta, leader);
+            const bool member = big && start == gs;
+            const uint32_t body_off = desc_body_offset(gmeta);
+            const int status = coop_runs_lf<PACK16>(ix.data + gs + body_off, gbytes - body_off, desc_class(gmeta) == 2, member, offset,
+                                                    n0, o0, n1, o1, ok, next_node, next_offset);
+            if (status != COOP_DONE && member) serial = true;
+            todo &= ~__ballot(member);
+        }
+        if (serial) ok = serial_record_lf(ix, start, bytes, offset, next_node, next_offset);
+        if (active) {
+            active = ok;
+            node = next_node; offset = next_offset;
+        }
+    }
+    if (owner) {
+        a.head[k] = sink.head;
+        a.lengths[k] = sink.length();
+    }
 }
 
 // One wave per path: follow the block chain and copy it to its CSR row.
@@ -431,9 +550,35 @@ void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t s
     hipLaunchKernelGGL(k_record_stats, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_stats);
 }
 
-void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_sample_counts, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc);
+    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_sample_counts);
+}
+
+void launch_fill_samples(const DeviceIndex &ix, const uint32_t *d_sample_counts, const uint32_t *d_sbase, uint4 *d_samples, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_samples, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_sample_counts, d_sbase, d_samples);
+}
+
+// exclusive scan of the per-record sample counts into sbase (SAMPLE_NONE where the count is 0); returns the total
+__global__ void __launch_bounds__(256) k_mark_unsampled(const uint32_t *counts, uint32_t *sbase, uint64_t n) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec < n && counts[rec] == 0) sbase[rec] = SAMPLE_NONE;
+}
+
+size_t sample_scan_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), static_cast<int>(n));
+    return bytes;
+}
+
+void launch_sample_scan(const uint32_t *d_counts, uint32_t *d_sbase, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream) {
+    if (n == 0) return;
+    (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_sbase, static_cast<int>(n), stream);
+}
+
+void launch_mark_unsampled(const uint32_t *d_counts, uint32_t *d_sbase, uint64_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_mark_unsampled, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_sbase, n);
 }
 
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream) {
@@ -453,13 +598,13 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
     }
     const unsigned p = args.paths_per_wave ? args.paths_per_wave : WAVE;
     const dim3 grid(grid_for(args.n, p)), block(WAVE);
-    if (args.prof) {
-        if (args.pack16) hipLaunchKernelGGL((k_walk_coop<true, true>), grid, block, 0, stream, ix, args);
-        else hipLaunchKernelGGL((k_walk_coop<true, false>), grid, block, 0, stream, ix, args);
-    } else {
-        if (args.pack16) hipLaunchKernelGGL((k_walk_coop<false, true>), grid, block, 0, stream, ix, args);
-        else hipLaunchKernelGGL((k_walk_coop<false, false>), grid, block, 0, stream, ix, args);
+    if (args.mode == WALK_COOP) {
+        if (args.pack16) hipLaunchKernelGGL((k_walk_coop<true>), grid, block, 0, stream, ix, args);
+        else hipLaunchKernelGGL((k_walk_coop<false>), grid, block, 0, stream, ix, args);
+        return;
     }
+    if (args.prof) hipLaunchKernelGGL((k_walk_sampled<true>), grid, block, 0, stream, ix, args);
+    else hipLaunchKernelGGL((k_walk_sampled<false>), grid, block, 0, stream, ix, args);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

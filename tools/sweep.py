@@ -15,7 +15,7 @@ ap.add_argument("--sites", type=int, default=50000)
 ap.add_argument("--haplotypes", type=int, default=5000)
 ap.add_argument("--model", default="mosaic")
 ap.add_argument("--alleles", type=int, default=2)
-ap.add_argument("--configs", default="0:64:16,0:64:0,0:32:16,0:16:16,0:8:16,0:4:16,0:20:16,0:64:64,0:16:64,1:64:16")
+ap.add_argument("--configs", default="0:64:16,0:16:16,0:4:16,2:64:16,2:8:16,1:64:16")
 ap.add_argument("--reps", type=int, default=2)
 args = ap.parse_args()
 
