@@ -132,7 +132,7 @@ void upload(gbwt_hip_index &ix) {
     d.sample_shift = ix.sample_shift;
     {
         const uint64_t nr = std::max<uint64_t>(n_records, 1);
-        ix.desc.reserve(nr * 2 * sizeof(uint4));
+        ix.desc.reserve(nr * 4 * sizeof(uint4));
         ix.sbase.reserve(nr * sizeof(uint32_t));
         DeviceBuffer counts, scan_tmp;
         counts.reserve(nr * sizeof(uint32_t));
@@ -151,11 +151,12 @@ void upload(gbwt_hip_index &ix) {
             if (h.size / (uint64_t(1) << ix.sample_shift) + n_records >= 0xFFFFFFF0ull) throw InvalidData("index too large for 32-bit sample indices: raise GBWT_HIP_SAMPLE_SHIFT");
             launch_mark_unsampled(counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), n_records, nullptr);
         }
-        ix.samples.reserve(std::max<uint64_t>(n_samples, 1) * sizeof(uint4));
+        ix.samples.reserve(std::max<uint64_t>(n_samples, 1) * 2 * sizeof(uint4));
         d.sbase = ix.sbase.as<uint32_t>();
         d.samples = ix.samples.as<uint4>();
         d.n_samples = n_samples;
         if (n_samples > 0) launch_fill_samples(d, counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), ix.samples.as<uint4>(), nullptr);
+        launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
     }
@@ -391,7 +392,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             double gr = c[1] ? static_cast<double>(c[1]) : 1.0;
             (void)gr;
             fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu run-scans %llu | cycles/step (s_memtime, loads drained at each mark): "
-                            "push %.0f descriptor %.0f sample %.0f scan %.0f\n",
+                            "push %.0f fetch(desc+sample) %.0f (unused %.0f) scan %.0f\n",
                     (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st);
         }
         uint64_t total = 0;

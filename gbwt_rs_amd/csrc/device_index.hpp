@@ -9,23 +9,29 @@
 //   endmarker : record 0 fully decompressed at open (src/gbwt.rs:413-414), one (node, offset) per sequence
 //
 // Built on the device at open and read by the walk kernels:
-//   desc      : one 32-byte descriptor per record, two uint4 (A = desc[2 * rec], B = desc[2 * rec + 1]):
+//   desc      : one 64-byte descriptor per record, four uint4 (desc[4 * rec + 0..3]), fetched with four aligned
+//               dwordx4 loads that travel together:
 //                 A = {successor 0, offset 0, successor 1, offset 1}         decoded edge list (class 1 / 2 only)
 //                 B = {start (low 32 bits), length in bytes, meta, Record::len}
-//                 meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
-//                 class 1 / 2 = outdegree 1 / 2 with the edges in A and "body offset" = where the run stream starts
-//                 inside the record; class 0 = any other non-empty record (walked by the generic lane-serial code)
+//                     meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
+//                     class 1 / 2 = outdegree 1 / 2 with the edges in A and "body offset" = where the run stream
+//                     starts inside the record; class 0 = any other non-empty record (generic lane-serial decode)
+//                 C = {sample base of successor 0, sample base of successor 1, 0, 0}    (SAMPLE_NONE if unsampled)
+//                 D = the first 16 bytes of the run stream, so short records need no second load
 //               empty / None record : B.y = 0
 //               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 and a body that is exactly one run
 //                 (every node on a linear stretch of the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w,
-//                 so a step through it costs one descriptor load and one add.
-//   sbase     : per record, index of its first rank sample or SAMPLE_NONE
-//   samples   : rank samples ("superblocks") of the long class 1 / 2 records: sample k of a record describes the
-//               run that contains offset k << sample_shift: {byte position of that run relative to the record
-//               start, offsets before the run, value-0 offsets before the run, 0}.  A lane jumps to the sample of
-//               its offset and scans at most (1 << sample_shift) offsets worth of runs, so the cost of a step does
-//               not grow with the length of the record (the reference scans from the start of the record,
-//               src/bwt.rs:483-494).  Like simple-sds's rank/select supports these are rebuilt at load, never stored.
+//                 so a step through it costs one descriptor fetch and one add.
+//   sbase     : per record, index of its first rank sample or SAMPLE_NONE (needed where a walk starts; afterwards
+//               the sample base of the next record rides along in C of the current one)
+//   samples   : rank samples ("superblocks") of the long class 1 / 2 records, 32 bytes each (two uint4): sample k of
+//               a record describes the run that contains offset k << sample_shift:
+//                 S0 = {byte position of that run relative to the record start, offsets before the run,
+//                       value-0 offsets before the run, 0},  S1 = 16 bytes of the run stream from that run on.
+//               A lane fetches the descriptor and the sample of its offset in ONE round trip and usually finishes
+//               the scan from S1 in registers, so a step costs the same whatever the length of the record (the
+//               reference scans from the start of the record, src/bwt.rs:483-494).  Like simple-sds's rank/select
+//               supports, descriptors and samples are rebuilt at load, never stored.
 #pragma once
 
 #include <cstdint>
@@ -41,9 +47,9 @@ struct DeviceIndex {
     const uint32_t *starts32;  // exactly one of starts32 / starts64 is non-null
     const uint64_t *starts64;
     const uint2 *endmarker;    // .x = node, .y = offset
-    const uint4 *desc;         // 2 * n_records entries
+    const uint4 *desc;         // 4 * n_records entries
     const uint32_t *sbase;     // n_records entries
-    const uint4 *samples;      // n_samples entries
+    const uint4 *samples;      // 2 * n_samples entries
     uint64_t data_len;
     uint64_t n_records;
     uint64_t n_sequences;      // header.sequences

@@ -32,13 +32,20 @@ __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *
     atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
 }
 
-// One lane per record: the 32-byte descriptor (device_index.hpp) and the number of rank samples the record gets.
+// 16 bytes of the stream at data[pos..], zero-filled past `limit`.
+__device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t pos, uint64_t limit) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16 && pos + k < limit; k++) w[k >> 2] |= static_cast<uint32_t>(data[pos + k]) << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One lane per record: descriptor parts A, B, D (device_index.hpp) and the number of rank samples the record gets.
 __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *sample_counts) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
-    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
+    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), D = make_uint4(0, 0, 0, 0);
     uint32_t n_samples = 0;
     if (limit > start) {
         ByteCursor c(ix.data, start, limit);
@@ -53,8 +60,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                 if (good && sigma == 2) good = c.varint(d1) && c.varint(o1);
                 const uint64_t body = c.pos - start;
                 if (good && body <= 0xFFFF && n0 + d1 <= 0xFFFFFFFFull && o0 <= 0xFFFFFFFFull && o1 <= 0xFFFFFFFFull) {
-                    // Record::len and the shape of the run stream
-                    RunDecoder rd(sigma);
+                    RunDecoder rd(sigma);  // Record::len and the shape of the run stream
                     uint64_t total = 0, runs = 0, value, len;
                     while (rd.next(c, value, len)) { total += len; runs++; }
                     if (total < 0xFFFFFFFFull) {
@@ -63,6 +69,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                         A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
                         B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
                         B.w = static_cast<uint32_t>(total);
+                        D = stream_bytes16(ix.data, start + body, limit);
                         if (sigma == 1 && runs == 1 && c.at_end()) B.y = DESC_UNARY;
                         else if (total > (uint64_t(1) << ix.sample_shift)) n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);
                     }
@@ -77,9 +84,24 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
             }
         }
     }
-    desc[2 * rec] = A;
-    desc[2 * rec + 1] = B;
+    desc[4 * rec] = A;
+    desc[4 * rec + 1] = B;
+    desc[4 * rec + 3] = D;
     sample_counts[rec] = n_samples;
+}
+
+// One lane per record: descriptor part C = the sample bases of the successors (so that a walk arriving at a
+// record can fetch its rank sample together with the descriptor).
+__global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *desc) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint4 A = desc[4 * rec], B = desc[4 * rec + 1];
+    uint4 C = make_uint4(SAMPLE_NONE, SAMPLE_NONE, 0, 0);
+    if (B.y != 0 && desc_class(B.z) != 0) {
+        if (A.x >= ix.first_node && A.x - ix.alphabet_offset < ix.n_records) C.x = ix.sbase[A.x - ix.alphabet_offset];
+        if (desc_class(B.z) == 2 && A.z >= ix.first_node && A.z - ix.alphabet_offset < ix.n_records) C.y = ix.sbase[A.z - ix.alphabet_offset];
+    }
+    desc[4 * rec + 2] = C;
 }
 
 // One lane per sampled record: sample k = the run containing offset k << sample_shift (device_index.hpp).
@@ -88,19 +110,20 @@ __global__ void __launch_bounds__(256) k_fill_samples(DeviceIndex ix, const uint
     if (rec >= ix.n_records) return;
     const uint32_t count = sample_counts[rec];
     if (count == 0) return;
-    const uint4 B = ix.desc[2 * rec + 1];
-    const uint64_t start = desc_start(B.x, B.z);
-    ByteCursor c(ix.data, start + desc_body_offset(B.z), start + B.y);
+    const uint4 B = ix.desc[4 * rec + 1];
+    const uint64_t start = desc_start(B.x, B.z), limit = start + B.y;
+    ByteCursor c(ix.data, start + desc_body_offset(B.z), limit);
     RunDecoder rd(desc_class(B.z));
-    uint4 *out = samples + sbase[rec];
+    uint4 *out = samples + 2 * static_cast<uint64_t>(sbase[rec]);
     uint64_t cum = 0, c0 = 0, value, len;
     uint32_t k = 0;
     while (k < count) {
-        const uint64_t run_pos = c.pos - start;
+        const uint64_t run_pos = c.pos;
         if (!rd.next(c, value, len)) break;
-        while (k < count && (static_cast<uint64_t>(k) << ix.sample_shift) < cum + len) {
-            out[k] = make_uint4(static_cast<uint32_t>(run_pos), static_cast<uint32_t>(cum), static_cast<uint32_t>(c0), 0u);
-            k++;
+        if ((static_cast<uint64_t>(k) << ix.sample_shift) < cum + len) {
+            const uint4 S0 = make_uint4(static_cast<uint32_t>(run_pos - start), static_cast<uint32_t>(cum), static_cast<uint32_t>(c0), 0u);
+            const uint4 S1 = stream_bytes16(ix.data, run_pos, limit);
+            while (k < count && (static_cast<uint64_t>(k) << ix.sample_shift) < cum + len) { out[2 * k] = S0; out[2 * k + 1] = S1; k++; }
         }
         cum += len;
         if (value == 0) c0 += len;
@@ -155,30 +178,59 @@ __global__ void k_endmarker_decompress(DeviceIndex ix, uint2 *out, uint64_t n_ou
 // to a chain of 1 KiB blocks drawn from a shared pool; a second, bandwidth-bound kernel lays the
 // chains out as CSR once the lengths (and their prefix sums) exist.
 
-// Appends `node` to the lane's block chain (shared by both walk kernels).  Returns false on pool overflow.
+// Output sink of one lane: the nodes a sequence visits go to a chain of 1 KiB pool blocks.  Stores are staged in
+// LDS (SINK_STAGE entries per lane, entry-major so a wave's writes hit 64 distinct banks) and flushed as 64-byte
+// pieces: on gfx9 loads and stores share the in-order vmcnt counter, so a store issued every step would put its
+// ~700-cycle acknowledgement on the critical path of the next dependent load.
+constexpr uint32_t SINK_STAGE = 16;
+static_assert(POOL_BLOCK_NODES % SINK_STAGE == 0, "a block must hold a whole number of flushes");
+
 struct PathSink {
+    uint32_t *stage;             // this lane's column of the wave's LDS staging buffer (stride WAVE)
     uint32_t *wp = nullptr;      // next slot in the current block
     uint32_t left = 0;           // free slots in the current block
+    uint32_t staged = 0;         // entries waiting in LDS
     uint32_t cur = POOL_NONE, head = POOL_NONE, blocks = 0;
-    __device__ __forceinline__ bool push(const WalkArgs &a, uint32_t node) {
+    bool overflow = false;
+    __device__ __forceinline__ explicit PathSink(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    __device__ __forceinline__ void flush(const WalkArgs &a) {
+        if (staged == 0 || overflow) { staged = 0; return; }
         if (left == 0) {
             uint32_t nb = atomicAdd(a.counter, 1u);
-            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); return false; }
+            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); overflow = true; staged = 0; return; }
             a.next[nb] = POOL_NONE;
             if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
             cur = nb; blocks++;
             wp = a.pool + static_cast<uint64_t>(nb) * POOL_BLOCK_NODES;
             left = POOL_BLOCK_NODES;
         }
-        if (!a.debug_nostore) *wp = node;
-        wp++;
-        left--;
-        return true;
+        if (staged == SINK_STAGE) {
+            uint4 *dst = reinterpret_cast<uint4 *>(wp);
+#pragma unroll
+            for (uint32_t q = 0; q < SINK_STAGE / 4; q++)
+                dst[q] = make_uint4(stage[(4 * q) * WAVE], stage[(4 * q + 1) * WAVE], stage[(4 * q + 2) * WAVE], stage[(4 * q + 3) * WAVE]);
+        } else {
+            for (uint32_t e = 0; e < staged; e++) wp[e] = stage[e * WAVE];
+        }
+        wp += staged; left -= staged; staged = 0;
     }
-    __device__ __forceinline__ uint64_t length() const { return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left; }
+    // returns false once the pool has overflowed (the host grows the pool and walks again)
+    __device__ __forceinline__ bool push(const WalkArgs &a, uint32_t node) {
+        if (a.debug_nostore) { staged++; if (staged == SINK_STAGE) { left = left ? left : POOL_BLOCK_NODES; left -= SINK_STAGE; blocks += left == POOL_BLOCK_NODES - SINK_STAGE; staged = 0; } return true; }
+        stage[staged * WAVE] = node;
+        staged++;
+        if (staged == SINK_STAGE) flush(a);
+        return !overflow;
+    }
+    __device__ __forceinline__ uint64_t finish(const WalkArgs &a) {
+        flush(a);
+        return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left;
+    }
 };
 
 __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
+    __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
+    PathSink sink(sink_lds, threadIdx.x);
     uint64_t k = blockIdx.x * static_cast<uint64_t>(WAVE) + threadIdx.x;
     if (k >= a.n) return;
     const uint64_t id = a.seq_ids[k];
@@ -189,35 +241,37 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
         node = e.x; offset = e.y;
         valid = node != 0;
     }
-    PathSink sink;
     while (valid) {
         if (!sink.push(a, static_cast<uint32_t>(node))) break;
         uint64_t nn, no;
         valid = gbwt_forward(ix, node, offset, nn, no);
         node = nn; offset = no;
     }
+    a.lengths[k] = sink.finish(a);
     a.head[k] = sink.head;
-    a.lengths[k] = sink.length();
 }
 
-// Run scan of a class 1 / 2 record by one lane: starting at byte `pos` with `cum` offsets and `c0` value-0 offsets
-// already passed, finds the run containing offset i (RLEIter::next src/support.rs:1413-1430 for sigma <= 2, the
-// loop of Record::lf src/bwt.rs:483-494).  Returns 1 on a hit, 0 when the stream ends first (lf -> None) and
-// -1 when a run-length varint is too long for the 4-byte fast decoder (caller falls back to the generic code).
-__device__ __forceinline__ int scan_runs(const uint8_t *data, uint64_t pos, uint64_t limit, bool two, uint32_t cum, uint32_t c0,
+// Run scan of a class 1 / 2 record by one lane (RLEIter::next src/support.rs:1413-1430 for sigma <= 2, the loop of
+// Record::lf src/bwt.rs:483-494).  The first 16 stream bytes are already in registers (`inl`, from the descriptor or
+// the rank sample); more are fetched from data[pos + 16 ...] only if the run holding offset i lies beyond them.
+// Entry: `cum` offsets and `c0` value-0 offsets precede the byte at `pos`.  Returns 1 on a hit, 0 when the stream
+// ends first (lf -> None), -1 when a run-length varint is too long for the 4-byte decoder (generic fallback).
+__device__ __forceinline__ int scan_runs(const uint8_t *data, uint64_t pos, uint64_t limit, uint4 inl, bool two, uint32_t cum, uint32_t c0,
                                          uint32_t i, uint32_t &value, uint32_t &rank, uint32_t &delta) {
     const uint32_t threshold = two ? 128u : 256u, saturated = two ? 254u : 255u;
-    uint64_t w = 0;
-    uint32_t avail = 0;
+    uint64_t lo = (static_cast<uint64_t>(inl.y) << 32) | inl.x, hi = (static_cast<uint64_t>(inl.w) << 32) | inl.z;
+    uint32_t avail = 16;
     for (;;) {
         if (pos >= limit) return 0;
-        if (avail < 5) { w = load_u64_unaligned(data + pos); avail = 8; }  // a run is at most 1 + 4 bytes here
-        const uint32_t b = static_cast<uint32_t>(w) & 0xFFu;
+        if (__builtin_expect(avail < 5, 0)) {  // a run is at most 1 + 4 bytes here; refill 8 bytes from memory
+            lo = load_u64_unaligned(data + pos); hi = 0; avail = 8;
+        }
+        const uint32_t b = static_cast<uint32_t>(lo) & 0xFFu;
         const uint32_t v = two ? (b & 1u) : 0u;
         uint32_t len = (two ? (b >> 1) : b) + 1, nb = 1;
         if (b >= saturated) {
             uint32_t n;
-            const uint32_t extra = window_varint32(static_cast<uint32_t>(w >> 8), n);
+            const uint32_t extra = window_varint32(static_cast<uint32_t>(lo >> 8), n);
             if (n == 0) return -1;
             len = threshold + extra; nb = 1 + n;
         }
@@ -229,12 +283,15 @@ __device__ __forceinline__ int scan_runs(const uint8_t *data, uint64_t pos, uint
         }
         cum += len;
         if (!v) c0 += len;
-        pos += nb; w >>= 8 * nb; avail -= nb;
+        pos += nb; avail -= nb;
+        const uint32_t sh = 8 * nb;  // 8 .. 40
+        lo = (lo >> sh) | (hi << (64 - sh));
+        hi >>= sh;
     }
 }
 
 // Generic lane-serial Record::lf for the record of the current descriptor (class 0, or fallback).
-__device__ __forceinline__ bool serial_record_lf(const DeviceIndex &ix, uint64_t start, uint32_t bytes, uint32_t offset,
+__device__ __attribute__((noinline)) bool serial_record_lf(const DeviceIndex &ix, uint64_t start, uint32_t bytes, uint32_t offset,
                                                  uint32_t &next_node, uint32_t &next_offset) {
     ByteCursor c(ix.data, start, start + bytes);
     uint64_t sigma, nn, no;
@@ -245,16 +302,19 @@ __device__ __forceinline__ bool serial_record_lf(const DeviceIndex &ix, uint64_t
     return false;
 }
 
-// Default walk: one lane per sequence, no cross-lane work.  Per step: descriptor (two 16-byte loads + sbase),
-// for long records the rank sample of the current offset, then a short run scan.
+// Default walk: one lane per sequence, no cross-lane work.  A step is one round trip to memory: the 64-byte
+// descriptor of the record and -- for long records, whose sample base arrived with the previous step -- the
+// 32-byte rank sample of the current offset travel together; the run scan then works on registers.
 template <bool PROF>
 __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs a) {
-    uint64_t t_push = 0, t_desc = 0, t_sample = 0, t_scan = 0, n_steps = 0, n_scans = 0, t0 = 0, t1 = 0;
+    uint64_t t_push = 0, t_fetch = 0, t_scan = 0, n_steps = 0, n_scans = 0, t0 = 0, t1 = 0;
 #define PROF_MARK(acc) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } } while (0)
+    __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
     const uint32_t lane = threadIdx.x;
+    PathSink sink(sink_lds, lane);
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
-    uint32_t node = 0, offset = 0;
+    uint32_t node = 0, offset = 0, sb = SAMPLE_NONE;
     bool active = false;
     if (owner) {
         const uint64_t id = a.seq_ids[k];
@@ -262,68 +322,66 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
             uint2 e = ix.endmarker[id];
             node = e.x; offset = e.y;
             active = node != 0;
+            if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) sb = ix.sbase[node - ix.alphabet_offset];
         }
     }
-    PathSink sink;
     if (PROF) t0 = __builtin_amdgcn_s_memtime();
     while (__ballot(active) != 0) {
         // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
         if (active && !sink.push(a, node)) active = false;
         PROF_MARK(t_push);
-        bool ok = false;
-        uint32_t next_node = 0, next_offset = 0;
-        uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
-        uint32_t sb = SAMPLE_NONE;
         // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130) via the descriptor
-        if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
-            const uint64_t rec = node - ix.alphabet_offset;
-            A = ix.desc[2 * rec]; B = ix.desc[2 * rec + 1]; sb = ix.sbase[rec];
-        }
-        PROF_MARK(t_desc);
-        const uint32_t cls = desc_class(B.z);
-        int state = 0;  // 0 = resolved, 1 = scan runs, 2 = generic lane-serial decode
-        uint64_t start = 0, pos = 0;
-        uint32_t cum = 0, c0 = 0;
-        if (B.y == DESC_UNARY) {                    // one run, one successor: lf(i) = (A.x, A.y + i) for i < len
-            ok = offset < B.w && A.x != 0;
-            next_node = A.x; next_offset = A.y + offset;
-        } else if (B.y != 0) {
-            start = desc_start(B.x, B.z);
-            if (cls == 0) state = 2;
-            else if (offset < B.w) {                // i >= Record::len -> None
-                state = 1;
-                pos = start + desc_body_offset(B.z);
-                if (sb != SAMPLE_NONE) {
-                    const uint4 S = ix.samples[sb + (offset >> ix.sample_shift)];
-                    pos = start + S.x; cum = S.y; c0 = S.z;
-                }
+        const bool in_range = active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records;
+        uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), C = make_uint4(SAMPLE_NONE, SAMPLE_NONE, 0, 0), D = make_uint4(0, 0, 0, 0);
+        uint4 S0 = make_uint4(0, 0, 0, 0), S1 = make_uint4(0, 0, 0, 0);
+        if (in_range) {
+            const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(node - ix.alphabet_offset);
+            A = d[0]; B = d[1]; C = d[2]; D = d[3];
+            if (sb != SAMPLE_NONE) {
+                const uint4 *sp = ix.samples + 2 * (static_cast<uint64_t>(sb) + (offset >> ix.sample_shift));
+                S0 = sp[0]; S1 = sp[1];
             }
         }
-        PROF_MARK(t_sample);
-        if (state == 1) {
+        PROF_MARK(t_fetch);
+        bool ok = false;
+        uint32_t next_node = 0, next_offset = 0, next_sb = SAMPLE_NONE;
+        if (B.y == DESC_UNARY) {                    // one run, one successor: lf(i) = (A.x, A.y + i) for i < len
+            ok = offset < B.w && A.x != 0;
+            next_node = A.x; next_offset = A.y + offset; next_sb = C.x;
+        } else if (B.y != 0) {
+            const uint64_t start = desc_start(B.x, B.z);
+            const uint32_t cls = desc_class(B.z);
+            int r = -1;
             uint32_t value = 0, rank = 0, delta = 0;
-            const int r = scan_runs(ix.data, pos, start + B.y, cls == 2, cum, c0, offset, value, rank, delta);
+            if (cls != 0) {
+                if (PROF) n_scans++;
+                if (offset >= B.w) r = 0;           // i >= Record::len -> None
+                else if (sb != SAMPLE_NONE) r = scan_runs(ix.data, start + S0.x, start + B.y, S1, cls == 2, S0.y, S0.z, offset, value, rank, delta);
+                else r = scan_runs(ix.data, start + desc_body_offset(B.z), start + B.y, D, cls == 2, 0, 0, offset, value, rank, delta);
+            }
             if (r == 1) {
                 next_node = value ? A.z : A.x;
                 next_offset = (value ? A.w : A.y) + rank + delta;
-                ok = next_node != 0;             // ENDMARKER successor: the sequence ends
-            } else if (r < 0) state = 2;
-            if (PROF) n_scans++;
+                next_sb = value ? C.y : C.x;
+                ok = next_node != 0;                 // ENDMARKER successor: the sequence ends
+            } else if (r < 0) {                      // class 0 or an over-long varint: generic decode, then look the sample base up
+                ok = serial_record_lf(ix, start, B.y, offset, next_node, next_offset);
+                if (ok && next_node >= ix.first_node && next_node - ix.alphabet_offset < ix.n_records) next_sb = ix.sbase[next_node - ix.alphabet_offset];
+            }
         }
-        if (state == 2) ok = serial_record_lf(ix, start, B.y, offset, next_node, next_offset);
         PROF_MARK(t_scan);
         if (PROF) n_steps++;
         if (active) {
             active = ok;
-            node = next_node; offset = next_offset;
+            node = next_node; offset = next_offset; sb = next_sb;
         }
     }
     if (owner) {
+        a.lengths[k] = sink.finish(a);
         a.head[k] = sink.head;
-        a.lengths[k] = sink.length();
     }
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0) {
-        a.prof[0] = n_steps; a.prof[1] = n_scans; a.prof[2] = t_push; a.prof[3] = t_desc; a.prof[4] = t_sample; a.prof[5] = t_scan;
+        a.prof[0] = n_steps; a.prof[1] = n_scans; a.prof[2] = t_push; a.prof[3] = t_fetch; a.prof[4] = 0; a.prof[5] = t_scan;
     }
 #undef PROF_MARK
 }
@@ -346,7 +404,8 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
             active = node != 0;
         }
     }
-    PathSink sink;
+    __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
+    PathSink sink(sink_lds, lane);
     while (__ballot(active) != 0) {
         if (active && !sink.push(a, node)) active = false;
         uint64_t start = 0;
@@ -355,7 +414,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         uint32_t next_node = 0, next_offset = 0;
         if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
             const uint64_t rec = node - ix.alphabet_offset;
-            const uint4 A = ix.desc[2 * rec], B = ix.desc[2 * rec + 1];
+            const uint4 A = ix.desc[4 * rec], B = ix.desc[4 * rec + 1];
             if (B.y == DESC_UNARY) {
                 ok = offset < B.w && A.x != 0;
                 next_node = A.x; next_offset = A.y + offset;
@@ -387,8 +446,8 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         }
     }
     if (owner) {
+        a.lengths[k] = sink.finish(a);
         a.head[k] = sink.head;
-        a.lengths[k] = sink.length();
     }
 }
 
@@ -553,6 +612,11 @@ void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t s
 void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_sample_counts, hipStream_t stream) {
     if (ix.n_records == 0) return;
     hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_sample_counts);
+}
+
+void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc);
 }
 
 void launch_fill_samples(const DeviceIndex &ix, const uint32_t *d_sample_counts, const uint32_t *d_sbase, uint4 *d_samples, hipStream_t stream) {
