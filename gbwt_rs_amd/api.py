@@ -198,7 +198,7 @@ class GBWT:
         check(self._L.gbwt_hip_last_kernel_ms(self._ws, C.byref(walk), C.byref(total)))
         return walk.value, total.value
 
-    def tune(self, walk_mode=0, paths_per_wave=64, small_record=16):
+    def tune(self, walk_mode=0, paths_per_wave=0, small_record=16):
         """Kernel tuning knobs of gbwt_hip_workspace_tune (results never depend on them)."""
         check(self._L.gbwt_hip_workspace_tune(self._ws, walk_mode, paths_per_wave, small_record))
 

@@ -76,7 +76,7 @@ struct gbwt_hip_workspace {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
-    uint32_t walk_mode = WALK_SAMPLED, paths_per_wave = 64, small_record = 16;
+    uint32_t walk_mode = WALK_SAMPLED, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
     bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
     DeviceBuffer prof;
     DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
@@ -317,7 +317,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
     if (const char *v = std::getenv("GBWT_HIP_PROFILE")) ws->profile = std::atoi(v) != 0;
     if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ws->walk_mode = static_cast<uint32_t>(m); }
-    if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 1 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
+    if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 0 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
     if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
     *out = ws;
     return GBWT_HIP_OK;
@@ -326,7 +326,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws) { delete ws; }
 
 gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record) {
-    if (!ws || walk_mode > WALK_COOP || paths_per_wave < 1 || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
+    if (!ws || walk_mode > WALK_COOP || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
     ws->walk_mode = walk_mode; ws->paths_per_wave = paths_per_wave; ws->small_record = small_record;
     return GBWT_HIP_OK;
 }
@@ -364,7 +364,11 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.pool = ws->pool.as<uint32_t>(); a.next = ws->next.as<uint32_t>(); a.pool_blocks = static_cast<uint32_t>(pool_blocks);
             a.counter = ws->counters.as<uint32_t>(); a.flags = ws->counters.as<uint32_t>() + 1;
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
-            a.mode = ws->walk_mode; a.paths_per_wave = ws->paths_per_wave; a.small_record = ws->small_record;
+            a.mode = ws->walk_mode; a.small_record = ws->small_record;
+            // automatic: the walk is latency-bound, so spread the sequences over about one wavefront per SIMD
+            // (256 CUs x 4); fewer owners per wave also means less divergence in the run scan
+            a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
+                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(4, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
             a.debug_nostore = std::getenv("GBWT_HIP_DEBUG_NOSTORE") ? 1u : 0u;
             a.prof = nullptr;

@@ -60,28 +60,31 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                 if (good && sigma == 2) good = c.varint(d1) && c.varint(o1);
                 const uint64_t body = c.pos - start;
                 if (good && body <= 0xFFFF && n0 + d1 <= 0xFFFFFFFFull && o0 <= 0xFFFFFFFFull && o1 <= 0xFFFFFFFFull) {
-                    RunDecoder rd(sigma);  // Record::len and the shape of the run stream
+                    // Record::len and the shape of the run stream.  The walk's scanner trusts class 1 / 2 streams: they
+                    // must parse to the last byte and every run must fit in 1 + 4 bytes (length < 2^28 + threshold).
+                    RunDecoder rd(sigma);
                     uint64_t total = 0, runs = 0, value, len;
-                    while (rd.next(c, value, len)) { total += len; runs++; }
-                    if (total < 0xFFFFFFFFull) {
+                    bool lean = true;
+                    for (;;) {
+                        const uint64_t before = c.pos;
+                        if (!rd.next(c, value, len)) break;
+                        if (c.pos - before > 5) lean = false;
+                        total += len; runs++;
+                    }
+                    if (!c.at_end() || runs == 0) lean = false;
+                    if (lean && total < 0xFFFFFFFFull) {
                         classed = true;
                         A.x = static_cast<uint32_t>(n0); A.y = static_cast<uint32_t>(o0);
                         A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
                         B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
                         B.w = static_cast<uint32_t>(total);
                         D = stream_bytes16(ix.data, start + body, limit);
-                        if (sigma == 1 && runs == 1 && c.at_end()) B.y = DESC_UNARY;
+                        if (sigma == 1 && runs == 1) B.y = DESC_UNARY;
                         else if (total > (uint64_t(1) << ix.sample_shift)) n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);
                     }
                 }
             }
-            if (!classed) {  // class 0: Record::len for the statistics only
-                ByteCursor c2(ix.data, start, limit);
-                uint64_t s2 = 0;
-                c2.varint(s2);
-                uint64_t total = record_len(c2, s2);
-                B.w = total < 0xFFFFFFFFull ? static_cast<uint32_t>(total) : 0xFFFFFFFFu;
-            }
+            if (!classed) { A = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0; }  // class 0: B.w = 0 keeps the fast path out
         }
     }
     desc[4 * rec] = A;
@@ -251,55 +254,56 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
     a.head[k] = sink.head;
 }
 
+// Forces a loaded value to be live in VGPRs at this point (keeps the compiler from sinking the load).
+__device__ __forceinline__ void pin(uint4 &q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
+
 // Run scan of a class 1 / 2 record by one lane (RLEIter::next src/support.rs:1413-1430 for sigma <= 2, the loop of
-// Record::lf src/bwt.rs:483-494).  The first 16 stream bytes are already in registers (`inl`, from the descriptor or
-// the rank sample); more are fetched from data[pos + 16 ...] only if the run holding offset i lies beyond them.
-// Entry: `cum` offsets and `c0` value-0 offsets precede the byte at `pos`.  Returns 1 on a hit, 0 when the stream
-// ends first (lf -> None), -1 when a run-length varint is too long for the 4-byte decoder (generic fallback).
-__device__ __forceinline__ int scan_runs(const uint8_t *data, uint64_t pos, uint64_t limit, uint4 inl, bool two, uint32_t cum, uint32_t c0,
-                                         uint32_t i, uint32_t &value, uint32_t &rank, uint32_t &delta) {
+// Record::lf src/bwt.rs:483-494).  The 16 stream bytes starting at byte `rel` of the record are already in registers
+// (w0..w3: from the descriptor or the rank sample) with `cum` offsets and `c0` value-0 offsets before them.  The
+// caller guarantees i < Record::len and k_build_desc has checked that the stream is well formed, so the scan
+// always ends in a hit and needs no bounds checks.  Output: value of the run, rank of i among that value, i.e.
+// lf(i) = (successor(value), offset(value) + rank).
+__device__ __forceinline__ void scan_runs(const uint8_t *record, uint32_t rel, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, bool two,
+                                          uint32_t cum, uint32_t c0, uint32_t i, uint32_t &value, uint32_t &rank) {
     const uint32_t threshold = two ? 128u : 256u, saturated = two ? 254u : 255u;
-    uint64_t lo = (static_cast<uint64_t>(inl.y) << 32) | inl.x, hi = (static_cast<uint64_t>(inl.w) << 32) | inl.z;
-    uint32_t avail = 16;
+    uint32_t used = 0;
     for (;;) {
-        if (pos >= limit) return 0;
-        if (__builtin_expect(avail < 5, 0)) {  // a run is at most 1 + 4 bytes here; refill 8 bytes from memory
-            lo = load_u64_unaligned(data + pos); hi = 0; avail = 8;
+        if (__builtin_expect(used > 11, 0)) {  // fewer than 5 bytes left in the window: fetch the next 16
+            rel += used; used = 0;
+            uint4 q;
+            __builtin_memcpy(&q, record + rel, 16);
+            w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w;
         }
-        const uint32_t b = static_cast<uint32_t>(lo) & 0xFFu;
+        const uint32_t b = w0 & 0xFFu;
         const uint32_t v = two ? (b & 1u) : 0u;
-        uint32_t len = (two ? (b >> 1) : b) + 1, nb = 1;
-        if (b >= saturated) {
+        uint32_t len = (two ? (b >> 1) : b) + 1;
+        if (__builtin_expect(b >= saturated, 0)) {  // long run: length extension in the next 1-4 bytes
             uint32_t n;
-            const uint32_t extra = window_varint32(static_cast<uint32_t>(lo >> 8), n);
-            if (n == 0) return -1;
-            len = threshold + extra; nb = 1 + n;
+            len = threshold + window_varint32(__builtin_amdgcn_alignbit(w1, w0, 8), n);
+            const uint32_t nb = 1 + n;
+            if (cum + len > i) { value = v; rank = (v ? cum - c0 : c0) + (i - cum); return; }
+            cum += len; c0 += v ? 0u : len; used += nb;
+            const uint32_t sh = 8 * nb;  // 16 .. 40: shift the 128-bit window down by nb bytes
+            uint64_t lo = (static_cast<uint64_t>(w1) << 32) | w0, hi = (static_cast<uint64_t>(w3) << 32) | w2;
+            lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh;
+            w0 = static_cast<uint32_t>(lo); w1 = static_cast<uint32_t>(lo >> 32); w2 = static_cast<uint32_t>(hi); w3 = static_cast<uint32_t>(hi >> 32);
+            continue;
         }
-        if (pos + nb > limit) return 0;  // run cut off by the end of the record
-        if (cum + len > i) {
-            value = v; delta = i - cum;
-            rank = v ? (cum - c0) : c0;
-            return 1;
-        }
-        cum += len;
-        if (!v) c0 += len;
-        pos += nb; avail -= nb;
-        const uint32_t sh = 8 * nb;  // 8 .. 40
-        lo = (lo >> sh) | (hi << (64 - sh));
-        hi >>= sh;
+        if (cum + len > i) { value = v; rank = (v ? cum - c0 : c0) + (i - cum); return; }
+        cum += len; c0 += v ? 0u : len; used += 1;
+        w0 = __builtin_amdgcn_alignbit(w1, w0, 8); w1 = __builtin_amdgcn_alignbit(w2, w1, 8);
+        w2 = __builtin_amdgcn_alignbit(w3, w2, 8); w3 >>= 8;
     }
 }
 
-// Generic lane-serial Record::lf for the record of the current descriptor (class 0, or fallback).
-__device__ __attribute__((noinline)) bool serial_record_lf(const DeviceIndex &ix, uint64_t start, uint32_t bytes, uint32_t offset,
-                                                 uint32_t &next_node, uint32_t &next_offset) {
-    ByteCursor c(ix.data, start, start + bytes);
+// Generic lane-serial Record::lf on the record bytes [start, start + bytes) (class 0 records, fallbacks).  Out of
+// line and by-value only, so that the hot loops stay small and nothing is forced into scratch.  Returns
+// (node, offset); node == 0 <=> None.
+__device__ __attribute__((noinline)) uint2 serial_record_lf(const uint8_t *data, uint64_t start, uint32_t bytes, uint32_t offset) {
+    ByteCursor c(data, start, start + bytes);
     uint64_t sigma, nn, no;
-    if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) {
-        next_node = static_cast<uint32_t>(nn); next_offset = static_cast<uint32_t>(no);
-        return true;
-    }
-    return false;
+    if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) return make_uint2(static_cast<uint32_t>(nn), static_cast<uint32_t>(no));
+    return make_uint2(0u, 0u);
 }
 
 // Default walk: one lane per sequence, no cross-lane work.  A step is one round trip to memory: the 64-byte
@@ -314,6 +318,8 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
     PathSink sink(sink_lds, lane);
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
+    const uint32_t n_rec = static_cast<uint32_t>(ix.n_records), shift = ix.sample_shift;
+    // state of the walk: record id (node - alphabet_offset; >= n_rec when there is no record), offset, sample base
     uint32_t node = 0, offset = 0, sb = SAMPLE_NONE;
     bool active = false;
     if (owner) {
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
             uint2 e = ix.endmarker[id];
             node = e.x; offset = e.y;
             active = node != 0;
-            if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) sb = ix.sbase[node - ix.alphabet_offset];
+            if (active && node >= ix.first_node && node - ix.alphabet_offset < n_rec) sb = ix.sbase[node - ix.alphabet_offset];
         }
     }
     if (PROF) t0 = __builtin_amdgcn_s_memtime();
@@ -330,51 +336,48 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
         // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
         if (active && !sink.push(a, node)) active = false;
         PROF_MARK(t_push);
-        // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130) via the descriptor
-        const bool in_range = active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records;
-        uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), C = make_uint4(SAMPLE_NONE, SAMPLE_NONE, 0, 0), D = make_uint4(0, 0, 0, 0);
-        uint4 S0 = make_uint4(0, 0, 0, 0), S1 = make_uint4(0, 0, 0, 0);
-        if (in_range) {
-            const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(node - ix.alphabet_offset);
-            A = d[0]; B = d[1]; C = d[2]; D = d[3];
-            if (sb != SAMPLE_NONE) {
-                const uint4 *sp = ix.samples + 2 * (static_cast<uint64_t>(sb) + (offset >> ix.sample_shift));
-                S0 = sp[0]; S1 = sp[1];
-            }
-        }
+        // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130): descriptor 0 (the endmarker,
+        // never a forward() target) stands in for "no such record" so that the loads need no branch
+        uint32_t rec = node - ix.alphabet_offset;
+        const bool in_range = active && node >= ix.first_node && rec < n_rec;
+        rec = in_range ? rec : 0u;
+        const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(rec);
+        const uint32_t sidx = sb == SAMPLE_NONE ? 0u : sb + (offset >> shift);
+        const uint4 *sp = ix.samples + 2 * static_cast<uint64_t>(sidx);
+        uint4 A = d[0], B = d[1], C = d[2], D = d[3], S0 = sp[0], S1 = sp[1];
+        // all six loads are issued back to back and waited for together: without the pins the compiler sinks some
+        // of them into the branches below, which turns one round trip into two or three dependent ones
+        pin(A); pin(B); pin(C); pin(D); pin(S0); pin(S1);
         PROF_MARK(t_fetch);
         bool ok = false;
         uint32_t next_node = 0, next_offset = 0, next_sb = SAMPLE_NONE;
-        if (B.y == DESC_UNARY) {                    // one run, one successor: lf(i) = (A.x, A.y + i) for i < len
-            ok = offset < B.w && A.x != 0;
-            next_node = A.x; next_offset = A.y + offset; next_sb = C.x;
-        } else if (B.y != 0) {
-            const uint64_t start = desc_start(B.x, B.z);
-            const uint32_t cls = desc_class(B.z);
-            int r = -1;
-            uint32_t value = 0, rank = 0, delta = 0;
-            if (cls != 0) {
+        if (in_range && offset < B.w) {             // i >= Record::len -> None (B.w = 0 for class 0: handled below)
+            if (B.y == DESC_UNARY) {                // one run, one successor: lf(i) = (A.x, A.y + i)
+                next_node = A.x; next_offset = A.y + offset; next_sb = C.x;
+            } else {
                 if (PROF) n_scans++;
-                if (offset >= B.w) r = 0;           // i >= Record::len -> None
-                else if (sb != SAMPLE_NONE) r = scan_runs(ix.data, start + S0.x, start + B.y, S1, cls == 2, S0.y, S0.z, offset, value, rank, delta);
-                else r = scan_runs(ix.data, start + desc_body_offset(B.z), start + B.y, D, cls == 2, 0, 0, offset, value, rank, delta);
-            }
-            if (r == 1) {
+                const bool sampled = sb != SAMPLE_NONE, two = desc_class(B.z) == 2;
+                uint32_t value, rank;
+                scan_runs(ix.data + desc_start(B.x, B.z), sampled ? S0.x : desc_body_offset(B.z),
+                          sampled ? S1.x : D.x, sampled ? S1.y : D.y, sampled ? S1.z : D.z, sampled ? S1.w : D.w, two,
+                          sampled ? S0.y : 0u, sampled ? S0.z : 0u, offset, value, rank);
                 next_node = value ? A.z : A.x;
-                next_offset = (value ? A.w : A.y) + rank + delta;
+                next_offset = (value ? A.w : A.y) + rank;
                 next_sb = value ? C.y : C.x;
-                ok = next_node != 0;                 // ENDMARKER successor: the sequence ends
-            } else if (r < 0) {                      // class 0 or an over-long varint: generic decode, then look the sample base up
-                ok = serial_record_lf(ix, start, B.y, offset, next_node, next_offset);
-                if (ok && next_node >= ix.first_node && next_node - ix.alphabet_offset < ix.n_records) next_sb = ix.sbase[next_node - ix.alphabet_offset];
             }
+            ok = next_node != 0;                    // ENDMARKER successor: the sequence ends
+        }
+        if (__builtin_expect(in_range && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0, 0)) {
+            // class 0 (outdegree > 2 or a stream the lean scanner cannot take): generic decode, then look the sample base up
+            const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
+            next_node = r.x; next_offset = r.y; next_sb = SAMPLE_NONE;
+            ok = r.x != 0;
+            if (ok && r.x >= ix.first_node && r.x - ix.alphabet_offset < n_rec) next_sb = ix.sbase[r.x - ix.alphabet_offset];
         }
         PROF_MARK(t_scan);
         if (PROF) n_steps++;
-        if (active) {
-            active = ok;
-            node = next_node; offset = next_offset; sb = next_sb;
-        }
+        active = active && ok;
+        node = next_node; offset = next_offset; sb = next_sb;
     }
     if (owner) {
         a.lengths[k] = sink.finish(a);
@@ -439,7 +442,10 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
             if (status != COOP_DONE && member) serial = true;
             todo &= ~__ballot(member);
         }
-        if (serial) ok = serial_record_lf(ix, start, bytes, offset, next_node, next_offset);
+        if (serial) {
+            const uint2 r = serial_record_lf(ix.data, start, bytes, offset);
+            next_node = r.x; next_offset = r.y; ok = r.x != 0;
+        }
         if (active) {
             active = ok;
             node = next_node; offset = next_offset;

@@ -102,7 +102,8 @@ void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws);
  *   walk_mode      0 = one lane per sequence with the rank samples built at open (default),
  *                  1 = lane-serial scan from the start of every record (the reference's access pattern),
  *                  2 = wave-cooperative decode of long records (all 64 lanes scan one record's runs)
- *   paths_per_wave lanes of each wavefront that own a sequence, 1..64 (default 64)
+ *   paths_per_wave lanes of each wavefront that own a sequence, 1..64; 0 = automatic (default): about one wavefront
+ *                  per SIMD, at least 4 owners per wave -- the walk is latency-bound, not throughput-bound
  *   small_record   mode 2 only: records of at most this many bytes are decoded by their own lane (default 16)
  * Environment overrides read at workspace creation: GBWT_HIP_WALK_MODE, GBWT_HIP_PATHS_PER_WAVE, GBWT_HIP_SMALL_RECORD;
  * at open: GBWT_HIP_SAMPLE_SHIFT (log2 of the rank sampling interval, default 6). */
