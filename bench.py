@@ -185,7 +185,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_walk",
+                "kernel": "k_walk_sampled",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1,0 +1,61 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU plumbing: sharding of the path set and the final ordered gather.
+The per-rank "extraction" is done by the oracle here (test infrastructure); on the GPU box the same code moves
+device tensors over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from gbwt_rs_amd import dist as D
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, interleaved, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle = O.OracleGBWT.load(os.path.join(O.GOLDEN, "with-empty.gbwt"))
+        ids = np.arange(oracle.sequences(), dtype=np.uint64)
+        mine = D.shard_ids(ids, rank, world, interleaved=interleaved)
+        offsets, nodes = oracle.extract(mine)
+        lengths = torch.from_numpy(np.diff(offsets).astype(np.int64))
+        values = torch.from_numpy(nodes.astype(np.int64))
+        g_off, g_val = D.gather_rows(lengths, values, dst=0, interleaved=interleaved)
+        if rank == 0:
+            full_off, full_nodes = oracle.extract(ids)
+            assert np.array_equal(g_off.numpy(), full_off.astype(np.int64))
+            assert np.array_equal(g_val.numpy(), full_nodes.astype(np.int64))
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+        else:
+            assert g_off is None and g_val is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_shard_and_gather_world2(tmp_path, interleaved):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, interleaved, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 5000, 5001):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    ids = np.arange(10)
+    assert sorted(np.concatenate([D.shard_ids(ids, r, 3, interleaved=True) for r in range(3)]).tolist()) == list(range(10))
