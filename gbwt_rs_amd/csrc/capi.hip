@@ -64,7 +64,7 @@ gbwt_hip_status status_of(const HipError &e) {
 struct gbwt_hip_index {
     HostIndex host;
     int device = 0;
-    DeviceBuffer data, starts, endmarker, desc, sbase, samples;
+    DeviceBuffer data, starts, endmarker, desc, desc_raw, sbase, samples;
     uint32_t sample_shift = 6;   // rank sample every 64 offsets (GBWT_HIP_SAMPLE_SHIFT)
     DeviceIndex dev{};
     gbwt_hip_stats stats{};
@@ -133,10 +133,12 @@ void upload(gbwt_hip_index &ix) {
     {
         const uint64_t nr = std::max<uint64_t>(n_records, 1);
         ix.desc.reserve(nr * 4 * sizeof(uint4));
+        ix.desc_raw.reserve(nr * 4 * sizeof(uint4));
         ix.sbase.reserve(nr * sizeof(uint32_t));
         DeviceBuffer counts, scan_tmp;
         counts.reserve(nr * sizeof(uint32_t));
-        launch_build_desc(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), nullptr);
+        launch_build_desc(d, ix.desc_raw.as<uint4>(), counts.as<uint32_t>(), nullptr);
+        d.desc_raw = ix.desc_raw.as<uint4>();
         d.desc = ix.desc.as<uint4>();
         uint64_t n_samples = 0;
         if (n_records > 0) {

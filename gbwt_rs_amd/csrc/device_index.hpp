@@ -9,19 +9,24 @@
 //   endmarker : record 0 fully decompressed at open (src/gbwt.rs:413-414), one (node, offset) per sequence
 //
 // Built on the device at open and read by the walk kernels:
-//   desc      : one 64-byte descriptor per record, four uint4 (desc[4 * rec + 0..3]), fetched with four aligned
-//               dwordx4 loads that travel together:
+//   desc_raw  : one 64-byte descriptor per record, four uint4 (desc_raw[4 * rec + 0..3]):
 //                 A = {successor 0, offset 0, successor 1, offset 1}         decoded edge list (class 1 / 2 only)
 //                 B = {start (low 32 bits), length in bytes, meta, Record::len}
-//                     meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
+//                     meta = body offset (bits 0-15) | class (bits 16-17) | fused flags (bits 18-19, walk descriptor
+//                     only) | start (bits 32-39 of it, in bits 24-31)
 //                     class 1 / 2 = outdegree 1 / 2 with the edges in A and "body offset" = where the run stream
 //                     starts inside the record; class 0 = any other non-empty record (generic lane-serial decode)
-//                 C = {sample base of successor 0, sample base of successor 1, 0, 0}    (SAMPLE_NONE if unsampled)
+//                 C = {value-0 positions of the record, 0, 0, 0}
 //                 D = the first 16 bytes of the run stream, so short records need no second load
 //               empty / None record : B.y = 0
 //               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 and a body that is exactly one run
-//                 (every node on a linear stretch of the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w,
-//                 so a step through it costs one descriptor fetch and one add.
+//                 (every node on a linear stretch of the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w.
+//   desc      : the walk descriptor derived from desc_raw (k_link_desc), fetched by the sampled walk with four
+//               aligned dwordx4 loads that travel together: B and D as above, and one uint4 per edge,
+//                 A = edge 0, C = edge 1 = {successor, offset base, landing node, sample base of the landing record}.
+//               An edge whose successor is a unary record is FUSED with it (flag in meta): taking the edge emits the
+//               successor and lands on the successor's successor at offset base + rank, so a walk spends one
+//               iteration -- one round trip to memory -- on a branching node plus the unary node behind it.
 //   sbase     : per record, index of its first rank sample or SAMPLE_NONE (needed where a walk starts; afterwards
 //               the sample base of the next record rides along in C of the current one)
 //   samples   : rank samples ("superblocks") of the long class 1 / 2 records, 32 bytes each (two uint4): sample k of
@@ -39,6 +44,8 @@
 namespace gbwt_hip {
 
 constexpr uint32_t DESC_UNARY = 0xFFFFFFFFu;
+constexpr uint32_t DESC_FUSED_SHIFT = 18;
+constexpr uint32_t DESC_FUSED0 = 1u << DESC_FUSED_SHIFT;
 constexpr uint32_t SAMPLE_NONE = 0xFFFFFFFFu;
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start
 
@@ -47,7 +54,8 @@ struct DeviceIndex {
     const uint32_t *starts32;  // exactly one of starts32 / starts64 is non-null
     const uint64_t *starts64;
     const uint2 *endmarker;    // .x = node, .y = offset
-    const uint4 *desc;         // 4 * n_records entries
+    const uint4 *desc;         // 4 * n_records entries (walk descriptors)
+    const uint4 *desc_raw;     // 4 * n_records entries (raw descriptors)
     const uint32_t *sbase;     // n_records entries
     const uint4 *samples;      // 2 * n_samples entries
     uint64_t data_len;

@@ -39,13 +39,13 @@ __device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t po
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// One lane per record: descriptor parts A, B, D (device_index.hpp) and the number of rank samples the record gets.
+// One lane per record: the RAW descriptor (device_index.hpp) and the number of rank samples the record gets.
 __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *sample_counts) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
-    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), D = make_uint4(0, 0, 0, 0);
+    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), C = make_uint4(0, 0, 0, 0), D = make_uint4(0, 0, 0, 0);
     uint32_t n_samples = 0;
     if (limit > start) {
         ByteCursor c(ix.data, start, limit);
@@ -63,13 +63,14 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                     // Record::len and the shape of the run stream.  The walk's scanner trusts class 1 / 2 streams: they
                     // must parse to the last byte and every run must fit in 1 + 4 bytes (length < 2^28 + threshold).
                     RunDecoder rd(sigma);
-                    uint64_t total = 0, runs = 0, value, len;
+                    uint64_t total = 0, total0 = 0, runs = 0, value, len;
                     bool lean = true;
                     for (;;) {
                         const uint64_t before = c.pos;
                         if (!rd.next(c, value, len)) break;
                         if (c.pos - before > 5) lean = false;
                         total += len; runs++;
+                        if (value == 0) total0 += len;
                     }
                     if (!c.at_end() || runs == 0) lean = false;
                     if (lean && total < 0xFFFFFFFFull) {
@@ -78,33 +79,61 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                         A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
                         B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
                         B.w = static_cast<uint32_t>(total);
+                        C.x = static_cast<uint32_t>(total0);
                         D = stream_bytes16(ix.data, start + body, limit);
                         if (sigma == 1 && runs == 1) B.y = DESC_UNARY;
                         else if (total > (uint64_t(1) << ix.sample_shift)) n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);
                     }
                 }
             }
-            if (!classed) { A = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0; }  // class 0: B.w = 0 keeps the fast path out
+            if (!classed) { A = make_uint4(0, 0, 0, 0); C = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0; }  // class 0: B.w = 0 keeps the fast path out
         }
     }
     desc[4 * rec] = A;
     desc[4 * rec + 1] = B;
+    desc[4 * rec + 2] = C;
     desc[4 * rec + 3] = D;
     sample_counts[rec] = n_samples;
 }
 
-// One lane per record: descriptor part C = the sample bases of the successors (so that a walk arriving at a
-// record can fetch its rank sample together with the descriptor).
-__global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *desc) {
+// One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Every edge gets the sample base of the
+// record a walk lands in, and an edge whose successor is a unary record is FUSED with it: the walk then emits that
+// successor and lands directly on the successor's successor.  Fusing is exact when every offset the edge can produce
+// exists in the unary record, i.e. edge offset + (positions of this record that take the edge) <= its length --
+// always true in a valid GBWT, checked here so that no run-time test is needed.
+__global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
-    const uint4 A = desc[4 * rec], B = desc[4 * rec + 1];
-    uint4 C = make_uint4(SAMPLE_NONE, SAMPLE_NONE, 0, 0);
-    if (B.y != 0 && desc_class(B.z) != 0) {
-        if (A.x >= ix.first_node && A.x - ix.alphabet_offset < ix.n_records) C.x = ix.sbase[A.x - ix.alphabet_offset];
-        if (desc_class(B.z) == 2 && A.z >= ix.first_node && A.z - ix.alphabet_offset < ix.n_records) C.y = ix.sbase[A.z - ix.alphabet_offset];
+    const uint4 *raw = ix.desc_raw;
+    const uint4 A = raw[4 * rec], C = raw[4 * rec + 2], D = raw[4 * rec + 3];
+    uint4 B = raw[4 * rec + 1];
+    uint4 E0 = make_uint4(0, 0, 0, SAMPLE_NONE), E1 = make_uint4(0, 0, 0, SAMPLE_NONE);
+    const uint32_t cls = B.y != 0 ? desc_class(B.z) : 0u;
+    if (cls != 0) {
+        const uint32_t count[2] = {cls == 2 ? C.x : B.w, cls == 2 ? B.w - C.x : 0u};
+        const uint32_t succ[2] = {A.x, A.z}, off[2] = {A.y, A.w};
+        uint4 E[2] = {E0, E1};
+        for (uint32_t e = 0; e < cls; e++) {
+            uint32_t node = succ[e], base = off[e], land = 0, sb = SAMPLE_NONE;
+            bool fused = false;
+            if (node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
+                const uint64_t r = node - ix.alphabet_offset;
+                const uint4 SB = raw[4 * r + 1], SA = raw[4 * r];
+                if (SB.y == DESC_UNARY && static_cast<uint64_t>(base) + count[e] <= SB.w) {
+                    fused = true;
+                    land = SA.x; base += SA.y;
+                    if (land >= ix.first_node && land - ix.alphabet_offset < ix.n_records) sb = ix.sbase[land - ix.alphabet_offset];
+                } else sb = ix.sbase[r];
+            }
+            E[e] = make_uint4(node, base, land, sb);
+            if (fused) B.z |= DESC_FUSED0 << e;
+        }
+        E0 = E[0]; E1 = E[1];
     }
-    desc[4 * rec + 2] = C;
+    out[4 * rec] = E0;
+    out[4 * rec + 1] = B;
+    out[4 * rec + 2] = E1;
+    out[4 * rec + 3] = D;
 }
 
 // One lane per sampled record: sample k = the run containing offset k << sample_shift (device_index.hpp).
@@ -113,7 +142,7 @@ __global__ void __launch_bounds__(256) k_fill_samples(DeviceIndex ix, const uint
     if (rec >= ix.n_records) return;
     const uint32_t count = sample_counts[rec];
     if (count == 0) return;
-    const uint4 B = ix.desc[4 * rec + 1];
+    const uint4 B = ix.desc_raw[4 * rec + 1];
     const uint64_t start = desc_start(B.x, B.z), limit = start + B.y;
     ByteCursor c(ix.data, start + desc_body_offset(B.z), limit);
     RunDecoder rd(desc_class(B.z));
@@ -352,20 +381,24 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
         bool ok = false;
         uint32_t next_node = 0, next_offset = 0, next_sb = SAMPLE_NONE;
         if (in_range && offset < B.w) {             // i >= Record::len -> None (B.w = 0 for class 0: handled below)
-            if (B.y == DESC_UNARY) {                // one run, one successor: lf(i) = (A.x, A.y + i)
-                next_node = A.x; next_offset = A.y + offset; next_sb = C.x;
-            } else {
+            uint32_t value = 0, rank = offset;      // unary record: one run, one successor, lf(i) = (succ, off + i)
+            if (B.y != DESC_UNARY) {
                 if (PROF) n_scans++;
                 const bool sampled = sb != SAMPLE_NONE, two = desc_class(B.z) == 2;
-                uint32_t value, rank;
                 scan_runs(ix.data + desc_start(B.x, B.z), sampled ? S0.x : desc_body_offset(B.z),
                           sampled ? S1.x : D.x, sampled ? S1.y : D.y, sampled ? S1.z : D.z, sampled ? S1.w : D.w, two,
                           sampled ? S0.y : 0u, sampled ? S0.z : 0u, offset, value, rank);
-                next_node = value ? A.z : A.x;
-                next_offset = (value ? A.w : A.y) + rank;
-                next_sb = value ? C.y : C.x;
             }
+            // edge `value`: {successor, offset base, landing node of a fused unary successor, sample base of the landing record}
+            const uint4 E = value ? C : A;
+            next_node = E.x; next_offset = E.y + rank; next_sb = E.w;
             ok = next_node != 0;                    // ENDMARKER successor: the sequence ends
+            if ((B.z >> (DESC_FUSED_SHIFT + value)) & 1u) {
+                // the successor is a unary record: emit it here and land on ITS successor (SequenceIter would take two steps)
+                if (!sink.push(a, next_node)) ok = false;
+                next_node = E.z;
+                ok = ok && next_node != 0;
+            }
         }
         if (__builtin_expect(in_range && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0, 0)) {
             // class 0 (outdegree > 2 or a stream the lean scanner cannot take): generic decode, then look the sample base up
@@ -417,7 +450,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
         uint32_t next_node = 0, next_offset = 0;
         if (active && node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
             const uint64_t rec = node - ix.alphabet_offset;
-            const uint4 A = ix.desc[4 * rec], B = ix.desc[4 * rec + 1];
+            const uint4 A = ix.desc_raw[4 * rec], B = ix.desc_raw[4 * rec + 1];
             if (B.y == DESC_UNARY) {
                 ok = offset < B.w && A.x != 0;
                 next_node = A.x; next_offset = A.y + offset;
