@@ -159,6 +159,14 @@ def main():
         cpu = None if args.no_cpu_baseline else cpu_baseline(index_path, n_paths, args.cpu_seconds)
         b_per_step, sampled_steps = algorithmic_bytes(index_path, n_paths, args.bytes_sample)
         walk_avg_ms = float(np.mean(walk_ms))
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+        # (profiles/*_hbm_traffic.json); it is only quoted when the workload is the one those passes ran.
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_fused_hbm_traffic.json")
+        if os.path.exists(tpath) and (args.sites, args.haplotypes, args.model, args.seed) == (333334, 5000, "mosaic", 42):
+            tj = json.load(open(tpath))
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_note = "profiles/r01_fused_hbm_traffic.json: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
         achieved = b_per_step * steps_done / (walk_avg_ms * 1e-3) / 1e9
         result = {
             "metric": "LF-steps/sec (batched path extract)",
@@ -190,7 +198,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "algorithmic_bytes_per_step": b_per_step,
                 "bytes_sample": f"exact H+P+4 over {sampled_steps} LF-steps of {min(args.bytes_sample, n_paths)} paths, scaled to {steps_done}",
                 "kernel_ms": walk_avg_ms,
