@@ -65,6 +65,7 @@ SIGNATURES = {
     "gbwt_hip_extend_forward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_extend_backward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_search": (_int, [_p, _p, _p, _u64, _u64, _p, _p]),
+    "gbwt_hip_bd_search": (_int, [_p, _p, _p, _u64, _u64, _u64, _p, _p]),
     "gbwt_hip_path_sums": (_int, [_p, _p, _p, _u64]),
     "gbwt_hip_copy_path": (_int, [_p, _p, _u64, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_last_kernel_ms": (_int, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

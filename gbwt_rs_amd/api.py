@@ -254,6 +254,16 @@ class GBWT:
         return out, valid.astype(bool)
 
 
+    def bd_search(self, queries, first):
+        """bd_find(q[first]) then alternating extend_forward / extend_backward over every row of the query matrix."""
+        q = np.ascontiguousarray(queries, dtype=np.uint64)
+        assert q.ndim == 2
+        out = np.zeros(q.shape[0], dtype=BD_DTYPE)
+        valid = np.zeros(q.shape[0], dtype=np.uint8)
+        check(self._L.gbwt_hip_bd_search(self._h, self._ws, _ptr(q), q.shape[0], q.shape[1], first, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+
 class GBZ(GBWT):
     """gbz::GBZ for the hot path: GBZ::path / paths (src/gbz.rs:446-466)."""
 

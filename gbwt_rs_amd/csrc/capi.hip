@@ -558,4 +558,12 @@ gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws
     });
 }
 
+gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *queries, uint64_t n,
+                                   uint64_t len, uint64_t first, gbwt_hip_bd_state *out, uint8_t *valid) {
+    if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
+    return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
+        launch_bd_search(ix->dev, ws->in_a.as<uint64_t>(), n, len, first, ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
 }  // extern "C"

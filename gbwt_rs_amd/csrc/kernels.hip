@@ -79,14 +79,21 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                         A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
                         B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
                         B.w = static_cast<uint32_t>(total);
-                        C.x = static_cast<uint32_t>(total0);
+                        C.x = static_cast<uint32_t>(total0); C.y = static_cast<uint32_t>(total);
                         D = stream_bytes16(ix.data, start + body, limit);
                         if (sigma == 1 && runs == 1) B.y = DESC_UNARY;
                         else if (total > (uint64_t(1) << ix.sample_shift)) n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);
                     }
                 }
             }
-            if (!classed) { A = make_uint4(0, 0, 0, 0); C = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0; }  // class 0: B.w = 0 keeps the fast path out
+            if (!classed) {  // class 0: B.w = 0 keeps the walk's fast path out; Record::len goes to C.y for find()
+                A = make_uint4(0, 0, 0, 0); C = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0;
+                ByteCursor c2(ix.data, start, limit);
+                uint64_t s2 = 0;
+                c2.varint(s2);
+                const uint64_t total = record_len(c2, s2);
+                C.y = total < 0xFFFFFFFFull ? static_cast<uint32_t>(total) : 0xFFFFFFFFu;
+            }
         }
     }
     desc[4 * rec] = A;
@@ -549,22 +556,93 @@ __global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_
     out[k] = r; valid[k] = ok;
 }
 
-// GBWT::find, src/gbwt.rs:269-281
-__device__ __forceinline__ bool dev_find(const DeviceIndex &ix, uint64_t node, gbwt_hip_state &st) {
-    ByteCursor c(ix.data, 0, 0);
-    uint64_t sigma;
-    if (!open_record(ix, node, c, sigma)) return false;
-    st.node = node; st.start = 0; st.end = record_len(c, sigma);
+// ---- search on descriptors + rank samples ------------------------------------------------------------
+// For class 1 / 2 records everything Record::follow / bd_follow compute (src/bwt.rs:595-656) is a difference of
+// "how many of the first p positions take edge r", which the rank samples answer in O(1): two sample lookups
+// replace the reference's scan of all runs up to range.end.  Other records use the generic scan of lf_device.hpp.
+
+struct RawDesc { uint4 A, B, C, D; };
+
+__device__ __forceinline__ bool load_raw_desc(const DeviceIndex &ix, uint64_t node, RawDesc &d, uint64_t &rec) {
+    if (node < ix.first_node) return false;
+    rec = node - ix.alphabet_offset;
+    if (rec >= ix.n_records) return false;
+    d.A = ix.desc_raw[4 * rec]; d.B = ix.desc_raw[4 * rec + 1]; d.C = ix.desc_raw[4 * rec + 2]; d.D = ix.desc_raw[4 * rec + 3];
+    return d.B.y != 0;   // empty record / sigma == 0 -> None
+}
+
+// value-0 positions among the first p positions (p <= Record::len) of a class 1 / 2 record
+__device__ __forceinline__ uint32_t count0_before(const DeviceIndex &ix, const RawDesc &d, uint64_t rec, uint32_t p) {
+    if (desc_class(d.B.z) == 1) return p;
+    if (p >= d.B.w) return d.C.x;
+    const uint32_t sb = ix.sbase[rec];
+    uint32_t rel = desc_body_offset(d.B.z), cum = 0, c0 = 0;
+    uint4 w = d.D;
+    if (sb != SAMPLE_NONE) {
+        const uint4 *sp = ix.samples + 2 * (static_cast<uint64_t>(sb) + (p >> ix.sample_shift));
+        const uint4 S0 = sp[0];
+        w = sp[1]; rel = S0.x; cum = S0.y; c0 = S0.z;
+    }
+    uint32_t value, rank;
+    scan_runs(ix.data + desc_start(d.B.x, d.B.z), rel, w.x, w.y, w.z, w.w, true, cum, c0, p, value, rank);
+    return value ? p - rank : rank;
+}
+
+// Record::follow / bd_follow on a class 1 / 2 record.
+template <bool BD>
+__device__ __forceinline__ bool sampled_follow(const DeviceIndex &ix, const RawDesc &d, uint64_t rec, uint64_t start, uint64_t end, uint64_t dest,
+                                               uint64_t &rstart, uint64_t &rend, uint64_t &count) {
+    if (start >= end || dest == 0) return false;
+    const bool two = desc_class(d.B.z) == 2;
+    uint32_t rank;                                   // Record::edge_to
+    if (d.A.x == dest) rank = 0;
+    else if (two && d.A.z == dest) rank = 1;
+    else return false;
+    const uint32_t len = d.B.w;
+    const uint32_t ps = start < len ? static_cast<uint32_t>(start) : len, pe = end < len ? static_cast<uint32_t>(end) : len;
+    const uint32_t z0 = count0_before(ix, d, rec, ps), z1 = count0_before(ix, d, rec, pe);
+    const uint32_t before_s = rank ? ps - z0 : z0, before_e = rank ? pe - z1 : z1;
+    const uint64_t base = rank ? d.A.w : d.A.y;
+    rstart = base + before_s; rend = base + before_e;
+    if (rstart >= rend) return false;
+    if (BD) {  // positions of [start, end) whose successor s has flip(s) < flip(dest)  (src/bwt.rs:646-648)
+        const uint64_t reverse = dest ^ 1;
+        uint64_t c = 0;
+        if ((static_cast<uint64_t>(d.A.x) ^ 1) < reverse) c += z1 - z0;
+        if (two && (static_cast<uint64_t>(d.A.z) ^ 1) < reverse) c += (pe - z1) - (ps - z0);
+        count = c;
+    }
     return true;
+}
+
+// GBWT::find, src/gbwt.rs:269-281: Record::len was computed when the descriptors were built
+__device__ __forceinline__ bool dev_find(const DeviceIndex &ix, uint64_t node, gbwt_hip_state &st) {
+    RawDesc d;
+    uint64_t rec;
+    if (!load_raw_desc(ix, node, d, rec)) return false;
+    st.node = node; st.start = 0; st.end = d.C.y;
+    return true;
+}
+
+template <bool BD>
+__device__ __forceinline__ bool dev_follow(const DeviceIndex &ix, uint64_t from, uint64_t start, uint64_t end, uint64_t dest,
+                                           uint64_t &rs, uint64_t &re, uint64_t &count) {
+    RawDesc d;
+    uint64_t rec;
+    if (!load_raw_desc(ix, from, d, rec)) return false;
+    if (desc_class(d.B.z) != 0) return sampled_follow<BD>(ix, d, rec, start, end, dest, rs, re, count);
+    const uint64_t rstart = desc_start(d.B.x, d.B.z);
+    ByteCursor c(ix.data, rstart, rstart + d.B.y);
+    uint64_t sigma;
+    if (!c.varint(sigma) || sigma == 0) return false;
+    return record_follow<BD>(c, sigma, start, end, dest, rs, re, count);
 }
 
 // GBWT::extend, src/gbwt.rs:292-304
 __device__ __forceinline__ bool dev_extend(const DeviceIndex &ix, const gbwt_hip_state &st, uint64_t node, gbwt_hip_state &out) {
     if (node < ix.first_node) return false;
-    ByteCursor c(ix.data, 0, 0);
-    uint64_t sigma, rs, re, count;
-    if (!open_record(ix, st.node, c, sigma)) return false;
-    if (!record_follow<false>(c, sigma, st.start, st.end, node, rs, re, count)) return false;
+    uint64_t rs, re, count;
+    if (!dev_follow<false>(ix, st.node, st.start, st.end, node, rs, re, count)) return false;
     out.node = node; out.start = rs; out.end = re;
     return true;
 }
@@ -572,10 +650,8 @@ __device__ __forceinline__ bool dev_extend(const DeviceIndex &ix, const gbwt_hip
 // GBWT::extend_forward + bd_internal, src/gbwt.rs:339-347, 371-384
 __device__ __forceinline__ bool dev_extend_forward(const DeviceIndex &ix, const gbwt_hip_bd_state &st, uint64_t node, gbwt_hip_bd_state &out) {
     if (node < ix.first_node) return false;
-    ByteCursor c(ix.data, 0, 0);
-    uint64_t sigma, rs, re, count;
-    if (!open_record(ix, st.forward.node, c, sigma)) return false;
-    if (!record_follow<true>(c, sigma, st.forward.start, st.forward.end, node, rs, re, count)) return false;
+    uint64_t rs, re, count = 0;
+    if (!dev_follow<true>(ix, st.forward.node, st.forward.start, st.forward.end, node, rs, re, count)) return false;
     out.forward.node = node; out.forward.start = rs; out.forward.end = re;
     uint64_t pos = st.reverse.start + count;
     out.reverse.node = st.reverse.node; out.reverse.start = pos; out.reverse.end = pos + (re - rs);
@@ -635,6 +711,31 @@ __global__ void __launch_bounds__(256) k_search(DeviceIndex ix, const uint64_t *
         gbwt_hip_state nx;
         ok = dev_extend(ix, st, q[j], nx);
         st = nx;
+    }
+    out[k] = ok ? st : zero; valid[k] = ok ? 1 : 0;
+}
+
+// bd_find(q[first]) then alternating extend_forward / extend_backward until the whole row is consumed
+__global__ void __launch_bounds__(256) k_bd_search(DeviceIndex ix, const uint64_t *queries, uint64_t n, uint64_t len, uint64_t first,
+                                                    gbwt_hip_bd_state *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t *q = queries + k * len;
+    gbwt_hip_bd_state st{{0, 0, 0}, {0, 0, 0}}, zero{{0, 0, 0}, {0, 0, 0}};
+    gbwt_hip_state f{0, 0, 0};
+    bool ok = first < len && dev_find(ix, q[first], f);
+    if (ok) { st.forward = f; st.reverse.node = f.node ^ 1; st.reverse.start = f.start; st.reverse.end = f.end; }
+    uint64_t fw = first + 1, bw = first;
+    while (ok && (fw < len || bw > 0)) {
+        gbwt_hip_bd_state nx;
+        if (fw < len) { ok = dev_extend_forward(ix, st, q[fw], nx); st = nx; fw++; }
+        if (ok && bw > 0) {  // extend_backward = flip(extend_forward(flip(state), node ^ 1)), src/gbwt.rs:362-367
+            gbwt_hip_bd_state fl;
+            fl.forward = st.reverse; fl.reverse = st.forward;
+            ok = dev_extend_forward(ix, fl, q[bw - 1] ^ 1, nx);
+            st.forward = nx.reverse; st.reverse = nx.forward;
+            bw--;
+        }
     }
     out[k] = ok ? st : zero; valid[k] = ok ? 1 : 0;
 }
@@ -742,6 +843,11 @@ void launch_bd_extend(const DeviceIndex &ix, const gbwt_hip_bd_state *states, co
 void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, gbwt_hip_state *out,
                    uint8_t *valid, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_search, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, queries, n, len, out, valid);
+}
+
+void launch_bd_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, uint64_t first,
+                      gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bd_search, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, queries, n, len, first, out, valid);
 }
 
 size_t scan_temp_bytes(uint64_t n) {

@@ -72,6 +72,9 @@ void launch_bd_extend(const DeviceIndex &ix, const gbwt_hip_bd_state *states, co
 void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, gbwt_hip_state *out,
                    uint8_t *valid, hipStream_t s);
 
+void launch_bd_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, uint64_t first,
+                      gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s);
+
 // inclusive scan of lengths[n] into offsets[1..n], offsets[0] = 0 (hipcub); temp storage managed by caller
 size_t scan_temp_bytes(uint64_t n);
 void launch_scan(const uint64_t *d_lengths, uint64_t *d_offsets, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t s);

@@ -164,6 +164,12 @@ gbwt_hip_status gbwt_hip_extend_backward(const gbwt_hip_index *index, gbwt_hip_w
 gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *queries,
                                 uint64_t n, uint64_t len, gbwt_hip_state *out, uint8_t *valid);
 
+/* Bidirectional form of the same: bd_find(q[first]), then alternately extend_forward over q[first+1..] and
+ * extend_backward over q[first-1..0] until both ends of the row are consumed (the usage pattern of
+ * GBWT::bd_find / extend_forward / extend_backward, src/gbwt.rs:311-367). */
+gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *queries,
+                                   uint64_t n, uint64_t len, uint64_t first, gbwt_hip_bd_state *out, uint8_t *valid);
+
 /* ---- checking hooks for device-resident results -------------------------------------------------
  * Per-path sums of the node ids of the last gbwt_hip_extract_device call on `ws` (a wave-per-path
  * reduction on the device), copied to out_sums[n]: a cheap full-size checksum of the extraction. */

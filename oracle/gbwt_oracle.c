@@ -730,6 +730,73 @@ uint64_t go_gbwt_extract_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t 
     return job.steps;
 }
 
+/* Batched search (src/bin/benchmark.rs:155-169 shape) ------------------------------------------------- */
+typedef struct {
+    const go_gbwt *g; const uint64_t *queries; uint64_t n, len, first; int bd;
+    go_state *out; go_bdstate *out_bd; uint8_t *valid; uint64_t next, found;
+} search_job;
+
+static void *search_worker(void *arg) {
+    search_job *job = (search_job *)arg;
+    uint64_t found = 0;
+    for (;;) {
+        uint64_t base = __atomic_fetch_add(&job->next, 256, __ATOMIC_RELAXED);
+        if (base >= job->n) break;
+        uint64_t limit = base + 256 < job->n ? base + 256 : job->n;
+        for (uint64_t k = base; k < limit; k++) {
+            const uint64_t *q = job->queries + k * job->len;
+            int ok;
+            if (!job->bd) {
+                go_state st = {0, 0, 0}, nx;
+                ok = job->len > 0 && go_gbwt_find(job->g, q[0], &st);
+                for (uint64_t j = 1; ok && j < job->len; j++) { ok = go_gbwt_extend(job->g, &st, q[j], &nx); st = nx; }
+                if (!ok) { st.node = 0; st.start = 0; st.end = 0; }
+                job->out[k] = st;
+            } else {
+                go_bdstate st, nx;
+                memset(&st, 0, sizeof(st));
+                ok = job->first < job->len && go_gbwt_bd_find(job->g, q[job->first], &st) == 1;
+                uint64_t fw = job->first + 1, bw = job->first;   /* next forward column, columns below bw are still to do */
+                while (ok && (fw < job->len || bw > 0)) {
+                    if (fw < job->len) { ok = go_gbwt_extend_forward(job->g, &st, q[fw], &nx) == 1; st = nx; fw++; }
+                    if (ok && bw > 0) { ok = go_gbwt_extend_backward(job->g, &st, q[bw - 1], &nx) == 1; st = nx; bw--; }
+                }
+                if (!ok) memset(&st, 0, sizeof(st));
+                job->out_bd[k] = st;
+            }
+            job->valid[k] = (uint8_t)(ok ? 1 : 0);
+            found += ok ? 1 : 0;
+        }
+    }
+    __atomic_fetch_add(&job->found, found, __ATOMIC_RELAXED);
+    return NULL;
+}
+
+static uint64_t run_search(search_job *job, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads == 1) { search_worker(job); return job->found; }
+    pthread_t *tids = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) pthread_create(&tids[t], NULL, search_worker, job);
+    for (int t = 0; t < threads; t++) pthread_join(tids[t], NULL);
+    free(tids);
+    return job->found;
+}
+
+uint64_t go_gbwt_search_mt(const go_gbwt *g, const uint64_t *queries, uint64_t n, uint64_t len, int threads, go_state *out, uint8_t *valid) {
+    search_job job;
+    memset(&job, 0, sizeof(job));
+    job.g = g; job.queries = queries; job.n = n; job.len = len; job.out = out; job.valid = valid;
+    return run_search(&job, threads);
+}
+
+uint64_t go_gbwt_bd_search_mt(const go_gbwt *g, const uint64_t *queries, uint64_t n, uint64_t len, uint64_t first, int threads,
+                              go_bdstate *out, uint8_t *valid) {
+    search_job job;
+    memset(&job, 0, sizeof(job));
+    job.g = g; job.queries = queries; job.n = n; job.len = len; job.first = first; job.bd = 1; job.out_bd = out; job.valid = valid;
+    return run_search(&job, threads);
+}
+
 /* Algorithmic bytes per LF-step (SURVEY 8d / BASELINE.md 3): B(v,i) = H(v) + P(v,i) + 4, where H is
  * the header length (sigma varint + edge list, src/bwt.rs:378-395), P the run-stream bytes through
  * the end of the run containing i (src/bwt.rs:483-494), 4 the emitted u32 node id. */

@@ -130,6 +130,14 @@ int go_gbwt_extend_backward(const go_gbwt *g, const go_bdstate *state, uint64_t 
  * Returns total LF steps (nodes emitted).  With nodes == NULL only lengths[] is filled. */
 uint64_t go_gbwt_extract_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t n, int threads,
                             uint64_t *lengths, const uint64_t *offsets, uint32_t *nodes);
+/* Batched search with a worker pool, the loop of src/bin/benchmark.rs:155-169: for query q (row q of the n x len
+ * matrix) find(q[0]) then extend by q[1..]; out[q] / valid[q] describe the final state.  With bidirectional != 0 the
+ * query starts with bd_find(q[first]) and alternates extend_forward (q[first+1], ...) / extend_backward (q[first-1], ...)
+ * until both ends are reached; out_bd is filled instead.  Returns the number of successful queries. */
+uint64_t go_gbwt_search_mt(const go_gbwt *g, const uint64_t *queries, uint64_t n, uint64_t len, int threads,
+                           go_state *out, uint8_t *valid);
+uint64_t go_gbwt_bd_search_mt(const go_gbwt *g, const uint64_t *queries, uint64_t n, uint64_t len, uint64_t first, int threads,
+                              go_bdstate *out, uint8_t *valid);
 /* Instrumented (untimed) pass: algorithmic bytes W = sum over steps of H(v)+P(v,i)+4. */
 uint64_t go_gbwt_extract_bytes(const go_gbwt *g, const uint64_t *seq_ids, uint64_t n, uint64_t *steps);
 

@@ -131,6 +131,8 @@ def lib():
         "go_gbwt_extend_forward": (C.c_int, [p, C.POINTER(BdState), u64, C.POINTER(BdState)]),
         "go_gbwt_extend_backward": (C.c_int, [p, C.POINTER(BdState), u64, C.POINTER(BdState)]),
         "go_gbwt_extract_mt": (u64, [p, p, u64, C.c_int, p, p, p]),
+        "go_gbwt_search_mt": (u64, [p, p, u64, u64, C.c_int, p, p]),
+        "go_gbwt_bd_search_mt": (u64, [p, p, u64, u64, u64, C.c_int, p, p]),
         "go_gbwt_extract_bytes": (u64, [p, p, u64, C.POINTER(u64)]),
         "go_gbwt_load": (p, [C.c_char_p, C.c_char_p, C.c_size_t]),
         "go_gbz_load": (p, [C.c_char_p, C.c_char_p, C.c_size_t]),
@@ -438,6 +440,21 @@ class OracleGBWT:
         """Counting-only run (what the cpu_baseline leg times): returns total LF steps."""
         ids = np.ascontiguousarray(seq_ids, dtype=np.uint64)
         return self.L.go_gbwt_extract_mt(self.h, ids.ctypes.data, len(ids), threads, None, None, None)
+
+    def search_batch(self, queries, threads=1):
+        """find + extend over every row (src/bin/benchmark.rs:155-169); returns (states[n,3] u64, valid[n] bool)."""
+        q = np.ascontiguousarray(queries, dtype=np.uint64)
+        out = np.zeros((q.shape[0], 3), dtype=np.uint64)
+        valid = np.zeros(q.shape[0], dtype=np.uint8)
+        self.L.go_gbwt_search_mt(self.h, q.ctypes.data, q.shape[0], q.shape[1], threads, out.ctypes.data, valid.ctypes.data)
+        return out, valid.astype(bool)
+
+    def bd_search_batch(self, queries, first, threads=1):
+        q = np.ascontiguousarray(queries, dtype=np.uint64)
+        out = np.zeros((q.shape[0], 6), dtype=np.uint64)
+        valid = np.zeros(q.shape[0], dtype=np.uint8)
+        self.L.go_gbwt_bd_search_mt(self.h, q.ctypes.data, q.shape[0], q.shape[1], first, threads, out.ctypes.data, valid.ctypes.data)
+        return out, valid.astype(bool)
 
     def algorithmic_bytes(self, seq_ids):
         ids = np.ascontiguousarray(seq_ids, dtype=np.uint64)

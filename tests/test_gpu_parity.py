@@ -434,3 +434,67 @@ def test_random_paths_all_variants():
         for i, p in enumerate(paths):
             assert list(nodes[offsets[2 * i]:offsets[2 * i + 1]]) == p, t
             assert list(nodes[offsets[2 * i + 1]:offsets[2 * i + 2]]) == kat.reverse_path(p), t
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3 shape: batched unidirectional and bidirectional search at scale
+
+
+def make_queries(s, rng, n_queries, length, corrupt=0.2):
+    """Queries like src/bin/benchmark.rs:124-153 (subpaths of real paths, forward or reverse), some corrupted."""
+    queries = np.zeros((n_queries, length), dtype=np.uint64)
+    for k in range(n_queries):
+        p = s.path(rng.randrange(s.paths))
+        a = rng.randrange(0, len(p) - length)
+        q = p[a:a + length].astype(np.uint64)
+        if rng.random() < 0.5:
+            q = (q ^ 1)[::-1]
+        if rng.random() < corrupt:
+            q = q.copy()
+            q[rng.randrange(length)] ^= 2
+        queries[k] = q
+    return queries
+
+
+@pytest.mark.parametrize("model,haplotypes", [(S.MOSAIC, 5008), (S.IID, 1000)])
+def test_config_c3_search_bit_exact(model, haplotypes):
+    """BASELINE config 3 (chr22-scale stand-in, reduced number of sites): find + 9 x extend and the bidirectional
+    walk for 20 000 queries of 10 nodes, every final state compared with the oracle."""
+    s = S.Synth.chain(sites=3000, haplotypes=haplotypes, alleles=2, model=model, founders=32, switch_rate=2e-3, seed=22)
+    dev, oracle = open_synth(s), oracle_of(s)
+    rng = random.Random(3)
+    queries = make_queries(s, rng, 20000, 10)
+    st, ok = dev.search(queries)
+    o_st, o_ok = oracle.search_batch(queries, threads=8)
+    assert np.array_equal(ok, o_ok) and 0.5 < ok.mean() < 1.0
+    got = np.stack([st["node"], st["start"], st["end"]], axis=1)
+    assert np.array_equal(got[ok], o_st[o_ok])
+    for first in (0, 4, 9):
+        bd, bok = dev.bd_search(queries, first)
+        o_bd, o_bok = oracle.bd_search_batch(queries, first, threads=8)
+        assert np.array_equal(bok, o_bok)
+        got = np.stack([bd["forward"]["node"], bd["forward"]["start"], bd["forward"]["end"],
+                        bd["reverse"]["node"], bd["reverse"]["start"], bd["reverse"]["end"]], axis=1)
+        assert np.array_equal(got[bok], o_bd[o_bok])
+        # a found bidirectional state has equal forward / reverse range lengths and the right end nodes
+        assert np.array_equal(got[bok][:, 2] - got[bok][:, 1], got[bok][:, 5] - got[bok][:, 4])
+        assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
+
+
+def test_high_degree_search_and_extract():
+    """BASELINE config 5 shape (outdegree >= 255, two-varint runs): extraction and search stay bit-exact."""
+    s = S.Synth.chain(sites=30, haplotypes=2500, alleles=300, model=S.IID, zipf=0.3, seed=5)
+    dev, oracle = open_synth(s), oracle_of(s)
+    assert dev.stats.max_outdegree >= 255
+    ids = np.arange(0, s.sequences, dtype=np.uint64)
+    offsets, nodes = dev.sequences_csr(ids)
+    o_off, o_nodes = oracle.extract(ids, threads=8)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    queries = make_queries(s, random.Random(8), 3000, 6)
+    st, ok = dev.search(queries)
+    o_st, o_ok = oracle.search_batch(queries, threads=8)
+    assert np.array_equal(ok, o_ok)
+    assert np.array_equal(np.stack([st["node"], st["start"], st["end"]], axis=1)[ok], o_st[o_ok])
+    bd, bok = dev.bd_search(queries, 2)
+    o_bd, o_bok = oracle.bd_search_batch(queries, 2, threads=8)
+    assert np.array_equal(bok, o_bok)

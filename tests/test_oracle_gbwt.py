@@ -217,3 +217,25 @@ def test_rejects_bad_files(tmp_path):
         O.OracleGBWT.load(str(p))
     with pytest.raises(ValueError, match="not bidirectional|Invalid tag"):
         O.OracleGBZ(os.path.join(O.GOLDEN, "example.gbwt"))
+
+
+def test_batched_search_matches_single_calls():
+    g = load("example.gbwt")
+    paths = kat.true_paths(False)
+    queries = [p[j:j + 3] for p in paths + [kat.reverse_path(x) for x in paths] for j in range(len(p) - 2)] + [[24, 30, 34], [0, 22, 24]]
+    out, ok = g.search_batch(queries, threads=3)
+    for q, r, v in zip(queries, out, ok):
+        exp = g.find(q[0])
+        for x in q[1:]:
+            exp = g.extend(exp, x) if exp else None
+        assert bool(v) == (exp is not None)
+        if exp:
+            assert tuple(int(x) for x in r) == exp
+    for first in (0, 1, 2):
+        bout, bok = g.bd_search_batch(queries, first, threads=2)
+        for q, r, v in zip(queries, bout, bok):
+            exp = bd_search(g, q, first, 0, 3)
+            # bd_search() extends forward first, then backward; the batched form alternates -- same final state
+            assert bool(v) == (exp is not None)
+            if exp:
+                assert (tuple(int(x) for x in r[:3]), tuple(int(x) for x in r[3:])) == exp
