@@ -275,6 +275,19 @@ class GBZ(GBWT):
         seq = self.sequence(encode_path(path_id, orientation))
         return None if seq is None else [decode_node(x) for x in seq]
 
+    def path_lines(self, path_ids, mode):
+        """gbunzip's P-lines (mode 0) or W-lines (mode 1) for the given paths, as bytes (src/bin/gbunzip.rs:438-550)."""
+        ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, None, 0, C.byref(total)))
+        buf = C.create_string_buffer(max(1, total.value))
+        check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, buf, total.value, C.byref(total)))
+        return buf.raw[: total.value]
+
+    def write_gfa(self, path):
+        """The file `gbunzip -t 1` writes for this GBZ (src/bin/gbunzip.rs:205-226)."""
+        check(self._L.gbwt_hip_write_gfa(self._h, self._ws, os.fsencode(path)))
+
     def paths_csr(self, path_ids, orientation=FORWARD):
         ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
         offsets = np.zeros(ids.size + 1, dtype=np.uint64)

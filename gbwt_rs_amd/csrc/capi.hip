@@ -11,81 +11,18 @@
 #include <string>
 #include <vector>
 
-#include "../../include/gbwt_hip.h"
-#include "device_index.hpp"
-#include "host_index.hpp"
-#include "kernels.hpp"
+#include "capi_internal.hpp"
 
 using namespace gbwt_hip;
 
-namespace {
-
-thread_local std::string g_last_error;
-
-gbwt_hip_status fail(gbwt_hip_status st, const std::string &msg) {
-    g_last_error = msg;
-    return st;
+namespace gbwt_hip {
+std::string &last_error_slot() {
+    thread_local std::string slot;
+    return slot;
 }
+}  // namespace gbwt_hip
 
-struct HipError { hipError_t err; const char *what; };
-
-#define HIP_CHECK(expr)                                            \
-    do {                                                           \
-        hipError_t e_ = (expr);                                    \
-        if (e_ != hipSuccess) throw HipError{e_, #expr};           \
-    } while (0)
-
-// Grow-only device buffer.
-struct DeviceBuffer {
-    void *ptr = nullptr;
-    size_t bytes = 0;
-    ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
-    DeviceBuffer() = default;
-    DeviceBuffer(const DeviceBuffer &) = delete;
-    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
-    void reserve(size_t need) {
-        if (need <= bytes) return;
-        if (ptr) { HIP_CHECK(hipFree(ptr)); ptr = nullptr; bytes = 0; }
-        size_t want = std::max<size_t>(need, 256);
-        HIP_CHECK(hipMalloc(&ptr, want));
-        bytes = want;
-    }
-    template <class T> T *as() const { return static_cast<T *>(ptr); }
-};
-
-gbwt_hip_status status_of(const HipError &e) {
-    std::string msg = std::string(e.what) + ": " + hipGetErrorString(e.err);
-    if (e.err == hipErrorNoDevice || e.err == hipErrorInvalidDevice) return fail(GBWT_HIP_NO_DEVICE, msg);
-    return fail(GBWT_HIP_DEVICE_ERROR, msg);
-}
-
-}  // namespace
-
-struct gbwt_hip_index {
-    HostIndex host;
-    int device = 0;
-    DeviceBuffer data, starts, endmarker, desc, desc_raw, sbase, samples;
-    uint32_t sample_shift = 6;   // rank sample every 64 offsets (GBWT_HIP_SAMPLE_SHIFT)
-    DeviceIndex dev{};
-    gbwt_hip_stats stats{};
-};
-
-struct gbwt_hip_workspace {
-    const gbwt_hip_index *index = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool timed = false;
-    uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
-    uint32_t walk_mode = WALK_SAMPLED, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
-    bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
-    DeviceBuffer prof;
-    DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
-    DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
-    ~gbwt_hip_workspace() {
-        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
+namespace gbwt_hip { void upload_label_lengths(gbwt_hip_index &ix); }
 
 namespace {
 
@@ -197,6 +134,7 @@ gbwt_hip_status open_common(gbwt_hip_index *ix, gbwt_hip_index **out) {
             return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
         }
         upload(*ix);
+        upload_label_lengths(*ix);
         *out = ix;
         return GBWT_HIP_OK;
     } catch (const InvalidData &e) {
@@ -241,7 +179,7 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
 
 extern "C" {
 
-const char *gbwt_hip_last_error(void) { return g_last_error.c_str(); }
+const char *gbwt_hip_last_error(void) { return last_error_slot().c_str(); }
 
 int gbwt_hip_device_count(void) {
     int count = 0;

@@ -1,0 +1,83 @@
+// capi_internal.hpp -- handle / workspace structures shared by the C-ABI translation units (capi.hip, gfa.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/gbwt_hip.h"
+#include "device_index.hpp"
+#include "host_index.hpp"
+#include "kernels.hpp"
+
+namespace gbwt_hip {
+
+std::string &last_error_slot();   // thread-local message of the last failing call
+
+inline gbwt_hip_status fail(gbwt_hip_status st, const std::string &msg) {
+    last_error_slot() = msg;
+    return st;
+}
+
+struct HipError { hipError_t err; const char *what; };
+
+#define HIP_CHECK(expr)                                            \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) throw gbwt_hip::HipError{e_, #expr}; \
+    } while (0)
+
+// Grow-only device buffer.
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void reserve(size_t need) {
+        if (need <= bytes) return;
+        if (ptr) { HIP_CHECK(hipFree(ptr)); ptr = nullptr; bytes = 0; }
+        size_t want = std::max<size_t>(need, 256);
+        HIP_CHECK(hipMalloc(&ptr, want));
+        bytes = want;
+    }
+    template <class T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+inline gbwt_hip_status status_of(const HipError &e) {
+    std::string msg = std::string(e.what) + ": " + hipGetErrorString(e.err);
+    if (e.err == hipErrorNoDevice || e.err == hipErrorInvalidDevice) return fail(GBWT_HIP_NO_DEVICE, msg);
+    return fail(GBWT_HIP_DEVICE_ERROR, msg);
+}
+
+}  // namespace gbwt_hip
+
+struct gbwt_hip_index {
+    gbwt_hip::HostIndex host;
+    int device = 0;
+    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, sbase, samples;
+    gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)
+    uint32_t sample_shift = 6;          // rank sample every 64 offsets (GBWT_HIP_SAMPLE_SHIFT)
+    gbwt_hip::DeviceIndex dev{};
+    gbwt_hip_stats stats{};
+};
+
+struct gbwt_hip_workspace {
+    const gbwt_hip_index *index = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
+    uint32_t walk_mode = gbwt_hip::WALK_SAMPLED, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
+    bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
+    gbwt_hip::DeviceBuffer prof;
+    gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
+    gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
+    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text;  // GFA line formatting
+    ~gbwt_hip_workspace() {
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};

@@ -1,0 +1,302 @@
+// gfa.hip -- gbunzip's GFA text (src/bin/gbunzip.rs:193-550) on top of the device extraction.
+//
+// P- and W-lines are where the LF-steps go, so they are produced on the device: the forward sequences of a
+// batch of paths are extracted (k_walk_*), a statistics kernel sizes every line, the host -- which owns the
+// metadata strings -- builds the per-line headers, and a formatting kernel writes the node tokens
+// (">123" / "<123" for walks, "123+" / "123-" joined by commas for paths).  H-, S- and L-lines are serial
+// host work in the reference as well (write_segments / write_links) and stay on the host.
+//
+// Node-to-segment translation (Graph::has_translation, src/graph.rs:158-160) is not handled yet: such files
+// return GBWT_HIP_UNSUPPORTED.
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "capi_internal.hpp"
+
+using namespace gbwt_hip;
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int FORMAT_THREADS = 256;
+const char *const GENERIC_SAMPLE = "_gbwt_ref";  // src/lib.rs
+
+__device__ __forceinline__ uint32_t decimal_digits(uint32_t v) {
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) +
+           (v >= 100000000u) + (v >= 1000000000u);
+}
+
+// One wave per path: text bytes of the node tokens and the summed label lengths (W-line end coordinate,
+// src/bin/gbunzip.rs:532-536: sequence_len(node).unwrap_or(0)).
+__global__ void __launch_bounds__(256) k_line_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint32_t *label_len,
+                                                     uint64_t n_labels, uint32_t first_node, int p_lines, uint64_t *text_len, uint64_t *seq_len) {
+    const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (path >= n) return;
+    const uint64_t begin = offsets[path], end = offsets[path + 1];
+    uint64_t text = 0, labels = 0;
+    for (uint64_t k = begin + lane; k < end; k += WAVE) {
+        const uint32_t node = nodes[k], id = node >> 1;
+        text += decimal_digits(id) + 1 + ((p_lines && k > begin) ? 1 : 0);
+        const uint64_t seq = (static_cast<uint64_t>(node & ~1u) - first_node) / 2;   // GBZ::graph_node_to_sequence, src/gbz.rs:246-255
+        if ((node & ~1u) >= first_node && seq < n_labels) labels += label_len[seq];
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) { text += __shfl_down(text, d, WAVE); labels += __shfl_down(labels, d, WAVE); }
+    if (lane == 0) { text_len[path] = text; seq_len[path] = labels; }
+}
+
+// One workgroup per line: header bytes, node tokens, trailer.
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, int p_lines,
+                                                                  const uint64_t *line_start, const uint8_t *headers, const uint64_t *header_off,
+                                                                  uint8_t *out) {
+    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
+    __shared__ typename BlockScan::TempStorage scan_storage;
+    const uint64_t path = blockIdx.x;
+    if (path >= n) return;
+    const uint32_t t = threadIdx.x;
+    uint8_t *line = out + line_start[path];
+    const uint64_t h0 = header_off[path], h1 = header_off[path + 1];
+    for (uint64_t k = t; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
+    uint64_t cursor = h1 - h0;
+    const uint64_t begin = offsets[path], end = offsets[path + 1];
+    for (uint64_t base = begin; base < end; base += FORMAT_THREADS) {
+        const uint64_t k = base + t;
+        char tok[13];
+        uint32_t len = 0;
+        if (k < end) {
+            const uint32_t node = nodes[k], id = node >> 1, digits = decimal_digits(id);
+            if (p_lines) {
+                if (k > begin) tok[len++] = ',';
+            } else tok[len++] = (node & 1u) ? '<' : '>';
+            uint32_t v = id;
+            for (uint32_t d = 0; d < digits; d++) { tok[len + digits - 1 - d] = static_cast<char>('0' + v % 10u); v /= 10u; }
+            len += digits;
+            if (p_lines) tok[len++] = (node & 1u) ? '-' : '+';
+        }
+        uint32_t pos, total;
+        BlockScan(scan_storage).ExclusiveSum(len, pos, total);
+        for (uint32_t j = 0; j < len; j++) line[cursor + pos + j] = static_cast<uint8_t>(tok[j]);
+        cursor += total;
+        __syncthreads();
+    }
+    // trailer: "\t*\n" for P-lines (src/bin/gbunzip.rs:476), "\n" for W-lines (:548)
+    if (t == 0) {
+        if (p_lines) { line[cursor] = '\t'; line[cursor + 1] = '*'; line[cursor + 2] = '\n'; }
+        else line[cursor] = '\n';
+    }
+}
+
+std::string name_or_id(const Strings &names, bool has_names, uint64_t id) {
+    // Metadata::sample_name / contig_name fall back to the number (src/gbwt.rs:744-761, 792-809)
+    if (has_names && id < names.size()) return names.str(id);
+    return std::to_string(id);
+}
+
+void require_gfa_capable(const gbwt_hip_index *ix) {
+    if (!ix->host.is_gbz) throw InvalidData("GFA lines need a GBZ (graph + metadata), this handle holds a bare GBWT");
+    if (!ix->host.has_metadata) throw InvalidData("GFA lines need path metadata");
+}
+
+// Edge list of a record, decoded on the host (Record::decompress_edges, src/bwt.rs:378-395) for the L-lines.
+bool host_edges(const HostIndex &h, uint64_t rec, std::vector<std::pair<uint64_t, uint64_t>> &edges) {
+    edges.clear();
+    if (rec >= h.records()) return false;
+    const uint8_t *p = h.data.data() + h.starts[rec], *end = h.data.data() + h.starts[rec + 1];
+    auto varint = [&](uint64_t &v) -> bool {
+        v = 0;
+        unsigned shift = 0;
+        while (p < end) {
+            uint8_t b = *p++;
+            if (shift < 64) v += static_cast<uint64_t>(b & 0x7F) << shift;
+            shift += 7;
+            if (!(b & 0x80)) return true;
+        }
+        return false;
+    };
+    uint64_t sigma = 0, node = 0;
+    if (!varint(sigma) || sigma == 0) return false;
+    for (uint64_t e = 0; e < sigma; e++) {
+        uint64_t delta, off;
+        if (!varint(delta) || !varint(off)) return false;
+        node += delta;
+        edges.emplace_back(node, off);
+    }
+    return true;
+}
+
+}  // namespace
+
+namespace gbwt_hip {
+
+// Uploads the label length of every potential node (0 where GBZ::has_node is false, src/gbz.rs:286-289).
+void upload_label_lengths(gbwt_hip_index &ix) {
+    const HostIndex &h = ix.host;
+    if (!h.is_gbz) return;
+    const uint64_t first = h.alphabet_offset + 1;
+    std::vector<uint32_t> len(h.sequences_labels.size() + 1, 0);
+    for (uint64_t s = 0; s < h.sequences_labels.size(); s++) {
+        const uint64_t node = 2 * s + first;                  // forward GBWT node of sequence s
+        const uint64_t rec = node - h.alphabet_offset;
+        bool real = rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;   // BWT::id_iter
+        len[s] = real ? static_cast<uint32_t>(h.sequences_labels.len(s)) : 0u;
+    }
+    ix.label_len.reserve(len.size() * sizeof(uint32_t));
+    HIP_CHECK(hipMemcpy(ix.label_len.ptr, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
+}  // namespace gbwt_hip
+
+// Implementation of gbwt_hip_path_lines; with `grow` the text goes into that vector (sized here) instead of `out`.
+static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
+                                       char *out, uint64_t capacity, uint64_t *total, std::vector<char> *grow) {
+    if (!ix || !ws || ws->index != ix || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (n && !path_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null path_ids");
+    if (mode != 0 && mode != 1) return fail(GBWT_HIP_BAD_ARGUMENT, "mode must be 0 (P-lines) or 1 (W-lines)");
+    try {
+        require_gfa_capable(ix);
+        const HostIndex &h = ix->host;
+        if (h.has_translation) return fail(GBWT_HIP_UNSUPPORTED, "node-to-segment translation is not supported by the device formatter yet");
+        for (uint64_t k = 0; k < n; k++)
+            if (path_ids[k] >= h.path_names.size()) return fail(GBWT_HIP_BAD_ARGUMENT, "path id out of range");
+        *total = 0;
+        if (n == 0) return GBWT_HIP_OK;
+        // 1. forward sequences of the paths (GBZ::path(id, Forward), src/bin/gbunzip.rs:462, 532)
+        std::vector<uint64_t> seq_ids(n);
+        for (uint64_t k = 0; k < n; k++) seq_ids[k] = 2 * path_ids[k];
+        gbwt_hip_paths paths{};
+        gbwt_hip_status st = gbwt_hip_extract_device(ix, ws, seq_ids.data(), n, &paths);
+        if (st != GBWT_HIP_OK) return st;
+        HIP_CHECK(hipSetDevice(ix->device));
+        hipStream_t s = ws->stream;
+        // 2. size of every line
+        ws->gfa_a.reserve(2 * n * sizeof(uint64_t));
+        uint64_t *d_text_len = ws->gfa_a.as<uint64_t>(), *d_seq_len = d_text_len + n;
+        hipLaunchKernelGGL(k_line_stats, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n,
+                           ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
+                           static_cast<uint32_t>(h.alphabet_offset + 1), mode == 0 ? 1 : 0, d_text_len, d_seq_len);
+        std::vector<uint64_t> lens(2 * n);
+        HIP_CHECK(hipMemcpyAsync(lens.data(), d_text_len, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipGetLastError());
+        // 3. headers (path_to_p_line / path_to_w_line, src/bin/gbunzip.rs:480-524)
+        const bool sample_names = (h.metadata_flags & 2) != 0, contig_names = (h.metadata_flags & 4) != 0;
+        std::string headers;
+        std::vector<uint64_t> header_off(n + 1, 0), line_start(n + 1, 0);
+        for (uint64_t k = 0; k < n; k++) {
+            const PathName &pn = h.path_names[path_ids[k]];
+            if (mode == 0) {
+                headers += "P\t" + name_or_id(h.contig_names, contig_names, pn.contig) + "\t";
+            } else {
+                headers += "W\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "\t" + std::to_string(pn.phase) + "\t" +
+                           name_or_id(h.contig_names, contig_names, pn.contig) + "\t" + std::to_string(pn.fragment) + "\t" +
+                           std::to_string(static_cast<uint64_t>(pn.fragment) + lens[n + k]) + "\t";
+            }
+            header_off[k + 1] = headers.size();
+            line_start[k + 1] = line_start[k] + (header_off[k + 1] - header_off[k]) + lens[k] + (mode == 0 ? 3 : 1);
+        }
+        *total = line_start[n];
+        if (grow) { grow->resize(*total); out = grow->data(); capacity = *total; }
+        if (!out) return GBWT_HIP_OK;
+        if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the lines");
+        // 4. format on the device, copy back
+        ws->gfa_b.reserve((2 * (n + 1)) * sizeof(uint64_t));
+        ws->gfa_c.reserve(std::max<size_t>(headers.size(), 16));
+        ws->gfa_text.reserve(std::max<uint64_t>(*total, 16));
+        uint64_t *d_line_start = ws->gfa_b.as<uint64_t>(), *d_header_off = d_line_start + (n + 1);
+        HIP_CHECK(hipMemcpyAsync(d_line_start, line_start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_header_off, header_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(ws->gfa_c.ptr, headers.data(), headers.size(), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_format_lines, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                           mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, ws->gfa_text.ptr, *total, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return GBWT_HIP_OK;
+    } catch (const InvalidData &e) {
+        return fail(GBWT_HIP_BAD_ARGUMENT, e.what());
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+extern "C" {
+
+gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
+                                    char *out, uint64_t capacity, uint64_t *total) {
+    return path_lines_impl(ix, ws, path_ids, n, mode, out, capacity, total, nullptr);
+}
+
+gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path) {
+    if (!ix || !ws || ws->index != ix || !path) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    try {
+        require_gfa_capable(ix);
+        const HostIndex &h = ix->host;
+        if (h.has_translation) return fail(GBWT_HIP_UNSUPPORTED, "node-to-segment translation is not supported by the device formatter yet");
+        std::unique_ptr<FILE, int (*)(FILE *)> f(std::fopen(path, "wb"), std::fclose);
+        if (!f) return fail(GBWT_HIP_IO_ERROR, std::string("cannot create ") + path);
+        std::string text;
+        // header (write_gfa_header, src/bin/gbunzip.rs:193-203)
+        if (const std::string *rs = h.tag("reference_samples")) text = "H\tVN:Z:1.1\tRS:Z:" + *rs + "\n";
+        else text = "H\tVN:Z:1.1\n";
+        // segments + links over the real nodes (write_segments / write_links, src/bin/gbunzip.rs:230-317)
+        const uint64_t first = h.alphabet_offset + 1, potential = h.sequences_labels.size();
+        auto real = [&](uint64_t seq) {
+            const uint64_t rec = 2 * seq + first - h.alphabet_offset;
+            return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;
+        };
+        for (uint64_t seq = 0; seq < potential; seq++) {
+            if (!real(seq)) continue;
+            const uint64_t node_id = (2 * seq + first) / 2;
+            text += "S\t" + std::to_string(node_id) + "\t" + h.sequences_labels.str(seq) + "\n";
+            if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+        }
+        std::vector<std::pair<uint64_t, uint64_t>> edges;
+        for (uint64_t seq = 0; seq < potential; seq++) {
+            if (!real(seq)) continue;
+            const uint64_t node_id = (2 * seq + first) / 2;
+            for (int rev = 0; rev < 2; rev++) {
+                if (!host_edges(h, 2 * node_id + rev - h.alphabet_offset, edges)) continue;
+                for (auto &e : edges) {
+                    if (e.first == 0) continue;                       // EdgeIter skips the ENDMARKER edge (src/gbz.rs:833)
+                    const uint64_t succ = e.first / 2;
+                    const bool succ_rev = (e.first & 1) != 0;
+                    const bool canonical = rev ? (succ > node_id || (succ == node_id && !succ_rev)) : (succ >= node_id);
+                    if (!canonical) continue;
+                    text += "L\t" + std::to_string(node_id) + (rev ? "\t-\t" : "\t+\t") + std::to_string(succ) + (succ_rev ? "\t-\t*\n" : "\t+\t*\n");
+                }
+            }
+            if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+        }
+        std::fwrite(text.data(), 1, text.size(), f.get());
+        // paths, then walks, ascending path id (-t 1 order; write_paths / write_walks, src/bin/gbunzip.rs:343-417)
+        uint64_t ref_sample = 0;
+        const bool have_ref = (h.metadata_flags & 2) && h.sample_names.find(GENERIC_SAMPLE, ref_sample);
+        if (!have_ref) ref_sample = h.sample_count;
+        for (int mode = 0; mode < 2; mode++) {
+            if (mode == 0 && !have_ref) continue;
+            std::vector<uint64_t> ids;
+            for (uint64_t p = 0; p < h.path_names.size(); p++)
+                if ((h.path_names[p].sample == ref_sample) == (mode == 0)) ids.push_back(p);
+            const uint64_t batch = 4096;
+            std::vector<char> buf;
+            for (uint64_t b0 = 0; b0 < ids.size(); b0 += batch) {
+                const uint64_t nb = std::min<uint64_t>(batch, ids.size() - b0);
+                uint64_t total = 0;
+                gbwt_hip_status st = path_lines_impl(ix, ws, ids.data() + b0, nb, mode, nullptr, 0, &total, &buf);
+                if (st != GBWT_HIP_OK) return st;
+                if (std::fwrite(buf.data(), 1, total, f.get()) != total) return fail(GBWT_HIP_IO_ERROR, "short write");
+            }
+        }
+        return GBWT_HIP_OK;
+    } catch (const InvalidData &e) {
+        return fail(GBWT_HIP_BAD_ARGUMENT, e.what());
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+}  // extern "C"

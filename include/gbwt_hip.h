@@ -170,6 +170,19 @@ gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *index, gbwt_hip_workspace 
 gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *queries,
                                    uint64_t n, uint64_t len, uint64_t first, gbwt_hip_bd_state *out, uint8_t *valid);
 
+/* ---- GFA text (GBZ handles with metadata) ------------------------------------------------------------
+ * gbwt_hip_path_lines: the lines gbunzip writes for the given paths, in the order given, byte for byte:
+ * mode 0 = P-lines (write_p_line / path_to_p_line, src/bin/gbunzip.rs:438-485), mode 1 = W-lines
+ * (path_to_w_line, src/bin/gbunzip.rs:495-550).  The forward sequences are walked and the node tokens
+ * formatted on the device; the host only contributes the name fields.  `*total` receives the number of bytes;
+ * out == NULL is a size query; capacity < total -> GBWT_HIP_CAPACITY.  Graphs with a node-to-segment
+ * translation -> GBWT_HIP_UNSUPPORTED (next round). */
+gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n,
+                                    int mode, char *out, uint64_t capacity, uint64_t *total);
+/* gbwt_hip_write_gfa: the whole file `gbunzip -t 1` writes (write_gfa_impl, src/bin/gbunzip.rs:205-226, default
+ * path mode): H, S and L lines from the host copy of the graph, then P-lines and W-lines in ascending path id. */
+gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const char *path);
+
 /* ---- checking hooks for device-resident results -------------------------------------------------
  * Per-path sums of the node ids of the last gbwt_hip_extract_device call on `ws` (a wave-per-path
  * reduction on the device), copied to out_sums[n]: a cheap full-size checksum of the extraction. */
