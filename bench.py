@@ -94,11 +94,20 @@ def main():
 
     import torch
     dist = None
+    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1 exist only to rehearse the N > 1 flow on a 1-GPU box
+    # (all ranks on cuda:0, reductions on CPU tensors); the driver's runs use RCCL, one GPU per rank.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    comm_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: gbwt_rs_amd has no CPU fallback")
 
@@ -145,18 +154,36 @@ def main():
     for h in (0, n_paths // 2, n_paths - 1):
         assert np.array_equal(index.copy_path(h), s.path(h))
 
+    gather_info = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([steps_done], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([steps_done], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         all_steps = float(tot.item())
+        # The one exchange of the job (outside the timed region): the ordered gather on rank 0 that stands for
+        # the final GFA concatenation.  Row lengths + per-path checksums of every rank travel over RCCL
+        # point-to-point sends (gbwt_rs_amd/dist.py); the 13 GB of node ids per rank stay where they are.
+        try:
+            from gbwt_rs_amd import dist as D
+            tg = time.perf_counter()
+            lengths = torch.full((n_paths,), 1, dtype=torch.int64, device=comm_device)
+            values = torch.from_numpy(sums.astype(np.int64)).to(comm_device)
+            g_off, g_val = D.gather_rows(lengths, values, dst=0)
+            if comm_device == "cuda":
+                torch.cuda.synchronize()
+            gather_info = {"ms": (time.perf_counter() - tg) * 1e3, "payload": "per-path checksums of every rank"}
+            if rank == 0:
+                assert g_val.numel() == world * n_paths and np.array_equal(g_val[:n_paths].cpu().numpy(), sums.astype(np.int64))
+        except Exception as e:  # never lose the measurement to the bookkeeping exchange
+            gather_info = {"error": repr(e)}
     else:
         all_steps = float(steps_done)
 
     if rank == 0:
-        cpu = None if args.no_cpu_baseline else cpu_baseline(index_path, n_paths, args.cpu_seconds)
+        # cpu_baseline is reported at N = 1 only (rank 0's host cores)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(index_path, n_paths, args.cpu_seconds)
         b_per_step, sampled_steps = algorithmic_bytes(index_path, n_paths, args.bytes_sample)
         walk_avg_ms = float(np.mean(walk_ms))
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
@@ -208,6 +235,8 @@ def main():
         }
         if cpu is not None:
             result["cpu_baseline"] = cpu
+        if gather_info is not None:
+            result["config"]["final_gather"] = gather_info
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
