@@ -310,7 +310,6 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                                    : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(4, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
-            a.debug_nostore = std::getenv("GBWT_HIP_DEBUG_NOSTORE") ? 1u : 0u;
             a.prof = nullptr;
             if (ws->profile) {
                 ws->prof.reserve(16 * sizeof(uint64_t));

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                         C.x = static_cast<uint32_t>(total0); C.y = static_cast<uint32_t>(total);
                         D = stream_bytes16(ix.data, start + body, limit);
                         if (sigma == 1 && runs == 1) B.y = DESC_UNARY;
-                        else if (total > (uint64_t(1) << ix.sample_shift)) n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);
+                        else n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);  // >= 1
                     }
                 }
             }
@@ -253,13 +253,11 @@ struct PathSink {
         }
         wp += staged; left -= staged; staged = 0;
     }
-    // returns false once the pool has overflowed (the host grows the pool and walks again)
-    __device__ __forceinline__ bool push(const WalkArgs &a, uint32_t node) {
-        if (a.debug_nostore) { staged++; if (staged == SINK_STAGE) { left = left ? left : POOL_BLOCK_NODES; left -= SINK_STAGE; blocks += left == POOL_BLOCK_NODES - SINK_STAGE; staged = 0; } return true; }
+    // after a pool overflow the sink drops what it gets: the host grows the pool and walks again
+    __device__ __forceinline__ void push(const WalkArgs &a, uint32_t node) {
         stage[staged * WAVE] = node;
         staged++;
-        if (staged == SINK_STAGE) flush(a);
-        return !overflow;
+        if (__builtin_expect(staged == SINK_STAGE, 0)) flush(a);
     }
     __device__ __forceinline__ uint64_t finish(const WalkArgs &a) {
         flush(a);
@@ -281,7 +279,8 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
         valid = node != 0;
     }
     while (valid) {
-        if (!sink.push(a, static_cast<uint32_t>(node))) break;
+        sink.push(a, static_cast<uint32_t>(node));
+        if (sink.overflow) break;
         uint64_t nn, no;
         valid = gbwt_forward(ix, node, offset, nn, no);
         node = nn; offset = no;
@@ -342,21 +341,36 @@ __device__ __attribute__((noinline)) uint2 serial_record_lf(const uint8_t *data,
     return make_uint2(0u, 0u);
 }
 
-// Default walk: one lane per sequence, no cross-lane work.  A step is one round trip to memory: the 64-byte
-// descriptor of the record and -- for long records, whose sample base arrived with the previous step -- the
-// 32-byte rank sample of the current offset travel together; the run scan then works on registers.
-template <bool PROF>
+// What one iteration of the sampled walk needs from memory: the walk descriptor of the record (edges A / C and
+// B) and the rank sample of the current offset.  All five loads are independent of each other.
+struct Fetch { uint4 A, B, C, S0, S1; };
+
+__device__ __forceinline__ bool issue_fetch(const DeviceIndex &ix, uint32_t n_rec, bool active, uint32_t node, uint32_t offset, uint32_t sb, Fetch &f) {
+    // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130).  Descriptor 0 (the endmarker,
+    // never a forward() target) and sample 0 stand in for "nothing to fetch" so that the loads need no branch.
+    uint32_t rec = node - ix.alphabet_offset;
+    const bool in_range = active && node >= ix.first_node && rec < n_rec;
+    rec = in_range ? rec : 0u;
+    const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(rec);
+    const uint32_t sidx = sb == SAMPLE_NONE ? 0u : sb + (offset >> ix.sample_shift);
+    const uint4 *sp = ix.samples + 2 * static_cast<uint64_t>(sidx);
+    f.A = d[0]; f.B = d[1]; f.C = d[2]; f.S0 = sp[0]; f.S1 = sp[1];
+    return in_range;
+}
+
+// Default walk: one lane per sequence, no cross-lane work.  An iteration is ONE round trip to memory (descriptor +
+// rank sample travel together; the sample base of the next record arrived with the previous descriptor), a run
+// scan on registers, and one or two emitted nodes (two when the edge taken is fused with a unary successor).
+// The loop is software-pipelined: the next iteration's loads are issued as soon as the next position is known,
+// BEFORE this iteration's nodes are staged and the loop bookkeeping runs, so that part overlaps the memory latency.
 __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs a) {
-    uint64_t t_push = 0, t_fetch = 0, t_scan = 0, n_steps = 0, n_scans = 0, t0 = 0, t1 = 0;
-#define PROF_MARK(acc) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } } while (0)
     __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
     const uint32_t lane = threadIdx.x;
     PathSink sink(sink_lds, lane);
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
-    const uint32_t n_rec = static_cast<uint32_t>(ix.n_records), shift = ix.sample_shift;
-    // state of the walk: record id (node - alphabet_offset; >= n_rec when there is no record), offset, sample base
-    uint32_t node = 0, offset = 0, sb = SAMPLE_NONE;
+    const uint32_t n_rec = static_cast<uint32_t>(ix.n_records);
+    uint32_t node = 0, offset = 0, sb = SAMPLE_NONE;   // position of the walk + sample base of its record
     bool active = false;
     if (owner) {
         const uint64_t id = a.seq_ids[k];
@@ -367,45 +381,27 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
             if (active && node >= ix.first_node && node - ix.alphabet_offset < n_rec) sb = ix.sbase[node - ix.alphabet_offset];
         }
     }
-    if (PROF) t0 = __builtin_amdgcn_s_memtime();
+    Fetch f;
+    bool in_range = issue_fetch(ix, n_rec, active, node, offset, sb, f);
     while (__ballot(active) != 0) {
-        // SequenceIter::next (src/gbwt.rs:560-567): emit pos.node, then next = forward(pos)
-        if (active && !sink.push(a, node)) active = false;
-        PROF_MARK(t_push);
-        // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130): descriptor 0 (the endmarker,
-        // never a forward() target) stands in for "no such record" so that the loads need no branch
-        uint32_t rec = node - ix.alphabet_offset;
-        const bool in_range = active && node >= ix.first_node && rec < n_rec;
-        rec = in_range ? rec : 0u;
-        const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(rec);
-        const uint32_t sidx = sb == SAMPLE_NONE ? 0u : sb + (offset >> shift);
-        const uint4 *sp = ix.samples + 2 * static_cast<uint64_t>(sidx);
-        uint4 A = d[0], B = d[1], C = d[2], D = d[3], S0 = sp[0], S1 = sp[1];
-        // all six loads are issued back to back and waited for together: without the pins the compiler sinks some
-        // of them into the branches below, which turns one round trip into two or three dependent ones
-        pin(A); pin(B); pin(C); pin(D); pin(S0); pin(S1);
-        PROF_MARK(t_fetch);
-        bool ok = false;
-        uint32_t next_node = 0, next_offset = 0, next_sb = SAMPLE_NONE;
+        // the loads were issued one iteration ago; the pins make the compiler wait for all five here instead of
+        // sinking some of them into the branches below (which would add dependent round trips)
+        pin(f.A); pin(f.B); pin(f.C); pin(f.S0); pin(f.S1);
+        const uint4 A = f.A, B = f.B, C = f.C, S0 = f.S0, S1 = f.S1;
+        const uint32_t cur = node;
+        const bool emit = active;
+        bool ok = false, fused = false;
+        uint32_t next_node = 0, next_offset = 0, next_sb = SAMPLE_NONE, via = 0;
         if (in_range && offset < B.w) {             // i >= Record::len -> None (B.w = 0 for class 0: handled below)
             uint32_t value = 0, rank = offset;      // unary record: one run, one successor, lf(i) = (succ, off + i)
-            if (B.y != DESC_UNARY) {
-                if (PROF) n_scans++;
-                const bool sampled = sb != SAMPLE_NONE, two = desc_class(B.z) == 2;
-                scan_runs(ix.data + desc_start(B.x, B.z), sampled ? S0.x : desc_body_offset(B.z),
-                          sampled ? S1.x : D.x, sampled ? S1.y : D.y, sampled ? S1.z : D.z, sampled ? S1.w : D.w, two,
-                          sampled ? S0.y : 0u, sampled ? S0.z : 0u, offset, value, rank);
-            }
+            if (B.y != DESC_UNARY)
+                scan_runs(ix.data + desc_start(B.x, B.z), S0.x, S1.x, S1.y, S1.z, S1.w, desc_class(B.z) == 2, S0.y, S0.z, offset, value, rank);
             // edge `value`: {successor, offset base, landing node of a fused unary successor, sample base of the landing record}
             const uint4 E = value ? C : A;
             next_node = E.x; next_offset = E.y + rank; next_sb = E.w;
-            ok = next_node != 0;                    // ENDMARKER successor: the sequence ends
-            if ((B.z >> (DESC_FUSED_SHIFT + value)) & 1u) {
-                // the successor is a unary record: emit it here and land on ITS successor (SequenceIter would take two steps)
-                if (!sink.push(a, next_node)) ok = false;
-                next_node = E.z;
-                ok = ok && next_node != 0;
-            }
+            fused = ((B.z >> (DESC_FUSED_SHIFT + value)) & 1u) != 0;
+            if (fused) { via = E.x; next_node = E.z; }   // emit the unary successor, land on ITS successor
+            ok = next_node != 0;                    // ENDMARKER: the sequence ends
         }
         if (__builtin_expect(in_range && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0, 0)) {
             // class 0 (outdegree > 2 or a stream the lean scanner cannot take): generic decode, then look the sample base up
@@ -414,19 +410,20 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
             ok = r.x != 0;
             if (ok && r.x >= ix.first_node && r.x - ix.alphabet_offset < n_rec) next_sb = ix.sbase[r.x - ix.alphabet_offset];
         }
-        PROF_MARK(t_scan);
-        if (PROF) n_steps++;
         active = active && ok;
         node = next_node; offset = next_offset; sb = next_sb;
+        in_range = issue_fetch(ix, n_rec, active, node, offset, sb, f);
+        asm volatile("" ::: "memory");              // keep the loads above the stores of the sink
+        // SequenceIter::next (src/gbwt.rs:560-567) emits pos.node before stepping; with a fused edge two nodes per iteration
+        if (emit) {
+            sink.push(a, cur);
+            if (fused) sink.push(a, via);
+        }
     }
     if (owner) {
         a.lengths[k] = sink.finish(a);
         a.head[k] = sink.head;
     }
-    if (PROF && a.prof && blockIdx.x == 0 && lane == 0) {
-        a.prof[0] = n_steps; a.prof[1] = n_scans; a.prof[2] = t_push; a.prof[3] = t_fetch; a.prof[4] = 0; a.prof[5] = t_scan;
-    }
-#undef PROF_MARK
 }
 
 // Wave-cooperative walk (WALK_COOP): lanes 0..P-1 of each wave own one sequence each; long class 1 / 2 records are
@@ -450,7 +447,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
     __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
     PathSink sink(sink_lds, lane);
     while (__ballot(active) != 0) {
-        if (active && !sink.push(a, node)) active = false;
+        if (active) sink.push(a, node);
         uint64_t start = 0;
         uint32_t bytes = 0, meta = 0, n0 = 0, o0 = 0, n1 = 0, o1 = 0;
         bool has_record = false, ok = false;
@@ -807,8 +804,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         else hipLaunchKernelGGL((k_walk_coop<false>), grid, block, 0, stream, ix, args);
         return;
     }
-    if (args.prof) hipLaunchKernelGGL((k_walk_sampled<true>), grid, block, 0, stream, ix, args);
-    else hipLaunchKernelGGL((k_walk_sampled<false>), grid, block, 0, stream, ix, args);
+    hipLaunchKernelGGL(k_walk_sampled, grid, block, 0, stream, ix, args);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

@@ -49,7 +49,6 @@ struct WalkArgs {
     uint32_t mode;             // WALK_SAMPLED (default), WALK_LANE_SERIAL or WALK_COOP
     uint32_t paths_per_wave;   // lanes of a wave that own a path (1..64)
     uint32_t small_record;     // WALK_COOP: records of at most this many bytes are decoded lane-serially
-    uint32_t debug_nostore;    // experiments only (GBWT_HIP_DEBUG_NOSTORE=1): skip the node stores, results are garbage
     uint32_t pack16;           // WALK_COOP: every record is shorter than 2^16 (stats.max_record_len): one packed scan
     uint64_t *prof;            // optional [16] cycle counters of wave 0 (GBWT_HIP_PROFILE=1), else null
 };
