@@ -63,38 +63,37 @@ void upload(gbwt_hip_index &ix) {
         d.starts64 = ix.starts.as<uint64_t>();
     }
 
-    // Load-time device passes: per-record descriptors + rank samples, record statistics, then the endmarker
+    // Load-time device passes: per-record descriptors + rank blocks, record statistics, then the endmarker
     // (src/gbwt.rs:413-414).
-    if (const char *v = std::getenv("GBWT_HIP_SAMPLE_SHIFT")) { int sh = std::atoi(v); if (sh >= 3 && sh <= 20) ix.sample_shift = static_cast<uint32_t>(sh); }
-    d.sample_shift = ix.sample_shift;
     {
         const uint64_t nr = std::max<uint64_t>(n_records, 1);
         ix.desc.reserve(nr * 4 * sizeof(uint4));
         ix.desc_raw.reserve(nr * 4 * sizeof(uint4));
-        ix.sbase.reserve(nr * sizeof(uint32_t));
+        ix.block_base.reserve(nr * sizeof(uint32_t));
         DeviceBuffer counts, scan_tmp;
         counts.reserve(nr * sizeof(uint32_t));
         launch_build_desc(d, ix.desc_raw.as<uint4>(), counts.as<uint32_t>(), nullptr);
         d.desc_raw = ix.desc_raw.as<uint4>();
         d.desc = ix.desc.as<uint4>();
-        uint64_t n_samples = 0;
+        uint64_t n_blocks = 1;  // block 0: all zero, read by the records that have no blocks of their own
         if (n_records > 0) {
             if (n_records >= (uint64_t(1) << 31)) throw InvalidData("more than 2^31 records are not supported");
-            size_t tb = sample_scan_temp_bytes(n_records);
+            if ((h.size >> RANK_BLOCK_SHIFT) + n_records >= 0xFFFFFFF0ull) throw InvalidData("index too large for 32-bit rank block indices");
+            size_t tb = block_scan_temp_bytes(n_records);
             scan_tmp.reserve(std::max<size_t>(tb, 16));
-            launch_sample_scan(counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), n_records, scan_tmp.ptr, tb, nullptr);
+            launch_block_scan(counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), n_records, scan_tmp.ptr, tb, nullptr);
             uint32_t last_base = 0, last_count = 0;
-            HIP_CHECK(hipMemcpy(&last_base, ix.sbase.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(&last_base, ix.block_base.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
             HIP_CHECK(hipMemcpy(&last_count, counts.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
-            n_samples = static_cast<uint64_t>(last_base) + last_count;
-            if (h.size / (uint64_t(1) << ix.sample_shift) + n_records >= 0xFFFFFFF0ull) throw InvalidData("index too large for 32-bit sample indices: raise GBWT_HIP_SAMPLE_SHIFT");
-            launch_mark_unsampled(counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), n_records, nullptr);
+            n_blocks += static_cast<uint64_t>(last_base) + last_count;
+            launch_finish_block_base(counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), n_records, nullptr);
         }
-        ix.samples.reserve(std::max<uint64_t>(n_samples, 1) * 2 * sizeof(uint4));
-        d.sbase = ix.sbase.as<uint32_t>();
-        d.samples = ix.samples.as<uint4>();
-        d.n_samples = n_samples;
-        if (n_samples > 0) launch_fill_samples(d, counts.as<uint32_t>(), ix.sbase.as<uint32_t>(), ix.samples.as<uint4>(), nullptr);
+        ix.blocks.reserve(n_blocks * sizeof(uint4));
+        HIP_CHECK(hipMemsetAsync(ix.blocks.ptr, 0, sizeof(uint4), nullptr));
+        d.block_base = ix.block_base.as<uint32_t>();
+        d.blocks = ix.blocks.as<uint4>();
+        d.n_blocks = n_blocks;
+        if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
         launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
@@ -255,7 +254,6 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
         delete ws; return status_of(e);
     }
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
-    if (const char *v = std::getenv("GBWT_HIP_PROFILE")) ws->profile = std::atoi(v) != 0;
     if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ws->walk_mode = static_cast<uint32_t>(m); }
     if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 0 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
     if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
@@ -310,12 +308,6 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                                    : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(4, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
-            a.prof = nullptr;
-            if (ws->profile) {
-                ws->prof.reserve(16 * sizeof(uint64_t));
-                HIP_CHECK(hipMemsetAsync(ws->prof.ptr, 0, 16 * sizeof(uint64_t), s));
-                a.prof = ws->prof.as<uint64_t>();
-            }
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);
@@ -328,16 +320,6 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             pool_blocks *= 2;  // duplicate ids can exceed the distinct-id bound: grow and walk again
         }
         if (flags & FLAG_POOL_OVERFLOW) return fail(GBWT_HIP_DEVICE_ERROR, "path pool overflow");
-        if (ws->profile && a.prof) {
-            uint64_t c[9];
-            HIP_CHECK(hipMemcpy(c, a.prof, sizeof(c), hipMemcpyDeviceToHost));
-            double st = c[0] ? static_cast<double>(c[0]) : 1.0;
-            double gr = c[1] ? static_cast<double>(c[1]) : 1.0;
-            (void)gr;
-            fprintf(stderr, "[gbwt_hip profile] wave 0: steps %llu run-scans %llu | cycles/step (s_memtime, loads drained at each mark): "
-                            "push %.0f fetch(desc+sample) %.0f (unused %.0f) scan %.0f\n",
-                    (unsigned long long)c[0], (unsigned long long)c[1], c[2] / st, c[3] / st, c[4] / st, c[5] / st);
-        }
         uint64_t total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));

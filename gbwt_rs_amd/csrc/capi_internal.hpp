@@ -57,9 +57,8 @@ inline gbwt_hip_status status_of(const HipError &e) {
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
-    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, sbase, samples;
+    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks;
     gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)
-    uint32_t sample_shift = 6;          // rank sample every 64 offsets (GBWT_HIP_SAMPLE_SHIFT)
     gbwt_hip::DeviceIndex dev{};
     gbwt_hip_stats stats{};
 };
@@ -71,8 +70,6 @@ struct gbwt_hip_workspace {
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
     uint32_t walk_mode = gbwt_hip::WALK_SAMPLED, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
-    bool profile = false;     // GBWT_HIP_PROFILE=1: phase cycle counters of wave 0, printed to stderr
-    gbwt_hip::DeviceBuffer prof;
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
     gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text;  // GFA line formatting

@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t window_varint32(uint32_t w, uint32_t &nbytes
 // Called by all 64 lanes with identical body / body_len / two; `member` marks the lanes whose path stands
 // in this record at offset i, and (n0, o0, n1, o1) are that record's decoded edges (from the descriptor).
 // PACK16: every record of the index is shorter than 2^16, so run ends and value-0 counts share one scan.
-struct CoopProf { uint64_t load = 0, scan = 0, search = 0, t = 0; };  // cycle counters for GBWT_HIP_PROFILE runs
+struct CoopProf { uint64_t load = 0, scan = 0, search = 0, t = 0; };  // cycle counters for experiments
 
 template <bool PACK16, bool PROF = false>
 __device__ __forceinline__ int coop_runs_lf(const uint8_t *body, uint32_t body_len, bool two, bool member, uint32_t i,

@@ -14,29 +14,29 @@
 //                 B = {start (low 32 bits), length in bytes, meta, Record::len}
 //                     meta = body offset (bits 0-15) | class (bits 16-17) | fused flags (bits 18-19, walk descriptor
 //                     only) | start (bits 32-39 of it, in bits 24-31)
-//                     class 1 / 2 = outdegree 1 / 2 with the edges in A and "body offset" = where the run stream
+//                     class 1 / 2 = outdegree 1 / 2 (class 1 is always unary, class 2 has rank blocks) with the edges in A and "body offset" = where the run stream
 //                     starts inside the record; class 0 = any other non-empty record (generic lane-serial decode)
 //                 C = {value-0 positions of the record, 0, 0, 0}
 //                 D = the first 16 bytes of the run stream, so short records need no second load
 //               empty / None record : B.y = 0
-//               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 and a body that is exactly one run
-//                 (every node on a linear stretch of the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w.
-//   desc      : the walk descriptor derived from desc_raw (k_link_desc), fetched by the sampled walk with four
-//               aligned dwordx4 loads that travel together: B and D as above, and one uint4 per edge,
-//                 A = edge 0, C = edge 1 = {successor, offset base, landing node, sample base of the landing record}.
+//               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 (every node on a linear stretch of
+//                 the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w, however the body splits its runs.
+//   desc      : the walk descriptor derived from desc_raw (k_link_desc), fetched by the default walk with three
+//               aligned dwordx4 loads that travel together: B as above, and one uint4 per edge,
+//                 A = edge 0, C = edge 1 = {successor, offset base, landing node, block base of the landing record}.
 //               An edge whose successor is a unary record is FUSED with it (flag in meta): taking the edge emits the
 //               successor and lands on the successor's successor at offset base + rank, so a walk spends one
 //               iteration -- one round trip to memory -- on a branching node plus the unary node behind it.
-//   sbase     : per record, index of its first rank sample or SAMPLE_NONE (needed where a walk starts; afterwards
-//               the sample base of the next record rides along in C of the current one)
-//   samples   : rank samples ("superblocks") of the long class 1 / 2 records, 32 bytes each (two uint4): sample k of
-//               a record describes the run that contains offset k << sample_shift:
-//                 S0 = {byte position of that run relative to the record start, offsets before the run,
-//                       value-0 offsets before the run, 0},  S1 = 16 bytes of the run stream from that run on.
-//               A lane fetches the descriptor and the sample of its offset in ONE round trip and usually finishes
-//               the scan from S1 in registers, so a step costs the same whatever the length of the record (the
-//               reference scans from the start of the record, src/bwt.rs:483-494).  Like simple-sds's rank/select
-//               supports, descriptors and samples are rebuilt at load, never stored.
+//   block_base: per record, index of its first rank block or BLOCK_NONE (needed where a walk starts; afterwards
+//               the block base of the next record rides along in the edge taken)
+//   blocks    : the outdegree-2 records decoded once at open (k_fill_blocks) into RANK BLOCKS of 64 offsets, 16 bytes
+//               each: {values of offsets 64k .. 64k+63 as one bit each (two words), value-1 offsets before 64k, 0}.
+//               Record::lf (src/bwt.rs:480-496) at offset i becomes: value = bit i, rank = ones-before (value 1) or
+//               i - ones-before (value 0) -- one popcount instead of the reference's scan over the runs from the
+//               start of the record.  A lane fetches the descriptor and the block of its offset in ONE round trip.
+//               Cost: 2.5 bits per BWT position of an outdegree-2 record, whatever its run structure (sized for
+//               HBM, not for disk).  Block 0 is all zero and shared: it is what unary records read (value 0, rank = i).
+//               Like simple-sds's rank/select supports, descriptors and blocks are rebuilt at load, never stored.
 #pragma once
 
 #include <cstdint>
@@ -46,7 +46,8 @@ namespace gbwt_hip {
 constexpr uint32_t DESC_UNARY = 0xFFFFFFFFu;
 constexpr uint32_t DESC_FUSED_SHIFT = 18;
 constexpr uint32_t DESC_FUSED0 = 1u << DESC_FUSED_SHIFT;
-constexpr uint32_t SAMPLE_NONE = 0xFFFFFFFFu;
+constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
+constexpr uint32_t RANK_BLOCK_SHIFT = 6;   // 64 offsets per rank block
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start
 
 struct DeviceIndex {
@@ -56,16 +57,15 @@ struct DeviceIndex {
     const uint2 *endmarker;    // .x = node, .y = offset
     const uint4 *desc;         // 4 * n_records entries (walk descriptors)
     const uint4 *desc_raw;     // 4 * n_records entries (raw descriptors)
-    const uint32_t *sbase;     // n_records entries
-    const uint4 *samples;      // 2 * n_samples entries
+    const uint32_t *block_base; // n_records entries
+    const uint4 *blocks;       // n_blocks entries
     uint64_t data_len;
     uint64_t n_records;
     uint64_t n_sequences;      // header.sequences
     uint64_t n_endmarker;      // decompressed endmarker length
-    uint64_t n_samples;
+    uint64_t n_blocks;
     uint32_t alphabet_offset;
     uint32_t first_node;       // alphabet_offset + 1
-    uint32_t sample_shift;     // log2 of the sampling interval (in record offsets)
 };
 
 __host__ __device__ inline uint32_t desc_body_offset(uint32_t meta) { return meta & 0xFFFFu; }

@@ -39,14 +39,14 @@ __device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t po
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// One lane per record: the RAW descriptor (device_index.hpp) and the number of rank samples the record gets.
-__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *sample_counts) {
+// One lane per record: the RAW descriptor (device_index.hpp) and the number of rank blocks the record gets.
+__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *block_counts) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
     uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), C = make_uint4(0, 0, 0, 0), D = make_uint4(0, 0, 0, 0);
-    uint32_t n_samples = 0;
+    uint32_t n_blocks = 0;
     if (limit > start) {
         ByteCursor c(ix.data, start, limit);
         uint64_t sigma = 0;
@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                         B.w = static_cast<uint32_t>(total);
                         C.x = static_cast<uint32_t>(total0); C.y = static_cast<uint32_t>(total);
                         D = stream_bytes16(ix.data, start + body, limit);
-                        if (sigma == 1 && runs == 1) B.y = DESC_UNARY;
-                        else n_samples = static_cast<uint32_t>((total + (uint64_t(1) << ix.sample_shift) - 1) >> ix.sample_shift);  // >= 1
+                        // outdegree 1: Record::lf(i) = (n0, o0 + i) however the body splits its runs
+                        if (sigma == 1) B.y = DESC_UNARY;
+                        else n_blocks = static_cast<uint32_t>((total >> RANK_BLOCK_SHIFT) + 1);  // position `total` is addressable too
                     }
                 }
             }
@@ -100,10 +101,10 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
     desc[4 * rec + 1] = B;
     desc[4 * rec + 2] = C;
     desc[4 * rec + 3] = D;
-    sample_counts[rec] = n_samples;
+    block_counts[rec] = n_blocks;
 }
 
-// One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Every edge gets the sample base of the
+// One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Every edge gets the block base of the
 // record a walk lands in, and an edge whose successor is a unary record is FUSED with it: the walk then emits that
 // successor and lands directly on the successor's successor.  Fusing is exact when every offset the edge can produce
 // exists in the unary record, i.e. edge offset + (positions of this record that take the edge) <= its length --
@@ -114,14 +115,14 @@ __global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
     const uint4 *raw = ix.desc_raw;
     const uint4 A = raw[4 * rec], C = raw[4 * rec + 2], D = raw[4 * rec + 3];
     uint4 B = raw[4 * rec + 1];
-    uint4 E0 = make_uint4(0, 0, 0, SAMPLE_NONE), E1 = make_uint4(0, 0, 0, SAMPLE_NONE);
+    uint4 E0 = make_uint4(0, 0, 0, BLOCK_NONE), E1 = make_uint4(0, 0, 0, BLOCK_NONE);
     const uint32_t cls = B.y != 0 ? desc_class(B.z) : 0u;
     if (cls != 0) {
         const uint32_t count[2] = {cls == 2 ? C.x : B.w, cls == 2 ? B.w - C.x : 0u};
         const uint32_t succ[2] = {A.x, A.z}, off[2] = {A.y, A.w};
         uint4 E[2] = {E0, E1};
         for (uint32_t e = 0; e < cls; e++) {
-            uint32_t node = succ[e], base = off[e], land = 0, sb = SAMPLE_NONE;
+            uint32_t node = succ[e], base = off[e], land = 0, sb = BLOCK_NONE;
             bool fused = false;
             if (node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
                 const uint64_t r = node - ix.alphabet_offset;
@@ -129,8 +130,8 @@ __global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
                 if (SB.y == DESC_UNARY && static_cast<uint64_t>(base) + count[e] <= SB.w) {
                     fused = true;
                     land = SA.x; base += SA.y;
-                    if (land >= ix.first_node && land - ix.alphabet_offset < ix.n_records) sb = ix.sbase[land - ix.alphabet_offset];
-                } else sb = ix.sbase[r];
+                    if (land >= ix.first_node && land - ix.alphabet_offset < ix.n_records) sb = ix.block_base[land - ix.alphabet_offset];
+                } else sb = ix.block_base[r];
             }
             E[e] = make_uint4(node, base, land, sb);
             if (fused) B.z |= DESC_FUSED0 << e;
@@ -143,30 +144,34 @@ __global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
     out[4 * rec + 3] = D;
 }
 
-// One lane per sampled record: sample k = the run containing offset k << sample_shift (device_index.hpp).
-__global__ void __launch_bounds__(256) k_fill_samples(DeviceIndex ix, const uint32_t *sample_counts, const uint32_t *sbase, uint4 *samples) {
+// One lane per outdegree-2 record: decode the runs ONCE and lay the record out as rank blocks (device_index.hpp):
+// block k = {64 values (one bit each), value-1 positions before the block}.  Record::lf (src/bwt.rs:480-496) at
+// offset i is then value = bit i, rank = ones-before or i - ones-before, without scanning any run.
+__global__ void __launch_bounds__(256) k_fill_blocks(DeviceIndex ix, const uint32_t *block_counts, const uint32_t *block_base, uint4 *blocks) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
-    const uint32_t count = sample_counts[rec];
+    const uint32_t count = block_counts[rec];
     if (count == 0) return;
     const uint4 B = ix.desc_raw[4 * rec + 1];
     const uint64_t start = desc_start(B.x, B.z), limit = start + B.y;
     ByteCursor c(ix.data, start + desc_body_offset(B.z), limit);
     RunDecoder rd(desc_class(B.z));
-    uint4 *out = samples + 2 * static_cast<uint64_t>(sbase[rec]);
-    uint64_t cum = 0, c0 = 0, value, len;
-    uint32_t k = 0;
-    while (k < count) {
-        const uint64_t run_pos = c.pos;
-        if (!rd.next(c, value, len)) break;
-        if ((static_cast<uint64_t>(k) << ix.sample_shift) < cum + len) {
-            const uint4 S0 = make_uint4(static_cast<uint32_t>(run_pos - start), static_cast<uint32_t>(cum), static_cast<uint32_t>(c0), 0u);
-            const uint4 S1 = stream_bytes16(ix.data, run_pos, limit);
-            while (k < count && (static_cast<uint64_t>(k) << ix.sample_shift) < cum + len) { out[2 * k] = S0; out[2 * k + 1] = S1; k++; }
+    uint4 *out = blocks + block_base[rec];
+    uint64_t bits = 0, value, len;
+    uint32_t k = 0, fill = 0, ones = 0;
+    while (k < count && rd.next(c, value, len)) {
+        while (len > 0 && k < count) {
+            const uint32_t take = static_cast<uint32_t>(len < 64 - fill ? len : 64 - fill);
+            if (value) bits |= (take == 64 ? ~uint64_t(0) : ((uint64_t(1) << take) - 1)) << fill;
+            fill += take; len -= take;
+            if (fill == 64) {
+                out[k++] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
+                ones += __popcll(bits);
+                bits = 0; fill = 0;
+            }
         }
-        cum += len;
-        if (value == 0) c0 += len;
     }
+    if (k < count) out[k] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
 }
 
 // Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
@@ -292,45 +297,6 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
 // Forces a loaded value to be live in VGPRs at this point (keeps the compiler from sinking the load).
 __device__ __forceinline__ void pin(uint4 &q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
 
-// Run scan of a class 1 / 2 record by one lane (RLEIter::next src/support.rs:1413-1430 for sigma <= 2, the loop of
-// Record::lf src/bwt.rs:483-494).  The 16 stream bytes starting at byte `rel` of the record are already in registers
-// (w0..w3: from the descriptor or the rank sample) with `cum` offsets and `c0` value-0 offsets before them.  The
-// caller guarantees i < Record::len and k_build_desc has checked that the stream is well formed, so the scan
-// always ends in a hit and needs no bounds checks.  Output: value of the run, rank of i among that value, i.e.
-// lf(i) = (successor(value), offset(value) + rank).
-__device__ __forceinline__ void scan_runs(const uint8_t *record, uint32_t rel, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, bool two,
-                                          uint32_t cum, uint32_t c0, uint32_t i, uint32_t &value, uint32_t &rank) {
-    const uint32_t threshold = two ? 128u : 256u, saturated = two ? 254u : 255u;
-    uint32_t used = 0;
-    for (;;) {
-        if (__builtin_expect(used > 11, 0)) {  // fewer than 5 bytes left in the window: fetch the next 16
-            rel += used; used = 0;
-            uint4 q;
-            __builtin_memcpy(&q, record + rel, 16);
-            w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w;
-        }
-        const uint32_t b = w0 & 0xFFu;
-        const uint32_t v = two ? (b & 1u) : 0u;
-        uint32_t len = (two ? (b >> 1) : b) + 1;
-        if (__builtin_expect(b >= saturated, 0)) {  // long run: length extension in the next 1-4 bytes
-            uint32_t n;
-            len = threshold + window_varint32(__builtin_amdgcn_alignbit(w1, w0, 8), n);
-            const uint32_t nb = 1 + n;
-            if (cum + len > i) { value = v; rank = (v ? cum - c0 : c0) + (i - cum); return; }
-            cum += len; c0 += v ? 0u : len; used += nb;
-            const uint32_t sh = 8 * nb;  // 16 .. 40: shift the 128-bit window down by nb bytes
-            uint64_t lo = (static_cast<uint64_t>(w1) << 32) | w0, hi = (static_cast<uint64_t>(w3) << 32) | w2;
-            lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh;
-            w0 = static_cast<uint32_t>(lo); w1 = static_cast<uint32_t>(lo >> 32); w2 = static_cast<uint32_t>(hi); w3 = static_cast<uint32_t>(hi >> 32);
-            continue;
-        }
-        if (cum + len > i) { value = v; rank = (v ? cum - c0 : c0) + (i - cum); return; }
-        cum += len; c0 += v ? 0u : len; used += 1;
-        w0 = __builtin_amdgcn_alignbit(w1, w0, 8); w1 = __builtin_amdgcn_alignbit(w2, w1, 8);
-        w2 = __builtin_amdgcn_alignbit(w3, w2, 8); w3 >>= 8;
-    }
-}
-
 // Generic lane-serial Record::lf on the record bytes [start, start + bytes) (class 0 records, fallbacks).  Out of
 // line and by-value only, so that the hot loops stay small and nothing is forced into scratch.  Returns
 // (node, offset); node == 0 <=> None.
@@ -341,36 +307,36 @@ __device__ __attribute__((noinline)) uint2 serial_record_lf(const uint8_t *data,
     return make_uint2(0u, 0u);
 }
 
-// What one iteration of the sampled walk needs from memory: the walk descriptor of the record (edges A / C and
-// B) and the rank sample of the current offset.  All five loads are independent of each other.
-struct Fetch { uint4 A, B, C, S0, S1; };
+// What one iteration of the walk needs from memory: the walk descriptor of the record (edges A / C, and B) and the
+// rank block of the current offset.  The four loads are independent of each other.
+struct Fetch { uint4 A, B, C, K; };
 
-__device__ __forceinline__ bool issue_fetch(const DeviceIndex &ix, uint32_t n_rec, bool active, uint32_t node, uint32_t offset, uint32_t sb, Fetch &f) {
+__device__ __forceinline__ bool issue_fetch(const DeviceIndex &ix, uint32_t n_rec, bool active, uint32_t node, uint32_t offset, uint32_t bb, Fetch &f) {
     // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130).  Descriptor 0 (the endmarker,
-    // never a forward() target) and sample 0 stand in for "nothing to fetch" so that the loads need no branch.
+    // never a forward() target) stands in for "nothing to fetch", and block 0 (all zero: value 0, rank = offset) is
+    // what a record without blocks reads, so that the loads need no branch.
     uint32_t rec = node - ix.alphabet_offset;
     const bool in_range = active && node >= ix.first_node && rec < n_rec;
     rec = in_range ? rec : 0u;
     const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(rec);
-    const uint32_t sidx = sb == SAMPLE_NONE ? 0u : sb + (offset >> ix.sample_shift);
-    const uint4 *sp = ix.samples + 2 * static_cast<uint64_t>(sidx);
-    f.A = d[0]; f.B = d[1]; f.C = d[2]; f.S0 = sp[0]; f.S1 = sp[1];
+    const uint32_t bidx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+    f.A = d[0]; f.B = d[1]; f.C = d[2]; f.K = ix.blocks[bidx];
     return in_range;
 }
 
 // Default walk: one lane per sequence, no cross-lane work.  An iteration is ONE round trip to memory (descriptor +
-// rank sample travel together; the sample base of the next record arrived with the previous descriptor), a run
-// scan on registers, and one or two emitted nodes (two when the edge taken is fused with a unary successor).
+// rank block travel together; the block base of the next record arrived with the previous descriptor), a popcount,
+// and one or two emitted nodes (two when the edge taken is fused with a unary successor).
 // The loop is software-pipelined: the next iteration's loads are issued as soon as the next position is known,
 // BEFORE this iteration's nodes are staged and the loop bookkeeping runs, so that part overlaps the memory latency.
-__global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs a) {
+__global__ void __launch_bounds__(WAVE) k_walk_blocks(DeviceIndex ix, WalkArgs a) {
     __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
     const uint32_t lane = threadIdx.x;
     PathSink sink(sink_lds, lane);
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
     const uint32_t n_rec = static_cast<uint32_t>(ix.n_records);
-    uint32_t node = 0, offset = 0, sb = SAMPLE_NONE;   // position of the walk + sample base of its record
+    uint32_t node = 0, offset = 0, bb = BLOCK_NONE;   // position of the walk + block base of its record
     bool active = false;
     if (owner) {
         const uint64_t id = a.seq_ids[k];
@@ -378,41 +344,45 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
             uint2 e = ix.endmarker[id];
             node = e.x; offset = e.y;
             active = node != 0;
-            if (active && node >= ix.first_node && node - ix.alphabet_offset < n_rec) sb = ix.sbase[node - ix.alphabet_offset];
+            if (active && node >= ix.first_node && node - ix.alphabet_offset < n_rec) bb = ix.block_base[node - ix.alphabet_offset];
         }
     }
     Fetch f;
-    bool in_range = issue_fetch(ix, n_rec, active, node, offset, sb, f);
+    bool in_range = issue_fetch(ix, n_rec, active, node, offset, bb, f);
     while (__ballot(active) != 0) {
-        // the loads were issued one iteration ago; the pins make the compiler wait for all five here instead of
+        // the loads were issued one iteration ago; the pins make the compiler wait for all four here instead of
         // sinking some of them into the branches below (which would add dependent round trips)
-        pin(f.A); pin(f.B); pin(f.C); pin(f.S0); pin(f.S1);
-        const uint4 A = f.A, B = f.B, C = f.C, S0 = f.S0, S1 = f.S1;
+        pin(f.A); pin(f.B); pin(f.C); pin(f.K);
+        const uint4 A = f.A, B = f.B, C = f.C, K = f.K;
         const uint32_t cur = node;
         const bool emit = active;
         bool ok = false, fused = false;
-        uint32_t next_node = 0, next_offset = 0, next_sb = SAMPLE_NONE, via = 0;
+        uint32_t next_node = 0, next_offset = 0, next_bb = BLOCK_NONE, via = 0;
         if (in_range && offset < B.w) {             // i >= Record::len -> None (B.w = 0 for class 0: handled below)
-            uint32_t value = 0, rank = offset;      // unary record: one run, one successor, lf(i) = (succ, off + i)
-            if (B.y != DESC_UNARY)
-                scan_runs(ix.data + desc_start(B.x, B.z), S0.x, S1.x, S1.y, S1.z, S1.w, desc_class(B.z) == 2, S0.y, S0.z, offset, value, rank);
-            // edge `value`: {successor, offset base, landing node of a fused unary successor, sample base of the landing record}
+            // Record::lf on the rank block: value = bit `offset` of the record, rank = equal values before it.
+            // A unary record reads the zero block: value 0, rank = offset.
+            const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+            const uint32_t bit = offset & 63u;
+            const uint32_t value = static_cast<uint32_t>(bits >> bit) & 1u;
+            const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << bit) - 1));
+            const uint32_t rank = value ? ones : offset - ones;
+            // edge `value`: {successor, offset base, landing node of a fused unary successor, block base of the landing record}
             const uint4 E = value ? C : A;
-            next_node = E.x; next_offset = E.y + rank; next_sb = E.w;
+            next_node = E.x; next_offset = E.y + rank; next_bb = E.w;
             fused = ((B.z >> (DESC_FUSED_SHIFT + value)) & 1u) != 0;
             if (fused) { via = E.x; next_node = E.z; }   // emit the unary successor, land on ITS successor
             ok = next_node != 0;                    // ENDMARKER: the sequence ends
         }
         if (__builtin_expect(in_range && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0, 0)) {
-            // class 0 (outdegree > 2 or a stream the lean scanner cannot take): generic decode, then look the sample base up
+            // class 0 (outdegree > 2 or a stream outside the descriptor's limits): generic decode, then look the block base up
             const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
-            next_node = r.x; next_offset = r.y; next_sb = SAMPLE_NONE;
+            next_node = r.x; next_offset = r.y; next_bb = BLOCK_NONE;
             ok = r.x != 0;
-            if (ok && r.x >= ix.first_node && r.x - ix.alphabet_offset < n_rec) next_sb = ix.sbase[r.x - ix.alphabet_offset];
+            if (ok && r.x >= ix.first_node && r.x - ix.alphabet_offset < n_rec) next_bb = ix.block_base[r.x - ix.alphabet_offset];
         }
         active = active && ok;
-        node = next_node; offset = next_offset; sb = next_sb;
-        in_range = issue_fetch(ix, n_rec, active, node, offset, sb, f);
+        node = next_node; offset = next_offset; bb = next_bb;
+        in_range = issue_fetch(ix, n_rec, active, node, offset, bb, f);
         asm volatile("" ::: "memory");              // keep the loads above the stores of the sink
         // SequenceIter::next (src/gbwt.rs:560-567) emits pos.node before stepping; with a fused edge two nodes per iteration
         if (emit) {
@@ -428,7 +398,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_sampled(DeviceIndex ix, WalkArgs 
 
 // Wave-cooperative walk (WALK_COOP): lanes 0..P-1 of each wave own one sequence each; long class 1 / 2 records are
 // decoded one distinct record at a time by the whole wave (coop_device.hpp), so sequences that sit in the same record
-// share one decode.  Kept as an alternative to the sampled walk: it needs no rank samples.
+// share one decode.  Kept as an alternative to the default walk: it needs no rank blocks.
 template <bool PACK16>
 __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) {
     const uint32_t lane = threadIdx.x;
@@ -553,9 +523,9 @@ __global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_
     out[k] = r; valid[k] = ok;
 }
 
-// ---- search on descriptors + rank samples ------------------------------------------------------------
+// ---- search on descriptors + rank blocks --------------------------------------------------------------
 // For class 1 / 2 records everything Record::follow / bd_follow compute (src/bwt.rs:595-656) is a difference of
-// "how many of the first p positions take edge r", which the rank samples answer in O(1): two sample lookups
+// "how many of the first p positions take edge r", which the rank blocks answer in O(1): two block lookups
 // replace the reference's scan of all runs up to range.end.  Other records use the generic scan of lf_device.hpp.
 
 struct RawDesc { uint4 A, B, C, D; };
@@ -572,22 +542,14 @@ __device__ __forceinline__ bool load_raw_desc(const DeviceIndex &ix, uint64_t no
 __device__ __forceinline__ uint32_t count0_before(const DeviceIndex &ix, const RawDesc &d, uint64_t rec, uint32_t p) {
     if (desc_class(d.B.z) == 1) return p;
     if (p >= d.B.w) return d.C.x;
-    const uint32_t sb = ix.sbase[rec];
-    uint32_t rel = desc_body_offset(d.B.z), cum = 0, c0 = 0;
-    uint4 w = d.D;
-    if (sb != SAMPLE_NONE) {
-        const uint4 *sp = ix.samples + 2 * (static_cast<uint64_t>(sb) + (p >> ix.sample_shift));
-        const uint4 S0 = sp[0];
-        w = sp[1]; rel = S0.x; cum = S0.y; c0 = S0.z;
-    }
-    uint32_t value, rank;
-    scan_runs(ix.data + desc_start(d.B.x, d.B.z), rel, w.x, w.y, w.z, w.w, true, cum, c0, p, value, rank);
-    return value ? p - rank : rank;
+    const uint4 K = ix.blocks[ix.block_base[rec] + (p >> RANK_BLOCK_SHIFT)];
+    const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+    return p - (K.z + __popcll(bits & ((uint64_t(1) << (p & 63u)) - 1)));
 }
 
 // Record::follow / bd_follow on a class 1 / 2 record.
 template <bool BD>
-__device__ __forceinline__ bool sampled_follow(const DeviceIndex &ix, const RawDesc &d, uint64_t rec, uint64_t start, uint64_t end, uint64_t dest,
+__device__ __forceinline__ bool block_follow(const DeviceIndex &ix, const RawDesc &d, uint64_t rec, uint64_t start, uint64_t end, uint64_t dest,
                                                uint64_t &rstart, uint64_t &rend, uint64_t &count) {
     if (start >= end || dest == 0) return false;
     const bool two = desc_class(d.B.z) == 2;
@@ -627,7 +589,7 @@ __device__ __forceinline__ bool dev_follow(const DeviceIndex &ix, uint64_t from,
     RawDesc d;
     uint64_t rec;
     if (!load_raw_desc(ix, from, d, rec)) return false;
-    if (desc_class(d.B.z) != 0) return sampled_follow<BD>(ix, d, rec, start, end, dest, rs, re, count);
+    if (desc_class(d.B.z) != 0) return block_follow<BD>(ix, d, rec, start, end, dest, rs, re, count);
     const uint64_t rstart = desc_start(d.B.x, d.B.z);
     ByteCursor c(ix.data, rstart, rstart + d.B.y);
     uint64_t sigma;
@@ -746,9 +708,9 @@ void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t s
     hipLaunchKernelGGL(k_record_stats, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_stats);
 }
 
-void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_sample_counts, hipStream_t stream) {
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_sample_counts);
+    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts);
 }
 
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
@@ -756,30 +718,31 @@ void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) 
     hipLaunchKernelGGL(k_link_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc);
 }
 
-void launch_fill_samples(const DeviceIndex &ix, const uint32_t *d_sample_counts, const uint32_t *d_sbase, uint4 *d_samples, hipStream_t stream) {
+void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_fill_samples, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_sample_counts, d_sbase, d_samples);
+    hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_block_base, d_blocks);
 }
 
-// exclusive scan of the per-record sample counts into sbase (SAMPLE_NONE where the count is 0); returns the total
-__global__ void __launch_bounds__(256) k_mark_unsampled(const uint32_t *counts, uint32_t *sbase, uint64_t n) {
+// exclusive scan of the per-record block counts, then block_base = 1 + scan (block 0 is the shared all-zero block)
+// or BLOCK_NONE where the count is 0
+__global__ void __launch_bounds__(256) k_finish_block_base(const uint32_t *counts, uint32_t *block_base, uint64_t n) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (rec < n && counts[rec] == 0) sbase[rec] = SAMPLE_NONE;
+    if (rec < n) block_base[rec] = counts[rec] == 0 ? BLOCK_NONE : block_base[rec] + 1;
 }
 
-size_t sample_scan_temp_bytes(uint64_t n) {
+size_t block_scan_temp_bytes(uint64_t n) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), static_cast<int>(n));
     return bytes;
 }
 
-void launch_sample_scan(const uint32_t *d_counts, uint32_t *d_sbase, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream) {
+void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream) {
     if (n == 0) return;
-    (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_sbase, static_cast<int>(n), stream);
+    (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_block_base, static_cast<int>(n), stream);
 }
 
-void launch_mark_unsampled(const uint32_t *d_counts, uint32_t *d_sbase, uint64_t n, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_mark_unsampled, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_sbase, n);
+void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_finish_block_base, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_block_base, n);
 }
 
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream) {
@@ -804,7 +767,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         else hipLaunchKernelGGL((k_walk_coop<false>), grid, block, 0, stream, ix, args);
         return;
     }
-    hipLaunchKernelGGL(k_walk_sampled, grid, block, 0, stream, ix, args);
+    hipLaunchKernelGGL(k_walk_blocks, grid, block, 0, stream, ix, args);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

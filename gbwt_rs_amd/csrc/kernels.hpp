@@ -20,16 +20,16 @@ constexpr uint32_t FLAG_POOL_OVERFLOW = 1u;
 void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream);
 // Record::decompress of record 0 into d_out[n_out] (src/gbwt.rs:413-414); d_scratch: 2 * sigma u64.
 // d_result[0] = number of positions produced, d_result[1] = outdegree of record 0 (first call sizes scratch)
-// per-record descriptors + rank samples (device_index.hpp): d_desc has 4 * n_records entries; build_desc also
-// writes the number of samples of every record, sample_scan turns the counts into first-sample indices,
-// mark_unsampled writes SAMPLE_NONE where there are none, fill_samples writes the samples (2 uint4 each),
-// link_desc stores the successors' sample bases into the descriptors.
-void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_sample_counts, hipStream_t stream);
-size_t sample_scan_temp_bytes(uint64_t n);
-void launch_sample_scan(const uint32_t *d_counts, uint32_t *d_sbase, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream);
-void launch_mark_unsampled(const uint32_t *d_counts, uint32_t *d_sbase, uint64_t n, hipStream_t stream);
+// per-record descriptors + rank blocks (device_index.hpp): d_desc has 4 * n_records entries; build_desc also
+// writes the number of rank blocks of every record, block_scan + finish_block_base turn the counts into
+// first-block indices (BLOCK_NONE where there are none; block 0 is the shared zero block), fill_blocks decodes
+// the outdegree-2 records into their blocks, link_desc stores the successors' block bases into the descriptors.
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, hipStream_t stream);
+size_t block_scan_temp_bytes(uint64_t n);
+void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream);
+void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream);
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream);
-void launch_fill_samples(const DeviceIndex &ix, const uint32_t *d_sample_counts, const uint32_t *d_sbase, uint4 *d_samples, hipStream_t stream);
+void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream);
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream);
 void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
                                  uint64_t *d_result, hipStream_t stream);
@@ -50,7 +50,6 @@ struct WalkArgs {
     uint32_t paths_per_wave;   // lanes of a wave that own a path (1..64)
     uint32_t small_record;     // WALK_COOP: records of at most this many bytes are decoded lane-serially
     uint32_t pack16;           // WALK_COOP: every record is shorter than 2^16 (stats.max_record_len): one packed scan
-    uint64_t *prof;            // optional [16] cycle counters of wave 0 (GBWT_HIP_PROFILE=1), else null
 };
 constexpr uint32_t WALK_SAMPLED = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);

@@ -378,7 +378,7 @@ def test_headline_scale_properties():
 # ---------------------------------------------------------------------------------------------
 # kernel variants: results never depend on the tuning
 
-TUNINGS = [dict(walk_mode=0, paths_per_wave=64, small_record=16),   # default: rank samples, one lane per sequence
+TUNINGS = [dict(walk_mode=0, paths_per_wave=64, small_record=16),   # default: rank blocks, one lane per sequence
            dict(walk_mode=0, paths_per_wave=7, small_record=16),
            dict(walk_mode=2, paths_per_wave=64, small_record=16),   # cooperative for long records (bpermute search)
            dict(walk_mode=2, paths_per_wave=64, small_record=0),    # every class 1/2 record through the cooperative path
