@@ -77,7 +77,7 @@ void upload(gbwt_hip_index &ix) {
         d.desc = ix.desc.as<uint4>();
         uint64_t n_blocks = 1;  // block 0: all zero, read by the records that have no blocks of their own
         if (n_records > 0) {
-            if (n_records >= (uint64_t(1) << 31)) throw InvalidData("more than 2^31 records are not supported");
+            if (n_records >= (uint64_t(1) << 30)) throw InvalidData("more than 2^30 records are not supported");
             if ((h.size >> RANK_BLOCK_SHIFT) + n_records >= 0xFFFFFFF0ull) throw InvalidData("index too large for 32-bit rank block indices");
             size_t tb = block_scan_temp_bytes(n_records);
             scan_tmp.reserve(std::max<size_t>(tb, 16));
@@ -95,6 +95,11 @@ void upload(gbwt_hip_index &ix) {
         d.n_blocks = n_blocks;
         if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
         launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
+        {
+            uint32_t hops = 2;
+            if (const char *v = std::getenv("GBWT_HIP_LOOKAHEAD_HOPS")) hops = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+            launch_link_lookahead(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), hops, nullptr);
+        }
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
     }

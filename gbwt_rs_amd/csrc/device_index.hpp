@@ -44,8 +44,10 @@
 namespace gbwt_hip {
 
 constexpr uint32_t DESC_UNARY = 0xFFFFFFFFu;
-constexpr uint32_t DESC_FUSED_SHIFT = 18;
-constexpr uint32_t DESC_FUSED0 = 1u << DESC_FUSED_SHIFT;
+constexpr uint32_t EDGE_EMIT2 = 1u << 31;            // walk descriptor, per edge: fused with a unary successor
+constexpr uint32_t EDGE_CONT = 1u << 30;             // walk descriptor, per edge: the walk continues behind the edge
+constexpr uint32_t DESC_SLOW = 1u << 31;             // walk descriptor, D.x: generic decode (class 0, unchecked edges)
+constexpr uint32_t LOOKAHEAD_COUNT_MASK = (1u << 29) - 1;
 constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANK_BLOCK_SHIFT = 6;   // 64 offsets per rank block
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start

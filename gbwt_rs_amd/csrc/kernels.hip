@@ -104,44 +104,98 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
     block_counts[rec] = n_blocks;
 }
 
-// One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Every edge gets the block base of the
-// record a walk lands in, and an edge whose successor is a unary record is FUSED with it: the walk then emits that
-// successor and lands directly on the successor's successor.  Fusing is exact when every offset the edge can produce
-// exists in the unary record, i.e. edge offset + (positions of this record that take the edge) <= its length --
-// always true in a valid GBWT, checked here so that no run-time test is needed.
+// One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Everything the walk would otherwise
+// test per step is decided here, once:
+//  * an edge whose successor is a unary record is FUSED with it: the walk emits that successor and lands directly on
+//    the successor's successor, one iteration (one round trip to memory) for two nodes;
+//  * every edge knows whether the walk continues behind it (EDGE_CONT: the landing record exists and is not empty --
+//    GBWT::forward's guards and BWT::record, src/gbwt.rs:222-229, src/bwt.rs:124-130), the record index of the
+//    landing record and its block base;
+//  * every offset an edge can produce is checked against the length of the landing record (offset base + number of
+//    positions of this record that take the edge <= Record::len of the landing record; always true in a valid GBWT),
+//    so the walk needs no "i >= Record::len -> None" test (src/bwt.rs:481).  A record with an edge that fails the
+//    check is marked DESC_SLOW and goes through the generic decoder, which tests everything the reference tests.
+__device__ __forceinline__ bool landing_record(const DeviceIndex &ix, uint32_t node, uint64_t &rec) {
+    if (node < ix.first_node) return false;
+    rec = node - ix.alphabet_offset;
+    return rec < ix.n_records;
+}
+
 __global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     const uint4 *raw = ix.desc_raw;
-    const uint4 A = raw[4 * rec], C = raw[4 * rec + 2], D = raw[4 * rec + 3];
-    uint4 B = raw[4 * rec + 1];
-    uint4 E0 = make_uint4(0, 0, 0, BLOCK_NONE), E1 = make_uint4(0, 0, 0, BLOCK_NONE);
+    const uint4 A = raw[4 * rec], B = raw[4 * rec + 1], C = raw[4 * rec + 2];
+    uint4 E[2] = {make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE)};
+    uint32_t flags[2] = {0, 0};
     const uint32_t cls = B.y != 0 ? desc_class(B.z) : 0u;
+    bool slow = cls == 0;   // class 0 and empty records (the latter are never landed on)
     if (cls != 0) {
-        const uint32_t count[2] = {cls == 2 ? C.x : B.w, cls == 2 ? B.w - C.x : 0u};
+        const uint64_t count[2] = {cls == 2 ? C.x : B.w, cls == 2 ? B.w - C.x : 0u};
         const uint32_t succ[2] = {A.x, A.z}, off[2] = {A.y, A.w};
-        uint4 E[2] = {E0, E1};
         for (uint32_t e = 0; e < cls; e++) {
-            uint32_t node = succ[e], base = off[e], land = 0, sb = BLOCK_NONE;
-            bool fused = false;
-            if (node >= ix.first_node && node - ix.alphabet_offset < ix.n_records) {
-                const uint64_t r = node - ix.alphabet_offset;
-                const uint4 SB = raw[4 * r + 1], SA = raw[4 * r];
-                if (SB.y == DESC_UNARY && static_cast<uint64_t>(base) + count[e] <= SB.w) {
-                    fused = true;
-                    land = SA.x; base += SA.y;
-                    if (land >= ix.first_node && land - ix.alphabet_offset < ix.n_records) sb = ix.block_base[land - ix.alphabet_offset];
-                } else sb = ix.block_base[r];
+            const uint32_t node = succ[e];
+            uint64_t base = off[e], r = 0, land = 0;
+            uint32_t z = 0, bb = BLOCK_NONE;
+            bool cont = false, emit2 = false;
+            if (node != 0 && landing_record(ix, node, r)) {
+                const uint4 SA = raw[4 * r], SB = raw[4 * r + 1];
+                if (SB.y == DESC_UNARY && base + count[e] <= SB.w) {
+                    // plain edge to the unary record is safe; fuse when what lies behind it is safe too
+                    cont = true; z = static_cast<uint32_t>(r);
+                    const uint64_t base2 = base + SA.y;
+                    if (SA.x == 0) { cont = false; z = 0; }            // the unary node is the last one of these sequences
+                    else if (landing_record(ix, SA.x, land) && base2 + count[e] <= 0xFFFFFFFFull) {
+                        const uint4 LB = raw[4 * land + 1];
+                        if (LB.y != 0 && (desc_class(LB.z) == 0 || base2 + count[e] <= LB.w)) {
+                            emit2 = true; z = static_cast<uint32_t>(land); base = base2; bb = ix.block_base[land];
+                        }
+                    }
+                } else if (SB.y != 0) {
+                    if (desc_class(SB.z) == 0 || base + count[e] <= SB.w) { cont = true; z = static_cast<uint32_t>(r); bb = ix.block_base[r]; }
+                    else slow = true;
+                }
             }
-            E[e] = make_uint4(node, base, land, sb);
-            if (fused) B.z |= DESC_FUSED0 << e;
+            E[e] = make_uint4(node, static_cast<uint32_t>(base), z, cont ? bb : BLOCK_NONE);
+            flags[e] = (cont ? EDGE_CONT : 0u) | (emit2 ? EDGE_EMIT2 : 0u);
         }
-        E0 = E[0]; E1 = E[1];
     }
-    out[4 * rec] = E0;
-    out[4 * rec + 1] = B;
-    out[4 * rec + 2] = E1;
-    out[4 * rec + 3] = D;
+    if (rec == 0) {
+        // record 0 (the endmarker) is never landed on (GBWT::forward, src/gbwt.rs:224): its walk descriptor is where
+        // lanes without a walk are parked -- nothing to emit, does not continue, lands on record 0, not DESC_SLOW
+        E[0] = E[1] = make_uint4(0, 0, 0, BLOCK_NONE); flags[0] = flags[1] = 0; slow = false;
+    }
+    out[4 * rec] = E[0];
+    out[4 * rec + 1] = E[1];
+    out[4 * rec + 2] = make_uint4(slow ? DESC_SLOW : 0u, flags[0], 0u, flags[1]);
+    out[4 * rec + 3] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// One lane per record, after k_link_desc: the look-ahead targets.  For edge e: the record a walk that takes e
+// reaches `hops` iterations later if it keeps taking edge 0 afterwards (a guess in general graphs; exact where the
+// alleles of a site rejoin), as {first rank block, number of rank blocks}.  The walk touches one line of that block
+// array per iteration, so the blocks are already in the L2 of its XCD when the walk gets there.
+__global__ void __launch_bounds__(256) k_link_lookahead(DeviceIndex ix, uint4 *desc, const uint32_t *block_counts, uint32_t hops) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    uint4 D = desc[4 * rec + 2];
+    if (D.x & DESC_SLOW) return;
+    uint32_t base[2] = {0, 0}, count[2] = {0, 0};
+    for (uint32_t e = 0; e < 2; e++) {
+        uint64_t r = rec;
+        uint32_t edge = e;
+        bool good = true;
+        for (uint32_t h = 0; h <= hops; h++) {
+            const uint4 RD = desc[4 * r + 2];
+            const uint32_t f = edge ? RD.w : RD.y;
+            if ((RD.x & DESC_SLOW) || !(f & EDGE_CONT)) { good = false; break; }
+            r = desc[4 * r + edge].z;
+            edge = 0;
+        }
+        if (good && ix.block_base[r] != BLOCK_NONE && ix.block_base[r] < DESC_SLOW) { base[e] = ix.block_base[r]; count[e] = block_counts[r] & LOOKAHEAD_COUNT_MASK; }
+    }
+    D.x |= base[0]; D.y |= count[0]; D.z = base[1]; D.w |= count[1];
+    desc[4 * rec + 2] = D;
 }
 
 // One lane per outdegree-2 record: decode the runs ONCE and lay the record out as rank blocks (device_index.hpp):
@@ -294,8 +348,6 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
     a.head[k] = sink.head;
 }
 
-// Forces a loaded value to be live in VGPRs at this point (keeps the compiler from sinking the load).
-__device__ __forceinline__ void pin(uint4 &q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
 
 // Generic lane-serial Record::lf on the record bytes [start, start + bytes) (class 0 records, fallbacks).  Out of
 // line and by-value only, so that the hot loops stay small and nothing is forced into scratch.  Returns
@@ -307,88 +359,252 @@ __device__ __attribute__((noinline)) uint2 serial_record_lf(const uint8_t *data,
     return make_uint2(0u, 0u);
 }
 
-// What one iteration of the walk needs from memory: the walk descriptor of the record (edges A / C, and B) and the
-// rank block of the current offset.  The four loads are independent of each other.
-struct Fetch { uint4 A, B, C, K; };
+// Output staging of the default walk: a ring of RING slots per lane in LDS.  Pushes are unconditional LDS writes
+// (the slot only advances when the node counts), and a lane moves 16 slots = 64 bytes to its pool block with four
+// dwordx4 stores whenever that many are waiting.  The pool is the same chain of POOL_BLOCK_NODES-sized blocks as
+// PathSink's.  After a pool overflow the sink drops what it gets: the host grows the pool and walks again.
+constexpr uint32_t RING = 64;
+constexpr uint32_t RING_FLUSH = 16;
+constexpr uint32_t RING_URGENT = RING - 4;   // the hot loop hands over to the flush code once a lane has more than this waiting
+static_assert(POOL_BLOCK_NODES % RING_FLUSH == 0, "a block must hold a whole number of flushes");
 
-__device__ __forceinline__ bool issue_fetch(const DeviceIndex &ix, uint32_t n_rec, bool active, uint32_t node, uint32_t offset, uint32_t bb, Fetch &f) {
-    // GBWT::forward guards + BWT::record (src/gbwt.rs:222-229, src/bwt.rs:124-130).  Descriptor 0 (the endmarker,
-    // never a forward() target) stands in for "nothing to fetch", and block 0 (all zero: value 0, rank = offset) is
-    // what a record without blocks reads, so that the loads need no branch.
-    uint32_t rec = node - ix.alphabet_offset;
-    const bool in_range = active && node >= ix.first_node && rec < n_rec;
-    rec = in_range ? rec : 0u;
-    const uint4 *d = ix.desc + 4 * static_cast<uint64_t>(rec);
-    const uint32_t bidx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
-    f.A = d[0]; f.B = d[1]; f.C = d[2]; f.K = ix.blocks[bidx];
-    return in_range;
+struct RingSink {
+    uint32_t *stage;             // this lane's column of the ring: slot s at stage[s * WAVE]
+    uint32_t wr = 0, flushed = 0;   // nodes pushed / nodes written to the pool
+    uint32_t *wp = nullptr;
+    uint32_t left = 0;
+    uint32_t cur = POOL_NONE, head = POOL_NONE, blocks = 0;
+    bool overflow = false;
+    __device__ __forceinline__ RingSink(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    __device__ __forceinline__ void push(uint32_t node, bool counts) {
+        stage[(wr & (RING - 1)) * WAVE] = node;
+        wr += counts ? 1u : 0u;
+    }
+    __device__ __forceinline__ bool needs_flush() const { return wr - flushed >= RING_FLUSH; }
+    __device__ __forceinline__ bool new_block(const WalkArgs &a) {
+        uint32_t nb = atomicAdd(a.counter, 1u);
+        if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); overflow = true; return false; }
+        a.next[nb] = POOL_NONE;
+        if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
+        cur = nb; blocks++;
+        wp = a.pool + static_cast<uint64_t>(nb) * POOL_BLOCK_NODES;
+        left = POOL_BLOCK_NODES;
+        return true;
+    }
+    __device__ __forceinline__ void flush16(const WalkArgs &a) {
+        if (!overflow && (left != 0 || new_block(a))) {
+            const uint32_t *src = stage + (flushed & (RING - 1)) * WAVE;   // slot 0, 16, 32 or 48
+            uint4 *dst = reinterpret_cast<uint4 *>(wp);
+#pragma unroll
+            for (uint32_t q = 0; q < RING_FLUSH / 4; q++)
+                dst[q] = make_uint4(src[(4 * q) * WAVE], src[(4 * q + 1) * WAVE], src[(4 * q + 2) * WAVE], src[(4 * q + 3) * WAVE]);
+            wp += RING_FLUSH; left -= RING_FLUSH;
+        }
+        flushed += RING_FLUSH;
+    }
+    __device__ __forceinline__ uint64_t finish(const WalkArgs &a) {
+        while (needs_flush()) flush16(a);
+        const uint32_t tail = wr - flushed;
+        if (tail != 0 && !overflow && (left != 0 || new_block(a))) {
+            for (uint32_t e = 0; e < tail; e++) wp[e] = stage[((flushed + e) & (RING - 1)) * WAVE];
+            left -= tail;
+        }
+        return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left;
+    }
+};
+
+// Arrival at (node, offset) from outside the linked descriptors (the start of a sequence, a generic step): the tests
+// of GBWT::forward / BWT::record / Record::lf (src/gbwt.rs:222-229, src/bwt.rs:124-130, 481) that k_link_desc
+// settles in advance for the linked edges.
+__device__ __forceinline__ bool arrive(const DeviceIndex &ix, uint32_t node, uint32_t offset, uint32_t &rec, uint32_t &bb) {
+    uint64_t r;
+    if (!landing_record(ix, node, r)) return false;
+    const uint4 LB = ix.desc_raw[4 * r + 1];
+    if (LB.y == 0 || (desc_class(LB.z) != 0 && offset >= LB.w)) return false;
+    rec = static_cast<uint32_t>(r); bb = ix.block_base[r];
+    return true;
 }
 
-// Default walk: one lane per sequence, no cross-lane work.  An iteration is ONE round trip to memory (descriptor +
-// rank block travel together; the block base of the next record arrived with the previous descriptor), a popcount,
-// and one or two emitted nodes (two when the edge taken is fused with a unary successor).
-// The loop is software-pipelined: the next iteration's loads are issued as soon as the next position is known,
-// BEFORE this iteration's nodes are staged and the loop bookkeeping runs, so that part overlaps the memory latency.
+// The hot loop of the default walk, written in gfx950 assembly so that every wait is exactly where it has to be:
+// hipcc's s_waitcnt placement cannot keep the look-ahead touch in flight across the loop's back edge (vmcnt retires
+// in order and the touch is the YOUNGEST load, so `vmcnt(1)` is the wait for the four demand loads), and its register
+// shuffling around the cold paths more than doubled the instruction count of the loop.
+//
+// All 64 lanes run every instruction; lanes without a walk are PARKED on record 0, whose walk descriptor says
+// "nothing to emit, lands on record 0" and which reads the zero block, so a parked lane stays parked.
+// One iteration (Record::lf src/bwt.rs:480-496 + GBWT::forward src/gbwt.rs:222-229 for one or, fused, two nodes):
+//     wait for A, C, D (walk descriptor) and K (rank block)                      s_waitcnt vmcnt(1)
+//     any lane on a DESC_SLOW record -> leave BEFORE changing any state          (generic decode outside)
+//     value = bit `offset` of K, ones = K.z + popcount(K bits below `offset`)
+//     rank = value ? ones : offset - ones;  E = value ? C : A;  flags/look-ahead = value ? D.zw : D.xy
+//     rec = E.z; offset = E.y + rank; bb = E.w                                    (the new position)
+//     issue the four loads of the new position, then the look-ahead touch
+//     push E.x (counts if != 0), push rec + alphabet_offset (counts if EDGE_EMIT2) into the LDS ring
+//     leave if no lane is walking any more, or a lane has more than RING_URGENT nodes waiting in its ring
+// On exit nothing is in flight (vmcnt(0), lgkmcnt(0)).  Returns 1 when it left because of a DESC_SLOW record.
+// Hazards: a VALU write of VCC / an SGPR needs two wait states before a VALU reads it (gfx940+); the string keeps two
+// independent instructions (or an s_nop) in every such pair.  Registers v40-v87 and s40-s47 are named literally and
+// listed as clobbers.
+__device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4 *blocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                  uint32_t flushed, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t &hash) {
+#ifdef GBWT_HIP_CXX_LOOP
+    // the same loop in plain C++ (no pipelining, no look-ahead): what the assembly below must compute
+    for (;;) {
+        const uint4 *d = desc + 4 * static_cast<uint64_t>(rec);
+        const uint4 A = d[0], C = d[1], D = d[2];
+        const uint4 K = blocks[bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT)];
+        if (__ballot(static_cast<int32_t>(D.x) < 0) != 0) return 1;
+        const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+        const uint32_t bit = offset & 63u;
+        const uint32_t value = static_cast<uint32_t>(bits >> bit) & 1u;
+        const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << bit) - 1));
+        const uint32_t rank = value ? ones : offset - ones;
+        const uint4 E = value ? C : A;
+        const uint32_t flags = value ? D.w : D.y;
+        rec = E.z; offset = E.y + rank; bb = E.w;
+        __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
+        ring[(wr & (RING - 1)) * WAVE] = E.x;
+        wr += E.x != 0 ? 1u : 0u;
+        ring[(wr & (RING - 1)) * WAVE] = rec + alphabet_offset;
+        wr += static_cast<int32_t>(flags) < 0 ? 1u : 0u;
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > RING_URGENT) != 0) return 0;
+    }
+#else
+    uint32_t reason;
+#define GBWT_WALK_ISSUE                                                                                   \
+    "v_lshlrev_b32_e32 v82, 2, v40\n\t"                 /* v_lshl_add_u64 shifts by at most 4 */        \
+    "v_lshl_add_u64 v[66:67], v[82:83], 4, %[desc]\n\t"   /* descriptor of rec (64 bytes each) */        \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "global_load_dwordx4 v[48:51], v[66:67], off\n\t"                                                     \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "global_load_dwordx4 v[52:55], v[66:67], off offset:16\n\t"                                           \
+    "v_lshl_add_u64 v[68:69], v[70:71], 4, %[blocks]\n\t"                                                 \
+    "global_load_dwordx4 v[56:59], v[66:67], off offset:32\n\t"                                           \
+    "global_load_dwordx4 v[60:63], v[68:69], off\n\t"                                                     \
+    "v_and_b32_e32 v72, s42, v85\n\t"                     /* look-ahead: number of blocks of the target */ \
+    "v_mul_hi_u32 v72, v45, v72\n\t"                      /* pseudo-random block of it */                 \
+    "v_add_u32_e32 v72, v72, v84\n\t"                                                                     \
+    "v_lshl_add_u64 v[74:75], v[72:73], 4, %[blocks]\n\t"                                                 \
+    "global_load_dword v64, v[74:75], off offset:12\n\t"                                                  \
+    "v_add_u32_e32 v45, 0x9e3779b1, v45\n\t"
+    asm volatile(
+        "v_mov_b32_e32 v40, %[rec]\n\t"
+        "v_mov_b32_e32 v83, 0\n\t"
+        "v_mov_b32_e32 v42, %[offset]\n\t"
+        "v_mov_b32_e32 v43, %[bb]\n\t"
+        "v_mov_b32_e32 v44, %[wr]\n\t"
+        "v_mov_b32_e32 v45, %[hash]\n\t"
+        "v_mov_b32_e32 v71, 0\n\t"
+        "v_mov_b32_e32 v73, 0\n\t"
+        "v_mov_b32_e32 v84, 0\n\t"
+        "v_mov_b32_e32 v85, 0\n\t"
+        "s_mov_b32 s42, 0x1fffffff\n\t"
+        "s_mov_b32 %[reason], 0\n\t"
+        GBWT_WALK_ISSUE
+        ".Lgbwt_walk_loop_%=:\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_cmp_gt_i32_e32 vcc, 0, v56\n\t"                  /* DESC_SLOW = sign of D.x */
+        "v_lshrrev_b64 v[76:77], v42, v[60:61]\n\t"         /* bit `offset & 63` -> bit 0 */
+        "v_lshlrev_b64 v[78:79], v42, -1\n\t"               /* bits at and above it */
+        "s_cbranch_vccnz .Lgbwt_walk_slow_%=\n\t"
+        "v_and_b32_e32 v76, 1, v76\n\t"                     /* value */
+        "v_bfi_b32 v78, v78, 0, v60\n\t"                    /* K bits below */
+        "v_bfi_b32 v79, v79, 0, v61\n\t"
+        "v_cmp_eq_u32_e32 vcc, 1, v76\n\t"
+        "v_bcnt_u32_b32 v78, v78, v62\n\t"                  /* + value-1 positions before the block */
+        "v_bcnt_u32_b32 v78, v79, v78\n\t"                  /* ones */
+        "v_sub_u32_e32 v79, v42, v78\n\t"                   /* offset - ones */
+        "v_cndmask_b32_e32 v79, v79, v78, vcc\n\t"          /* rank */
+        "v_cndmask_b32_e32 v86, v48, v52, vcc\n\t"          /* E.x: node to emit */
+        "v_cndmask_b32_e32 v80, v49, v53, vcc\n\t"          /* E.y: offset base */
+        "v_cndmask_b32_e32 v40, v50, v54, vcc\n\t"          /* E.z: landing record */
+        "v_cndmask_b32_e32 v43, v51, v55, vcc\n\t"          /* E.w: its block base */
+        "v_cndmask_b32_e32 v84, v56, v58, vcc\n\t"          /* look-ahead base */
+        "v_cndmask_b32_e32 v85, v57, v59, vcc\n\t"          /* flags | look-ahead count */
+        "v_add_u32_e32 v42, v80, v79\n\t"                   /* offset in the landing record */
+        GBWT_WALK_ISSUE
+        "v_and_b32_e32 v76, 63, v44\n\t"                    /* ring slot of the next node */
+        "v_cmp_ne_u32_e32 vcc, 0, v86\n\t"
+        "v_lshl_add_u32 v76, v76, 8, %[ring]\n\t"
+        "v_add_u32_e32 v87, s41, v40\n\t"                   /* node of the landing record */
+        "ds_write_b32 v76, v86\n\t"
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */
+        "v_cmp_gt_i32_e32 vcc, 0, v85\n\t"                  /* EDGE_EMIT2 = sign of the flags */
+        "v_and_b32_e32 v76, 63, v44\n\t"
+        "v_lshl_add_u32 v76, v76, 8, %[ring]\n\t"
+        "ds_write_b32 v76, v87\n\t"
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
+        "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */
+        "v_sub_u32_e32 v76, v44, %[flushed]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[urgent], v76\n\t"
+        "s_cmp_eq_u64 s[44:45], 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_walk_out_%=\n\t"
+        "s_cbranch_vccz .Lgbwt_walk_loop_%=\n\t"
+        "s_branch .Lgbwt_walk_out_%=\n\t"
+        ".Lgbwt_walk_slow_%=:\n\t"
+        "s_mov_b32 %[reason], 1\n\t"
+        ".Lgbwt_walk_out_%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "v_mov_b32_e32 %[rec], v40\n\t"
+        "v_mov_b32_e32 %[offset], v42\n\t"
+        "v_mov_b32_e32 %[bb], v43\n\t"
+        "v_mov_b32_e32 %[wr], v44\n\t"
+        "v_mov_b32_e32 %[hash], v45\n\t"
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [hash] "+v"(hash), [reason] "=&s"(reason)
+        : [desc] "s"(desc), [blocks] "s"(blocks), [ring] "v"(ring_base), [flushed] "v"(flushed), [urgent] "i"(RING_URGENT),
+          "{s41}"(alphabet_offset)
+        : "memory", "vcc", "scc", "s42", "s44", "s45",
+          "v40", "v42", "v43", "v44", "v45", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63", "v64", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
+          "v79", "v80", "v82", "v83", "v84", "v85", "v86", "v87");
+#undef GBWT_WALK_ISSUE
+    return reason;
+#endif
+}
+
+// Default walk: one lane per sequence, no cross-lane work.  An iteration of the hot loop is ONE round trip to memory
+// (descriptor + rank block travel together; record index and block base of the next record arrived with the edge
+// taken), a popcount, and one or two emitted nodes.  Nodes are emitted on arrival: SequenceIter::next
+// (src/gbwt.rs:560-567) yields pos.node and then steps; here the start node is pushed before the loop and every
+// iteration pushes the node(s) it steps to.  This function is the cold frame around walk_hot_loop: the start of the
+// sequences, the generic step for DESC_SLOW records, and moving full ring chunks to the pool.
 __global__ void __launch_bounds__(WAVE) k_walk_blocks(DeviceIndex ix, WalkArgs a) {
-    __shared__ uint32_t sink_lds[SINK_STAGE * WAVE];
+    __shared__ uint32_t ring_lds[RING * WAVE];
     const uint32_t lane = threadIdx.x;
-    PathSink sink(sink_lds, lane);
+    RingSink sink(ring_lds, lane);
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
-    const uint32_t n_rec = static_cast<uint32_t>(ix.n_records);
-    uint32_t node = 0, offset = 0, bb = BLOCK_NONE;   // position of the walk + block base of its record
-    bool active = false;
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;   // position of the walk (record index; 0 = parked) + block base of the record
     if (owner) {
         const uint64_t id = a.seq_ids[k];
         if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
-            uint2 e = ix.endmarker[id];
-            node = e.x; offset = e.y;
-            active = node != 0;
-            if (active && node >= ix.first_node && node - ix.alphabet_offset < n_rec) bb = ix.block_base[node - ix.alphabet_offset];
+            const uint2 e = ix.endmarker[id];
+            if (e.x != 0) {
+                sink.push(e.x, true);
+                offset = e.y;
+                if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
         }
     }
-    Fetch f;
-    bool in_range = issue_fetch(ix, n_rec, active, node, offset, bb, f);
-    while (__ballot(active) != 0) {
-        // the loads were issued one iteration ago; the pins make the compiler wait for all four here instead of
-        // sinking some of them into the branches below (which would add dependent round trips)
-        pin(f.A); pin(f.B); pin(f.C); pin(f.K);
-        const uint4 A = f.A, B = f.B, C = f.C, K = f.K;
-        const uint32_t cur = node;
-        const bool emit = active;
-        bool ok = false, fused = false;
-        uint32_t next_node = 0, next_offset = 0, next_bb = BLOCK_NONE, via = 0;
-        if (in_range && offset < B.w) {             // i >= Record::len -> None (B.w = 0 for class 0: handled below)
-            // Record::lf on the rank block: value = bit `offset` of the record, rank = equal values before it.
-            // A unary record reads the zero block: value 0, rank = offset.
-            const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
-            const uint32_t bit = offset & 63u;
-            const uint32_t value = static_cast<uint32_t>(bits >> bit) & 1u;
-            const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << bit) - 1));
-            const uint32_t rank = value ? ones : offset - ones;
-            // edge `value`: {successor, offset base, landing node of a fused unary successor, block base of the landing record}
-            const uint4 E = value ? C : A;
-            next_node = E.x; next_offset = E.y + rank; next_bb = E.w;
-            fused = ((B.z >> (DESC_FUSED_SHIFT + value)) & 1u) != 0;
-            if (fused) { via = E.x; next_node = E.z; }   // emit the unary successor, land on ITS successor
-            ok = next_node != 0;                    // ENDMARKER: the sequence ends
+    const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));   // LDS byte address (low half of the flat one)
+    uint32_t hash = (lane + WAVE * blockIdx.x) * 0x85EBCA6Bu;
+    while (__ballot(rec != 0) != 0) {
+        const uint32_t slow_exit = walk_hot_loop(ix.desc, ix.blocks, ix.alphabet_offset, ring_base, sink.flushed, rec, offset, bb, sink.wr, hash);
+        if (slow_exit) {
+            // generic step for the lanes on a DESC_SLOW record (outdegree > 2, streams outside the descriptor's limits,
+            // edges k_link_desc could not vouch for): Record::lf on the record bytes, then the arrival tests
+            const bool slow = rec != 0 && static_cast<int32_t>(ix.desc[4 * static_cast<uint64_t>(rec) + 2].x) < 0;
+            if (slow) {
+                const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1];
+                const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
+                sink.push(r.x, r.x != 0);
+                offset = r.y;
+                if (r.x == 0 || !arrive(ix, r.x, r.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
         }
-        if (__builtin_expect(in_range && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0, 0)) {
-            // class 0 (outdegree > 2 or a stream outside the descriptor's limits): generic decode, then look the block base up
-            const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
-            next_node = r.x; next_offset = r.y; next_bb = BLOCK_NONE;
-            ok = r.x != 0;
-            if (ok && r.x >= ix.first_node && r.x - ix.alphabet_offset < n_rec) next_bb = ix.block_base[r.x - ix.alphabet_offset];
-        }
-        active = active && ok;
-        node = next_node; offset = next_offset; bb = next_bb;
-        in_range = issue_fetch(ix, n_rec, active, node, offset, bb, f);
-        asm volatile("" ::: "memory");              // keep the loads above the stores of the sink
-        // SequenceIter::next (src/gbwt.rs:560-567) emits pos.node before stepping; with a fused edge two nodes per iteration
-        if (emit) {
-            sink.push(a, cur);
-            if (fused) sink.push(a, via);
-        }
+        while (sink.needs_flush()) sink.flush16(a);
     }
     if (owner) {
         a.lengths[k] = sink.finish(a);
@@ -716,6 +932,11 @@ void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_c
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
     if (ix.n_records == 0) return;
     hipLaunchKernelGGL(k_link_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc);
+}
+
+void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_lookahead, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts, hops);
 }
 
 void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream) {

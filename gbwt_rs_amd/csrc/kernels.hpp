@@ -29,6 +29,7 @@ size_t block_scan_temp_bytes(uint64_t n);
 void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream);
 void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream);
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream);
+void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
 void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream);
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream);
 void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,

@@ -17,13 +17,19 @@ ap.add_argument("--model", default="mosaic")
 ap.add_argument("--alleles", type=int, default=2)
 ap.add_argument("--configs", default="0:64:16,0:16:16,0:4:16,2:64:16,2:8:16,1:64:16")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--subset", type=int, default=0, help="walk only the first N paths")
+ap.add_argument("--dup", type=int, default=1, help="every DUP consecutive lanes walk the same path (memory-coalescing experiment)")
 args = ap.parse_args()
 
 s = S.Synth.chain(args.sites, args.haplotypes, alleles=args.alleles, model=S.MOSAIC if args.model == "mosaic" else S.IID, seed=42)
 dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True)
 ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
-truth = np.array([s.path_checksum(h) for h in range(s.paths)], dtype=np.uint64)
-steps = (s.size - s.sequences) // 2
+if args.subset:
+    ids = ids[:args.subset]
+if args.dup > 1:
+    ids = np.repeat(ids[::args.dup], args.dup)[:len(ids)]
+truth = np.array([s.path_checksum(int(i) // 2) for i in ids], dtype=np.uint64)
+steps = (s.size - s.sequences) // 2 * len(ids) // s.paths
 for cfg in args.configs.split(","):
     mode, p, small = (int(x) for x in cfg.split(":"))
     dev.tune(mode, p, small)
