@@ -311,7 +311,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             // automatic: the walk is latency-bound, so spread the sequences over about one wavefront per SIMD
             // (256 CUs x 4); fewer owners per wave also means less divergence in the run scan
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
-                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(4, (n + 1023) / 1024)));
+                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));

@@ -12,8 +12,7 @@
 //   desc_raw  : one 64-byte descriptor per record, four uint4 (desc_raw[4 * rec + 0..3]):
 //                 A = {successor 0, offset 0, successor 1, offset 1}         decoded edge list (class 1 / 2 only)
 //                 B = {start (low 32 bits), length in bytes, meta, Record::len}
-//                     meta = body offset (bits 0-15) | class (bits 16-17) | fused flags (bits 18-19, walk descriptor
-//                     only) | start (bits 32-39 of it, in bits 24-31)
+//                     meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
 //                     class 1 / 2 = outdegree 1 / 2 (class 1 is always unary, class 2 has rank blocks) with the edges in A and "body offset" = where the run stream
 //                     starts inside the record; class 0 = any other non-empty record (generic lane-serial decode)
 //                 C = {value-0 positions of the record, 0, 0, 0}
@@ -21,12 +20,20 @@
 //               empty / None record : B.y = 0
 //               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 (every node on a linear stretch of
 //                 the graph): Record::lf(i) = (A.x, A.y + i) for i < B.w, however the body splits its runs.
-//   desc      : the walk descriptor derived from desc_raw (k_link_desc), fetched by the default walk with three
-//               aligned dwordx4 loads that travel together: B as above, and one uint4 per edge,
-//                 A = edge 0, C = edge 1 = {successor, offset base, landing node, block base of the landing record}.
-//               An edge whose successor is a unary record is FUSED with it (flag in meta): taking the edge emits the
-//               successor and lands on the successor's successor at offset base + rank, so a walk spends one
-//               iteration -- one round trip to memory -- on a branching node plus the unary node behind it.
+//   desc      : the walk descriptor derived from desc_raw (k_link_desc, k_link_lookahead), fetched by the default
+//               walk with three aligned dwordx4 loads that travel together (desc[4 * rec + 0..2]; slot 3 is unused):
+//                 [0] = edge 0, [1] = edge 1 = {node to emit (0 = ENDMARKER: nothing), offset base, landing record
+//                       index (0 when the walk ends behind the edge), block base of the landing record}
+//                 [2] = {look-ahead base 0 | DESC_SLOW, flags 0 | look-ahead count 0, look-ahead base 1,
+//                        flags 1 | look-ahead count 1};  flags: EDGE_CONT = the walk continues behind the edge,
+//                       EDGE_EMIT2 = the edge is FUSED with a unary successor: taking it emits that successor AND the
+//                       node of the landing record, one iteration -- one round trip to memory -- for two nodes.
+//               Every offset an edge can produce was checked against the length of the landing record when the
+//               descriptors were linked, so the walk tests nothing per step; records that could not be vouched for
+//               (class 0, edges failing the check) carry DESC_SLOW and take the generic decoder.  Record 0 (the
+//               endmarker, never landed on) holds the PARKING descriptor: nothing to emit, lands on record 0.
+//               Look-ahead: per edge, the rank blocks {first, count} of the record a walk reaches a few iterations
+//               after taking the edge; the walk touches one of them per iteration to warm the L2 of its XCD.
 //   block_base: per record, index of its first rank block or BLOCK_NONE (needed where a walk starts; afterwards
 //               the block base of the next record rides along in the edge taken)
 //   blocks    : the outdegree-2 records decoded once at open (k_fill_blocks) into RANK BLOCKS of 64 offsets, 16 bytes

@@ -103,7 +103,7 @@ void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws);
  *                  1 = lane-serial scan from the start of every record (the reference's access pattern),
  *                  2 = wave-cooperative decode of long records (all 64 lanes scan one record's runs)
  *   paths_per_wave lanes of each wavefront that own a sequence, 1..64; 0 = automatic (default): about one wavefront
- *                  per SIMD, at least 4 owners per wave -- the walk is latency-bound, not throughput-bound
+ *                  per SIMD, at least 16 owners per wave -- the walk is latency-bound, not throughput-bound
  *   small_record   mode 2 only: records of at most this many bytes are decoded by their own lane (default 16)
  * Environment overrides read at workspace creation: GBWT_HIP_WALK_MODE, GBWT_HIP_PATHS_PER_WAVE, GBWT_HIP_SMALL_RECORD. */
 gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record);
