@@ -59,6 +59,7 @@ SIGNATURES = {
     "gbwt_hip_extract_paths": (_int, [_p, _p, _p, _u64, _int, _p, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_start": (_int, [_p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_forward": (_int, [_p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_backward": (_int, [_p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_find": (_int, [_p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_extend": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_bd_find": (_int, [_p, _p, _p, _u64, _p, _p]),

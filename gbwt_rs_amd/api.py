@@ -5,6 +5,7 @@ Method names, argument meaning and None-behaviour follow the Rust API (file:line
   GBWT.len / sequences / alphabet_size / alphabet_offset / first_node / is_bidirectional   src/gbwt.rs:108-174
   GBWT.start(ids)            GBWT::start            src/gbwt.rs:213-219
   GBWT.forward(positions)    GBWT::forward          src/gbwt.rs:222-229
+  GBWT.backward(positions)   GBWT::backward         src/gbwt.rs:236-250
   GBWT.sequence(id)          GBWT::sequence         src/gbwt.rs:253-261   (None for id >= sequences)
   GBWT.sequences_csr(ids)    the batched form of sequence(): CSR arrays
   GBWT.find / extend / bd_find / extend_forward / extend_backward     src/gbwt.rs:269-367
@@ -152,6 +153,14 @@ class GBWT:
         out = np.zeros(pos.size, dtype=POS_DTYPE)
         valid = np.zeros(pos.size, dtype=np.uint8)
         check(self._L.gbwt_hip_forward(self._h, self._ws, _ptr(pos), pos.size, _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
+
+    def backward(self, positions):
+        """GBWT::backward (src/gbwt.rs:236-250) for an array of positions -> (positions, valid)."""
+        pos = np.ascontiguousarray(positions, dtype=POS_DTYPE)
+        out = np.zeros(pos.size, dtype=POS_DTYPE)
+        valid = np.zeros(pos.size, dtype=np.uint8)
+        check(self._L.gbwt_hip_backward(self._h, self._ws, _ptr(pos), pos.size, _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 
     def sequences_csr(self, ids):

@@ -430,6 +430,14 @@ gbwt_hip_status gbwt_hip_forward(const gbwt_hip_index *ix, gbwt_hip_workspace *w
     });
 }
 
+gbwt_hip_status gbwt_hip_backward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
+                                  gbwt_hip_pos *out, uint8_t *valid) {
+    if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Following sequences backward requires a bidirectional GBWT");
+    return run_query(ix, ws, in, n * sizeof(gbwt_hip_pos), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
+        launch_backward(ix->dev, ws->in_a.as<gbwt_hip_pos>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    });
+}
+
 gbwt_hip_status gbwt_hip_find(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
                               gbwt_hip_state *out, uint8_t *valid) {
     return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {

@@ -833,6 +833,86 @@ __device__ __forceinline__ bool dev_extend_forward(const DeviceIndex &ix, const 
     return true;
 }
 
+// GBWT::backward, src/gbwt.rs:236-250: predecessor_at on the record of the flipped node, then offset_to in the
+// predecessor's record.  Class 1 / 2 records answer both from the descriptor and the rank blocks: the per-edge
+// counts are in the descriptor, and "the offset of the k-th position with value v" is a binary search over the
+// blocks' running counts plus a select inside one 64-bit word.
+__device__ __forceinline__ bool dev_predecessor_at(const DeviceIndex &ix, uint64_t node, uint64_t i, uint64_t &pred) {
+    RawDesc d;
+    uint64_t rec;
+    if (!load_raw_desc(ix, node, d, rec)) return false;
+    const uint32_t cls = desc_class(d.B.z);
+    if (cls == 0) {
+        const uint64_t start = desc_start(d.B.x, d.B.z);
+        ByteCursor c(ix.data, start, start + d.B.y);
+        uint64_t sigma;
+        if (!c.varint(sigma) || sigma == 0) return false;
+        return record_predecessor_at(c, sigma, i, pred);
+    }
+    const uint64_t count0 = cls == 2 ? d.C.x : d.B.w, count1 = cls == 2 ? d.B.w - d.C.x : 0;
+    uint64_t n0 = d.A.x == 0 ? 0 : (d.A.x ^ 1u), n1 = d.A.z == 0 ? 0 : (d.A.z ^ 1u);
+    uint64_t c0 = count0, c1 = count1;
+    if (cls == 2 && (n0 >> 1) == (n1 >> 1)) { uint64_t t = n0; n0 = n1; n1 = t; t = c0; c0 = c1; c1 = t; }
+    if (c0 > i) { pred = n0; return n0 != 0; }
+    if (cls == 2 && c0 + c1 > i) { pred = n1; return n1 != 0; }
+    return false;
+}
+
+__device__ __forceinline__ bool dev_offset_to(const DeviceIndex &ix, uint64_t pred, uint64_t node, uint64_t offset, uint64_t &out) {
+    RawDesc d;
+    uint64_t rec;
+    if (!load_raw_desc(ix, pred, d, rec)) return false;
+    const uint32_t cls = desc_class(d.B.z);
+    if (cls == 0) {
+        const uint64_t start = desc_start(d.B.x, d.B.z);
+        ByteCursor c(ix.data, start, start + d.B.y);
+        uint64_t sigma;
+        if (!c.varint(sigma) || sigma == 0) return false;
+        return record_offset_to(c, sigma, node, offset, out);
+    }
+    if (node == 0) return false;
+    uint32_t value;
+    uint64_t succ_rank;
+    if (d.A.x == node) { value = 0; succ_rank = d.A.y; }
+    else if (cls == 2 && d.A.z == node) { value = 1; succ_rank = d.A.w; }
+    else return false;
+    if (succ_rank > offset) return false;
+    const uint64_t k = offset - succ_rank;                      // the k-th position (from 0) with this value
+    const uint64_t total = value ? d.B.w - d.C.x : (cls == 2 ? d.C.x : d.B.w);
+    if (k >= total) return false;
+    if (cls == 1) { out = k; return true; }
+    // largest block whose running count of `value` is <= k
+    const uint4 *blocks = ix.blocks + ix.block_base[rec];
+    uint32_t lo = 0, hi = d.B.w >> RANK_BLOCK_SHIFT;            // last block index
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        const uint32_t ones = blocks[mid].z;
+        const uint64_t before = value ? ones : (static_cast<uint64_t>(mid) << RANK_BLOCK_SHIFT) - ones;
+        if (before <= k) lo = mid; else hi = mid - 1;
+    }
+    const uint4 K = blocks[lo];
+    uint64_t word = (static_cast<uint64_t>(K.y) << 32) | K.x;
+    if (!value) word = ~word;
+    uint64_t r = k - (value ? K.z : (static_cast<uint64_t>(lo) << RANK_BLOCK_SHIFT) - K.z);
+    while (r-- > 0) word &= word - 1;                           // drop the r lowest set bits
+    out = (static_cast<uint64_t>(lo) << RANK_BLOCK_SHIFT) + __builtin_ctzll(word);
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_backward(DeviceIndex ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const gbwt_hip_pos p = in[k];
+    gbwt_hip_pos r{0, 0};
+    uint8_t ok = 0;
+    uint64_t pred = 0, off = 0;
+    // "This also catches the endmarker" (src/gbwt.rs:239): pos.node <= first_node -> None
+    if (p.node > ix.first_node && dev_predecessor_at(ix, p.node ^ 1, p.offset, pred) && dev_offset_to(ix, pred, p.node, p.offset, off)) {
+        r.node = pred; r.offset = off; ok = 1;
+    }
+    out[k] = r; valid[k] = ok;
+}
+
 __global__ void __launch_bounds__(256) k_find(DeviceIndex ix, const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid) {
     uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (k >= n) return;
@@ -1005,6 +1085,9 @@ void launch_start(const DeviceIndex &ix, const uint64_t *ids, uint64_t n, gbwt_h
 }
 void launch_forward(const DeviceIndex &ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_forward, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, in, n, out, valid);
+}
+void launch_backward(const DeviceIndex &ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_backward, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, in, n, out, valid);
 }
 void launch_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_find, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, nodes, n, out, valid);

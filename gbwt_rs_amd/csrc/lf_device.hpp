@@ -16,6 +16,7 @@
 //   Record::edge_to      src/bwt.rs:543-555           (linear scan of the sorted edge list)
 //   Record::follow / bd_follow   src/bwt.rs:595-616, 630-656   record_follow()
 //   GBWT::forward        src/gbwt.rs:222-229          gbwt_forward()
+//   Record::predecessor_at / offset_to   src/bwt.rs:502-540, 558-584   record_predecessor_at(), record_offset_to()
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -247,6 +248,87 @@ __device__ __forceinline__ bool record_follow(ByteCursor &c, uint64_t sigma, uin
     if (rs >= re) return false;
     rstart = rs; rend = re; count = cnt;
     return true;
+}
+
+// Record::predecessor_at on an opened record (cursor after sigma): the predecessor of the sequence at offset i of the
+// OTHER orientation of this node.  The reference counts the positions per edge, flips the successors, swaps
+// neighbours that are the two orientations of one node, and takes the first edge whose cumulative count exceeds i.
+// Here the per-edge counts live in a 32-entry window (one pass over the runs per 32 edges; one pass in total for
+// every record of practical out-degree) and the swap is a one-edge delay line: an edge is emitted after its
+// successor in the list when both have the same node id.  (Three consecutive edges with one node id cannot occur:
+// a node has two orientations.)
+struct PredecessorScan {
+    uint64_t i, cum = 0, result = 0;
+    bool done = false, found = false;
+    __device__ __forceinline__ explicit PredecessorScan(uint64_t offset) : i(offset) {}
+    __device__ __forceinline__ void emit(uint64_t node, uint64_t count) {
+        if (done) return;
+        cum += count;
+        if (cum > i) { done = true; found = node != 0; result = node; }   // ENDMARKER: None
+    }
+};
+
+__device__ __forceinline__ bool record_predecessor_at(ByteCursor &c, uint64_t sigma, uint64_t i, uint64_t &out) {
+    constexpr uint32_t WINDOW = 32;
+    const uint64_t header = c.pos;
+    for (uint64_t k = 0; k < 2 * sigma; k++)
+        if (!c.skip_varint()) return false;
+    const uint64_t body = c.pos;
+    PredecessorScan scan(i);
+    uint64_t pending_node = 0, pending_count = 0, node = 0, edge_pos = header;
+    bool pending = false;
+    for (uint64_t lo = 0; lo < sigma && !scan.done; lo += WINDOW) {
+        const uint64_t hi = lo + WINDOW < sigma ? lo + WINDOW : sigma;
+        uint32_t counts[WINDOW];
+        for (uint32_t k = 0; k < WINDOW; k++) counts[k] = 0;
+        c.seek(body);
+        RunDecoder rd(sigma);
+        uint64_t value, len;
+        while (rd.next(c, value, len))
+            if (value >= lo && value < hi) counts[value - lo] += static_cast<uint32_t>(len);
+        c.seek(edge_pos);
+        for (uint64_t e = lo; e < hi; e++) {
+            uint64_t delta, off;
+            if (!c.varint(delta) || !c.varint(off)) return false;
+            node += delta;
+            const uint64_t flipped = node == 0 ? 0 : node ^ 1;
+            if (pending && (pending_node >> 1) == (flipped >> 1)) {
+                scan.emit(flipped, counts[e - lo]);
+                scan.emit(pending_node, pending_count);
+                pending = false;
+            } else {
+                if (pending) scan.emit(pending_node, pending_count);
+                pending = true; pending_node = flipped; pending_count = counts[e - lo];
+            }
+        }
+        edge_pos = c.pos;
+    }
+    if (pending) scan.emit(pending_node, pending_count);
+    out = scan.result;
+    return scan.found;
+}
+
+// Record::offset_to on an opened record: the offset for which Record::lf would return (node, offset).
+__device__ __forceinline__ bool record_offset_to(ByteCursor &c, uint64_t sigma, uint64_t node, uint64_t offset, uint64_t &out) {
+    if (node == 0) return false;
+    uint64_t cur = 0, outrank = 0, succ_rank = 0;
+    bool found = false;
+    for (uint64_t e = 0; e < sigma; e++) {   // Record::edge_to (the edge list is sorted and duplicate-free)
+        uint64_t delta, off;
+        if (!c.varint(delta) || !c.varint(off)) return false;
+        cur += delta;
+        if (cur == node) { found = true; outrank = e; succ_rank = off; }
+    }
+    if (!found || succ_rank > offset) return false;
+    RunDecoder rd(sigma);
+    uint64_t pos = 0, value, len;
+    while (rd.next(c, value, len)) {
+        pos += len;
+        if (value != outrank) continue;
+        succ_rank += len;
+        if (succ_rank > offset) { out = pos - (succ_rank - offset); return true; }
+    }
+    return false;
 }
 
 }  // namespace gbwt_hip

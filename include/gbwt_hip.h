@@ -140,6 +140,11 @@ gbwt_hip_status gbwt_hip_start(const gbwt_hip_index *index, gbwt_hip_workspace *
                                gbwt_hip_pos *out, uint8_t *valid);
 gbwt_hip_status gbwt_hip_forward(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
                                  gbwt_hip_pos *out, uint8_t *valid);
+/* GBWT::backward (src/gbwt.rs:236-250): Record::predecessor_at (src/bwt.rs:502-540) on the record of the flipped node,
+ * then Record::offset_to (558-584) in the predecessor's record.  The reference asserts a bidirectional index; here a
+ * unidirectional one returns GBWT_HIP_BAD_ARGUMENT. */
+gbwt_hip_status gbwt_hip_backward(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
+                                  gbwt_hip_pos *out, uint8_t *valid);
 
 /* ---- search ------------------------------------------------------------------------------------
  * GBWT::find (src/gbwt.rs:269-281), GBWT::extend (292-304). */

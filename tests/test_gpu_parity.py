@@ -63,6 +63,14 @@ def check_all_positions(dev, oracle):
         assert bool(v) == (exp is not None), q
         if exp is not None:
             assert tuple(int(x) for x in r) == exp, q
+    if oracle.is_bidirectional():
+        # GBWT::backward for the same positions (src/gbwt/tests.rs:191-214 walks every sequence backward)
+        out, ok = dev.backward(np.array(queries, dtype=G.POS_DTYPE))
+        for q, r, v in zip(queries, out, ok):
+            exp = oracle.backward(q)
+            assert bool(v) == (exp is not None), q
+            if exp is not None:
+                assert tuple(int(x) for x in r) == exp, q
 
 
 def check_search(dev, oracle, nodes_of_interest):
@@ -204,6 +212,8 @@ def test_unidirectional_index_rejects_bd_calls():
     dev = G.GBWT.from_records(bwt.data(), bwt.starts(), 0, 8, 3, 17, bidirectional=False)
     with pytest.raises(G.GbwtHipError):
         dev.bd_find([1])
+    with pytest.raises(G.GbwtHipError):
+        dev.backward(np.array([(1, 0)], dtype=G.POS_DTYPE))
     st, ok = dev.find([1, 2, 7, 8, 0])
     assert list(ok) == [True, True, True, False, False]
 
