@@ -59,6 +59,13 @@ struct gbwt_hip_index {
     int device = 0;
     gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks;
     gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)
+    // GBZ with a node-to-segment translation (src/graph.rs:186-218), flattened for the line formatter:
+    gbwt_hip::DeviceBuffer seg_of;        // u32 per node id < mapping_len: segment holding the node (~0 before the first segment)
+    gbwt_hip::DeviceBuffer seg_start;     // u32 per segment + 1: first node id of the segment, last = mapping_len
+    gbwt_hip::DeviceBuffer seg_name_off;  // u64 per segment + 1: offsets into seg_names
+    gbwt_hip::DeviceBuffer seg_names;     // segment names, concatenated
+    gbwt_hip::DeviceBuffer seg_seq_len;   // u64 per segment: length of the segment's sequence
+    gbwt_hip::DeviceBuffer node_real;     // u8 per node id < mapping_len: GBZ::has_node
     gbwt_hip::DeviceIndex dev{};
     gbwt_hip_stats stats{};
 };
@@ -72,7 +79,7 @@ struct gbwt_hip_workspace {
     uint32_t walk_mode = gbwt_hip::WALK_SAMPLED, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid;  // search staging
-    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text;  // GFA line formatting
+    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_valid;  // GFA line formatting
     ~gbwt_hip_workspace() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);

@@ -6,11 +6,18 @@
 // (">123" / "<123" for walks, "123+" / "123-" joined by commas for paths).  H-, S- and L-lines are serial
 // host work in the reference as well (write_segments / write_links) and stay on the host.
 //
-// Node-to-segment translation (Graph::has_translation, src/graph.rs:158-160) is not handled yet: such files
-// return GBWT_HIP_UNSUPPORTED.
+// Graphs with a node-to-segment translation (Graph::has_translation, src/graph.rs:158-160) print segment names:
+// SegmentPathIter (src/gbz.rs:1098-1169) turns the node sequence into one token per segment.  A path that is a
+// concatenation of whole segments -- every path of a GBZ built from a GFA -- is recognised and formatted on the
+// device (a position is a token iff it is the first node of its segment in the orientation of travel, and every
+// other position must continue its predecessor).  A path that is not makes the reference's iterator stop at an
+// input-dependent place; such paths are flagged by the device and formatted by the host with the reference's state
+// machine, from the node ids the device extracted.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
@@ -90,6 +97,106 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines(const uint64_t 
     }
 }
 
+// The translation tables as the kernels see them.
+struct SegmentTables {
+    const uint32_t *seg_of;
+    const uint32_t *seg_start;
+    const uint64_t *name_off;
+    const uint8_t *names;
+    const uint64_t *seq_len;
+    const uint8_t *node_real;
+    uint64_t mapping_len;
+};
+
+// What position k of a path is: 0 = continues the segment of position k - 1, 1 = first node of a segment (a token),
+// 2 = neither (the path is not a concatenation of whole segments here).
+__device__ __forceinline__ uint32_t classify_position(const SegmentTables &t, const uint32_t *nodes, uint64_t begin, uint64_t k, uint32_t &segment) {
+    const uint32_t node = nodes[k], id = node >> 1, rev = node & 1u;
+    segment = 0;
+    if (id >= t.mapping_len) return 2;
+    const uint32_t s = t.seg_of[id];
+    if (s == 0xFFFFFFFFu) return 2;
+    segment = s;
+    const uint32_t lo = t.seg_start[s], hi = t.seg_start[s + 1];
+    const bool first = rev ? (id == hi - 1) : (id == lo);
+    if (k == begin) return first && t.node_real[id] ? 1u : 2u;
+    const uint32_t prev = nodes[k - 1], pid = prev >> 1, prev_rev = prev & 1u;
+    if (pid >= t.mapping_len) return 2;
+    const uint32_t ps = t.seg_of[pid];
+    if (ps == 0xFFFFFFFFu) return 2;
+    const bool prev_last = prev_rev ? (pid == t.seg_start[ps]) : (pid == t.seg_start[ps + 1] - 1);
+    if (first && prev_last) return t.node_real[id] ? 1u : 2u;
+    if (!first && !prev_last && rev == prev_rev && s == ps && id == (rev ? pid - 1 : pid + 1)) return 0;
+    return 2;
+}
+
+// One wave per path, translation graphs: text bytes of the segment tokens, summed segment lengths, validity.
+__global__ void __launch_bounds__(256) k_line_stats_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, SegmentTables t, int p_lines,
+                                                              uint64_t *text_len, uint64_t *seq_len, uint8_t *valid) {
+    const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (path >= n) return;
+    const uint64_t begin = offsets[path], end = offsets[path + 1];
+    uint64_t text = 0, labels = 0;
+    uint32_t bad = 0;
+    for (uint64_t k = begin + lane; k < end; k += WAVE) {
+        uint32_t s;
+        const uint32_t kind = classify_position(t, nodes, begin, k, s);
+        if (kind == 2) bad = 1;
+        if (kind == 1) {
+            text += (t.name_off[s + 1] - t.name_off[s]) + 1 + ((p_lines && k > begin) ? 1 : 0);
+            labels += t.seq_len[s];
+        }
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) { text += __shfl_down(text, d, WAVE); labels += __shfl_down(labels, d, WAVE); bad |= __shfl_down(bad, d, WAVE); }
+    if (lane == 0) { text_len[path] = text; seq_len[path] = labels; valid[path] = bad ? 0 : 1; }
+}
+
+// One workgroup per line, translation graphs.  Lines of flagged paths are left to the host.
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, SegmentTables t,
+                                                                           int p_lines, const uint8_t *valid, const uint64_t *line_start,
+                                                                           const uint8_t *headers, const uint64_t *header_off, uint8_t *out) {
+    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
+    __shared__ typename BlockScan::TempStorage scan_storage;
+    const uint64_t path = blockIdx.x;
+    if (path >= n || !valid[path]) return;
+    const uint32_t tid = threadIdx.x;
+    uint8_t *line = out + line_start[path];
+    const uint64_t h0 = header_off[path], h1 = header_off[path + 1];
+    for (uint64_t k = tid; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
+    uint64_t cursor = h1 - h0;
+    const uint64_t begin = offsets[path], end = offsets[path + 1];
+    for (uint64_t base = begin; base < end; base += FORMAT_THREADS) {
+        const uint64_t k = base + tid;
+        uint32_t len = 0, s = 0, name_len = 0;
+        bool token = false, rev = false;
+        if (k < end) {
+            token = classify_position(t, nodes, begin, k, s) == 1;
+            if (token) {
+                rev = (nodes[k] & 1u) != 0;
+                name_len = static_cast<uint32_t>(t.name_off[s + 1] - t.name_off[s]);
+                len = name_len + 1 + ((p_lines && k > begin) ? 1 : 0);
+            }
+        }
+        uint32_t pos, total;
+        BlockScan(scan_storage).ExclusiveSum(len, pos, total);
+        if (token) {
+            uint8_t *w = line + cursor + pos;
+            if (p_lines) { if (k > begin) *w++ = ','; }
+            else *w++ = rev ? '<' : '>';
+            const uint8_t *name = t.names + t.name_off[s];
+            for (uint32_t j = 0; j < name_len; j++) w[j] = name[j];
+            if (p_lines) w[name_len] = rev ? '-' : '+';
+        }
+        cursor += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (p_lines) { line[cursor] = '\t'; line[cursor + 1] = '*'; line[cursor + 2] = '\n'; }
+        else line[cursor] = '\n';
+    }
+}
+
 std::string name_or_id(const Strings &names, bool has_names, uint64_t id) {
     // Metadata::sample_name / contig_name fall back to the number (src/gbwt.rs:744-761, 792-809)
     if (has_names && id < names.size()) return names.str(id);
@@ -128,6 +235,62 @@ bool host_edges(const HostIndex &h, uint64_t rec, std::vector<std::pair<uint64_t
     return true;
 }
 
+// GBZ::has_node (src/gbz.rs:286-289): the forward GBWT node is in the alphabet and its record is not empty
+bool host_has_node(const HostIndex &h, uint64_t node_id) {
+    const uint64_t node = 2 * node_id, first = h.alphabet_offset + 1;
+    if (node < first || node >= h.alphabet_size) return false;
+    const uint64_t rec = node - h.alphabet_offset;
+    return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;
+}
+
+// Graph::segment / node_to_segment (src/graph.rs:172-198): node range [start, end) of a segment, the segment of a node
+struct HostSegment { uint64_t id, start, end; };
+
+HostSegment host_segment(const HostIndex &h, uint64_t id) {
+    return HostSegment{id, h.segment_starts[id], id + 1 < h.segment_starts.size() ? h.segment_starts[id + 1] : h.mapping_len};
+}
+
+HostSegment host_node_to_segment(const HostIndex &h, uint64_t node_id) {
+    // SparseVector::predecessor: the last one at or before node_id
+    const auto it = std::upper_bound(h.segment_starts.begin(), h.segment_starts.end(), node_id);
+    return host_segment(h, static_cast<uint64_t>(it - h.segment_starts.begin()) - 1);
+}
+
+// Segment::sequence = labels of nodes start .. end - 1 concatenated (sequences.range(start - 1 .. end - 1))
+uint64_t host_segment_seq_len(const HostIndex &h, const HostSegment &s) {
+    return h.sequences_labels.offsets[s.end - 1] - h.sequences_labels.offsets[s.start - 1];
+}
+
+// SegmentPathIter (src/gbz.rs:1098-1169) over the extracted node ids of one path: the (segment, orientation) tokens up
+// to the point where the reference's iterator stops, and the summed segment lengths.
+void host_segment_path(const HostIndex &h, const uint32_t *nodes, uint64_t len, std::vector<std::pair<uint64_t, bool>> &tokens, uint64_t &seq_len) {
+    tokens.clear();
+    seq_len = 0;
+    bool have_next = false, next_rev = false;
+    uint64_t next_node = 0, seg_start = 0, seg_end = 0;
+    for (uint64_t k = 0; k < len; k++) {
+        const uint64_t node_id = nodes[k] >> 1;
+        const bool rev = (nodes[k] & 1u) != 0;
+        if (have_next) {
+            if (node_id != next_node || rev != next_rev) return;                  // fail
+        } else {
+            if (!host_has_node(h, node_id) || node_id >= h.mapping_len || node_id < h.segment_starts[0]) return;   // node_to_segment -> None
+            const HostSegment s = host_node_to_segment(h, node_id);
+            tokens.emplace_back(s.id, rev);
+            seq_len += host_segment_seq_len(h, s);
+            seg_start = s.start; seg_end = s.end;
+            next_node = rev ? seg_end - 1 : seg_start; next_rev = rev; have_next = true;   // visit()
+        }
+        if (!next_rev) { if (next_node + 1 < seg_end) next_node++; else have_next = false; }   // advance()
+        else { if (next_node > seg_start) next_node--; else have_next = false; }
+    }
+}
+
+SegmentTables segment_tables(const gbwt_hip_index *ix) {
+    return SegmentTables{ix->seg_of.as<uint32_t>(), ix->seg_start.as<uint32_t>(), ix->seg_name_off.as<uint64_t>(), ix->seg_names.as<uint8_t>(),
+                         ix->seg_seq_len.as<uint64_t>(), ix->node_real.as<uint8_t>(), ix->host.mapping_len};
+}
+
 }  // namespace
 
 namespace gbwt_hip {
@@ -146,6 +309,33 @@ void upload_label_lengths(gbwt_hip_index &ix) {
     }
     ix.label_len.reserve(len.size() * sizeof(uint32_t));
     HIP_CHECK(hipMemcpy(ix.label_len.ptr, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!h.has_translation || h.segment_starts.empty()) return;
+    // node-to-segment translation, flattened (Graph::node_to_segment is a predecessor query on a sparse vector in the
+    // reference, src/graph.rs:186-198; here every node id gets its segment)
+    if (h.mapping_len >= 0xFFFFFFFFull) throw InvalidData("Graph: node ids of the translation do not fit 32 bits");
+    const uint64_t n_seg = h.segment_starts.size();
+    std::vector<uint32_t> seg_of(h.mapping_len, 0xFFFFFFFFu), seg_start(n_seg + 1);
+    std::vector<uint64_t> seq_len(n_seg);
+    std::vector<uint8_t> node_real(h.mapping_len, 0);
+    for (uint64_t s = 0; s < n_seg; s++) {
+        const HostSegment seg = host_segment(h, s);
+        if (seg.start == 0 || seg.end > h.mapping_len || seg.end < seg.start) throw InvalidData("Graph: malformed node-to-segment mapping");
+        seg_start[s] = static_cast<uint32_t>(seg.start);
+        for (uint64_t v = seg.start; v < seg.end; v++) seg_of[v] = static_cast<uint32_t>(s);
+        seq_len[s] = host_segment_seq_len(h, seg);
+    }
+    seg_start[n_seg] = static_cast<uint32_t>(h.mapping_len);
+    for (uint64_t v = 0; v < h.mapping_len; v++) node_real[v] = host_has_node(h, v) ? 1 : 0;
+    auto put = [](DeviceBuffer &b, const void *src, size_t bytes) {
+        b.reserve(std::max<size_t>(bytes, 16));
+        if (bytes) HIP_CHECK(hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice));
+    };
+    put(ix.seg_of, seg_of.data(), seg_of.size() * sizeof(uint32_t));
+    put(ix.seg_start, seg_start.data(), seg_start.size() * sizeof(uint32_t));
+    put(ix.seg_name_off, h.segment_names.offsets.data(), h.segment_names.offsets.size() * sizeof(uint64_t));
+    put(ix.seg_names, h.segment_names.bytes.data(), h.segment_names.bytes.size());
+    put(ix.seg_seq_len, seq_len.data(), seq_len.size() * sizeof(uint64_t));
+    put(ix.node_real, node_real.data(), node_real.size());
 }
 
 }  // namespace gbwt_hip
@@ -159,7 +349,7 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
     try {
         require_gfa_capable(ix);
         const HostIndex &h = ix->host;
-        if (h.has_translation) return fail(GBWT_HIP_UNSUPPORTED, "node-to-segment translation is not supported by the device formatter yet");
+        const bool translated = h.has_translation && !h.segment_starts.empty();
         for (uint64_t k = 0; k < n; k++)
             if (path_ids[k] >= h.path_names.size()) return fail(GBWT_HIP_BAD_ARGUMENT, "path id out of range");
         *total = 0;
@@ -175,28 +365,60 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
         // 2. size of every line
         ws->gfa_a.reserve(2 * n * sizeof(uint64_t));
         uint64_t *d_text_len = ws->gfa_a.as<uint64_t>(), *d_seq_len = d_text_len + n;
-        hipLaunchKernelGGL(k_line_stats, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n,
-                           ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
-                           static_cast<uint32_t>(h.alphabet_offset + 1), mode == 0 ? 1 : 0, d_text_len, d_seq_len);
+        std::vector<uint8_t> valid(n, 1);
+        if (translated) {
+            ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
+            hipLaunchKernelGGL(k_line_stats_segments, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               segment_tables(ix), mode == 0 ? 1 : 0, d_text_len, d_seq_len, ws->gfa_valid.as<uint8_t>());
+            HIP_CHECK(hipMemcpyAsync(valid.data(), ws->gfa_valid.ptr, n, hipMemcpyDeviceToHost, s));
+        } else {
+            hipLaunchKernelGGL(k_line_stats, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
+                               static_cast<uint32_t>(h.alphabet_offset + 1), mode == 0 ? 1 : 0, d_text_len, d_seq_len);
+        }
         std::vector<uint64_t> lens(2 * n);
         HIP_CHECK(hipMemcpyAsync(lens.data(), d_text_len, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         HIP_CHECK(hipGetLastError());
-        // 3. headers (path_to_p_line / path_to_w_line, src/bin/gbunzip.rs:480-524)
         const bool sample_names = (h.metadata_flags & 2) != 0, contig_names = (h.metadata_flags & 4) != 0;
+        auto line_header = [&](uint64_t k, uint64_t seq_len) {
+            const PathName &pn = h.path_names[path_ids[k]];
+            if (mode == 0) return "P\t" + name_or_id(h.contig_names, contig_names, pn.contig) + "\t";
+            return "W\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "\t" + std::to_string(pn.phase) + "\t" +
+                   name_or_id(h.contig_names, contig_names, pn.contig) + "\t" + std::to_string(pn.fragment) + "\t" +
+                   std::to_string(static_cast<uint64_t>(pn.fragment) + seq_len) + "\t";
+        };
+        // 2b. paths that are not concatenations of whole segments: the reference's iterator stops somewhere inside them;
+        // the host replays it on the extracted node ids
+        std::vector<std::string> host_lines(translated ? n : 0);
+        if (translated && std::find(valid.begin(), valid.end(), uint8_t(0)) != valid.end()) {
+            std::vector<uint64_t> offs(n + 1);
+            HIP_CHECK(hipMemcpy(offs.data(), paths.d_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> nodes;
+            std::vector<std::pair<uint64_t, bool>> tokens;
+            for (uint64_t k = 0; k < n; k++) {
+                if (valid[k]) continue;
+                nodes.resize(offs[k + 1] - offs[k]);
+                if (!nodes.empty()) HIP_CHECK(hipMemcpy(nodes.data(), paths.d_nodes + offs[k], nodes.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint64_t seq_len = 0;
+                host_segment_path(h, nodes.data(), nodes.size(), tokens, seq_len);
+                std::string &line = host_lines[k];
+                line = line_header(k, seq_len);
+                for (size_t j = 0; j < tokens.size(); j++) {
+                    const std::string name = h.segment_names.str(tokens[j].first);
+                    if (mode == 0) line += (j ? "," : "") + name + (tokens[j].second ? "-" : "+");
+                    else line += (tokens[j].second ? "<" : ">") + name;
+                }
+                line += mode == 0 ? "\t*\n" : "\n";
+            }
+        }
+        // 3. headers (path_to_p_line / path_to_w_line, src/bin/gbunzip.rs:480-524)
         std::string headers;
         std::vector<uint64_t> header_off(n + 1, 0), line_start(n + 1, 0);
         for (uint64_t k = 0; k < n; k++) {
-            const PathName &pn = h.path_names[path_ids[k]];
-            if (mode == 0) {
-                headers += "P\t" + name_or_id(h.contig_names, contig_names, pn.contig) + "\t";
-            } else {
-                headers += "W\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "\t" + std::to_string(pn.phase) + "\t" +
-                           name_or_id(h.contig_names, contig_names, pn.contig) + "\t" + std::to_string(pn.fragment) + "\t" +
-                           std::to_string(static_cast<uint64_t>(pn.fragment) + lens[n + k]) + "\t";
-            }
+            if (valid[k]) headers += line_header(k, lens[n + k]);
             header_off[k + 1] = headers.size();
-            line_start[k + 1] = line_start[k] + (header_off[k + 1] - header_off[k]) + lens[k] + (mode == 0 ? 3 : 1);
+            line_start[k + 1] = line_start[k] + (valid[k] ? (header_off[k + 1] - header_off[k]) + lens[k] + (mode == 0 ? 3 : 1) : host_lines[k].size());
         }
         *total = line_start[n];
         if (grow) { grow->resize(*total); out = grow->data(); capacity = *total; }
@@ -210,11 +432,18 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
         HIP_CHECK(hipMemcpyAsync(d_line_start, line_start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_header_off, header_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(ws->gfa_c.ptr, headers.data(), headers.size(), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_format_lines, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                           mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
+        if (translated)
+            hipLaunchKernelGGL(k_format_lines_segments, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               segment_tables(ix), mode == 0 ? 1 : 0, ws->gfa_valid.as<uint8_t>(), d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off,
+                               ws->gfa_text.as<uint8_t>());
+        else
+            hipLaunchKernelGGL(k_format_lines, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, ws->gfa_text.ptr, *total, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        for (uint64_t k = 0; k < n; k++)
+            if (!valid[k]) std::memcpy(out + line_start[k], host_lines[k].data(), host_lines[k].size());
         return GBWT_HIP_OK;
     } catch (const InvalidData &e) {
         return fail(GBWT_HIP_BAD_ARGUMENT, e.what());
@@ -235,7 +464,7 @@ gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace 
     try {
         require_gfa_capable(ix);
         const HostIndex &h = ix->host;
-        if (h.has_translation) return fail(GBWT_HIP_UNSUPPORTED, "node-to-segment translation is not supported by the device formatter yet");
+        const bool translated = h.has_translation && !h.segment_starts.empty();
         std::unique_ptr<FILE, int (*)(FILE *)> f(std::fopen(path, "wb"), std::fclose);
         if (!f) return fail(GBWT_HIP_IO_ERROR, std::string("cannot create ") + path);
         std::string text;
@@ -248,14 +477,48 @@ gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace 
             const uint64_t rec = 2 * seq + first - h.alphabet_offset;
             return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;
         };
-        for (uint64_t seq = 0; seq < potential; seq++) {
+        std::vector<std::pair<uint64_t, uint64_t>> edges;
+        if (translated) {
+            // GBZ::segment_iter keeps the segments whose first node exists (src/gbz.rs:927-929); links go from the last
+            // node of the segment in the orientation of travel (segment_successors, src/gbz.rs:402-415) and are named by
+            // the segment of the successor; LinkIter ends at a successor without a segment (src/gbz.rs:996-999)
+            const uint64_t n_seg = h.segment_starts.size();
+            for (uint64_t id = 0; id < n_seg; id++) {
+                const HostSegment seg = host_segment(h, id);
+                if (!host_has_node(h, seg.start)) continue;
+                text += "S\t" + h.segment_names.str(id) + "\t";
+                text.append(reinterpret_cast<const char *>(h.sequences_labels.bytes.data()) + h.sequences_labels.offsets[seg.start - 1], host_segment_seq_len(h, seg));
+                text += "\n";
+                if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+            }
+            for (uint64_t id = 0; id < n_seg; id++) {
+                const HostSegment seg = host_segment(h, id);
+                if (!host_has_node(h, seg.start)) continue;
+                const std::string name = h.segment_names.str(id);
+                for (int rev = 0; rev < 2; rev++) {
+                    const uint64_t node_id = rev ? seg.start : seg.end - 1;
+                    if (!host_has_node(h, node_id) || !host_edges(h, 2 * node_id + rev - h.alphabet_offset, edges)) continue;
+                    for (auto &e : edges) {
+                        if (e.first == 0) continue;                   // EdgeIter skips the ENDMARKER edge (src/gbz.rs:833)
+                        const uint64_t succ = e.first / 2;
+                        const bool succ_rev = (e.first & 1) != 0;
+                        if (!host_has_node(h, succ) || succ >= h.mapping_len || succ < h.segment_starts[0]) break;
+                        const HostSegment to = host_node_to_segment(h, succ);
+                        const bool canonical = rev ? (to.id > id || (to.id == id && !succ_rev)) : (to.id >= id);
+                        if (!canonical) continue;
+                        text += "L\t" + name + (rev ? "\t-\t" : "\t+\t") + h.segment_names.str(to.id) + (succ_rev ? "\t-\t*\n" : "\t+\t*\n");
+                    }
+                }
+                if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+            }
+        }
+        for (uint64_t seq = 0; seq < potential && !translated; seq++) {
             if (!real(seq)) continue;
             const uint64_t node_id = (2 * seq + first) / 2;
             text += "S\t" + std::to_string(node_id) + "\t" + h.sequences_labels.str(seq) + "\n";
             if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
         }
-        std::vector<std::pair<uint64_t, uint64_t>> edges;
-        for (uint64_t seq = 0; seq < potential; seq++) {
+        for (uint64_t seq = 0; seq < potential && !translated; seq++) {
             if (!real(seq)) continue;
             const uint64_t node_id = (2 * seq + first) / 2;
             for (int rev = 0; rev < 2; rev++) {

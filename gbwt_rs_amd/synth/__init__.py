@@ -25,6 +25,8 @@ def lib():
         L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
         L.gbwt_synth_from_file.restype = p
         L.gbwt_synth_from_file.argtypes = [C.c_char_p, C.c_char_p, u64]
+        L.gbwt_synth_attach_gbz.restype = C.c_int
+        L.gbwt_synth_attach_gbz.argtypes = [p, p, u64, u64]
         L.gbwt_synth_free.restype = None
         L.gbwt_synth_free.argtypes = [p]
         L.gbwt_synth_data.restype = p
@@ -76,6 +78,14 @@ class Synth:
         if not h:
             raise ValueError(err.value.decode())
         return cls(h)
+
+    def attach_gbz(self, segment_starts=(), seed=1):
+        """Adds path metadata + node labels (+ a node-to-segment translation) so that the index can be saved as a GBZ."""
+        starts = np.array(list(segment_starts) or [0], dtype=np.uint64)
+        rc = self._L.gbwt_synth_attach_gbz(self._h, starts.ctypes.data, len(segment_starts), seed)
+        if rc != 0:
+            raise ValueError(f"gbwt_synth_attach_gbz failed ({rc})")
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -37,6 +37,12 @@ gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t allel
  * reverse sequence of every path (src/support.rs:310-314).  No metadata, no graph. */
 gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, int bidirectional);
 
+/* Turns a bidirectional index with alphabet offset 1 (e.g. one made by gbwt_synth_from_paths over node ids starting
+ * at 1) into a GBZ: path metadata as in gbwt_synth_chain, seeded 1-3 base labels for the nodes that have a record,
+ * and -- with n_segments > 0 -- a node-to-segment translation: segment k covers node ids segment_starts[k] up to the
+ * next start and is named "seg<start>" (src/graph.rs:84-89, 186-218).  Returns 0 on success. */
+int gbwt_synth_attach_gbz(gbwt_synth *s, const uint64_t *segment_starts, uint64_t n_segments, uint64_t seed);
+
 /* Loads a .gbwt / .gbz with the product loader (for writer round-trip tests). */
 gbwt_synth *gbwt_synth_from_file(const char *path, char *err, uint64_t errlen);
 

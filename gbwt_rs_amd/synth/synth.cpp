@@ -451,6 +451,55 @@ gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes
     return g;
 }
 
+int gbwt_synth_attach_gbz(gbwt_synth *g, const uint64_t *segment_starts, uint64_t n_segments, uint64_t seed) {
+    gbwt_hip::HostIndex &ix = g->index;
+    if (!ix.bidirectional || ix.alphabet_offset != 1) return 1;   // node id v <-> label v - 1, as the translation assumes
+    const uint64_t n = ix.sequences / 2;
+    ix.has_metadata = true;
+    ix.metadata_flags = 7;
+    ix.sample_names = gbwt_hip::Strings(); ix.contig_names = gbwt_hip::Strings();
+    const uint64_t n_samples = (n > 1 ? n / 2 : 0);
+    for (uint64_t k = 0; k < n_samples; k++) add_string(ix.sample_names, "s" + std::to_string(k));
+    add_string(ix.sample_names, "_gbwt_ref");
+    add_string(ix.contig_names, "chr1");
+    ix.sample_count = n_samples + 1; ix.haplotype_count = n; ix.contig_count = 1;
+    ix.path_names.resize(n);
+    if (n > 0) ix.path_names[0] = gbwt_hip::PathName{static_cast<uint32_t>(n_samples), 0, 0, 0};
+    for (uint64_t h = 1; h < n; h++) ix.path_names[h] = gbwt_hip::PathName{static_cast<uint32_t>((h - 1) / 2), 0, static_cast<uint32_t>((h - 1) % 2 + 1), 0};
+    // labels of 1-3 bases for the nodes that have a record, empty labels for the rest
+    ix.is_gbz = true;
+    const uint64_t first = ix.alphabet_offset + 1, potential = ix.alphabet_size > first ? (ix.alphabet_size - first + 1) / 2 : 0;
+    Rng rng(seed ^ 0x5E65E65Eull);
+    ix.sequences_labels = gbwt_hip::Strings();
+    uint64_t real = 0;
+    for (uint64_t q = 0; q < potential; q++) {
+        const uint64_t rec = 2 * q + first - ix.alphabet_offset;
+        const bool exists = rec < ix.records() && ix.starts[rec + 1] > ix.starts[rec] && ix.data[ix.starts[rec]] != 0;
+        if (exists) {
+            real++;
+            const uint64_t len = 1 + (rng.next() >> 62) % 3;
+            for (uint64_t k = 0; k < len; k++) ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]);
+        }
+        ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
+    }
+    ix.graph_nodes = real;
+    ix.gbz_tags.clear();
+    ix.gbz_tags.emplace_back("source", "gbwt_rs_amd/synth");
+    ix.has_translation = n_segments > 0;
+    ix.segment_names = gbwt_hip::Strings();
+    ix.segment_starts.clear();
+    ix.mapping_len = 0;
+    if (n_segments > 0) {
+        for (uint64_t k = 0; k < n_segments; k++) {
+            if (segment_starts[k] == 0 || segment_starts[k] > potential || (k > 0 && segment_starts[k] <= segment_starts[k - 1])) return 2;
+            ix.segment_starts.push_back(segment_starts[k]);
+            add_string(ix.segment_names, "seg" + std::to_string(segment_starts[k]));
+        }
+        ix.mapping_len = potential + 1;
+    }
+    return 0;
+}
+
 gbwt_synth *gbwt_synth_from_file(const char *path, char *err, uint64_t errlen) {
     gbwt_synth *g = new gbwt_synth;
     try {

@@ -180,7 +180,7 @@ gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspa
  * (path_to_w_line, src/bin/gbunzip.rs:495-550).  The forward sequences are walked and the node tokens
  * formatted on the device; the host only contributes the name fields.  `*total` receives the number of bytes;
  * out == NULL is a size query; capacity < total -> GBWT_HIP_CAPACITY.  Graphs with a node-to-segment
- * translation -> GBWT_HIP_UNSUPPORTED (next round). */
+ * translation print segment names (GBZ::segment_path / SegmentPathIter, src/gbz.rs:477-486, 1098-1169). */
 gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n,
                                     int mode, char *out, uint64_t capacity, uint64_t *total);
 /* gbwt_hip_write_gfa: the whole file `gbunzip -t 1` writes (write_gfa_impl, src/bin/gbunzip.rs:205-226, default

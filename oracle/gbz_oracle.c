@@ -518,7 +518,7 @@ static void write_segments_links(const go_gbz *z, sbuf *b) {
                 if (!z_successor_record(z, node_id, rev, &rec)) continue;   /* reference unwraps: would panic */
                 for (uint64_t k = edge_iter_first(&rec); k < rec.outdegree; k++) {
                     uint64_t succ_node = rec.edges[k].node / 2; int succ_rev = (int)(rec.edges[k].node & 1);
-                    if (!((z->graph.flags & 1) && z_has_node(z, succ_node))) continue;   /* LinkIter: node_to_segment -> None */
+                    if (!((z->graph.flags & 1) && z_has_node(z, succ_node))) break;   /* LinkIter::next (src/gbz.rs:996-999): node_to_segment -> None ends the iteration */
                     segment t = graph_node_to_segment(z, succ_node);
                     int canonical = rev ? (t.id > s.id || (t.id == s.id && !succ_rev)) : (t.id >= s.id);
                     if (canonical) write_link(b, s.name, s.name_len, rev, t.name, t.name_len, succ_rev);

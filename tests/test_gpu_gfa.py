@@ -29,11 +29,70 @@ def test_example_gbz_to_gfa(tmp_path, name):
     assert dev.path_lines([], 1) == b""
 
 
-def test_translation_graph_is_rejected_not_wrong():
-    dev = G.GBZ.load(os.path.join(O.GOLDEN, "translation.gbz"))
-    with pytest.raises(G.GbwtHipError) as e:
-        dev.path_lines([0], 1)
-    assert e.value.status == 7   # GBWT_HIP_UNSUPPORTED
+@pytest.mark.parametrize("name", ["translation.gbz", "translation-v1.gbz"])
+def test_translation_gbz_to_gfa(tmp_path, name):
+    """Segment names instead of node ids (SegmentPathIter, src/gbz.rs:1098-1169)."""
+    path = os.path.join(O.GOLDEN, name)
+    dev, oracle = G.GBZ.load(path), O.OracleGBZ(path)
+    out = tmp_path / "out.gfa"
+    dev.write_gfa(str(out))
+    text = out.read_bytes()
+    assert len(text) == kat.TRANSLATION_GFA_LEN
+    assert hashlib.sha256(text).hexdigest() == kat.TRANSLATION_GFA_SHA256
+    assert text == oracle.gfa()
+    ids = list(range(dev.paths()))
+    for mode in (0, 1):
+        assert dev.path_lines(ids, mode) == oracle.path_lines(ids, mode)
+        assert dev.path_lines(ids[::-1], mode) == oracle.path_lines(ids[::-1], mode)
+
+
+def translated_graph(tmp_path, paths, segment_starts, name):
+    s = S.Synth.from_paths(paths, bidirectional=True).attach_gbz(segment_starts, seed=5)
+    path = tmp_path / name
+    s.save(str(path), as_gbz=True)
+    return G.GBZ.load(str(path)), O.OracleGBZ(str(path))
+
+
+def test_synthetic_translation_valid_paths(tmp_path):
+    """Multi-node segments walked in both orientations, paths longer than one formatting chunk."""
+    # segments: [1,2,3] [4] [5,6] [7] [8,9,10,11] [12]
+    starts = [1, 4, 5, 7, 8, 12]
+    fwd = lambda a, b: [2 * v for v in range(a, b + 1)]
+    rev = lambda a, b: [2 * v + 1 for v in range(b, a - 1, -1)]
+    unit = fwd(1, 3) + fwd(4, 4) + rev(5, 6) + fwd(7, 7) + fwd(8, 11) + rev(12, 12)
+    paths = [unit, fwd(1, 3) + fwd(5, 6) + fwd(8, 11), rev(8, 11) + fwd(4, 4) + rev(1, 3), unit * 60, [], fwd(12, 12)]
+    dev, oracle = translated_graph(tmp_path, paths, starts, "segments.gbz")
+    out = tmp_path / "segments.gfa"
+    dev.write_gfa(str(out))
+    assert out.read_bytes() == oracle.gfa()
+    ids = list(range(len(paths)))
+    for mode in (0, 1):
+        assert dev.path_lines(ids, mode) == oracle.path_lines(ids, mode)
+
+
+def test_synthetic_translation_broken_paths(tmp_path):
+    """Paths that are not concatenations of whole segments: the reference's iterator stops inside them (fail flag,
+    src/gbz.rs:1147-1166); lines must be cut exactly where it stops."""
+    starts = [1, 4, 5, 7, 8, 12]
+    fwd = lambda a, b: [2 * v for v in range(a, b + 1)]
+    rev = lambda a, b: [2 * v + 1 for v in range(b, a - 1, -1)]
+    paths = [fwd(1, 3) + fwd(4, 4),                # valid
+             fwd(2, 3) + fwd(4, 4),                # enters segment [1,2,3] at its second node
+             fwd(1, 2) + fwd(4, 4),                # leaves segment [1,2,3] early
+             fwd(1, 3) + rev(5, 5) + fwd(7, 7),    # enters [5,6] reversed at the wrong end
+             fwd(4, 4) + fwd(9, 9),                # ends inside a segment entered in the middle
+             fwd(8, 9) + rev(9, 9),                # turns around inside a segment
+             fwd(1, 3) + fwd(1, 3),                # valid: the same segment twice
+             fwd(12, 12)]                          # (makes node 12 exist)
+    dev, oracle = translated_graph(tmp_path, paths, starts, "broken.gbz")
+    ids = list(range(len(paths)))
+    for mode in (0, 1):
+        for i in ids:
+            assert dev.path_lines([i], mode) == oracle.path_lines([i], mode), (i, mode)
+        assert dev.path_lines(ids, mode) == oracle.path_lines(ids, mode)
+    out = tmp_path / "broken.gfa"
+    dev.write_gfa(str(out))
+    assert out.read_bytes() == oracle.gfa()
 
 
 def test_bare_gbwt_has_no_gfa():
