@@ -64,6 +64,7 @@ SIGNATURES = {
     "gbwt_hip_extend": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_bd_find": (_int, [_p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_extend_forward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
+    "gbwt_hip_follow": (_int, [_p, _p, _p, _u64, _int, _p, _p, _u64, _p, _p]),
     "gbwt_hip_extend_backward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_search": (_int, [_p, _p, _p, _u64, _u64, _p, _p]),
     "gbwt_hip_bd_search": (_int, [_p, _p, _p, _u64, _u64, _u64, _p, _p]),

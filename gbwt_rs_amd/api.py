@@ -253,6 +253,18 @@ class GBWT:
     def extend_backward(self, states, nodes):
         return self._bd_extend(self._L.gbwt_hip_extend_backward, states, nodes)
 
+    def follow(self, states, backward=False):
+        """GBZ::follow_forward / follow_backward (src/gbz.rs:519-544) for an array of bidirectional states:
+        (offsets[n + 1], extensions, valid); valid[i] is False where the reference returns no iterator."""
+        st = np.ascontiguousarray(states, dtype=BD_DTYPE)
+        offsets = np.zeros(st.size + 1, dtype=np.uint64)
+        valid = np.zeros(st.size, dtype=np.uint8)
+        total = C.c_uint64(0)
+        check(self._L.gbwt_hip_follow(self._h, self._ws, _ptr(st), st.size, int(backward), _ptr(offsets), None, 0, C.byref(total), _ptr(valid)))
+        out = np.zeros(max(total.value, 1), dtype=BD_DTYPE)
+        check(self._L.gbwt_hip_follow(self._h, self._ws, _ptr(st), st.size, int(backward), _ptr(offsets), _ptr(out), out.size, C.byref(total), _ptr(valid)))
+        return offsets, out[:total.value], valid.astype(bool)
+
     def search(self, queries):
         """find(q[0]) + extend over q[1:] for every row of the (n, len) query matrix (src/bin/benchmark.rs:155-169)."""
         q = np.ascontiguousarray(queries, dtype=np.uint64)

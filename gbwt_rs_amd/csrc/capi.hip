@@ -483,6 +483,45 @@ gbwt_hip_status gbwt_hip_extend_backward(const gbwt_hip_index *ix, gbwt_hip_work
     return bd_extend(ix, ws, states, nodes, n, true, out, valid);
 }
 
+gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states, uint64_t n, int backward,
+                                uint64_t *out_offsets, gbwt_hip_bd_state *out_states, uint64_t capacity, uint64_t *total, uint8_t *valid) {
+    if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (!ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
+    if (!total || !out_offsets || (n && (!states || !valid))) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
+    *total = 0;
+    out_offsets[0] = 0;
+    if (n == 0) return GBWT_HIP_OK;
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        hipStream_t s = ws->stream;
+        ws->in_a.reserve(n * sizeof(gbwt_hip_bd_state));
+        ws->in_b.reserve(n * sizeof(uint64_t));
+        ws->out_valid.reserve(n);
+        ws->follow_off.reserve((n + 1) * sizeof(uint64_t));
+        const size_t temp_bytes = scan_temp_bytes(n);
+        ws->scan_temp.reserve(std::max<size_t>(temp_bytes, 16));
+        HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, states, n * sizeof(gbwt_hip_bd_state), hipMemcpyHostToDevice, s));
+        launch_follow_count(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), n, backward != 0, ws->in_b.as<uint64_t>(), ws->out_valid.as<uint8_t>(), s);
+        launch_scan(ws->in_b.as<uint64_t>(), ws->follow_off.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out_offsets, ws->follow_off.ptr, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        *total = out_offsets[n];
+        if (!out_states) return GBWT_HIP_OK;
+        if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the extensions");
+        if (*total == 0) return GBWT_HIP_OK;
+        ws->out_a.reserve(*total * sizeof(gbwt_hip_bd_state));
+        launch_follow_fill(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), n, backward != 0, ws->follow_off.as<uint64_t>(), ws->out_a.as<gbwt_hip_bd_state>(), s);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out_states, ws->out_a.ptr, *total * sizeof(gbwt_hip_bd_state), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
 gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *queries, uint64_t n,
                                 uint64_t len, gbwt_hip_state *out, uint8_t *valid) {
     return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {

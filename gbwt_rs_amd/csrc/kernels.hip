@@ -954,6 +954,58 @@ __global__ void __launch_bounds__(256) k_bd_extend(DeviceIndex ix, const gbwt_hi
     out[k] = ok ? r : zero; valid[k] = ok;
 }
 
+// GBZ::follow_forward / follow_backward + StateIter (src/gbz.rs:519-544, 1211-1251): every non-empty extension of a
+// bidirectional state by one node, in the order of the edge list of the state's last (first) node.  One lane per
+// state; `out` == nullptr only counts.  Returns the number of extensions, or -1 where the reference returns no
+// iterator (GBZ::successors: the node does not exist).  `backward`: the state is flipped, followed forward, and the
+// results are flipped back.
+__device__ __forceinline__ int64_t dev_follow_all(const DeviceIndex &ix, gbwt_hip_bd_state st, bool backward, gbwt_hip_bd_state *out) {
+    if (backward) { const gbwt_hip_state t = st.forward; st.forward = st.reverse; st.reverse = t; }
+    const uint64_t node = st.forward.node;
+    RawDesc d;
+    uint64_t rec;
+    if (!load_raw_desc(ix, node & ~uint64_t(1), d, rec)) return -1;   // GBZ::has_node: the forward record exists
+    if (!load_raw_desc(ix, node, d, rec)) return -1;
+    const uint32_t cls = desc_class(d.B.z);
+    const uint64_t start = desc_start(d.B.x, d.B.z);
+    ByteCursor c(ix.data, start, start + (cls == 0 ? d.B.y : 0u));
+    uint64_t sigma = cls;
+    if (cls == 0 && (!c.varint(sigma) || sigma == 0)) return -1;
+    int64_t count = 0;
+    uint64_t succ = 0;
+    for (uint64_t e = 0; e < sigma; e++) {
+        if (cls == 0) {
+            uint64_t delta, off;
+            if (!c.varint(delta) || !c.varint(off)) break;
+            succ += delta;
+        } else succ = e == 0 ? d.A.x : d.A.z;
+        if (succ == 0) continue;                       // EdgeIter starts behind an ENDMARKER edge (src/gbz.rs:833)
+        gbwt_hip_bd_state r;
+        if (!dev_extend_forward(ix, st, succ, r)) continue;   // bd_internal -> None: the extension is empty
+        if (out) {
+            if (backward) { const gbwt_hip_state t = r.forward; r.forward = r.reverse; r.reverse = t; }
+            out[count] = r;
+        }
+        count++;
+    }
+    return count;
+}
+
+__global__ void __launch_bounds__(256) k_follow_count(DeviceIndex ix, const gbwt_hip_bd_state *states, uint64_t n, bool backward, uint64_t *counts, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const int64_t c = dev_follow_all(ix, states[k], backward, nullptr);
+    counts[k] = c < 0 ? 0 : static_cast<uint64_t>(c);
+    valid[k] = c < 0 ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(256) k_follow_fill(DeviceIndex ix, const gbwt_hip_bd_state *states, uint64_t n, bool backward, const uint64_t *offsets,
+                                                      gbwt_hip_bd_state *out) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    if (offsets[k + 1] > offsets[k]) dev_follow_all(ix, states[k], backward, out + offsets[k]);
+}
+
 // find(q[0]) then extend over q[1..len) in one launch (src/bin/benchmark.rs:155-169)
 __global__ void __launch_bounds__(256) k_search(DeviceIndex ix, const uint64_t *queries, uint64_t n, uint64_t len,
                                                  gbwt_hip_state *out, uint8_t *valid) {
@@ -1102,6 +1154,13 @@ void launch_bd_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gb
 void launch_bd_extend(const DeviceIndex &ix, const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
                       bool backward, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_bd_extend, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, states, nodes, n, backward, out, valid);
+}
+void launch_follow_count(const DeviceIndex &ix, const gbwt_hip_bd_state *states, uint64_t n, bool backward, uint64_t *counts, uint8_t *valid, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_follow_count, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, states, n, backward, counts, valid);
+}
+void launch_follow_fill(const DeviceIndex &ix, const gbwt_hip_bd_state *states, uint64_t n, bool backward, const uint64_t *offsets,
+                        gbwt_hip_bd_state *out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_follow_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, states, n, backward, offsets, out);
 }
 void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, gbwt_hip_state *out,
                    uint8_t *valid, hipStream_t s) {

@@ -69,6 +69,11 @@ void launch_extend(const DeviceIndex &ix, const gbwt_hip_state *states, const ui
 void launch_bd_find(const DeviceIndex &ix, const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s);
 void launch_bd_extend(const DeviceIndex &ix, const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
                       bool backward, gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s);
+// GBZ::follow_forward / follow_backward: count pass (per-state number of extensions, valid = the iterator exists), then
+// fill pass at the offsets of an exclusive scan of the counts (offsets has n + 1 entries)
+void launch_follow_count(const DeviceIndex &ix, const gbwt_hip_bd_state *states, uint64_t n, bool backward, uint64_t *counts, uint8_t *valid, hipStream_t s);
+void launch_follow_fill(const DeviceIndex &ix, const gbwt_hip_bd_state *states, uint64_t n, bool backward, const uint64_t *offsets,
+                        gbwt_hip_bd_state *out, hipStream_t s);
 void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, gbwt_hip_state *out,
                    uint8_t *valid, hipStream_t s);
 

@@ -162,6 +162,14 @@ gbwt_hip_status gbwt_hip_extend_forward(const gbwt_hip_index *index, gbwt_hip_wo
 gbwt_hip_status gbwt_hip_extend_backward(const gbwt_hip_index *index, gbwt_hip_workspace *ws,
                                          const gbwt_hip_bd_state *states, const uint64_t *nodes, uint64_t n,
                                          gbwt_hip_bd_state *out, uint8_t *valid);
+/* GBZ::follow_forward / follow_backward + StateIter (src/gbz.rs:519-544, 1211-1251): every non-empty extension of each
+ * state by one node, listed in the order of the edge list (EdgeIter, src/gbz.rs:819-855).  CSR output: the extensions
+ * of state i are out_states[out_offsets[i] .. out_offsets[i+1]); valid[i] = 0 where the reference returns no iterator
+ * (GBZ::successors: the node does not exist).  `*total` always receives the number of extensions; out_states == NULL
+ * is a size query (out_offsets and valid are still filled); capacity < total -> GBWT_HIP_CAPACITY. */
+gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states, uint64_t n,
+                                int backward, uint64_t *out_offsets, gbwt_hip_bd_state *out_states, uint64_t capacity,
+                                uint64_t *total, uint8_t *valid);
 /* Whole query in one launch, the shape of src/bin/benchmark.rs:155-169: for query q (row q of the
  * n x len matrix `queries`), find(q[0]) then extend by q[1..]; out/valid describe the final state
  * (valid = 0 as soon as any step returns None). */

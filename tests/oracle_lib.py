@@ -417,6 +417,33 @@ class OracleGBWT:
         st = self._bd(state)
         return out.tup() if self.L.go_gbwt_extend_forward(self.h, C.byref(st), node, C.byref(out)) == 1 else None
 
+    def follow(self, state, backward=False):
+        """GBZ::follow_forward / follow_backward + StateIter::next (src/gbz.rs:519-544, 1226-1236), stated the way the
+        reference's own check_states does (src/gbz/tests.rs:100-168): extend_forward over the successors of the last
+        node, skipping the ENDMARKER edge; backward = the same on the flipped state, results flipped back.
+        Returns None where GBZ::successors returns None (node without a record)."""
+        fwd, rev = state
+        if backward:
+            fwd, rev = rev, fwd
+        node = fwd[0]
+        first = self.alphabet_offset() + 1
+        if node < first or node >= self.alphabet_size():
+            return None
+        bwt = self.bwt()
+        if bwt.record((node & ~1) - self.alphabet_offset()) is None:     # GBZ::has_node
+            return None
+        rec = bwt.record(node - self.alphabet_offset())
+        if rec is None:
+            return None
+        out = []
+        for succ, _ in rec.edges():
+            if succ == 0:
+                continue
+            ext = self.extend_forward((fwd, rev), succ)
+            if ext is not None:
+                out.append((ext[1], ext[0]) if backward else ext)
+        return out
+
     def extend_backward(self, state, node):
         out = BdState()
         st = self._bd(state)

@@ -125,6 +125,38 @@ def check_search(dev, oracle, nodes_of_interest):
                 assert bd_tuple(r) == exp, (s, d)
 
 
+def check_follow(dev, oracle, limit=400):
+    """GBZ::follow_forward / follow_backward the way src/gbz/tests.rs:100-168 exercises them: breadth-first over every
+    state reachable from every node, device extensions against the oracle's, in edge order."""
+    if not oracle.is_bidirectional():
+        return
+    nodes = list(range(0, oracle.alphabet_size() + 2))
+    frontier, seen = [], set()
+    for node in nodes:
+        st = oracle.bd_find(node)
+        if st is not None and st not in seen:
+            seen.add(st)
+            frontier.append(st)
+    # states for nodes that do not exist must give "no iterator"
+    bogus = [((n, 0, 1), (n ^ 1, 0, 1)) for n in (0, 1, oracle.alphabet_size(), oracle.alphabet_size() + 1)]
+    checked = 0
+    while frontier and checked < limit:
+        batch, frontier = frontier[:128], frontier[128:]
+        queries = batch + (bogus if checked == 0 else [])
+        checked += len(batch)
+        for backward in (False, True):
+            offsets, ext, ok = dev.follow(bd_states(queries), backward)
+            for k, st in enumerate(queries):
+                exp = oracle.follow(st, backward)
+                assert bool(ok[k]) == (exp is not None), (st, backward)
+                got = [bd_tuple(e) for e in ext[int(offsets[k]):int(offsets[k + 1])]]
+                assert got == (exp or []), (st, backward)
+                for e in exp or []:
+                    if e not in seen:
+                        seen.add(e)
+                        frontier.append(e)
+
+
 # ---------------------------------------------------------------------------------------------
 # reference fixtures
 
@@ -161,6 +193,7 @@ def test_fixture_navigation_and_search(name):
     dev, oracle = G.GBWT.load(path), O.OracleGBWT.load(path)
     check_all_positions(dev, oracle)
     check_search(dev, oracle, sorted(kat.true_nodes()))
+    check_follow(dev, oracle)
 
 
 def test_fixture_search_known_answers():
@@ -235,6 +268,7 @@ def test_paper_examples(edges, runs, n_seq, bidirectional):
     oracle = O.OracleGBWT.from_bwt(O.OracleBWT.from_parts(data, starts), n_seq, size, offset, alphabet, bidirectional)
     check_all_positions(dev, oracle)
     check_search(dev, oracle, list(range(offset + 1, alphabet)))
+    check_follow(dev, oracle)
     offsets, nodes = dev.sequences_csr(np.arange(n_seq))
     o_off, o_nodes = oracle.extract(np.arange(n_seq))
     assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
@@ -279,6 +313,7 @@ def test_random_path_sets(seed, cyclic):
     check_all_positions(dev, oracle)
     nodes_used = sorted({x for p in paths for x in p} | {x ^ 1 for p in paths for x in p})
     check_search(dev, oracle, nodes_used[:24])
+    check_follow(dev, oracle)
 
 
 @pytest.mark.parametrize("alleles,model,zipf", [(2, S.MOSAIC, 1.2), (2, S.IID, 1.2), (7, S.IID, 1.0), (300, S.IID, 0.2), (400, S.IID, 0.0)])

@@ -181,6 +181,20 @@ def test_doc_search_states():
     assert bd == ((30, 0, 2), (25, 0, 2))
 
 
+def test_doc_state_iter():
+    # doc-test of StateIter, src/gbz.rs:1184-1209: node 14 forward has 3 paths and 2 successors; the predecessors of the
+    # successors are (12 -> 15, 2 paths) and (13 -> 16, 1 path)
+    g = load("example.gbwt")
+    state = g.bd_find(2 * 14)
+    assert state[0][0] == 28 and state[0][2] - state[0][1] == 3
+    successors = g.follow(state)
+    assert len(successors) == 2
+    preds = [p for s in successors for p in g.follow(s, backward=True)]
+    summary = [(p[1][0] ^ 1, p[0][0], p[0][2] - p[0][1]) for p in preds]     # (from, to, len)
+    assert summary == [(2 * 12, 2 * 15, 2), (2 * 13, 2 * 16, 1)]
+    assert g.follow(((0, 0, 1), (1, 0, 1))) is None
+
+
 def test_extract_batched_and_bytes():
     g = load("example.gbwt")
     ids = list(range(12))
