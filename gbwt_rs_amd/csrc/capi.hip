@@ -96,7 +96,7 @@ void upload(gbwt_hip_index &ix) {
         if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
         launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
         {
-            uint32_t hops = 2;
+            uint32_t hops = 3;
             if (const char *v = std::getenv("GBWT_HIP_LOOKAHEAD_HOPS")) hops = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             launch_link_lookahead(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), hops, nullptr);
         }
@@ -308,10 +308,11 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.counter = ws->counters.as<uint32_t>(); a.flags = ws->counters.as<uint32_t>() + 1;
             a.head = ws->head.as<uint32_t>(); a.lengths = ws->lengths.as<uint64_t>();
             a.mode = ws->walk_mode; a.small_record = ws->small_record;
-            // automatic: the walk is latency-bound, so spread the sequences over about one wavefront per SIMD
-            // (256 CUs x 4); fewer owners per wave also means less divergence in the run scan
+            // automatic: the walk is latency-bound and every lane of a wave runs the same instructions whether it owns a
+            // sequence or not, so owners per wave cost nothing; at least 32 measured best (fewer, fuller waves keep the walks
+            // of an XCD closer together, which is what the look-ahead relies on), more only when there are > 32k sequences
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
-                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (n + 1023) / 1024)));
+                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(32, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));

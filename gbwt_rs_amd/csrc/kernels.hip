@@ -173,14 +173,15 @@ __global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
 
 // One lane per record, after k_link_desc: the look-ahead targets.  For edge e: the record a walk that takes e
 // reaches `hops` iterations later if it keeps taking edge 0 afterwards (a guess in general graphs; exact where the
-// alleles of a site rejoin), as {first rank block, number of rank blocks}.  The walk touches one line of that block
-// array per iteration, so the blocks are already in the L2 of its XCD when the walk gets there.
+// alleles of a site rejoin), as {first rank block, number of rank blocks} and, in slot 3 of the descriptor, its record
+// index.  The helper wave of the walk touches that record's descriptor and one line of its block array per iteration,
+// so both are already in the L2 of the XCD when the walk gets there.
 __global__ void __launch_bounds__(256) k_link_lookahead(DeviceIndex ix, uint4 *desc, const uint32_t *block_counts, uint32_t hops) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
     uint4 D = desc[4 * rec + 2];
     if (D.x & DESC_SLOW) return;
-    uint32_t base[2] = {0, 0}, count[2] = {0, 0};
+    uint32_t base[2] = {0, 0}, count[2] = {0, 0}, target[2] = {0, 0};
     for (uint32_t e = 0; e < 2; e++) {
         uint64_t r = rec;
         uint32_t edge = e;
@@ -192,10 +193,12 @@ __global__ void __launch_bounds__(256) k_link_lookahead(DeviceIndex ix, uint4 *d
             r = desc[4 * r + edge].z;
             edge = 0;
         }
+        if (good) target[e] = static_cast<uint32_t>(r);
         if (good && ix.block_base[r] != BLOCK_NONE && ix.block_base[r] < DESC_SLOW) { base[e] = ix.block_base[r]; count[e] = block_counts[r] & LOOKAHEAD_COUNT_MASK; }
     }
     D.x |= base[0]; D.y |= count[0]; D.z = base[1]; D.w |= count[1];
     desc[4 * rec + 2] = D;
+    desc[4 * rec + 3] = make_uint4(target[0], target[1], 0u, 0u);
 }
 
 // One lane per outdegree-2 record: decode the runs ONCE and lay the record out as rank blocks (device_index.hpp):
@@ -425,28 +428,27 @@ __device__ __forceinline__ bool arrive(const DeviceIndex &ix, uint32_t node, uin
     return true;
 }
 
-// The hot loop of the default walk, written in gfx950 assembly so that every wait is exactly where it has to be:
-// hipcc's s_waitcnt placement cannot keep the look-ahead touch in flight across the loop's back edge (vmcnt retires
-// in order and the touch is the YOUNGEST load, so `vmcnt(1)` is the wait for the four demand loads), and its register
-// shuffling around the cold paths more than doubled the instruction count of the loop.
+// The hot loop of the default walk, written in gfx950 assembly: hipcc's register shuffling around the cold paths and
+// its SGPR mask algebra more than doubled the instruction count of the loop, and the position of every load and wait
+// matters here.
 //
 // All 64 lanes run every instruction; lanes without a walk are PARKED on record 0, whose walk descriptor says
 // "nothing to emit, lands on record 0" and which reads the zero block, so a parked lane stays parked.
 // One iteration (Record::lf src/bwt.rs:480-496 + GBWT::forward src/gbwt.rs:222-229 for one or, fused, two nodes):
-//     wait for A, C, D (walk descriptor) and K (rank block)                      s_waitcnt vmcnt(1)
+//     wait for A, C, D (walk descriptor) and K (rank block)                      s_waitcnt vmcnt(0)
 //     any lane on a DESC_SLOW record -> leave BEFORE changing any state          (generic decode outside)
 //     value = bit `offset` of K, ones = K.z + popcount(K bits below `offset`)
 //     rank = value ? ones : offset - ones;  E = value ? C : A;  flags/look-ahead = value ? D.zw : D.xy
 //     rec = E.z; offset = E.y + rank; bb = E.w                                    (the new position)
-//     issue the four loads of the new position, then the look-ahead touch
+//     issue the four loads of the new position; post the look-ahead target in the helper wave's mailbox
 //     push E.x (counts if != 0), push rec + alphabet_offset (counts if EDGE_EMIT2) into the LDS ring
 //     leave if no lane is walking any more, or a lane has more than RING_URGENT nodes waiting in its ring
 // On exit nothing is in flight (vmcnt(0), lgkmcnt(0)).  Returns 1 when it left because of a DESC_SLOW record.
 // Hazards: a VALU write of VCC / an SGPR needs two wait states before a VALU reads it (gfx940+); the string keeps two
-// independent instructions (or an s_nop) in every such pair.  Registers v40-v87 and s40-s47 are named literally and
-// listed as clobbers.
+// independent instructions (or an s_nop) in every such pair.  Registers v40-v89 and s41, s44-s45 are named literally
+// and listed as clobbers.
 __device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4 *blocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                  uint32_t flushed, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t &hash) {
+                                                  uint32_t mail_slot, uint32_t flushed, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t &hash) {
 #ifdef GBWT_HIP_CXX_LOOP
     // the same loop in plain C++ (no pipelining, no look-ahead): what the assembly below must compute
     for (;;) {
@@ -472,39 +474,35 @@ __device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4
 #else
     uint32_t reason;
 #define GBWT_WALK_ISSUE                                                                                   \
-    "v_lshlrev_b32_e32 v82, 2, v40\n\t"                 /* v_lshl_add_u64 shifts by at most 4 */        \
-    "v_lshl_add_u64 v[66:67], v[82:83], 4, %[desc]\n\t"   /* descriptor of rec (64 bytes each) */        \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
     "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
     "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
-    "global_load_dwordx4 v[48:51], v[66:67], off\n\t"                                                     \
+    "v_lshlrev_b32_e32 v82, 2, v40\n\t"                 /* v_lshl_add_u64 shifts by at most 4 */        \
     "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
-    "global_load_dwordx4 v[52:55], v[66:67], off offset:16\n\t"                                           \
     "v_lshl_add_u64 v[68:69], v[70:71], 4, %[blocks]\n\t"                                                 \
+    "v_lshl_add_u64 v[66:67], v[82:83], 4, %[desc]\n\t"   /* descriptor of rec (64 bytes each) */        \
+    "global_load_dwordx4 v[60:63], v[68:69], off\n\t"   /* the rank block FIRST: the three descriptor loads hit one   */ \
+    "global_load_dwordx4 v[48:51], v[66:67], off\n\t"   /* line, and the L1 holds back everything behind a load that  */ \
+    "global_load_dwordx4 v[52:55], v[66:67], off offset:16\n\t" /* hits a line still in flight                        */ \
     "global_load_dwordx4 v[56:59], v[66:67], off offset:32\n\t"                                           \
-    "global_load_dwordx4 v[60:63], v[68:69], off\n\t"                                                     \
-    "v_and_b32_e32 v72, s42, v85\n\t"                     /* look-ahead: number of blocks of the target */ \
-    "v_mul_hi_u32 v72, v45, v72\n\t"                      /* pseudo-random block of it */                 \
-    "v_add_u32_e32 v72, v72, v84\n\t"                                                                     \
-    "v_lshl_add_u64 v[74:75], v[72:73], 4, %[blocks]\n\t"                                                 \
-    "global_load_dword v64, v[74:75], off offset:12\n\t"                                                  \
-    "v_add_u32_e32 v45, 0x9e3779b1, v45\n\t"
+    "global_load_dwordx2 v[90:91], v[66:67], off offset:48\n\t"                                           \
+    "v_add_u32_e32 v86, 0x9e3779b1, v86\n\t"              /* new sequence number = new pseudo-random number */ \
+    "ds_write_b128 %[mail], v[84:87]\n\t"                 /* look-ahead target for the helper wave */
     asm volatile(
         "v_mov_b32_e32 v40, %[rec]\n\t"
         "v_mov_b32_e32 v83, 0\n\t"
         "v_mov_b32_e32 v42, %[offset]\n\t"
         "v_mov_b32_e32 v43, %[bb]\n\t"
         "v_mov_b32_e32 v44, %[wr]\n\t"
-        "v_mov_b32_e32 v45, %[hash]\n\t"
+        "v_mov_b32_e32 v86, %[hash]\n\t"
+        "v_mov_b32_e32 v87, 0\n\t"
         "v_mov_b32_e32 v71, 0\n\t"
-        "v_mov_b32_e32 v73, 0\n\t"
         "v_mov_b32_e32 v84, 0\n\t"
         "v_mov_b32_e32 v85, 0\n\t"
-        "s_mov_b32 s42, 0x1fffffff\n\t"
         "s_mov_b32 %[reason], 0\n\t"
         GBWT_WALK_ISSUE
         ".Lgbwt_walk_loop_%=:\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
         "v_cmp_gt_i32_e32 vcc, 0, v56\n\t"                  /* DESC_SLOW = sign of D.x */
         "v_lshrrev_b64 v[76:77], v42, v[60:61]\n\t"         /* bit `offset & 63` -> bit 0 */
         "v_lshlrev_b64 v[78:79], v42, -1\n\t"               /* bits at and above it */
@@ -517,24 +515,25 @@ __device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4
         "v_bcnt_u32_b32 v78, v79, v78\n\t"                  /* ones */
         "v_sub_u32_e32 v79, v42, v78\n\t"                   /* offset - ones */
         "v_cndmask_b32_e32 v79, v79, v78, vcc\n\t"          /* rank */
-        "v_cndmask_b32_e32 v86, v48, v52, vcc\n\t"          /* E.x: node to emit */
+        "v_cndmask_b32_e32 v88, v48, v52, vcc\n\t"          /* E.x: node to emit */
         "v_cndmask_b32_e32 v80, v49, v53, vcc\n\t"          /* E.y: offset base */
         "v_cndmask_b32_e32 v40, v50, v54, vcc\n\t"          /* E.z: landing record */
         "v_cndmask_b32_e32 v43, v51, v55, vcc\n\t"          /* E.w: its block base */
         "v_cndmask_b32_e32 v84, v56, v58, vcc\n\t"          /* look-ahead base */
         "v_cndmask_b32_e32 v85, v57, v59, vcc\n\t"          /* flags | look-ahead count */
+        "v_cndmask_b32_e32 v87, v90, v91, vcc\n\t"          /* look-ahead record */
         "v_add_u32_e32 v42, v80, v79\n\t"                   /* offset in the landing record */
         GBWT_WALK_ISSUE
         "v_and_b32_e32 v76, 63, v44\n\t"                    /* ring slot of the next node */
-        "v_cmp_ne_u32_e32 vcc, 0, v86\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, v88\n\t"
         "v_lshl_add_u32 v76, v76, 8, %[ring]\n\t"
-        "v_add_u32_e32 v87, s41, v40\n\t"                   /* node of the landing record */
-        "ds_write_b32 v76, v86\n\t"
+        "v_add_u32_e32 v89, s41, v40\n\t"                   /* node of the landing record */
+        "ds_write_b32 v76, v88\n\t"
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */
         "v_cmp_gt_i32_e32 vcc, 0, v85\n\t"                  /* EDGE_EMIT2 = sign of the flags */
         "v_and_b32_e32 v76, 63, v44\n\t"
         "v_lshl_add_u32 v76, v76, 8, %[ring]\n\t"
-        "ds_write_b32 v76, v87\n\t"
+        "ds_write_b32 v76, v89\n\t"
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
         "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */
         "v_sub_u32_e32 v76, v44, %[flushed]\n\t"
@@ -551,28 +550,88 @@ __device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4
         "v_mov_b32_e32 %[offset], v42\n\t"
         "v_mov_b32_e32 %[bb], v43\n\t"
         "v_mov_b32_e32 %[wr], v44\n\t"
-        "v_mov_b32_e32 %[hash], v45\n\t"
+        "v_mov_b32_e32 %[hash], v86\n\t"
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [hash] "+v"(hash), [reason] "=&s"(reason)
-        : [desc] "s"(desc), [blocks] "s"(blocks), [ring] "v"(ring_base), [flushed] "v"(flushed), [urgent] "i"(RING_URGENT),
+        : [desc] "s"(desc), [blocks] "s"(blocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [flushed] "v"(flushed), [urgent] "i"(RING_URGENT),
           "{s41}"(alphabet_offset)
-        : "memory", "vcc", "scc", "s42", "s44", "s45",
-          "v40", "v42", "v43", "v44", "v45", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
-          "v60", "v61", "v62", "v63", "v64", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
-          "v79", "v80", "v82", "v83", "v84", "v85", "v86", "v87");
+        : "memory", "vcc", "scc", "s44", "s45",
+          "v40", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63", "v66", "v67", "v68", "v69", "v70", "v71", "v76", "v77", "v78",
+          "v79", "v80", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
 #undef GBWT_WALK_ISSUE
     return reason;
 #endif
+}
+
+// The look-ahead helper.  All walks of an XCD reach a record at about the same time, so the first one pays an L2
+// miss and the others wait on the same fill.  Touching the rank blocks a few records ahead fixes that, but not from
+// the walking wave: gfx9 returns a wave's loads in order, so a touch that misses holds back the demand loads issued
+// behind it, and the leader would still be paced by the miss.  The touches therefore come from a second wave of the
+// workgroup with a vmcnt of its own.  Every iteration a walking lane posts {first block, flags | block count, sequence
+// number, record} of the record it will reach a few iterations later (k_link_lookahead) in its LDS mailbox slot; the
+// helper polls the slots, and for every slot that changed loads the descriptor and one block of that record (lanes and
+// iterations follow one golden-ratio sequence, so together they cover the block array evenly) -- into registers nobody
+// reads, never waiting for them.  Leaves when the walking wave raises the done flag.
+__device__ __forceinline__ void lookahead_helper(const uint4 *desc, const uint4 *blocks, uint32_t mail_slot, uint32_t done_addr) {
+    asm volatile(
+        "v_mov_b32_e32 v40, 0\n\t"                          /* last sequence number seen */
+        "v_mov_b32_e32 v47, 0\n\t"
+        "s_mov_b32 s42, 0x1fffffff\n\t"
+        ".Lgbwt_helper_loop_%=:\n\t"
+        "ds_read_b128 v[48:51], %[mail]\n\t"
+        "ds_read_b32 v52, %[done]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ne_u32_e32 vcc, v50, v40\n\t"                /* slots with a new target */
+        "v_and_b32_e32 v53, s42, v49\n\t"                   /* number of blocks of the target */
+        "v_mov_b32_e32 v40, v50\n\t"
+        "v_cmp_ne_u32_e64 s[46:47], 0, v53\n\t"
+        "v_mul_hi_u32 v46, v50, v53\n\t"                    /* pseudo-random block of it */
+        "s_and_b64 vcc, vcc, s[46:47]\n\t"
+        "v_add_u32_e32 v46, v46, v48\n\t"
+        "v_lshlrev_b32_e32 v58, 2, v51\n\t"                /* descriptor of the target record: 64 bytes each */
+        "v_mov_b32_e32 v59, 0\n\t"
+        "s_and_saveexec_b64 s[44:45], vcc\n\t"
+        "v_lshl_add_u64 v[54:55], v[46:47], 4, %[blocks]\n\t"
+        "v_lshl_add_u64 v[58:59], v[58:59], 4, %[desc]\n\t"
+        "global_load_dword v56, v[54:55], off offset:12\n\t"
+        "global_load_dword v57, v[58:59], off\n\t"
+        "s_mov_b64 exec, s[44:45]\n\t"
+        "v_readfirstlane_b32 s46, v52\n\t"
+        "s_cmp_lg_u32 s46, 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_helper_out_%=\n\t"
+        "s_sleep 1\n\t"
+        "s_branch .Lgbwt_helper_loop_%=\n\t"
+        ".Lgbwt_helper_out_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        :
+        : [mail] "v"(mail_slot), [done] "v"(done_addr), [blocks] "s"(blocks), [desc] "s"(desc)
+        : "memory", "vcc", "scc", "s42", "s44", "s45", "s46", "s47", "v40", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+          "v57", "v58", "v59");
 }
 
 // Default walk: one lane per sequence, no cross-lane work.  An iteration of the hot loop is ONE round trip to memory
 // (descriptor + rank block travel together; record index and block base of the next record arrived with the edge
 // taken), a popcount, and one or two emitted nodes.  Nodes are emitted on arrival: SequenceIter::next
 // (src/gbwt.rs:560-567) yields pos.node and then steps; here the start node is pushed before the loop and every
-// iteration pushes the node(s) it steps to.  This function is the cold frame around walk_hot_loop: the start of the
-// sequences, the generic step for DESC_SLOW records, and moving full ring chunks to the pool.
-__global__ void __launch_bounds__(WAVE) k_walk_blocks(DeviceIndex ix, WalkArgs a) {
+// iteration pushes the node(s) it steps to.  Wave 0 of the workgroup walks; this function is the cold frame around
+// walk_hot_loop: the start of the sequences, the generic step for DESC_SLOW records, and moving full ring chunks to
+// the pool.  Wave 1 is the look-ahead helper.
+__global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkArgs a) {
     __shared__ uint32_t ring_lds[RING * WAVE];
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint4 mailbox[WAVE];
+    __shared__ uint32_t mail_done;
+    const uint32_t lane = threadIdx.x % WAVE;
+    const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
+    if (!helper) {
+        mailbox[lane] = make_uint4(0, 0, 0, 0);
+        if (lane == 0) mail_done = 0;
+    }
+    __syncthreads();
+    const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));   // LDS byte addresses
+    if (helper) {
+        lookahead_helper(ix.desc, ix.blocks, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mail_done)));
+        return;
+    }
     RingSink sink(ring_lds, lane);
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && k < a.n;
@@ -589,9 +648,9 @@ __global__ void __launch_bounds__(WAVE) k_walk_blocks(DeviceIndex ix, WalkArgs a
         }
     }
     const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));   // LDS byte address (low half of the flat one)
-    uint32_t hash = (lane + WAVE * blockIdx.x) * 0x85EBCA6Bu;
+    uint32_t hash = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;   // lanes and iterations walk one golden-ratio sequence: consecutive values spread evenly over the target's blocks
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk_hot_loop(ix.desc, ix.blocks, ix.alphabet_offset, ring_base, sink.flushed, rec, offset, bb, sink.wr, hash);
+        const uint32_t slow_exit = walk_hot_loop(ix.desc, ix.blocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, rec, offset, bb, sink.wr, hash);
         if (slow_exit) {
             // generic step for the lanes on a DESC_SLOW record (outdegree > 2, streams outside the descriptor's limits,
             // edges k_link_desc could not vouch for): Record::lf on the record bytes, then the arrival tests
@@ -606,6 +665,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_blocks(DeviceIndex ix, WalkArgs a
         }
         while (sink.needs_flush()) sink.flush16(a);
     }
+    if (lane == 0) *const_cast<volatile uint32_t *>(&mail_done) = 1;
     if (owner) {
         a.lengths[k] = sink.finish(a);
         a.head[k] = sink.head;
@@ -1120,7 +1180,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         else hipLaunchKernelGGL((k_walk_coop<false>), grid, block, 0, stream, ix, args);
         return;
     }
-    hipLaunchKernelGGL(k_walk_blocks, grid, block, 0, stream, ix, args);
+    hipLaunchKernelGGL(k_walk_blocks, grid, dim3(2 * WAVE), 0, stream, ix, args);   // walking wave + look-ahead helper wave
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {
