@@ -481,11 +481,13 @@ __device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4
     "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
     "v_lshl_add_u64 v[68:69], v[70:71], 4, %[blocks]\n\t"                                                 \
     "v_lshl_add_u64 v[66:67], v[82:83], 4, %[desc]\n\t"   /* descriptor of rec (64 bytes each) */        \
-    "global_load_dwordx4 v[60:63], v[68:69], off\n\t"   /* the rank block FIRST: the three descriptor loads hit one   */ \
-    "global_load_dwordx4 v[48:51], v[66:67], off\n\t"   /* line, and the L1 holds back everything behind a load that  */ \
-    "global_load_dwordx4 v[52:55], v[66:67], off offset:16\n\t" /* hits a line still in flight                        */ \
+    "s_mov_b64 exec, s[44:45]\n\t"                      /* only the lanes that were walking before this step load: a  */ \
+    "global_load_dwordx4 v[60:63], v[68:69], off\n\t"   /* lane that has just parked fetches the parking descriptor   */ \
+    "global_load_dwordx4 v[48:51], v[66:67], off\n\t"   /* once and keeps it; the texture path spends cycles on every */ \
+    "global_load_dwordx4 v[52:55], v[66:67], off offset:16\n\t" /* enabled lane                                       */ \
     "global_load_dwordx4 v[56:59], v[66:67], off offset:32\n\t"                                           \
     "global_load_dwordx2 v[90:91], v[66:67], off offset:48\n\t"                                           \
+    "s_mov_b64 exec, -1\n\t"                                                                              \
     "v_add_u32_e32 v86, 0x9e3779b1, v86\n\t"              /* new sequence number = new pseudo-random number */ \
     "ds_write_b128 %[mail], v[84:87]\n\t"                 /* look-ahead target for the helper wave */
     asm volatile(
@@ -500,6 +502,7 @@ __device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4
         "v_mov_b32_e32 v84, 0\n\t"
         "v_mov_b32_e32 v85, 0\n\t"
         "s_mov_b32 %[reason], 0\n\t"
+        "s_mov_b64 s[44:45], -1\n\t"
         GBWT_WALK_ISSUE
         ".Lgbwt_walk_loop_%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
