@@ -99,6 +99,15 @@ void upload(gbwt_hip_index &ix) {
             uint32_t hops = 3;
             if (const char *v = std::getenv("GBWT_HIP_LOOKAHEAD_HOPS")) hops = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             launch_link_lookahead(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), hops, nullptr);
+            // two-step walk: composed descriptors + two-step blocks
+            ix.desc2.reserve(nr * 8 * sizeof(uint4));
+            ix.cblocks.reserve(n_blocks * 2 * sizeof(uint4));
+            HIP_CHECK(hipMemsetAsync(ix.cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
+            d.desc2 = ix.desc2.as<uint4>();
+            d.cblocks = ix.cblocks.as<uint4>();
+            launch_link_desc2(d, ix.desc2.as<uint4>(), nullptr);
+            if (n_blocks > 1) launch_fill_cblocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), nullptr);
+            launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
@@ -259,7 +268,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
         delete ws; return status_of(e);
     }
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
-    if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 2) ws->walk_mode = static_cast<uint32_t>(m); }
+    if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 3) ws->walk_mode = static_cast<uint32_t>(m); }
     if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 0 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
     if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
     *out = ws;
@@ -269,7 +278,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws) { delete ws; }
 
 gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record) {
-    if (!ws || walk_mode > WALK_COOP || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
+    if (!ws || walk_mode > WALK_ONE_STEP || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
     ws->walk_mode = walk_mode; ws->paths_per_wave = paths_per_wave; ws->small_record = small_record;
     return GBWT_HIP_OK;
 }
@@ -314,6 +323,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                                    : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(32, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
+            a.helper_lanes = 64;
+            if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);

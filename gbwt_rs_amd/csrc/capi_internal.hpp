@@ -57,7 +57,7 @@ inline gbwt_hip_status status_of(const HipError &e) {
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
-    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks;
+    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks;
     gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)
     // GBZ with a node-to-segment translation (src/graph.rs:186-218), flattened for the line formatter:
     gbwt_hip::DeviceBuffer seg_of;        // u32 per node id < mapping_len: segment holding the node (~0 before the first segment)
@@ -76,7 +76,7 @@ struct gbwt_hip_workspace {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
-    uint32_t walk_mode = gbwt_hip::WALK_SAMPLED, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
+    uint32_t walk_mode = gbwt_hip::WALK_TWO_STEP, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid, follow_off;  // search staging
     gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_valid;  // GFA line formatting

@@ -55,6 +55,9 @@ constexpr uint32_t EDGE_EMIT2 = 1u << 31;            // walk descriptor, per edg
 constexpr uint32_t EDGE_CONT = 1u << 30;             // walk descriptor, per edge: the walk continues behind the edge
 constexpr uint32_t DESC_SLOW = 1u << 31;             // walk descriptor, D.x: generic decode (class 0, unchecked edges)
 constexpr uint32_t LOOKAHEAD_COUNT_MASK = (1u << 29) - 1;
+constexpr uint32_t REC_MASK = (1u << 30) - 1;       // record indices are < 2^30; bits 30-31 of a record word carry flags
+constexpr uint32_t LEAF_EMIT2 = 1u << 31;            // two-step descriptor: this step is fused with a unary successor
+constexpr uint32_t DESC2_SLOW = 1u << 30;            // two-step descriptor, word F1.x: generic decode
 constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANK_BLOCK_SHIFT = 6;   // 64 offsets per rank block
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start
@@ -68,6 +71,8 @@ struct DeviceIndex {
     const uint4 *desc_raw;     // 4 * n_records entries (raw descriptors)
     const uint32_t *block_base; // n_records entries
     const uint4 *blocks;       // n_blocks entries
+    const uint4 *desc2;        // 8 * n_records entries (two-step walk descriptors)
+    const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
     uint64_t data_len;
     uint64_t n_records;
     uint64_t n_sequences;      // header.sequences

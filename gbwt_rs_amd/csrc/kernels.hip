@@ -201,6 +201,143 @@ __global__ void __launch_bounds__(256) k_link_lookahead(DeviceIndex ix, uint4 *d
     desc[4 * rec + 3] = make_uint4(target[0], target[1], 0u, 0u);
 }
 
+// ---- two-step walk: descriptors and blocks -----------------------------------------------------------------
+// The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
+// The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
+// memory -- takes TWO LF steps (up to four nodes with fused unary successors):
+//   desc2[8 * v + 0] = F0 = {node to emit for edge 0, offset base in w_0, node to emit for edge 1, offset base in w_1}
+//   desc2[8 * v + 1] = F1 = {w_0 | LEAF_EMIT2 | DESC2_SLOW, w_1 | LEAF_EMIT2, 0, 0}      (first step; DESC2_SLOW: whole record)
+//   desc2[8 * v + 2 + 2 * a + b] = leaf (a, b) = {node to emit, offset base, landing record | LEAF_EMIT2, block base}
+//   desc2[8 * v + 6] = look-ahead {record, first block, number of blocks, 0};  [7] unused
+// The second step exists (is "real") when w_a is unary (descriptor only: its value is always 0) or when both v and w_a
+// have rank blocks: v's two-step block then carries, for each of its 64 offsets, the value the sequence has in w_a
+// (bits2) and the number of value-1 positions of w_a before the landing offset of the block's first a-path (R_a), so
+// the rank inside w_a is again one popcount.  Where the second step is not real (w_a generic, sequence ending, v
+// unary and w_a branching) the leaf (a, 0) is the identity: "emit nothing, stay in w_a at the offset reached".
+__global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    const uint4 *d1 = ix.desc;
+    const uint4 D = d1[4 * v + 2];
+    const uint4 VB = ix.desc_raw[4 * v + 1];
+    const uint32_t cls_v = VB.y != 0 ? desc_class(VB.z) : 0u;
+    uint32_t n1[2] = {0, 0}, base[2] = {0, 0}, wword[2] = {0, 0};
+    uint4 leaf[4] = {make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE)};
+    const bool slow = (D.x & DESC_SLOW) != 0;
+    if (!slow) {
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint4 E = d1[4 * v + a];
+            const uint32_t f = a ? D.w : D.y;
+            n1[a] = E.x; base[a] = E.y;
+            if (!(f & EDGE_CONT)) continue;                       // the walk ends behind this edge: both leaves park it
+            const uint32_t w = E.z;
+            wword[a] = w | ((f & EDGE_EMIT2) ? LEAF_EMIT2 : 0u);
+            const uint4 WD = d1[4 * static_cast<uint64_t>(w) + 2];
+            const uint4 WB = ix.desc_raw[4 * static_cast<uint64_t>(w) + 1];
+            const uint32_t cls_w = WB.y != 0 ? desc_class(WB.z) : 0u;
+            const bool real = !(WD.x & DESC_SLOW) && (cls_w == 1 || (cls_w == 2 && cls_v == 2));
+            if (!real) { leaf[2 * a] = make_uint4(0u, 0u, w, E.w); continue; }   // identity
+            for (uint32_t b = 0; b < cls_w; b++) {
+                const uint4 WE = d1[4 * static_cast<uint64_t>(w) + b];
+                const uint32_t wf = b ? WD.w : WD.y;
+                const bool cont = (wf & EDGE_CONT) != 0;
+                leaf[2 * a + b] = make_uint4(WE.x, WE.y, cont ? (WE.z | ((wf & EDGE_EMIT2) ? LEAF_EMIT2 : 0u)) : 0u, cont ? WE.w : BLOCK_NONE);
+            }
+        }
+    }
+    uint4 *o = out + 8 * v;
+    o[0] = make_uint4(n1[0], base[0], n1[1], base[1]);
+    o[1] = make_uint4(wword[0] | (slow ? DESC2_SLOW : 0u), wword[1], 0u, 0u);
+    o[2] = leaf[0]; o[3] = leaf[1]; o[4] = leaf[2]; o[5] = leaf[3];
+    o[6] = make_uint4(0u, 0u, 0u, 0u);
+    o[7] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// One lane per record with rank blocks: the two-step blocks (32 bytes per 64 offsets):
+//   cblocks[2 * k]     = {bits1 (values of v), bits2 (value in w_a of the sequence at each offset; 0 where the second
+//                         step is not a real step through a record with blocks)}
+//   cblocks[2 * k + 1] = {value-1 positions of v before the block, R_0, R_1, 0}
+// The a-paths of a block land on consecutive offsets of w_a (LF keeps their order), so their values there are a
+// contiguous bit range of w_a's blocks, spread back onto the positions of the a-paths.
+__global__ void __launch_bounds__(256) k_fill_cblocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *cblocks) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    const uint32_t count = block_counts[v];
+    if (count == 0) return;
+    const uint4 *d1 = ix.desc;
+    const uint4 D = d1[4 * v + 2];
+    const uint32_t len = ix.desc_raw[4 * v + 1].w;
+    const uint32_t bb = ix.block_base[v];
+    // per edge: landing record with blocks of its own, or none
+    const uint4 *wblocks[2] = {nullptr, nullptr};
+    uint32_t wbase[2] = {0, 0};
+    if (!(D.x & DESC_SLOW)) {
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint32_t f = a ? D.w : D.y;
+            if (!(f & EDGE_CONT)) continue;
+            const uint4 E = d1[4 * v + a];
+            const uint64_t w = E.z;
+            const uint4 WB = ix.desc_raw[4 * w + 1];
+            if ((d1[4 * w + 2].x & DESC_SLOW) || WB.y == 0 || desc_class(WB.z) != 2) continue;
+            wblocks[a] = ix.blocks + ix.block_base[w];
+            wbase[a] = E.y;
+        }
+    }
+    for (uint32_t k = 0; k < count; k++) {
+        const uint4 P = ix.blocks[bb + k];
+        const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
+        const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
+        const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
+        uint64_t bits2 = 0;
+        uint32_t R[2] = {0, 0};
+        for (uint32_t a = 0; a < 2; a++) {
+            if (!wblocks[a]) continue;
+            uint64_t m = (a ? bits1 : ~bits1) & valid;
+            const uint32_t cnt = __popcll(m);
+            if (cnt == 0) continue;
+            const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
+            const uint32_t j = wbase[a] + before;                                      // where the first a-path lands in w_a
+            const uint32_t q = j >> RANK_BLOCK_SHIFT, sh = j & 63u;
+            const uint4 W0 = wblocks[a][q];
+            const uint64_t w0 = (static_cast<uint64_t>(W0.y) << 32) | W0.x;
+            R[a] = W0.z + __popcll(w0 & ((uint64_t(1) << sh) - 1));
+            uint64_t val = w0 >> sh;
+            if (sh != 0 && cnt > 64 - sh) {
+                const uint4 W1 = wblocks[a][q + 1];
+                val |= ((static_cast<uint64_t>(W1.y) << 32) | W1.x) << (64 - sh);
+            }
+            while (m) {                                                                 // spread the low cnt bits of val over the set bits of m
+                const uint64_t low = m & (~m + 1);
+                if (val & 1) bits2 |= low;
+                val >>= 1;
+                m ^= low;
+            }
+        }
+        cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
+        cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
+    }
+}
+
+// One lane per record: where a walk that is at this record will be `hops` iterations later if it keeps taking leaf
+// (0, 0) (a guess in general graphs; exact where the alleles of a site rejoin): {record, first block, number of blocks}.
+__global__ void __launch_bounds__(256) k_link_lookahead2(DeviceIndex ix, uint4 *desc2, const uint32_t *block_counts, uint32_t hops) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    uint64_t r = v;
+    bool good = true;
+    for (uint32_t h = 0; h < hops && good; h++) {
+        if (desc2[8 * r + 1].x & DESC2_SLOW) { good = false; break; }
+        const uint32_t x = desc2[8 * r + 2].z & REC_MASK;
+        if (x == 0) good = false; else r = x;
+    }
+    uint4 look = make_uint4(0u, 0u, 0u, 0u);
+    if (good && r != v) {
+        look.x = static_cast<uint32_t>(r);
+        if (ix.block_base[r] != BLOCK_NONE) { look.y = ix.block_base[r]; look.z = block_counts[r]; }
+    }
+    desc2[8 * v + 6] = look;
+}
+
 // One lane per outdegree-2 record: decode the runs ONCE and lay the record out as rank blocks (device_index.hpp):
 // block k = {64 values (one bit each), value-1 positions before the block}.  Record::lf (src/bwt.rs:480-496) at
 // offset i is then value = bit i, rank = ones-before or i - ones-before, without scanning any run.
@@ -366,21 +503,24 @@ __device__ __attribute__((noinline)) uint2 serial_record_lf(const uint8_t *data,
 // (the slot only advances when the node counts), and a lane moves 16 slots = 64 bytes to its pool block with four
 // dwordx4 stores whenever that many are waiting.  The pool is the same chain of POOL_BLOCK_NODES-sized blocks as
 // PathSink's.  After a pool overflow the sink drops what it gets: the host grows the pool and walks again.
-constexpr uint32_t RING = 64;
+constexpr uint32_t RING = 64;                // single-step walk: at most 2 nodes per iteration
+constexpr uint32_t RING2 = 128;              // two-step walk: at most 4 nodes per iteration
 constexpr uint32_t RING_FLUSH = 16;
 constexpr uint32_t RING_URGENT = RING - 4;   // the hot loop hands over to the flush code once a lane has more than this waiting
+constexpr uint32_t RING2_URGENT = RING2 - 8;
 static_assert(POOL_BLOCK_NODES % RING_FLUSH == 0, "a block must hold a whole number of flushes");
 
-struct RingSink {
+template <uint32_t SLOTS>
+struct RingSinkT {
     uint32_t *stage;             // this lane's column of the ring: slot s at stage[s * WAVE]
     uint32_t wr = 0, flushed = 0;   // nodes pushed / nodes written to the pool
     uint32_t *wp = nullptr;
     uint32_t left = 0;
     uint32_t cur = POOL_NONE, head = POOL_NONE, blocks = 0;
     bool overflow = false;
-    __device__ __forceinline__ RingSink(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    __device__ __forceinline__ RingSinkT(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
     __device__ __forceinline__ void push(uint32_t node, bool counts) {
-        stage[(wr & (RING - 1)) * WAVE] = node;
+        stage[(wr & (SLOTS - 1)) * WAVE] = node;
         wr += counts ? 1u : 0u;
     }
     __device__ __forceinline__ bool needs_flush() const { return wr - flushed >= RING_FLUSH; }
@@ -396,7 +536,7 @@ struct RingSink {
     }
     __device__ __forceinline__ void flush16(const WalkArgs &a) {
         if (!overflow && (left != 0 || new_block(a))) {
-            const uint32_t *src = stage + (flushed & (RING - 1)) * WAVE;   // slot 0, 16, 32 or 48
+            const uint32_t *src = stage + (flushed & (SLOTS - 1)) * WAVE;   // slot 0, 16, 32 or 48
             uint4 *dst = reinterpret_cast<uint4 *>(wp);
 #pragma unroll
             for (uint32_t q = 0; q < RING_FLUSH / 4; q++)
@@ -409,12 +549,13 @@ struct RingSink {
         while (needs_flush()) flush16(a);
         const uint32_t tail = wr - flushed;
         if (tail != 0 && !overflow && (left != 0 || new_block(a))) {
-            for (uint32_t e = 0; e < tail; e++) wp[e] = stage[((flushed + e) & (RING - 1)) * WAVE];
+            for (uint32_t e = 0; e < tail; e++) wp[e] = stage[((flushed + e) & (SLOTS - 1)) * WAVE];
             left -= tail;
         }
         return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left;
     }
 };
+using RingSink = RingSinkT<RING>;
 
 // Arrival at (node, offset) from outside the linked descriptors (the start of a sequence, a generic step): the tests
 // of GBWT::forward / BWT::record / Record::lf (src/gbwt.rs:222-229, src/bwt.rs:124-130, 481) that k_link_desc
@@ -602,7 +743,7 @@ __device__ __forceinline__ void lookahead_helper(const uint4 *desc, const uint4 
         "v_readfirstlane_b32 s46, v52\n\t"
         "s_cmp_lg_u32 s46, 0\n\t"
         "s_cbranch_scc1 .Lgbwt_helper_out_%=\n\t"
-        "s_sleep 1\n\t"
+        "s_sleep 8\n\t"
         "s_branch .Lgbwt_helper_loop_%=\n\t"
         ".Lgbwt_helper_out_%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
@@ -632,6 +773,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
     __syncthreads();
     const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));   // LDS byte addresses
     if (helper) {
+        if (lane >= a.helper_lanes) return;
         lookahead_helper(ix.desc, ix.blocks, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mail_done)));
         return;
     }
@@ -659,6 +801,296 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
             // edges k_link_desc could not vouch for): Record::lf on the record bytes, then the arrival tests
             const bool slow = rec != 0 && static_cast<int32_t>(ix.desc[4 * static_cast<uint64_t>(rec) + 2].x) < 0;
             if (slow) {
+                const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1];
+                const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
+                sink.push(r.x, r.x != 0);
+                offset = r.y;
+                if (r.x == 0 || !arrive(ix, r.x, r.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+        while (sink.needs_flush()) sink.flush16(a);
+    }
+    if (lane == 0) *const_cast<volatile uint32_t *>(&mail_done) = 1;
+    if (owner) {
+        a.lengths[k] = sink.finish(a);
+        a.head[k] = sink.head;
+    }
+}
+
+// ---- two-step walk --------------------------------------------------------------------------------------
+// Same frame as k_walk_blocks; an iteration of the hot loop composes two LF steps (k_link_desc2, k_fill_cblocks):
+//     a = bit `offset` of bits1;  rank_a = equal values of v before it;        j = base_a + rank_a  (offset in w_a)
+//     b = bit `offset` of bits2;  rank_b = equal values of w_a before j = R_a + (a-paths of this block before `offset`
+//                                          whose value in w_a is 1), or j minus that
+//     leaf (a, b): rec = its landing record, offset = its base + rank_b
+//     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
+__device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                   uint32_t mail_slot, uint32_t flushed, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr,
+                                                   uint32_t &seq) {
+#ifdef GBWT_HIP_CXX_LOOP
+    // plain C++ statement of the loop (no pipelining)
+    __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
+    __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
+    for (;;) {
+        const uint4 *d = desc2 + 8 * static_cast<uint64_t>(rec);
+        const uint4 F0 = d[0], F1 = d[1], L00 = d[2], L01 = d[3], L10 = d[4], L11 = d[5], look = d[6];
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+        const uint4 K0 = cblocks[2 * idx], K1 = cblocks[2 * idx + 1];
+        if (__ballot((F1.x & DESC2_SLOW) != 0) != 0) return 1;
+        const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+        const uint32_t bit = offset & 63u;
+        const uint64_t below = (uint64_t(1) << bit) - 1;
+        const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u;
+        const uint64_t m = a ? bits1 : ~bits1;
+        const uint32_t p = __popcll(m & below);
+        const uint32_t rank_a = a ? K1.x + p : (offset - bit) - K1.x + p;
+        const uint32_t j = (a ? F0.w : F0.y) + rank_a;
+        const uint32_t b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+        const uint32_t ones_w = (a ? K1.z : K1.y) + __popcll(m & bits2 & below);
+        const uint32_t rank_b = b ? ones_w : j - ones_w;
+        const uint4 leaf = a ? (b ? L11 : L10) : (b ? L01 : L00);
+        const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
+        rec = leaf.z & REC_MASK; offset = leaf.y + rank_b; bb = leaf.w;
+        ring[(wr & (RING2 - 1)) * WAVE] = n1;
+        wr += n1 != 0 ? 1u : 0u;
+        ring[(wr & (RING2 - 1)) * WAVE] = (wword & REC_MASK) + alphabet_offset;
+        wr += (wword & LEAF_EMIT2) ? 1u : 0u;
+        ring[(wr & (RING2 - 1)) * WAVE] = leaf.x;
+        wr += leaf.x != 0 ? 1u : 0u;
+        ring[(wr & (RING2 - 1)) * WAVE] = rec + alphabet_offset;
+        wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
+        seq += 0x9E3779B1u;
+        mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = seq;
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > RING2_URGENT) != 0) return 0;
+    }
+#else
+    // The same loop in gfx950 assembly (see walk_hot_loop for the conventions: all lanes run everything, parked lanes sit
+    // on record 0, loads of the next position go out as early as possible, exits leave nothing in flight; a VALU write
+    // of VCC / an SGPR is kept two instructions away from the VALU that reads it).  Registers v40-v125, s41, s44-s47.
+    uint32_t reason;
+#define GBWT_WALK2_ISSUE                                                                                  \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "v_lshlrev_b64 v[88:89], 7, v[40:41]\n\t"             /* two-step descriptors are 128 bytes */        \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "v_lshl_add_u64 v[88:89], v[88:89], 0, %[desc2]\n\t"                                                  \
+    "v_lshlrev_b64 v[90:91], 5, v[70:71]\n\t"             /* two-step blocks are 32 bytes */              \
+    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
+    "s_mov_b64 exec, s[44:45]\n\t"                        /* only lanes that were walking before this step */ \
+    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"             /* K0: bits1, bits2 */                  \
+    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"   /* K1: ones1, R0, R1 */                 \
+    "global_load_dwordx4 v[48:51], v[88:89], off\n\t"             /* F0 */                                \
+    "global_load_dwordx2 v[52:53], v[88:89], off offset:16\n\t"   /* F1 */                                \
+    "global_load_dwordx4 v[56:59], v[88:89], off offset:32\n\t"   /* leaf (0, 0) */                       \
+    "global_load_dwordx4 v[60:63], v[88:89], off offset:48\n\t"   /* leaf (0, 1) */                       \
+    "global_load_dwordx4 v[64:67], v[88:89], off offset:64\n\t"   /* leaf (1, 0) */                       \
+    "global_load_dwordx4 v[72:75], v[88:89], off offset:80\n\t"   /* leaf (1, 1) */                       \
+    "global_load_dwordx3 v[76:78], v[88:89], off offset:96\n\t"   /* look-ahead target */                 \
+    "s_mov_b64 exec, -1\n\t"
+    asm volatile(
+        "v_mov_b32_e32 v40, %[rec]\n\t"
+        "v_mov_b32_e32 v41, 0\n\t"
+        "v_mov_b32_e32 v42, %[offset]\n\t"
+        "v_mov_b32_e32 v43, %[bb]\n\t"
+        "v_mov_b32_e32 v44, %[wr]\n\t"
+        "v_mov_b32_e32 v45, %[seq]\n\t"
+        "v_mov_b32_e32 v71, 0\n\t"
+        "s_mov_b32 %[reason], 0\n\t"
+        "s_mov_b64 s[44:45], -1\n\t"
+        GBWT_WALK2_ISSUE
+        ".Lgbwt_walk2_loop_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_lshlrev_b32_e32 v92, 1, v52\n\t"                 /* DESC2_SLOW (bit 30 of F1.x) -> sign */
+        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */
+        "v_cmp_gt_i32_e32 vcc, 0, v92\n\t"
+        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */
+        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */
+        "s_cbranch_vccnz .Lgbwt_walk2_slow_%=\n\t"
+        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */
+        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */
+        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */
+        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */
+        "v_xor_b32_e32 v101, v81, v98\n\t"
+        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */
+        "v_bfi_b32 v101, v97, 0, v101\n\t"
+        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */
+        "v_bcnt_u32_b32 v102, v100, 0\n\t"
+        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */
+        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */
+        "v_cndmask_b32_e32 v103, v49, v51, vcc\n\t"         /* offset base of edge a */
+        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */
+        "v_cndmask_b32_e32 v104, v48, v50, vcc\n\t"         /* node of edge a */
+        "v_add_u32_e32 v103, v103, v99\n\t"                 /* j: offset in w_a */
+        "v_cndmask_b32_e32 v105, v52, v53, vcc\n\t"         /* w_a | flags */
+        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */
+        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */
+        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */
+        "v_and_b32_e32 v101, v101, v83\n\t"
+        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */
+        "v_bcnt_u32_b32 v106, v100, v106\n\t"
+        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */
+        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */
+        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */
+        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */
+        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */
+        "v_cndmask_b32_e64 v112, v56, v60, s[46:47]\n\t"    /* leaf (0, b) */
+        "v_cndmask_b32_e64 v113, v57, v61, s[46:47]\n\t"
+        "v_cndmask_b32_e64 v114, v58, v62, s[46:47]\n\t"
+        "v_cndmask_b32_e64 v115, v59, v63, s[46:47]\n\t"
+        "v_cndmask_b32_e64 v116, v64, v72, s[46:47]\n\t"    /* leaf (1, b) */
+        "v_cndmask_b32_e64 v117, v65, v73, s[46:47]\n\t"
+        "v_cndmask_b32_e64 v118, v66, v74, s[46:47]\n\t"
+        "v_cndmask_b32_e64 v119, v67, v75, s[46:47]\n\t"
+        "v_cndmask_b32_e32 v112, v112, v116, vcc\n\t"       /* leaf (a, b): node to emit */
+        "v_cndmask_b32_e32 v113, v113, v117, vcc\n\t"       /* offset base */
+        "v_cndmask_b32_e32 v114, v114, v118, vcc\n\t"       /* landing record | flags */
+        "v_cndmask_b32_e32 v43, v115, v119, vcc\n\t"        /* its block base */
+        "v_add_u32_e32 v42, v113, v107\n\t"                 /* the new offset */
+        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */
+        "v_mov_b32_e32 v120, v76\n\t"                       /* look-ahead target of the record just left ... */
+        "v_mov_b32_e32 v121, v77\n\t"
+        "v_mov_b32_e32 v122, v78\n\t"
+        "v_add_u32_e32 v45, 0x9e3779b1, v45\n\t"            /* ... posted with a new sequence number */
+        "v_and_b32_e32 v92, 0x7f, v44\n\t"                  /* ring slot of the next node */
+        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t"
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
+        "v_mov_b32_e32 v123, v45\n\t"
+        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */
+        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */
+        "v_and_b32_e32 v92, 0x7f, v44\n\t"
+        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
+        "ds_write_b32 v92, v110\n\t"
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t"
+        "v_and_b32_e32 v92, 0x7f, v44\n\t"
+        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
+        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
+        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */
+        "v_and_b32_e32 v92, 0x7f, v44\n\t"
+        "ds_write_b128 %[mail], v[120:123]\n\t"
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
+        "ds_write_b32 v92, v111\n\t"
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
+        GBWT_WALK2_ISSUE
+        "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */
+        "v_sub_u32_e32 v92, v44, %[flushed]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[urgent], v92\n\t"
+        "s_cmp_eq_u64 s[44:45], 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_walk2_out_%=\n\t"
+        "s_cbranch_vccz .Lgbwt_walk2_loop_%=\n\t"
+        "s_branch .Lgbwt_walk2_out_%=\n\t"
+        ".Lgbwt_walk2_slow_%=:\n\t"
+        "s_mov_b32 %[reason], 1\n\t"
+        ".Lgbwt_walk2_out_%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "v_mov_b32_e32 %[rec], v40\n\t"
+        "v_mov_b32_e32 %[offset], v42\n\t"
+        "v_mov_b32_e32 %[bb], v43\n\t"
+        "v_mov_b32_e32 %[wr], v44\n\t"
+        "v_mov_b32_e32 %[seq], v45\n\t"
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [seq] "+v"(seq), [reason] "=&s"(reason)
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [flushed] "v"(flushed), [urgent] "i"(RING2_URGENT),
+          "{s41}"(alphabet_offset)
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47",
+          "v40", "v41", "v42", "v43", "v44", "v45", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+          "v64", "v65", "v66", "v67", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v80", "v81", "v82", "v83", "v84", "v85", "v86",
+          "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
+#undef GBWT_WALK2_ISSUE
+    return reason;
+#endif
+}
+
+// Look-ahead helper of the two-step walk: mailbox slot = {record, first block, number of blocks, sequence number} of
+// the record the walk reaches a few iterations later; touches its descriptor (128 bytes = two sectors) and one of its
+// two-step blocks.  Fire and forget, as lookahead_helper.
+__device__ __forceinline__ void lookahead_helper2(const uint4 *desc2, const uint4 *cblocks, uint32_t mail_slot, uint32_t done_addr, uint32_t spread) {
+    asm volatile(
+        "v_mov_b32_e32 v40, 0\n\t"                          /* last sequence number seen */
+        "v_mov_b32_e32 v47, 0\n\t"
+        "v_mov_b32_e32 v59, 0\n\t"
+        ".Lgbwt_helper2_loop_%=:\n\t"
+        "ds_read_b128 v[48:51], %[mail]\n\t"
+        "ds_read_b32 v52, %[done]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ne_u32_e32 vcc, v51, v40\n\t"                /* slots with a new target ... */
+        "v_mov_b32_e32 v58, v48\n\t"
+        "v_mov_b32_e32 v40, v51\n\t"
+        "v_cmp_ne_u32_e64 s[46:47], 0, v48\n\t"             /* ... that is a record */
+        "v_mov_b32_e32 v46, %[spread]\n\t"                  /* helper lane l takes the block (l + 1/2) / 64 of the way through */
+        "v_mul_hi_u32 v46, v46, v50\n\t"
+        "s_and_b64 vcc, vcc, s[46:47]\n\t"
+        "v_add_u32_e32 v46, v46, v49\n\t"
+        "s_and_saveexec_b64 s[44:45], vcc\n\t"
+        "v_lshlrev_b64 v[54:55], 5, v[46:47]\n\t"           /* two-step blocks are 32 bytes */
+        "v_lshlrev_b64 v[60:61], 7, v[58:59]\n\t"           /* two-step descriptors are 128 bytes */
+        "v_lshl_add_u64 v[54:55], v[54:55], 0, %[cblocks]\n\t"
+        "v_lshl_add_u64 v[60:61], v[60:61], 0, %[desc2]\n\t"
+        "global_load_dword v56, v[54:55], off\n\t"
+        "global_load_dword v57, v[60:61], off\n\t"
+        "global_load_dword v53, v[60:61], off offset:64\n\t"
+        "s_mov_b64 exec, s[44:45]\n\t"
+        "v_readfirstlane_b32 s46, v52\n\t"
+        "s_cmp_lg_u32 s46, 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_helper2_out_%=\n\t"
+        "s_sleep 8\n\t"
+        "s_branch .Lgbwt_helper2_loop_%=\n\t"
+        ".Lgbwt_helper2_out_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        :
+        : [mail] "v"(mail_slot), [done] "v"(done_addr), [spread] "v"(spread), [cblocks] "s"(cblocks), [desc2] "s"(desc2)
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "v40", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+          "v57", "v58", "v59", "v60", "v61");
+}
+
+__global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs a) {
+    __shared__ uint32_t ring_lds[RING2 * WAVE];
+    __shared__ uint4 mailbox[WAVE];
+    __shared__ uint32_t mail_done;
+    const uint32_t lane = threadIdx.x % WAVE;
+    const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
+    if (!helper) {
+        mailbox[lane] = make_uint4(0, 0, 0, 0);
+        if (lane == 0) mail_done = 0;
+    }
+    __syncthreads();
+    if (helper) {
+        // the 64 helper lanes share the slots of the owners: lane l serves slot l mod owners, and the lanes of one slot
+        // spread over the target's blocks (lane / 64 of the way round)
+        const uint32_t owners = a.paths_per_wave ? a.paths_per_wave : WAVE;
+        if (lane >= a.helper_lanes) return;
+        lookahead_helper2(ix.desc2, ix.cblocks, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane % owners])),
+                          static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mail_done)), (lane << 26) | (1u << 25));
+        return;
+    }
+    const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));   // LDS byte address
+    RingSinkT<RING2> sink(ring_lds, lane);
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
+    const bool owner = lane < a.paths_per_wave && k < a.n;
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;   // position of the walk (record index; 0 = parked) + block base of the record
+    if (owner) {
+        const uint64_t id = a.seq_ids[k];
+        if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+            const uint2 e = ix.endmarker[id];
+            if (e.x != 0) {
+                sink.push(e.x, true);
+                offset = e.y;
+                if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+    }
+    const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
+    uint32_t seq = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;
+    while (__ballot(rec != 0) != 0) {
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, rec, offset, bb, sink.wr, seq);
+        if (slow_exit) {
+            const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
+            if (slow) {   // one generic step, as in k_walk_blocks
                 const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1];
                 const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
                 sink.push(r.x, r.x != 0);
@@ -1134,6 +1566,21 @@ void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t 
     hipLaunchKernelGGL(k_link_lookahead, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts, hops);
 }
 
+void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2);
+}
+
+void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_cblocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_cblocks);
+}
+
+void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_lookahead2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, d_block_counts, hops);
+}
+
 void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream) {
     if (ix.n_records == 0) return;
     hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_block_base, d_blocks);
@@ -1183,7 +1630,9 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         else hipLaunchKernelGGL((k_walk_coop<false>), grid, block, 0, stream, ix, args);
         return;
     }
-    hipLaunchKernelGGL(k_walk_blocks, grid, dim3(2 * WAVE), 0, stream, ix, args);   // walking wave + look-ahead helper wave
+    // walking wave + look-ahead helper wave
+    if (args.mode == WALK_ONE_STEP) { hipLaunchKernelGGL(k_walk_blocks, grid, dim3(2 * WAVE), 0, stream, ix, args); return; }
+    hipLaunchKernelGGL(k_walk_two, grid, dim3(2 * WAVE), 0, stream, ix, args);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

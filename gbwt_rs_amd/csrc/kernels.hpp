@@ -30,6 +30,10 @@ void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_
 void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream);
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream);
 void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
+// two-step walk (device_index.hpp): composed descriptors, two-step rank blocks, look-ahead targets
+void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream);
+void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream);
+void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
 void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream);
 void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream);
 void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
@@ -47,12 +51,13 @@ struct WalkArgs {
     uint64_t *lengths;         // [n]
     uint32_t *flags;           // [1]
     // tuning (gbwt_hip_workspace_tune)
-    uint32_t mode;             // WALK_SAMPLED (default), WALK_LANE_SERIAL or WALK_COOP
+    uint32_t mode;             // WALK_TWO_STEP (default), WALK_LANE_SERIAL, WALK_COOP or WALK_ONE_STEP
     uint32_t paths_per_wave;   // lanes of a wave that own a path (1..64)
     uint32_t small_record;     // WALK_COOP: records of at most this many bytes are decoded lane-serially
     uint32_t pack16;           // WALK_COOP: every record is shorter than 2^16 (stats.max_record_len): one packed scan
+    uint32_t helper_lanes;     // lanes of the look-ahead helper wave that touch (64; 0 = no look-ahead; experiments)
 };
-constexpr uint32_t WALK_SAMPLED = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2;
+constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 

@@ -99,11 +99,12 @@ gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *
 gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_workspace **out);
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws);
 /* Tuning of the extraction kernel for this workspace (results never depend on it):
- *   walk_mode      0 = one lane per sequence on the rank blocks built at open (default),
+ *   walk_mode      0 = one lane per sequence, two LF steps per iteration on the two-step rank blocks built at open (default),
  *                  1 = lane-serial scan from the start of every record (the reference's access pattern),
- *                  2 = wave-cooperative decode of long records (all 64 lanes scan one record's runs)
- *   paths_per_wave lanes of each wavefront that own a sequence, 1..64; 0 = automatic (default): about one wavefront
- *                  per SIMD, at least 16 owners per wave -- the walk is latency-bound, not throughput-bound
+ *                  2 = wave-cooperative decode of long records (all 64 lanes scan one record's runs),
+ *                  3 = one lane per sequence, one LF step per iteration on the plain rank blocks
+ *   paths_per_wave lanes of each wavefront that own a sequence, 1..64; 0 = automatic (default): at least 32 owners per
+ *                  wave -- the walk is latency-bound, not throughput-bound, and every lane runs the same instructions
  *   small_record   mode 2 only: records of at most this many bytes are decoded by their own lane (default 16)
  * Environment overrides read at workspace creation: GBWT_HIP_WALK_MODE, GBWT_HIP_PATHS_PER_WAVE, GBWT_HIP_SMALL_RECORD. */
 gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record);

@@ -423,13 +423,15 @@ def test_headline_scale_properties():
 # ---------------------------------------------------------------------------------------------
 # kernel variants: results never depend on the tuning
 
-TUNINGS = [dict(walk_mode=0, paths_per_wave=64, small_record=16),   # default: rank blocks, one lane per sequence
+TUNINGS = [dict(walk_mode=0, paths_per_wave=64, small_record=16),   # default: two LF steps per iteration on rank blocks
            dict(walk_mode=0, paths_per_wave=7, small_record=16),
            dict(walk_mode=2, paths_per_wave=64, small_record=16),   # cooperative for long records (bpermute search)
            dict(walk_mode=2, paths_per_wave=64, small_record=0),    # every class 1/2 record through the cooperative path
            dict(walk_mode=2, paths_per_wave=5, small_record=0),     # few owners per wave (member-by-member resolution)
            dict(walk_mode=2, paths_per_wave=17, small_record=40),
-           dict(walk_mode=1, paths_per_wave=64, small_record=16)]   # lane-serial kernel
+           dict(walk_mode=1, paths_per_wave=64, small_record=16),   # lane-serial kernel
+           dict(walk_mode=3, paths_per_wave=64, small_record=16),   # one LF step per iteration on rank blocks
+           dict(walk_mode=3, paths_per_wave=5, small_record=16)]
 
 
 def variant_cases():
