@@ -109,6 +109,32 @@ void upload(gbwt_hip_index &ix) {
             if (n_blocks > 1) launch_fill_cblocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), nullptr);
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
+        // LF tables for the class 0 records, while they fit the budget
+        d.tables = nullptr;
+        if (n_records > 0) {
+            DeviceBuffer positions, sigmas, table_base, edge_base, edges;
+            positions.reserve(n_records * sizeof(uint64_t)); sigmas.reserve(n_records * sizeof(uint64_t));
+            table_base.reserve((n_records + 1) * sizeof(uint64_t)); edge_base.reserve((n_records + 1) * sizeof(uint64_t));
+            launch_table_counts(d, positions.as<uint64_t>(), sigmas.as<uint64_t>(), nullptr);
+            const size_t tb = scan_temp_bytes(n_records);
+            scan_tmp.reserve(std::max<size_t>(tb, 16));
+            launch_scan(positions.as<uint64_t>(), table_base.as<uint64_t>(), n_records, scan_tmp.ptr, tb, nullptr);
+            launch_scan(sigmas.as<uint64_t>(), edge_base.as<uint64_t>(), n_records, scan_tmp.ptr, tb, nullptr);
+            uint64_t total_positions = 0, total_edges = 0;
+            HIP_CHECK(hipMemcpy(&total_positions, table_base.as<uint64_t>() + n_records, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(&total_edges, edge_base.as<uint64_t>() + n_records, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            uint64_t budget = uint64_t(16) << 30;
+            if (const char *v = std::getenv("GBWT_HIP_TABLE_BYTES")) budget = std::strtoull(v, nullptr, 10);
+            if (total_positions > 0 && total_positions < 0xFFFFFFFFull && total_positions * sizeof(uint4) <= budget) {
+                ix.tables.reserve(total_positions * sizeof(uint4));
+                edges.reserve(std::max<uint64_t>(total_edges, 1) * sizeof(uint2));
+                d.tables = ix.tables.as<uint4>();
+                launch_fill_tables(d, ix.desc_raw.as<uint4>(), table_base.as<uint64_t>(), edge_base.as<uint64_t>(), ix.tables.as<uint4>(),
+                                   edges.as<uint2>(), nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+                HIP_CHECK(hipGetLastError());
+            }
+        }
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
     }

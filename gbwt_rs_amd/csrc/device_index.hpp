@@ -15,7 +15,7 @@
 //                     meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
 //                     class 1 / 2 = outdegree 1 / 2 (class 1 is always unary, class 2 has rank blocks) with the edges in A and "body offset" = where the run stream
 //                     starts inside the record; class 0 = any other non-empty record (generic lane-serial decode)
-//                 C = {value-0 positions of the record, 0, 0, 0}
+//                 C = {value-0 positions of the record, Record::len, first LF table entry, 1 if the record has an LF table}
 //                 D = the first 16 bytes of the run stream, so short records need no second load
 //               empty / None record : B.y = 0
 //               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 (every node on a linear stretch of
@@ -36,6 +36,11 @@
 //               after taking the edge; the walk touches one of them per iteration to warm the L2 of its XCD.
 //   block_base: per record, index of its first rank block or BLOCK_NONE (needed where a walk starts; afterwards
 //               the block base of the next record rides along in the edge taken)
+//   tables    : the class 0 records (outdegree > 2, streams outside the descriptor's limits) decompressed once at open
+//               (Record::decompress, src/bwt.rs:466-478) into one 16-byte entry per position: {successor node,
+//               offset in the successor, landing record index or 0 where the walk ends, block base of the landing
+//               record} -- Record::lf plus the arrival tests of GBWT::forward as one lookup.  Built only while they fit
+//               the budget (GBWT_HIP_TABLE_BYTES, default 16 GiB); otherwise such records are decoded serially.
 //   blocks    : the outdegree-2 records decoded once at open (k_fill_blocks) into RANK BLOCKS of 64 offsets, 16 bytes
 //               each: {values of offsets 64k .. 64k+63 as one bit each (two words), value-1 offsets before 64k, 0}.
 //               Record::lf (src/bwt.rs:480-496) at offset i becomes: value = bit i, rank = ones-before (value 1) or
@@ -72,6 +77,7 @@ struct DeviceIndex {
     const uint32_t *block_base; // n_records entries
     const uint4 *blocks;       // n_blocks entries
     const uint4 *desc2;        // 8 * n_records entries (two-step walk descriptors)
+    const uint4 *tables;       // LF tables of the class 0 records (desc_raw C.z = first entry, C.w = 1), or null
     const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
     uint64_t data_len;
     uint64_t n_records;

@@ -201,6 +201,70 @@ __global__ void __launch_bounds__(256) k_link_lookahead(DeviceIndex ix, uint4 *d
     desc[4 * rec + 3] = make_uint4(target[0], target[1], 0u, 0u);
 }
 
+// ---- LF tables for class 0 records -------------------------------------------------------------------------
+// One lane per record: number of positions and outdegree of the records that get a table (0 for all others).
+__global__ void __launch_bounds__(256) k_table_counts(DeviceIndex ix, uint64_t *positions, uint64_t *sigmas) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint4 B = ix.desc_raw[4 * rec + 1], C = ix.desc_raw[4 * rec + 2];
+    uint64_t pos = 0, sigma = 0;
+    if (rec != 0 && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0 && C.y != 0xFFFFFFFFu && C.y != 0) {
+        const uint64_t start = desc_start(B.x, B.z);
+        ByteCursor c(ix.data, start, start + B.y);
+        if (c.varint(sigma) && sigma != 0) pos = C.y; else sigma = 0;
+    }
+    positions[rec] = pos; sigmas[rec] = sigma;
+}
+
+// One lane per class 0 record: Record::decompress (src/bwt.rs:466-478) with the arrival tests of GBWT::forward folded in.
+// `edges` is scratch: {successor, running offset} per edge of the record.
+__global__ void __launch_bounds__(64) k_fill_tables(DeviceIndex ix, uint4 *desc_raw, const uint64_t *table_base, const uint64_t *edge_base, uint4 *tables,
+                                                    uint2 *edges) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint64_t count = table_base[rec + 1] - table_base[rec];
+    if (count == 0) return;
+    const uint4 B = desc_raw[4 * rec + 1];
+    const uint64_t start = desc_start(B.x, B.z);
+    ByteCursor c(ix.data, start, start + B.y);
+    uint64_t sigma = 0;
+    c.varint(sigma);
+    uint2 *e = edges + edge_base[rec];
+    uint64_t node = 0;
+    for (uint64_t k = 0; k < sigma; k++) {
+        uint64_t delta = 0, off = 0;
+        c.varint(delta); c.varint(off);
+        node += delta;
+        e[k] = make_uint2(static_cast<uint32_t>(node), static_cast<uint32_t>(off));
+    }
+    uint4 *out = tables + table_base[rec];
+    RunDecoder rd(sigma);
+    uint64_t pos = 0, value, len;
+    while (pos < count && rd.next(c, value, len)) {
+        if (value >= sigma) break;
+        const uint32_t succ = e[value].x;
+        uint32_t off = e[value].y;
+        uint64_t land = 0;
+        uint32_t lrec = 0, bb = BLOCK_NONE, llen = 0;
+        bool exists = false, checked = false;
+        if (succ != 0 && landing_record(ix, succ, land)) {
+            const uint4 LB = desc_raw[4 * land + 1];
+            exists = LB.y != 0;
+            checked = desc_class(LB.z) != 0;   // records with descriptors: the offset must be inside (src/bwt.rs:481)
+            llen = LB.w;
+            if (exists) { lrec = static_cast<uint32_t>(land); bb = ix.block_base[land]; }
+        }
+        for (uint64_t k = 0; k < len && pos < count; k++, pos++, off++) {
+            const bool cont = exists && (!checked || off < llen);
+            out[pos] = make_uint4(succ, off, cont ? lrec : 0u, cont ? bb : BLOCK_NONE);
+        }
+        e[value].y = off;
+    }
+    uint4 C = desc_raw[4 * rec + 2];
+    C.z = static_cast<uint32_t>(table_base[rec]); C.w = 1u;
+    desc_raw[4 * rec + 2] = C;
+}
+
 // ---- two-step walk: descriptors and blocks -----------------------------------------------------------------
 // The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
 // The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
@@ -569,6 +633,24 @@ __device__ __forceinline__ bool arrive(const DeviceIndex &ix, uint32_t node, uin
     return true;
 }
 
+// One generic step of a walk at a DESC_SLOW record: a lookup in the record's LF table when it has one, else Record::lf
+// on the record bytes followed by the arrival tests.
+template <class Sink>
+__device__ __forceinline__ void generic_step(const DeviceIndex &ix, Sink &sink, uint32_t &rec, uint32_t &offset, uint32_t &bb) {
+    const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1], C = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 2];
+    if (C.w == 1u) {
+        uint4 e = make_uint4(0u, 0u, 0u, BLOCK_NONE);
+        if (offset < C.y) e = ix.tables[static_cast<uint64_t>(C.z) + offset];   // i >= Record::len -> None (src/bwt.rs:481)
+        sink.push(e.x, e.x != 0);
+        offset = e.y; rec = e.z; bb = e.w;
+        return;
+    }
+    const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
+    sink.push(r.x, r.x != 0);
+    offset = r.y;
+    if (r.x == 0 || !arrive(ix, r.x, r.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+}
+
 // The hot loop of the default walk, written in gfx950 assembly: hipcc's register shuffling around the cold paths and
 // its SGPR mask algebra more than doubled the instruction count of the loop, and the position of every load and wait
 // matters here.
@@ -800,13 +882,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
             // generic step for the lanes on a DESC_SLOW record (outdegree > 2, streams outside the descriptor's limits,
             // edges k_link_desc could not vouch for): Record::lf on the record bytes, then the arrival tests
             const bool slow = rec != 0 && static_cast<int32_t>(ix.desc[4 * static_cast<uint64_t>(rec) + 2].x) < 0;
-            if (slow) {
-                const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1];
-                const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
-                sink.push(r.x, r.x != 0);
-                offset = r.y;
-                if (r.x == 0 || !arrive(ix, r.x, r.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
-            }
+            if (slow) generic_step(ix, sink, rec, offset, bb);
         }
         while (sink.needs_flush()) sink.flush16(a);
     }
@@ -1090,13 +1166,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
         const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, rec, offset, bb, sink.wr, seq);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
-            if (slow) {   // one generic step, as in k_walk_blocks
-                const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1];
-                const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
-                sink.push(r.x, r.x != 0);
-                offset = r.y;
-                if (r.x == 0 || !arrive(ix, r.x, r.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
-            }
+            if (slow) generic_step(ix, sink, rec, offset, bb);
         }
         while (sink.needs_flush()) sink.flush16(a);
     }
@@ -1564,6 +1634,17 @@ void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) 
 void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
     if (ix.n_records == 0) return;
     hipLaunchKernelGGL(k_link_lookahead, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts, hops);
+}
+
+void launch_table_counts(const DeviceIndex &ix, uint64_t *d_positions, uint64_t *d_sigmas, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_table_counts, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_positions, d_sigmas);
+}
+
+void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t *d_table_base, const uint64_t *d_edge_base, uint4 *d_tables,
+                        uint2 *d_edges, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_tables, dim3(grid_for(ix.n_records, 64)), dim3(64), 0, stream, ix, d_desc_raw, d_table_base, d_edge_base, d_tables, d_edges);
 }
 
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream) {

@@ -30,6 +30,10 @@ void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_
 void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream);
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream);
 void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
+// LF tables of the class 0 records (device_index.hpp): per-record positions / outdegrees, then the fill
+void launch_table_counts(const DeviceIndex &ix, uint64_t *d_positions, uint64_t *d_sigmas, hipStream_t stream);
+void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t *d_table_base, const uint64_t *d_edge_base, uint4 *d_tables,
+                        uint2 *d_edges, hipStream_t stream);
 // two-step walk (device_index.hpp): composed descriptors, two-step rank blocks, look-ahead targets
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream);
 void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream);
