@@ -207,6 +207,12 @@ class GBWT:
         check(self._L.gbwt_hip_last_kernel_ms(self._ws, C.byref(walk), C.byref(total)))
         return walk.value, total.value
 
+    def last_query_ms(self):
+        """Kernel time (HIP events) of the last start / forward / backward / find / extend / search / follow call."""
+        ms = C.c_float(0)
+        check(self._L.gbwt_hip_last_query_ms(self._ws, C.byref(ms)))
+        return ms.value
+
     def tune(self, walk_mode=0, paths_per_wave=0, small_record=16):
         """Kernel tuning knobs of gbwt_hip_workspace_tune (results never depend on them)."""
         check(self._L.gbwt_hip_workspace_tune(self._ws, walk_mode, paths_per_wave, small_record))

@@ -203,7 +203,11 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
             ws->in_b.reserve(b_bytes);
             HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, b_bytes, hipMemcpyHostToDevice, ws->stream));
         }
+        for (auto &e : ws->qev) if (!e) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(ws->qev[0], ws->stream));
         launch();
+        HIP_CHECK(hipEventRecord(ws->qev[1], ws->stream));
+        ws->query_timed = true;
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, ws->out_a.ptr, out_bytes, hipMemcpyDeviceToHost, ws->stream));
         HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, ws->stream));
@@ -451,6 +455,12 @@ gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *wal
         return fail(GBWT_HIP_DEVICE_ERROR, "hipEventElapsedTime failed");
     if (walk_ms) *walk_ms = a;
     if (total_ms) *total_ms = b;
+    return GBWT_HIP_OK;
+}
+
+gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kernel_ms) {
+    if (!ws || !ws->query_timed || !kernel_ms) return fail(GBWT_HIP_BAD_ARGUMENT, "no timed query on this workspace");
+    if (hipEventElapsedTime(kernel_ms, ws->qev[0], ws->qev[1]) != hipSuccess) return fail(GBWT_HIP_DEVICE_ERROR, "hipEventElapsedTime failed");
     return GBWT_HIP_OK;
 }
 

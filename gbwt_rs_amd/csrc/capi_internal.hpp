@@ -74,7 +74,8 @@ struct gbwt_hip_workspace {
     const gbwt_hip_index *index = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool timed = false;
+    hipEvent_t qev[2] = {nullptr, nullptr};   // around the kernel(s) of the last navigation / search call
+    bool timed = false, query_timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
     uint32_t walk_mode = gbwt_hip::WALK_TWO_STEP, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
@@ -82,6 +83,7 @@ struct gbwt_hip_workspace {
     gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_valid;  // GFA line formatting
     ~gbwt_hip_workspace() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto &e : qev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };

@@ -208,6 +208,9 @@ gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *index, gbwt_hip_workspa
  * Name and average duration (ms, from HIP events on the workspace stream) of the dominant kernel of
  * the last gbwt_hip_extract_device call, for bench.py's roofline object. */
 gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms);
+/* Kernel time (ms, HIP events on the workspace stream, host staging excluded) of the last navigation / search call
+ * (start, forward, backward, find, extend, bd_*, search, bd_search) on `ws`. */
+gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kernel_ms);
 
 #ifdef __cplusplus
 }
