@@ -1295,15 +1295,6 @@ __global__ void __launch_bounds__(256) k_start(DeviceIndex ix, const uint64_t *i
     out[k] = p; valid[k] = ok;
 }
 
-__global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid) {
-    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (k >= n) return;
-    gbwt_hip_pos p = in[k], r{0, 0};
-    uint8_t ok = gbwt_forward(ix, p.node, p.offset, r.node, r.offset) ? 1 : 0;
-    if (!ok) { r.node = 0; r.offset = 0; }
-    out[k] = r; valid[k] = ok;
-}
-
 // ---- search on descriptors + rank blocks --------------------------------------------------------------
 // For class 1 / 2 records everything Record::follow / bd_follow compute (src/bwt.rs:595-656) is a difference of
 // "how many of the first p positions take edge r", which the rank blocks answer in O(1): two block lookups
@@ -1317,6 +1308,45 @@ __device__ __forceinline__ bool load_raw_desc(const DeviceIndex &ix, uint64_t no
     if (rec >= ix.n_records) return false;
     d.A = ix.desc_raw[4 * rec]; d.B = ix.desc_raw[4 * rec + 1]; d.C = ix.desc_raw[4 * rec + 2]; d.D = ix.desc_raw[4 * rec + 3];
     return d.B.y != 0;   // empty record / sigma == 0 -> None
+}
+
+// GBWT::forward (src/gbwt.rs:222-229) for independent positions: one block lookup on class 1 / 2 records, one LF-table
+// lookup on class 0 records that have a table, the generic scan otherwise.
+__global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_pos *in, uint64_t n, gbwt_hip_pos *out, uint8_t *valid) {
+    uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const gbwt_hip_pos p = in[k];
+    gbwt_hip_pos r{0, 0};
+    uint8_t ok = 0;
+    RawDesc d;
+    uint64_t rec;
+    if (load_raw_desc(ix, p.node, d, rec)) {
+        const uint32_t cls = desc_class(d.B.z);
+        if (cls != 0) {
+            if (p.offset < d.B.w) {
+                const uint32_t i = static_cast<uint32_t>(p.offset);
+                uint32_t value = 0, rank = i;
+                if (cls == 2) {
+                    const uint4 K = ix.blocks[ix.block_base[rec] + (i >> RANK_BLOCK_SHIFT)];
+                    const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+                    value = static_cast<uint32_t>(bits >> (i & 63u)) & 1u;
+                    const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << (i & 63u)) - 1));
+                    rank = value ? ones : i - ones;
+                }
+                r.node = value ? d.A.z : d.A.x;
+                r.offset = static_cast<uint64_t>(value ? d.A.w : d.A.y) + rank;
+                ok = r.node != 0;
+            }
+        } else if (d.C.w == 1u) {
+            if (p.offset < d.C.y) {
+                const uint4 e = ix.tables[static_cast<uint64_t>(d.C.z) + p.offset];
+                r.node = e.x; r.offset = e.y;
+                ok = e.x != 0;
+            }
+        } else ok = gbwt_forward(ix, p.node, p.offset, r.node, r.offset) ? 1 : 0;
+    }
+    if (!ok) { r.node = 0; r.offset = 0; }
+    out[k] = r; valid[k] = ok;
 }
 
 // value-0 positions among the first p positions (p <= Record::len) of a class 1 / 2 record

@@ -528,6 +528,23 @@ def test_config_c3_search_bit_exact(model, haplotypes):
         assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
 
 
+def test_generic_records_without_lf_tables(monkeypatch):
+    """Outdegree > 2 with the LF tables switched off (GBWT_HIP_TABLE_BYTES=0, read at open): the serial Record::lf decode
+    behind the same walk frames, in every walk mode, and forward() through the generic scan."""
+    monkeypatch.setenv("GBWT_HIP_TABLE_BYTES", "0")
+    s = S.Synth.chain(sites=40, haplotypes=300, alleles=7, model=S.IID, zipf=0.5, seed=9)
+    dev, oracle = open_synth(s), oracle_of(s)
+    monkeypatch.delenv("GBWT_HIP_TABLE_BYTES")
+    ids = np.arange(0, s.sequences, dtype=np.uint64)
+    o_off, o_nodes = oracle.extract(ids, threads=4)
+    for mode in (0, 3, 2, 1):
+        dev.tune(mode, 0, 16)
+        offsets, nodes = dev.sequences_csr(ids)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes), mode
+    dev.tune(0, 0, 16)
+    check_all_positions(dev, oracle)
+
+
 def test_high_degree_search_and_extract():
     """BASELINE config 5 shape (outdegree >= 255, two-varint runs): extraction and search stay bit-exact."""
     s = S.Synth.chain(sites=30, haplotypes=2500, alleles=300, model=S.IID, zipf=0.3, seed=5)
