@@ -901,8 +901,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
 //     leaf (a, b): rec = its landing record, offset = its base + rank_b
 //     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
 __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                   uint32_t mail_slot, uint32_t flushed, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr,
-                                                   uint32_t &seq) {
+                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t &rec, uint32_t &offset, uint32_t &bb,
+                                                   uint32_t &wr, uint32_t &seq) {
 #ifdef GBWT_HIP_CXX_LOOP
     // plain C++ statement of the loop (no pipelining)
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
@@ -944,7 +944,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     // on record 0, loads of the next position go out as early as possible, exits leave nothing in flight; a VALU write
     // of VCC / an SGPR is kept two instructions away from the VALU that reads it).  Registers v40-v125, s41, s44-s47.
     uint32_t reason;
-#define GBWT_WALK2_ISSUE                                                                                  \
+#define GBWT_WALK2_ISSUE_WIDE                                                                                  \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
     "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
     "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
@@ -964,120 +964,138 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     "global_load_dwordx4 v[72:75], v[88:89], off offset:80\n\t"   /* leaf (1, 1) */                       \
     "global_load_dwordx3 v[76:78], v[88:89], off offset:96\n\t"   /* look-ahead target */                 \
     "s_mov_b64 exec, -1\n\t"
-    asm volatile(
-        "v_mov_b32_e32 v40, %[rec]\n\t"
-        "v_mov_b32_e32 v41, 0\n\t"
-        "v_mov_b32_e32 v42, %[offset]\n\t"
-        "v_mov_b32_e32 v43, %[bb]\n\t"
-        "v_mov_b32_e32 v44, %[wr]\n\t"
-        "v_mov_b32_e32 v45, %[seq]\n\t"
-        "v_mov_b32_e32 v71, 0\n\t"
-        "s_mov_b32 %[reason], 0\n\t"
-        "s_mov_b64 s[44:45], -1\n\t"
-        GBWT_WALK2_ISSUE
-        ".Lgbwt_walk2_loop_%=:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_lshlrev_b32_e32 v92, 1, v52\n\t"                 /* DESC2_SLOW (bit 30 of F1.x) -> sign */
-        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */
-        "v_cmp_gt_i32_e32 vcc, 0, v92\n\t"
-        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */
-        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */
-        "s_cbranch_vccnz .Lgbwt_walk2_slow_%=\n\t"
-        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */
-        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */
-        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */
-        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */
-        "v_xor_b32_e32 v101, v81, v98\n\t"
-        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */
-        "v_bfi_b32 v101, v97, 0, v101\n\t"
-        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */
-        "v_bcnt_u32_b32 v102, v100, 0\n\t"
-        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */
-        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */
-        "v_cndmask_b32_e32 v103, v49, v51, vcc\n\t"         /* offset base of edge a */
-        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */
-        "v_cndmask_b32_e32 v104, v48, v50, vcc\n\t"         /* node of edge a */
-        "v_add_u32_e32 v103, v103, v99\n\t"                 /* j: offset in w_a */
-        "v_cndmask_b32_e32 v105, v52, v53, vcc\n\t"         /* w_a | flags */
-        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */
-        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */
-        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */
-        "v_and_b32_e32 v101, v101, v83\n\t"
-        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */
-        "v_bcnt_u32_b32 v106, v100, v106\n\t"
-        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */
-        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */
-        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */
-        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */
-        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */
-        "v_cndmask_b32_e64 v112, v56, v60, s[46:47]\n\t"    /* leaf (0, b) */
-        "v_cndmask_b32_e64 v113, v57, v61, s[46:47]\n\t"
-        "v_cndmask_b32_e64 v114, v58, v62, s[46:47]\n\t"
-        "v_cndmask_b32_e64 v115, v59, v63, s[46:47]\n\t"
-        "v_cndmask_b32_e64 v116, v64, v72, s[46:47]\n\t"    /* leaf (1, b) */
-        "v_cndmask_b32_e64 v117, v65, v73, s[46:47]\n\t"
-        "v_cndmask_b32_e64 v118, v66, v74, s[46:47]\n\t"
-        "v_cndmask_b32_e64 v119, v67, v75, s[46:47]\n\t"
-        "v_cndmask_b32_e32 v112, v112, v116, vcc\n\t"       /* leaf (a, b): node to emit */
-        "v_cndmask_b32_e32 v113, v113, v117, vcc\n\t"       /* offset base */
-        "v_cndmask_b32_e32 v114, v114, v118, vcc\n\t"       /* landing record | flags */
-        "v_cndmask_b32_e32 v43, v115, v119, vcc\n\t"        /* its block base */
-        "v_add_u32_e32 v42, v113, v107\n\t"                 /* the new offset */
-        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */
-        "v_mov_b32_e32 v120, v76\n\t"                       /* look-ahead target of the record just left ... */
-        "v_mov_b32_e32 v121, v77\n\t"
-        "v_mov_b32_e32 v122, v78\n\t"
-        "v_add_u32_e32 v45, 0x9e3779b1, v45\n\t"            /* ... posted with a new sequence number */
-        "v_and_b32_e32 v92, 0x7f, v44\n\t"                  /* ring slot of the next node */
-        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t"
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
-        "v_mov_b32_e32 v123, v45\n\t"
-        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */
-        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */
-        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */
-        "v_and_b32_e32 v92, 0x7f, v44\n\t"
-        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
-        "ds_write_b32 v92, v110\n\t"
-        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t"
-        "v_and_b32_e32 v92, 0x7f, v44\n\t"
-        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
-        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */
-        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
-        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */
-        "v_and_b32_e32 v92, 0x7f, v44\n\t"
-        "ds_write_b128 %[mail], v[120:123]\n\t"
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t"
-        "ds_write_b32 v92, v111\n\t"
-        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
-        GBWT_WALK2_ISSUE
-        "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */
-        "v_sub_u32_e32 v92, v44, %[flushed]\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[urgent], v92\n\t"
-        "s_cmp_eq_u64 s[44:45], 0\n\t"
-        "s_cbranch_scc1 .Lgbwt_walk2_out_%=\n\t"
-        "s_cbranch_vccz .Lgbwt_walk2_loop_%=\n\t"
-        "s_branch .Lgbwt_walk2_out_%=\n\t"
-        ".Lgbwt_walk2_slow_%=:\n\t"
-        "s_mov_b32 %[reason], 1\n\t"
-        ".Lgbwt_walk2_out_%=:\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        "v_mov_b32_e32 %[rec], v40\n\t"
-        "v_mov_b32_e32 %[offset], v42\n\t"
-        "v_mov_b32_e32 %[bb], v43\n\t"
-        "v_mov_b32_e32 %[wr], v44\n\t"
-        "v_mov_b32_e32 %[seq], v45\n\t"
-        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [seq] "+v"(seq), [reason] "=&s"(reason)
-        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [flushed] "v"(flushed), [urgent] "i"(RING2_URGENT),
-          "{s41}"(alphabet_offset)
-        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47",
-          "v40", "v41", "v42", "v43", "v44", "v45", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-          "v64", "v65", "v66", "v67", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v80", "v81", "v82", "v83", "v84", "v85", "v86",
-          "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
-          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
-#undef GBWT_WALK2_ISSUE
+#define GBWT_WALK2_ISSUE_NARROW                                                                           \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "v_lshlrev_b32_e32 v88, 7, v40\n\t"                   /* two-step descriptors are 128 bytes */        \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
+    "s_mov_b64 exec, s[44:45]\n\t"                        /* only lanes that were walking before this step */ \
+    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
+    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
+    "global_load_dwordx4 v[48:51], v88, %[desc2]\n\t"               /* F0 */                              \
+    "global_load_dwordx2 v[52:53], v88, %[desc2] offset:16\n\t"     /* F1 */                              \
+    "global_load_dwordx4 v[56:59], v88, %[desc2] offset:32\n\t"     /* leaf (0, 0) */                     \
+    "global_load_dwordx4 v[60:63], v88, %[desc2] offset:48\n\t"     /* leaf (0, 1) */                     \
+    "global_load_dwordx4 v[64:67], v88, %[desc2] offset:64\n\t"     /* leaf (1, 0) */                     \
+    "global_load_dwordx4 v[72:75], v88, %[desc2] offset:80\n\t"     /* leaf (1, 1) */                     \
+    "global_load_dwordx3 v[76:78], v88, %[desc2] offset:96\n\t"     /* look-ahead target */               \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_WALK2_LOOP(ISSUE)                                                                             \
+    asm volatile( \
+        "v_mov_b32_e32 v40, %[rec]\n\t" \
+        "v_mov_b32_e32 v41, 0\n\t" \
+        "v_mov_b32_e32 v42, %[offset]\n\t" \
+        "v_mov_b32_e32 v43, %[bb]\n\t" \
+        "v_mov_b32_e32 v44, %[wr]\n\t" \
+        "v_mov_b32_e32 v79, %[seq]\n\t" \
+        "v_mov_b32_e32 v71, 0\n\t" \
+        "s_mov_b32 %[reason], 0\n\t" \
+        "s_mov_b64 s[44:45], -1\n\t" \
+        ISSUE \
+        ".Lgbwt_walk2_loop_%=:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_lshlrev_b32_e32 v92, 1, v52\n\t"                 /* DESC2_SLOW (bit 30 of F1.x) -> sign */ \
+        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v92\n\t" \
+        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
+        "s_cbranch_vccnz .Lgbwt_walk2_slow_%=\n\t" \
+        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
+        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v101, v81, v98\n\t" \
+        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v101, v97, 0, v101\n\t" \
+        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
+        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v103, v49, v51, vcc\n\t"         /* offset base of edge a */ \
+        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
+        "v_cndmask_b32_e32 v104, v48, v50, vcc\n\t"         /* node of edge a */ \
+        "v_add_u32_e32 v103, v103, v99\n\t"                 /* j: offset in w_a */ \
+        "v_cndmask_b32_e32 v105, v52, v53, vcc\n\t"         /* w_a | flags */ \
+        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
+        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
+        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v101, v101, v83\n\t" \
+        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
+        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
+        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */ \
+        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
+        "v_cndmask_b32_e64 v112, v56, v60, s[46:47]\n\t"    /* leaf (0, b) */ \
+        "v_cndmask_b32_e64 v113, v57, v61, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v114, v58, v62, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v115, v59, v63, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v116, v64, v72, s[46:47]\n\t"    /* leaf (1, b) */ \
+        "v_cndmask_b32_e64 v117, v65, v73, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v118, v66, v74, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v119, v67, v75, s[46:47]\n\t" \
+        "v_cndmask_b32_e32 v112, v112, v116, vcc\n\t"       /* leaf (a, b): node to emit */ \
+        "v_cndmask_b32_e32 v113, v113, v117, vcc\n\t"       /* offset base */ \
+        "v_cndmask_b32_e32 v114, v114, v118, vcc\n\t"       /* landing record | flags */ \
+        "v_cndmask_b32_e32 v43, v115, v119, vcc\n\t"        /* its block base */ \
+        "v_add_u32_e32 v42, v113, v107\n\t"                 /* the new offset */ \
+        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
+        "v_add_u32_e32 v79, 0x9e3779b1, v79\n\t"            /* new sequence number for the look-ahead target of the record just left */ \
+        "v_and_b32_e32 v92, 0x7f, v44\n\t"                  /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
+        "v_and_b32_e32 v92, 0x7f, v44\n\t" \
+        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "ds_write_b32 v92, v110\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
+        "v_and_b32_e32 v92, 0x7f, v44\n\t" \
+        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
+        "v_and_b32_e32 v92, 0x7f, v44\n\t" \
+        "ds_write_b128 %[mail], v[76:79]\n\t" \
+        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "ds_write_b32 v92, v111\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        ISSUE \
+        "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */ \
+        "v_cmp_lt_u32_e32 vcc, %[limit], v44\n\t"             /* more than RING2_URGENT nodes waiting in a ring */ \
+        "s_cmp_eq_u64 s[44:45], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2_out_%=\n\t" \
+        "s_cbranch_vccz .Lgbwt_walk2_loop_%=\n\t" \
+        "s_branch .Lgbwt_walk2_out_%=\n\t" \
+        ".Lgbwt_walk2_slow_%=:\n\t" \
+        "s_mov_b32 %[reason], 1\n\t" \
+        ".Lgbwt_walk2_out_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "v_mov_b32_e32 %[rec], v40\n\t" \
+        "v_mov_b32_e32 %[offset], v42\n\t" \
+        "v_mov_b32_e32 %[bb], v43\n\t" \
+        "v_mov_b32_e32 %[wr], v44\n\t" \
+        "v_mov_b32_e32 %[seq], v79\n\t" \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [seq] "+v"(seq), [reason] "=&s"(reason) \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), \
+          "{s41}"(alphabet_offset) \
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
+          "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
+          "v64", "v65", "v66", "v67", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
+          "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+    const uint32_t limit = flushed + RING2_URGENT;
+    if (narrow) { GBWT_WALK2_LOOP(GBWT_WALK2_ISSUE_NARROW) } else { GBWT_WALK2_LOOP(GBWT_WALK2_ISSUE_WIDE) }
+#undef GBWT_WALK2_LOOP
+#undef GBWT_WALK2_ISSUE_NARROW
+#undef GBWT_WALK2_ISSUE_WIDE
     return reason;
 #endif
 }
@@ -1162,8 +1180,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     }
     const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
     uint32_t seq = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;
+    // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
+    const bool narrow = ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, rec, offset, bb, sink.wr, seq);
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, rec, offset, bb, sink.wr, seq);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) generic_step(ix, sink, rec, offset, bb);
