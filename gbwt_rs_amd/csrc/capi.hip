@@ -355,6 +355,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
             a.helper_lanes = 64;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+            a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);

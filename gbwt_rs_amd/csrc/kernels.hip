@@ -1181,7 +1181,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
     uint32_t seq = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;
     // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
-    const bool narrow = ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
+    const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
         const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, rec, offset, bb, sink.wr, seq);
         if (slow_exit) {

@@ -60,6 +60,7 @@ struct WalkArgs {
     uint32_t small_record;     // WALK_COOP: records of at most this many bytes are decoded lane-serially
     uint32_t pack16;           // WALK_COOP: every record is shorter than 2^16 (stats.max_record_len): one packed scan
     uint32_t helper_lanes;     // lanes of the look-ahead helper wave that touch (64; 0 = no look-ahead; experiments)
+    uint32_t wide_addresses;   // force the 64-bit-address variant of the two-step loop (used above 4 GiB; tests)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);

@@ -528,6 +528,21 @@ def test_config_c3_search_bit_exact(model, haplotypes):
         assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
 
 
+def test_two_step_walk_with_64_bit_addresses(monkeypatch):
+    """The two-step loop has two addressing variants (SGPR base + 32-bit offsets below 4 GiB, 64-bit addresses above);
+    GBWT_HIP_WIDE_ADDRESSES forces the second one, which no test index is large enough to need."""
+    s = S.Synth.chain(sites=700, haplotypes=300, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.02, seed=21)
+    dev, oracle = open_synth(s), oracle_of(s)
+    ids = np.arange(0, s.sequences, dtype=np.uint64)
+    o_off, o_nodes = oracle.extract(ids, threads=4)
+    monkeypatch.setenv("GBWT_HIP_WIDE_ADDRESSES", "1")
+    offsets, nodes = dev.sequences_csr(ids)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    monkeypatch.delenv("GBWT_HIP_WIDE_ADDRESSES")
+    offsets, nodes = dev.sequences_csr(ids)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+
+
 def test_generic_records_without_lf_tables(monkeypatch):
     """Outdegree > 2 with the LF tables switched off (GBWT_HIP_TABLE_BYTES=0, read at open): the serial Record::lf decode
     behind the same walk frames, in every walk mode, and forward() through the generic scan."""
