@@ -1272,19 +1272,26 @@ __global__ void __launch_bounds__(256) k_compact(WalkArgs a, const uint64_t *off
     if (path >= a.n) return;
     uint64_t remaining = offsets[path + 1] - offsets[path];
     uint32_t *dst = nodes + offsets[path];
+    // The chain is a pointer chase; the link of the NEXT block is fetched while the current block is copied, and a
+    // full block moves as one 16-byte load + store per lane (rows start at arbitrary offsets, so the stores are only
+    // 4-byte aligned: they are split when the row start is not 16-byte aligned).
     uint32_t b = a.head[path];
+    uint32_t nb = (remaining > 0 && b != POOL_NONE) ? a.next[b] : POOL_NONE;
+    const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
     while (remaining > 0 && b != POOL_NONE) {
         const uint32_t cnt = remaining < POOL_BLOCK_NODES ? static_cast<uint32_t>(remaining) : POOL_BLOCK_NODES;
         const uint32_t *src = a.pool + static_cast<uint64_t>(b) * POOL_BLOCK_NODES;
-        const uint32_t nb = a.next[b];
-#pragma unroll
-        for (uint32_t j = 0; j < POOL_BLOCK_NODES / WAVE; j++) {
-            uint32_t idx = j * WAVE + lane;
-            if (idx < cnt) dst[idx] = src[idx];
+        const uint32_t nnb = (remaining > cnt && nb != POOL_NONE) ? a.next[nb] : POOL_NONE;
+        if (cnt == POOL_BLOCK_NODES) {
+            const uint4 v = reinterpret_cast<const uint4 *>(src)[lane];
+            if (aligned) reinterpret_cast<uint4 *>(dst)[lane] = v;
+            else { dst[4 * lane] = v.x; dst[4 * lane + 1] = v.y; dst[4 * lane + 2] = v.z; dst[4 * lane + 3] = v.w; }
+        } else {
+            for (uint32_t idx = lane; idx < cnt; idx += WAVE) dst[idx] = src[idx];
         }
         dst += cnt;
         remaining -= cnt;
-        b = nb;
+        b = nb; nb = nnb;
     }
 }
 
