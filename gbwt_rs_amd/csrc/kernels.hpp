@@ -1,4 +1,4 @@
-// kernels.hpp -- launch wrappers of the gfx950 kernels (implemented in kernels.hip).
+// kernels.hpp -- launch wrappers of the gfx950 kernels (load_kernels.hip, walk_kernels.hip, query_kernels.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

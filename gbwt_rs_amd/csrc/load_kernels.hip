@@ -1,0 +1,567 @@
+// load_kernels.hip -- load-time passes: descriptors, rank blocks, two-step descriptors and blocks, LF tables, endmarker
+// (hand-written HIP for gfx950, no MFMA: integer pointer-chasing over a byte stream).  Launch wrappers are declared in kernels.hpp.
+#include "kernels.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include "device_common.hpp"
+#include "lf_device.hpp"
+
+namespace gbwt_hip {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Load-time passes
+
+// One lane per record: Record::len and outdegree maxima (sizes u32 offsets on device, feeds stats).
+__global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *stats) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    uint64_t start, limit;
+    record_bounds(ix, rec, start, limit);
+    if (start >= limit) return;
+    ByteCursor c(ix.data, start, limit);
+    uint64_t sigma;
+    if (!c.varint(sigma)) { atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), 1ull); return; }
+    if (sigma == 0) return;
+    uint64_t len = record_len(c, sigma);
+    atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(len));
+    atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
+}
+
+// 16 bytes of the stream at data[pos..], zero-filled past `limit`.
+__device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t pos, uint64_t limit) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16 && pos + k < limit; k++) w[k >> 2] |= static_cast<uint32_t>(data[pos + k]) << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One lane per record: the RAW descriptor (device_index.hpp) and the number of rank blocks the record gets.
+__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *block_counts) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    uint64_t start, limit;
+    record_bounds(ix, rec, start, limit);
+    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), C = make_uint4(0, 0, 0, 0), D = make_uint4(0, 0, 0, 0);
+    uint32_t n_blocks = 0;
+    if (limit > start) {
+        ByteCursor c(ix.data, start, limit);
+        uint64_t sigma = 0;
+        if (c.varint(sigma) && sigma != 0) {
+            B.x = static_cast<uint32_t>(start); B.y = static_cast<uint32_t>(limit - start);
+            B.z = static_cast<uint32_t>((start >> 32) & 0xFF) << 24;
+            bool classed = false;
+            if (sigma <= 2 && (start >> 40) == 0) {
+                uint64_t n0 = 0, o0 = 0, d1 = 0, o1 = 0;
+                bool good = c.varint(n0) && c.varint(o0);
+                if (good && sigma == 2) good = c.varint(d1) && c.varint(o1);
+                const uint64_t body = c.pos - start;
+                if (good && body <= 0xFFFF && n0 + d1 <= 0xFFFFFFFFull && o0 <= 0xFFFFFFFFull && o1 <= 0xFFFFFFFFull) {
+                    // Record::len and the shape of the run stream.  The walk's scanner trusts class 1 / 2 streams: they
+                    // must parse to the last byte and every run must fit in 1 + 4 bytes (length < 2^28 + threshold).
+                    RunDecoder rd(sigma);
+                    uint64_t total = 0, total0 = 0, runs = 0, value, len;
+                    bool lean = true;
+                    for (;;) {
+                        const uint64_t before = c.pos;
+                        if (!rd.next(c, value, len)) break;
+                        if (c.pos - before > 5) lean = false;
+                        total += len; runs++;
+                        if (value == 0) total0 += len;
+                    }
+                    if (!c.at_end() || runs == 0) lean = false;
+                    if (lean && total < 0xFFFFFFFFull) {
+                        classed = true;
+                        A.x = static_cast<uint32_t>(n0); A.y = static_cast<uint32_t>(o0);
+                        A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
+                        B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
+                        B.w = static_cast<uint32_t>(total);
+                        C.x = static_cast<uint32_t>(total0); C.y = static_cast<uint32_t>(total);
+                        D = stream_bytes16(ix.data, start + body, limit);
+                        // outdegree 1: Record::lf(i) = (n0, o0 + i) however the body splits its runs
+                        if (sigma == 1) B.y = DESC_UNARY;
+                        else n_blocks = static_cast<uint32_t>((total >> RANK_BLOCK_SHIFT) + 1);  // position `total` is addressable too
+                    }
+                }
+            }
+            if (!classed) {  // class 0: B.w = 0 keeps the walk's fast path out; Record::len goes to C.y for find()
+                A = make_uint4(0, 0, 0, 0); C = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0;
+                ByteCursor c2(ix.data, start, limit);
+                uint64_t s2 = 0;
+                c2.varint(s2);
+                const uint64_t total = record_len(c2, s2);
+                C.y = total < 0xFFFFFFFFull ? static_cast<uint32_t>(total) : 0xFFFFFFFFu;
+            }
+        }
+    }
+    desc[4 * rec] = A;
+    desc[4 * rec + 1] = B;
+    desc[4 * rec + 2] = C;
+    desc[4 * rec + 3] = D;
+    block_counts[rec] = n_blocks;
+}
+
+// One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Everything the walk would otherwise
+// test per step is decided here, once:
+//  * an edge whose successor is a unary record is FUSED with it: the walk emits that successor and lands directly on
+//    the successor's successor, one iteration (one round trip to memory) for two nodes;
+//  * every edge knows whether the walk continues behind it (EDGE_CONT: the landing record exists and is not empty --
+//    GBWT::forward's guards and BWT::record, src/gbwt.rs:222-229, src/bwt.rs:124-130), the record index of the
+//    landing record and its block base;
+//  * every offset an edge can produce is checked against the length of the landing record (offset base + number of
+//    positions of this record that take the edge <= Record::len of the landing record; always true in a valid GBWT),
+//    so the walk needs no "i >= Record::len -> None" test (src/bwt.rs:481).  A record with an edge that fails the
+//    check is marked DESC_SLOW and goes through the generic decoder, which tests everything the reference tests.
+
+__global__ void __launch_bounds__(256) k_link_desc(DeviceIndex ix, uint4 *out) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint4 *raw = ix.desc_raw;
+    const uint4 A = raw[4 * rec], B = raw[4 * rec + 1], C = raw[4 * rec + 2];
+    uint4 E[2] = {make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE)};
+    uint32_t flags[2] = {0, 0};
+    const uint32_t cls = B.y != 0 ? desc_class(B.z) : 0u;
+    bool slow = cls == 0;   // class 0 and empty records (the latter are never landed on)
+    if (cls != 0) {
+        const uint64_t count[2] = {cls == 2 ? C.x : B.w, cls == 2 ? B.w - C.x : 0u};
+        const uint32_t succ[2] = {A.x, A.z}, off[2] = {A.y, A.w};
+        for (uint32_t e = 0; e < cls; e++) {
+            const uint32_t node = succ[e];
+            uint64_t base = off[e], r = 0, land = 0;
+            uint32_t z = 0, bb = BLOCK_NONE;
+            bool cont = false, emit2 = false;
+            if (node != 0 && landing_record(ix, node, r)) {
+                const uint4 SA = raw[4 * r], SB = raw[4 * r + 1];
+                if (SB.y == DESC_UNARY && base + count[e] <= SB.w) {
+                    // plain edge to the unary record is safe; fuse when what lies behind it is safe too
+                    cont = true; z = static_cast<uint32_t>(r);
+                    const uint64_t base2 = base + SA.y;
+                    if (SA.x == 0) { cont = false; z = 0; }            // the unary node is the last one of these sequences
+                    else if (landing_record(ix, SA.x, land) && base2 + count[e] <= 0xFFFFFFFFull) {
+                        const uint4 LB = raw[4 * land + 1];
+                        if (LB.y != 0 && (desc_class(LB.z) == 0 || base2 + count[e] <= LB.w)) {
+                            emit2 = true; z = static_cast<uint32_t>(land); base = base2; bb = ix.block_base[land];
+                        }
+                    }
+                } else if (SB.y != 0) {
+                    if (desc_class(SB.z) == 0 || base + count[e] <= SB.w) { cont = true; z = static_cast<uint32_t>(r); bb = ix.block_base[r]; }
+                    else slow = true;
+                }
+            }
+            E[e] = make_uint4(node, static_cast<uint32_t>(base), z, cont ? bb : BLOCK_NONE);
+            flags[e] = (cont ? EDGE_CONT : 0u) | (emit2 ? EDGE_EMIT2 : 0u);
+        }
+    }
+    if (rec == 0) {
+        // record 0 (the endmarker) is never landed on (GBWT::forward, src/gbwt.rs:224): its walk descriptor is where
+        // lanes without a walk are parked -- nothing to emit, does not continue, lands on record 0, not DESC_SLOW
+        E[0] = E[1] = make_uint4(0, 0, 0, BLOCK_NONE); flags[0] = flags[1] = 0; slow = false;
+    }
+    out[4 * rec] = E[0];
+    out[4 * rec + 1] = E[1];
+    out[4 * rec + 2] = make_uint4(slow ? DESC_SLOW : 0u, flags[0], 0u, flags[1]);
+    out[4 * rec + 3] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// One lane per record, after k_link_desc: the look-ahead targets.  For edge e: the record a walk that takes e
+// reaches `hops` iterations later if it keeps taking edge 0 afterwards (a guess in general graphs; exact where the
+// alleles of a site rejoin), as {first rank block, number of rank blocks} and, in slot 3 of the descriptor, its record
+// index.  The helper wave of the walk touches that record's descriptor and one line of its block array per iteration,
+// so both are already in the L2 of the XCD when the walk gets there.
+__global__ void __launch_bounds__(256) k_link_lookahead(DeviceIndex ix, uint4 *desc, const uint32_t *block_counts, uint32_t hops) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    uint4 D = desc[4 * rec + 2];
+    if (D.x & DESC_SLOW) return;
+    uint32_t base[2] = {0, 0}, count[2] = {0, 0}, target[2] = {0, 0};
+    for (uint32_t e = 0; e < 2; e++) {
+        uint64_t r = rec;
+        uint32_t edge = e;
+        bool good = true;
+        for (uint32_t h = 0; h <= hops; h++) {
+            const uint4 RD = desc[4 * r + 2];
+            const uint32_t f = edge ? RD.w : RD.y;
+            if ((RD.x & DESC_SLOW) || !(f & EDGE_CONT)) { good = false; break; }
+            r = desc[4 * r + edge].z;
+            edge = 0;
+        }
+        if (good) target[e] = static_cast<uint32_t>(r);
+        if (good && ix.block_base[r] != BLOCK_NONE && ix.block_base[r] < DESC_SLOW) { base[e] = ix.block_base[r]; count[e] = block_counts[r] & LOOKAHEAD_COUNT_MASK; }
+    }
+    D.x |= base[0]; D.y |= count[0]; D.z = base[1]; D.w |= count[1];
+    desc[4 * rec + 2] = D;
+    desc[4 * rec + 3] = make_uint4(target[0], target[1], 0u, 0u);
+}
+
+// ---- LF tables for class 0 records -------------------------------------------------------------------------
+// One lane per record: number of positions and outdegree of the records that get a table (0 for all others).
+__global__ void __launch_bounds__(256) k_table_counts(DeviceIndex ix, uint64_t *positions, uint64_t *sigmas) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint4 B = ix.desc_raw[4 * rec + 1], C = ix.desc_raw[4 * rec + 2];
+    uint64_t pos = 0, sigma = 0;
+    if (rec != 0 && B.y != 0 && B.y != DESC_UNARY && desc_class(B.z) == 0 && C.y != 0xFFFFFFFFu && C.y != 0) {
+        const uint64_t start = desc_start(B.x, B.z);
+        ByteCursor c(ix.data, start, start + B.y);
+        if (c.varint(sigma) && sigma != 0) pos = C.y; else sigma = 0;
+    }
+    positions[rec] = pos; sigmas[rec] = sigma;
+}
+
+// One lane per class 0 record: Record::decompress (src/bwt.rs:466-478) with the arrival tests of GBWT::forward folded in.
+// `edges` is scratch: {successor, running offset} per edge of the record.
+__global__ void __launch_bounds__(64) k_fill_tables(DeviceIndex ix, uint4 *desc_raw, const uint64_t *table_base, const uint64_t *edge_base, uint4 *tables,
+                                                    uint2 *edges) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint64_t count = table_base[rec + 1] - table_base[rec];
+    if (count == 0) return;
+    const uint4 B = desc_raw[4 * rec + 1];
+    const uint64_t start = desc_start(B.x, B.z);
+    ByteCursor c(ix.data, start, start + B.y);
+    uint64_t sigma = 0;
+    c.varint(sigma);
+    uint2 *e = edges + edge_base[rec];
+    uint64_t node = 0;
+    for (uint64_t k = 0; k < sigma; k++) {
+        uint64_t delta = 0, off = 0;
+        c.varint(delta); c.varint(off);
+        node += delta;
+        e[k] = make_uint2(static_cast<uint32_t>(node), static_cast<uint32_t>(off));
+    }
+    uint4 *out = tables + table_base[rec];
+    RunDecoder rd(sigma);
+    uint64_t pos = 0, value, len;
+    while (pos < count && rd.next(c, value, len)) {
+        if (value >= sigma) break;
+        const uint32_t succ = e[value].x;
+        uint32_t off = e[value].y;
+        uint64_t land = 0;
+        uint32_t lrec = 0, bb = BLOCK_NONE, llen = 0;
+        bool exists = false, checked = false;
+        if (succ != 0 && landing_record(ix, succ, land)) {
+            const uint4 LB = desc_raw[4 * land + 1];
+            exists = LB.y != 0;
+            checked = desc_class(LB.z) != 0;   // records with descriptors: the offset must be inside (src/bwt.rs:481)
+            llen = LB.w;
+            if (exists) { lrec = static_cast<uint32_t>(land); bb = ix.block_base[land]; }
+        }
+        for (uint64_t k = 0; k < len && pos < count; k++, pos++, off++) {
+            const bool cont = exists && (!checked || off < llen);
+            out[pos] = make_uint4(succ, off, cont ? lrec : 0u, cont ? bb : BLOCK_NONE);
+        }
+        e[value].y = off;
+    }
+    uint4 C = desc_raw[4 * rec + 2];
+    C.z = static_cast<uint32_t>(table_base[rec]); C.w = 1u;
+    desc_raw[4 * rec + 2] = C;
+}
+
+// ---- two-step walk: descriptors and blocks -----------------------------------------------------------------
+// The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
+// The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
+// memory -- takes TWO LF steps (up to four nodes with fused unary successors):
+//   desc2[8 * v + 0] = F0 = {node to emit for edge 0, offset base in w_0, node to emit for edge 1, offset base in w_1}
+//   desc2[8 * v + 1] = F1 = {w_0 | LEAF_EMIT2 | DESC2_SLOW, w_1 | LEAF_EMIT2, 0, 0}      (first step; DESC2_SLOW: whole record)
+//   desc2[8 * v + 2 + 2 * a + b] = leaf (a, b) = {node to emit, offset base, landing record | LEAF_EMIT2, block base}
+//   desc2[8 * v + 6] = look-ahead {record, first block, number of blocks, 0};  [7] unused
+// The second step exists (is "real") when w_a is unary (descriptor only: its value is always 0) or when both v and w_a
+// have rank blocks: v's two-step block then carries, for each of its 64 offsets, the value the sequence has in w_a
+// (bits2) and the number of value-1 positions of w_a before the landing offset of the block's first a-path (R_a), so
+// the rank inside w_a is again one popcount.  Where the second step is not real (w_a generic, sequence ending, v
+// unary and w_a branching) the leaf (a, 0) is the identity: "emit nothing, stay in w_a at the offset reached".
+__global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    const uint4 *d1 = ix.desc;
+    const uint4 D = d1[4 * v + 2];
+    const uint4 VB = ix.desc_raw[4 * v + 1];
+    const uint32_t cls_v = VB.y != 0 ? desc_class(VB.z) : 0u;
+    uint32_t n1[2] = {0, 0}, base[2] = {0, 0}, wword[2] = {0, 0};
+    uint4 leaf[4] = {make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE)};
+    const bool slow = (D.x & DESC_SLOW) != 0;
+    if (!slow) {
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint4 E = d1[4 * v + a];
+            const uint32_t f = a ? D.w : D.y;
+            n1[a] = E.x; base[a] = E.y;
+            if (!(f & EDGE_CONT)) continue;                       // the walk ends behind this edge: both leaves park it
+            const uint32_t w = E.z;
+            wword[a] = w | ((f & EDGE_EMIT2) ? LEAF_EMIT2 : 0u);
+            const uint4 WD = d1[4 * static_cast<uint64_t>(w) + 2];
+            const uint4 WB = ix.desc_raw[4 * static_cast<uint64_t>(w) + 1];
+            const uint32_t cls_w = WB.y != 0 ? desc_class(WB.z) : 0u;
+            const bool real = !(WD.x & DESC_SLOW) && (cls_w == 1 || (cls_w == 2 && cls_v == 2));
+            if (!real) { leaf[2 * a] = make_uint4(0u, 0u, w, E.w); continue; }   // identity
+            for (uint32_t b = 0; b < cls_w; b++) {
+                const uint4 WE = d1[4 * static_cast<uint64_t>(w) + b];
+                const uint32_t wf = b ? WD.w : WD.y;
+                const bool cont = (wf & EDGE_CONT) != 0;
+                leaf[2 * a + b] = make_uint4(WE.x, WE.y, cont ? (WE.z | ((wf & EDGE_EMIT2) ? LEAF_EMIT2 : 0u)) : 0u, cont ? WE.w : BLOCK_NONE);
+            }
+        }
+    }
+    uint4 *o = out + 8 * v;
+    o[0] = make_uint4(n1[0], base[0], n1[1], base[1]);
+    o[1] = make_uint4(wword[0] | (slow ? DESC2_SLOW : 0u), wword[1], 0u, 0u);
+    o[2] = leaf[0]; o[3] = leaf[1]; o[4] = leaf[2]; o[5] = leaf[3];
+    o[6] = make_uint4(0u, 0u, 0u, 0u);
+    o[7] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// One lane per record with rank blocks: the two-step blocks (32 bytes per 64 offsets):
+//   cblocks[2 * k]     = {bits1 (values of v), bits2 (value in w_a of the sequence at each offset; 0 where the second
+//                         step is not a real step through a record with blocks)}
+//   cblocks[2 * k + 1] = {value-1 positions of v before the block, R_0, R_1, 0}
+// The a-paths of a block land on consecutive offsets of w_a (LF keeps their order), so their values there are a
+// contiguous bit range of w_a's blocks, spread back onto the positions of the a-paths.
+__global__ void __launch_bounds__(256) k_fill_cblocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *cblocks) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    const uint32_t count = block_counts[v];
+    if (count == 0) return;
+    const uint4 *d1 = ix.desc;
+    const uint4 D = d1[4 * v + 2];
+    const uint32_t len = ix.desc_raw[4 * v + 1].w;
+    const uint32_t bb = ix.block_base[v];
+    // per edge: landing record with blocks of its own, or none
+    const uint4 *wblocks[2] = {nullptr, nullptr};
+    uint32_t wbase[2] = {0, 0};
+    if (!(D.x & DESC_SLOW)) {
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint32_t f = a ? D.w : D.y;
+            if (!(f & EDGE_CONT)) continue;
+            const uint4 E = d1[4 * v + a];
+            const uint64_t w = E.z;
+            const uint4 WB = ix.desc_raw[4 * w + 1];
+            if ((d1[4 * w + 2].x & DESC_SLOW) || WB.y == 0 || desc_class(WB.z) != 2) continue;
+            wblocks[a] = ix.blocks + ix.block_base[w];
+            wbase[a] = E.y;
+        }
+    }
+    for (uint32_t k = 0; k < count; k++) {
+        const uint4 P = ix.blocks[bb + k];
+        const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
+        const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
+        const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
+        uint64_t bits2 = 0;
+        uint32_t R[2] = {0, 0};
+        for (uint32_t a = 0; a < 2; a++) {
+            if (!wblocks[a]) continue;
+            uint64_t m = (a ? bits1 : ~bits1) & valid;
+            const uint32_t cnt = __popcll(m);
+            if (cnt == 0) continue;
+            const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
+            const uint32_t j = wbase[a] + before;                                      // where the first a-path lands in w_a
+            const uint32_t q = j >> RANK_BLOCK_SHIFT, sh = j & 63u;
+            const uint4 W0 = wblocks[a][q];
+            const uint64_t w0 = (static_cast<uint64_t>(W0.y) << 32) | W0.x;
+            R[a] = W0.z + __popcll(w0 & ((uint64_t(1) << sh) - 1));
+            uint64_t val = w0 >> sh;
+            if (sh != 0 && cnt > 64 - sh) {
+                const uint4 W1 = wblocks[a][q + 1];
+                val |= ((static_cast<uint64_t>(W1.y) << 32) | W1.x) << (64 - sh);
+            }
+            while (m) {                                                                 // spread the low cnt bits of val over the set bits of m
+                const uint64_t low = m & (~m + 1);
+                if (val & 1) bits2 |= low;
+                val >>= 1;
+                m ^= low;
+            }
+        }
+        cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
+        cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
+    }
+}
+
+// One lane per record: where a walk that is at this record will be `hops` iterations later if it keeps taking leaf
+// (0, 0) (a guess in general graphs; exact where the alleles of a site rejoin): {record, first block, number of blocks}.
+__global__ void __launch_bounds__(256) k_link_lookahead2(DeviceIndex ix, uint4 *desc2, const uint32_t *block_counts, uint32_t hops) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    uint64_t r = v;
+    bool good = true;
+    for (uint32_t h = 0; h < hops && good; h++) {
+        if (desc2[8 * r + 1].x & DESC2_SLOW) { good = false; break; }
+        const uint32_t x = desc2[8 * r + 2].z & REC_MASK;
+        if (x == 0) good = false; else r = x;
+    }
+    uint4 look = make_uint4(0u, 0u, 0u, 0u);
+    if (good && r != v) {
+        look.x = static_cast<uint32_t>(r);
+        if (ix.block_base[r] != BLOCK_NONE) { look.y = ix.block_base[r]; look.z = block_counts[r]; }
+    }
+    desc2[8 * v + 6] = look;
+}
+
+// One lane per outdegree-2 record: decode the runs ONCE and lay the record out as rank blocks (device_index.hpp):
+// block k = {64 values (one bit each), value-1 positions before the block}.  Record::lf (src/bwt.rs:480-496) at
+// offset i is then value = bit i, rank = ones-before or i - ones-before, without scanning any run.
+__global__ void __launch_bounds__(256) k_fill_blocks(DeviceIndex ix, const uint32_t *block_counts, const uint32_t *block_base, uint4 *blocks) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec >= ix.n_records) return;
+    const uint32_t count = block_counts[rec];
+    if (count == 0) return;
+    const uint4 B = ix.desc_raw[4 * rec + 1];
+    const uint64_t start = desc_start(B.x, B.z), limit = start + B.y;
+    ByteCursor c(ix.data, start + desc_body_offset(B.z), limit);
+    RunDecoder rd(desc_class(B.z));
+    uint4 *out = blocks + block_base[rec];
+    uint64_t bits = 0, value, len;
+    uint32_t k = 0, fill = 0, ones = 0;
+    while (k < count && rd.next(c, value, len)) {
+        while (len > 0 && k < count) {
+            const uint32_t take = static_cast<uint32_t>(len < 64 - fill ? len : 64 - fill);
+            if (value) bits |= (take == 64 ? ~uint64_t(0) : ((uint64_t(1) << take) - 1)) << fill;
+            fill += take; len -= take;
+            if (fill == 64) {
+                out[k++] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
+                ones += __popcll(bits);
+                bits = 0; fill = 0;
+            }
+        }
+    }
+    if (k < count) out[k] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
+}
+
+// Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
+__global__ void k_endmarker_sigma(DeviceIndex ix, uint64_t *result) {
+    result[0] = 0; result[1] = 0;
+    if (ix.n_records == 0) return;
+    uint64_t start, limit;
+    record_bounds(ix, 0, start, limit);
+    if (start >= limit) return;
+    ByteCursor c(ix.data, start, limit);
+    uint64_t sigma;
+    if (!c.varint(sigma) || sigma == 0) return;
+    result[1] = sigma;
+    result[0] = record_len(c, sigma);
+}
+
+// Record::decompress (src/bwt.rs:465-475) of the endmarker record, done once at open.  Single
+// lane: the record has one run per sequence in the worst case and this is load-time work.
+__global__ void k_endmarker_decompress(DeviceIndex ix, uint2 *out, uint64_t n_out, uint64_t *scratch, uint64_t *result) {
+    uint64_t start, limit;
+    record_bounds(ix, 0, start, limit);
+    ByteCursor c(ix.data, start, limit);
+    uint64_t sigma = 0;
+    c.varint(sigma);
+    uint64_t *nodes = scratch, *offsets = scratch + sigma;
+    uint64_t node = 0;
+    for (uint64_t e = 0; e < sigma; e++) {
+        uint64_t delta = 0, off = 0;
+        c.varint(delta); c.varint(off);
+        node += delta;
+        nodes[e] = node; offsets[e] = off;
+    }
+    RunDecoder rd(sigma);
+    uint64_t produced = 0, value, len;
+    while (rd.next(c, value, len)) {
+        if (value >= sigma) break;  // malformed
+        for (uint64_t k = 0; k < len && produced < n_out; k++) {
+            out[produced++] = make_uint2(static_cast<uint32_t>(nodes[value]), static_cast<uint32_t>(offsets[value]));
+            offsets[value]++;
+        }
+    }
+    result[0] = produced;
+}
+
+}  // namespace
+
+void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_record_stats, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_stats);
+}
+
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts);
+}
+
+void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc);
+}
+
+void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_lookahead, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts, hops);
+}
+
+void launch_table_counts(const DeviceIndex &ix, uint64_t *d_positions, uint64_t *d_sigmas, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_table_counts, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_positions, d_sigmas);
+}
+
+void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t *d_table_base, const uint64_t *d_edge_base, uint4 *d_tables,
+                        uint2 *d_edges, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_tables, dim3(grid_for(ix.n_records, 64)), dim3(64), 0, stream, ix, d_desc_raw, d_table_base, d_edge_base, d_tables, d_edges);
+}
+
+void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2);
+}
+
+void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_cblocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_cblocks);
+}
+
+void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_link_lookahead2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, d_block_counts, hops);
+}
+
+void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_block_base, d_blocks);
+}
+
+// exclusive scan of the per-record block counts, then block_base = 1 + scan (block 0 is the shared all-zero block)
+// or BLOCK_NONE where the count is 0
+__global__ void __launch_bounds__(256) k_finish_block_base(const uint32_t *counts, uint32_t *block_base, uint64_t n) {
+    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec < n) block_base[rec] = counts[rec] == 0 ? BLOCK_NONE : block_base[rec] + 1;
+}
+
+size_t block_scan_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), static_cast<int>(n));
+    return bytes;
+}
+
+void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream) {
+    if (n == 0) return;
+    (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_block_base, static_cast<int>(n), stream);
+}
+
+void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_finish_block_base, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_block_base, n);
+}
+
+void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream) {
+    hipLaunchKernelGGL(k_endmarker_sigma, dim3(1), dim3(1), 0, stream, ix, d_result);
+}
+
+void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
+                                 uint64_t *d_result, hipStream_t stream) {
+    hipLaunchKernelGGL(k_endmarker_decompress, dim3(1), dim3(1), 0, stream, ix, d_out, n_out, d_scratch, d_result);
+}
+
+size_t scan_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, static_cast<const uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr),
+                                     static_cast<int>(n));
+    return bytes;
+}
+
+void launch_scan(const uint64_t *d_lengths, uint64_t *d_offsets, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t s) {
+    (void)hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), s);
+    if (n == 0) return;
+    (void)hipcub::DeviceScan::InclusiveSum(d_temp, temp_bytes, d_lengths, d_offsets + 1, static_cast<int>(n), s);
+}
+
+}  // namespace gbwt_hip
