@@ -100,3 +100,20 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "liboracle" not in src and "oracle_lib" not in src and "gbwt_oracle" not in src, f
+
+
+def test_cpp_mirror_compiles_and_reports_no_device(tmp_path):
+    """include/gbwt_hip.hpp (the C++ mirror of the reference's GBWT / GBZ interface) compiles with a plain host compiler
+    against the C ABI; without a GPU the test program must see GBWT_HIP_NO_DEVICE (no CPU fallback)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "test_reference_api"
+    csrc = os.path.join(root, "gbwt_rs_amd", "csrc")
+    subprocess.run([shutil.which("g++") or "g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-o", str(exe),
+                    os.path.join(root, "tests", "cpp", "test_reference_api.cpp"), "-L", csrc, "-lgbwt_hip", "-Wl,-rpath," + csrc], check=True)
+    out = subprocess.run([str(exe), os.path.join(root, "tests", "golden")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    import gbwt_rs_amd as G
+    if G.device_count() == 0:
+        assert "GBWT_HIP_NO_DEVICE" in out.stdout

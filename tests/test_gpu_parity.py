@@ -577,3 +577,17 @@ def test_high_degree_search_and_extract():
     bd, bok = dev.bd_search(queries, 2)
     o_bd, o_bok = oracle.bd_search_batch(queries, 2, threads=8)
     assert np.array_equal(bok, o_bok)
+
+
+def test_cpp_mirror_of_the_reference_tests(tmp_path):
+    """tests/cpp/test_reference_api.cpp: the reference's own tests restated against include/gbwt_hip.hpp."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "test_reference_api"
+    csrc = os.path.join(root, "gbwt_rs_amd", "csrc")
+    subprocess.run([shutil.which("g++") or "g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "include"), "-o", str(exe),
+                    os.path.join(root, "tests", "cpp", "test_reference_api.cpp"), "-L", csrc, "-lgbwt_hip", "-Wl,-rpath," + csrc], check=True)
+    out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
