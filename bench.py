@@ -220,7 +220,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_walk_two",
+                "kernel": "k_walk_direct",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -162,6 +162,27 @@ void upload(gbwt_hip_index &ix) {
     }
     d.endmarker = ix.endmarker.as<uint2>();
     d.n_endmarker = end_len;
+    // Lengths of all sequences: one counting walk at open (GBWT_HIP_SEQ_LEN=0 skips it; extractions then go through the
+    // pool of chained blocks and walk every sequence from one end).
+    d.seq_len = nullptr;
+    const char *want_len = std::getenv("GBWT_HIP_SEQ_LEN");
+    if (h.sequences > 0 && !(want_len && std::atoi(want_len) == 0)) {
+        ix.seq_len.reserve(h.sequences * sizeof(uint32_t));
+        DeviceBuffer prints;
+        prints.reserve(h.sequences * 2 * sizeof(uint64_t));
+        HIP_CHECK(hipMemset(d_stats, 0, 2 * sizeof(uint64_t)));
+        uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_stats);   // [0] = a length overflowed, [2] = a pair does not match
+        launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), d_flags, nullptr);
+        if (h.bidirectional && h.sequences % 2 == 0)
+            launch_check_orientation_pairs(ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), h.sequences / 2, d_flags + 2, nullptr);
+        uint32_t flags[4] = {0, 0, 0, 0};
+        HIP_CHECK(hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipGetLastError());
+        if (!flags[0]) {
+            d.seq_len = ix.seq_len.as<uint32_t>();
+            ix.orientation_pairs = h.bidirectional && h.sequences % 2 == 0 && !flags[2];
+        }
+    }
 }
 
 gbwt_hip_status open_common(gbwt_hip_index *ix, gbwt_hip_index **out) {
@@ -336,6 +357,38 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         const uint64_t all_nodes = ix->host.size >= ix->host.sequences ? ix->host.size - ix->host.sequences : 0;
         uint64_t pool_blocks = all_nodes / POOL_BLOCK_NODES + n + 1;
         if (n) HIP_CHECK(hipMemcpyAsync(ws->seq_ids.ptr, seq_ids, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        const char *no_direct = std::getenv("GBWT_HIP_DIRECT");
+        if (n && ix->dev.seq_len && ws->walk_mode == WALK_TWO_STEP && !(no_direct && std::atoi(no_direct) == 0)) {
+            // Lengths known: offsets first, then every lane writes into its row; in a bidirectional index two walkers per
+            // sequence, one from each end.
+            launch_gather_lengths(ix->dev.seq_len, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), s);
+            launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+            uint64_t total = 0;
+            HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            ws->nodes.reserve(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
+            WalkArgs a{};
+            a.seq_ids = ws->seq_ids.as<uint64_t>(); a.n = n;
+            a.mode = ws->walk_mode;
+            const uint64_t walkers = ix->orientation_pairs ? 2 * n : n;   // upper bound (GBWT_HIP_BOTH_ENDS=0 halves it)
+            a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
+                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(32, (walkers + 1023) / 1024)));
+            a.helper_lanes = 64;
+            if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+            a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
+            a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
+            const char *both = std::getenv("GBWT_HIP_BOTH_ENDS");
+            a.both_ends = ix->orientation_pairs && !(both && std::atoi(both) == 0) ? 1u : 0u;
+            HIP_CHECK(hipEventRecord(ws->ev[0], s));
+            launch_walk(ix->dev, a, s);
+            HIP_CHECK(hipEventRecord(ws->ev[1], s));
+            HIP_CHECK(hipEventRecord(ws->ev[2], s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipGetLastError());
+            ws->timed = true; ws->last_n = n; ws->last_total = total;
+            out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = total; out->n = n;
+            return GBWT_HIP_OK;
+        }
         uint32_t flags = 0;
         WalkArgs a{};
         for (int attempt = 0; attempt < 8; attempt++) {

@@ -57,7 +57,7 @@ inline gbwt_hip_status status_of(const HipError &e) {
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
-    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks, tables;
+    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks, tables, seq_len;
     gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)
     // GBZ with a node-to-segment translation (src/graph.rs:186-218), flattened for the line formatter:
     gbwt_hip::DeviceBuffer seg_of;        // u32 per node id < mapping_len: segment holding the node (~0 before the first segment)
@@ -67,6 +67,7 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceBuffer seg_seq_len;   // u64 per segment: length of the segment's sequence
     gbwt_hip::DeviceBuffer node_real;     // u8 per node id < mapping_len: GBZ::has_node
     gbwt_hip::DeviceIndex dev{};
+    bool orientation_pairs = false;   // verified at open: sequence 2k + 1 is sequence 2k reversed (rows can be filled from both ends)
     gbwt_hip_stats stats{};
 };
 

@@ -41,6 +41,12 @@
 //               offset in the successor, landing record index or 0 where the walk ends, block base of the landing
 //               record} -- Record::lf plus the arrival tests of GBWT::forward as one lookup.  Built only while they fit
 //               the budget (GBWT_HIP_TABLE_BYTES, default 16 GiB); otherwise such records are decoded serially.
+//   seq_len   : length (nodes) of every sequence, counted by one walk of all sequences at open.  With the lengths known
+//               an extraction knows its CSR offsets before it starts: lanes write straight into their rows (no pool of
+//               chained blocks, no compaction pass), and in a bidirectional index every sequence is walked from BOTH
+//               ends at once -- sequence id from its start for the first half, sequence id ^ 1 (the same path
+//               reversed, src/support.rs:310-314) from ITS start for the second half, written back to front with the
+//               nodes flipped.  The LF steps are the same ones; the dependent chain per sequence is half as long.
 //   blocks    : the outdegree-2 records decoded once at open (k_fill_blocks) into RANK BLOCKS of 64 offsets, 16 bytes
 //               each: {values of offsets 64k .. 64k+63 as one bit each (two words), value-1 offsets before 64k, 0}.
 //               Record::lf (src/bwt.rs:480-496) at offset i becomes: value = bit i, rank = ones-before (value 1) or
@@ -78,6 +84,7 @@ struct DeviceIndex {
     const uint4 *blocks;       // n_blocks entries
     const uint4 *desc2;        // 8 * n_records entries (two-step walk descriptors)
     const uint4 *tables;       // LF tables of the class 0 records (desc_raw C.z = first entry, C.w = 1), or null
+    const uint32_t *seq_len;   // number of nodes of every sequence (counted once at open), or null
     const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
     uint64_t data_len;
     uint64_t n_records;

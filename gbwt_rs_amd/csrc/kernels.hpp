@@ -61,9 +61,18 @@ struct WalkArgs {
     uint32_t pack16;           // WALK_COOP: every record is shorter than 2^16 (stats.max_record_len): one packed scan
     uint32_t helper_lanes;     // lanes of the look-ahead helper wave that touch (64; 0 = no look-ahead; experiments)
     uint32_t wide_addresses;   // force the 64-bit-address variant of the two-step loop (used above 4 GiB; tests)
+    // direct output (sequence lengths known): rows of the CSR are written in place, both ends of a sequence at once
+    uint32_t *out_nodes;       // [offsets[n]] CSR nodes, or null = pool output
+    const uint64_t *out_offsets;   // [n + 1]
+    uint32_t both_ends;        // 1: walkers n .. 2n-1 walk sequence id ^ 1 for the second half of row k = w - n
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);
+// lengths of all sequences (one lane per sequence, counting walk) and their gather for a batch of ids
+void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_t *d_prints, uint32_t *d_overflow, hipStream_t stream);
+// bidirectional indexes: is sequence 2k + 1 the reverse of sequence 2k for every k (fingerprints from the pass above)?
+void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d_prints, uint64_t n_pairs, uint32_t *d_mismatch, hipStream_t stream);
+void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, hipStream_t stream);
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 
 // per-path sum of node ids over CSR rows (checking hook)

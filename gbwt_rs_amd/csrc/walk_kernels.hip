@@ -439,8 +439,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
 //     leaf (a, b): rec = its landing record, offset = its base + rank_b
 //     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
 __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t &rec, uint32_t &offset, uint32_t &bb,
-                                                   uint32_t &wr, uint32_t &seq) {
+                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t &rec, uint32_t &offset,
+                                                   uint32_t &bb, uint32_t &wr, uint32_t &seq) {
 #ifdef GBWT_HIP_CXX_LOOP
     // plain C++ statement of the loop (no pipelining)
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
@@ -475,6 +475,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
         seq += 0x9E3779B1u;
         mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = seq;
+        if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
         if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > RING2_URGENT) != 0) return 0;
     }
 #else
@@ -605,6 +606,10 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
         "ds_write_b32 v92, v111\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks (both-ends walks) */ \
+        "s_nop 1\n\t" \
+        "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
+        "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
         ISSUE \
         "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */ \
         "v_cmp_lt_u32_e32 vcc, %[limit], v44\n\t"             /* more than RING2_URGENT nodes waiting in a ring */ \
@@ -622,7 +627,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_mov_b32_e32 %[wr], v44\n\t" \
         "v_mov_b32_e32 %[seq], v79\n\t" \
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [seq] "+v"(seq), [reason] "=&s"(reason) \
-        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
           "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
@@ -721,7 +726,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, rec, offset, bb, sink.wr, seq);
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, rec, offset, bb, sink.wr, seq);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) generic_step(ix, sink, rec, offset, bb);
@@ -733,6 +738,236 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
         a.lengths[k] = sink.finish(a);
         a.head[k] = sink.head;
     }
+}
+
+// ---- extraction with known lengths ---------------------------------------------------------------------------
+// Output of a walker that knows where its row lives: the LDS ring as in RingSinkT, but 16 staged nodes go straight
+// into the CSR row -- front to back for the walker of the sequence itself, back to front with the nodes flipped for
+// the walker that comes from the other end (sequence id ^ 1 visits the same nodes reversed and flipped).
+template <uint32_t SLOTS>
+struct DirectSinkT {
+    uint32_t *stage;
+    uint32_t wr = 0, flushed = 0;
+    uint32_t *row = nullptr;     // first node of the row
+    uint64_t len = 0;            // nodes in the row
+    bool backward = false;
+    __device__ __forceinline__ DirectSinkT(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    __device__ __forceinline__ void push(uint32_t node, bool counts) {
+        stage[(wr & (SLOTS - 1)) * WAVE] = node;
+        wr += counts ? 1u : 0u;
+    }
+    __device__ __forceinline__ bool needs_flush() const { return wr - flushed >= RING_FLUSH; }
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & (SLOTS - 1)) * WAVE]; }
+    __device__ __forceinline__ void put(uint32_t k) {   // node number k of this walker -> its place in the row
+        if (k >= len) return;                            // cannot happen in a consistent index; never write outside the row
+        if (backward) row[len - 1 - k] = slot(k) ^ 1u; else row[k] = slot(k);
+    }
+    __device__ __forceinline__ void flush16(const WalkArgs &) {
+        const uint32_t c = flushed;
+        if (static_cast<uint64_t>(c) + RING_FLUSH <= len) {
+            uint32_t v[RING_FLUSH];
+#pragma unroll
+            for (uint32_t t = 0; t < RING_FLUSH; t++) v[t] = slot(c + t);
+            if (!backward) {
+                uint32_t *dst = row + c;
+                if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+#pragma unroll
+                    for (uint32_t q = 0; q < RING_FLUSH / 4; q++) reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (uint32_t t = 0; t < RING_FLUSH; t++) dst[t] = v[t];
+                }
+            } else {
+                uint32_t *dst = row + (len - c - RING_FLUSH);   // node c + t goes to dst[15 - t]
+                if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+#pragma unroll
+                    for (uint32_t q = 0; q < RING_FLUSH / 4; q++)
+                        reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[15 - 4 * q] ^ 1u, v[14 - 4 * q] ^ 1u, v[13 - 4 * q] ^ 1u, v[12 - 4 * q] ^ 1u);
+                } else {
+#pragma unroll
+                    for (uint32_t t = 0; t < RING_FLUSH; t++) dst[RING_FLUSH - 1 - t] = v[t] ^ 1u;
+                }
+            }
+        } else {
+            for (uint32_t t = 0; t < RING_FLUSH; t++) put(c + t);
+        }
+        flushed += RING_FLUSH;
+    }
+    __device__ __forceinline__ void finish() {
+        while (needs_flush()) flush16(WalkArgs{});
+        for (uint32_t k = flushed; k < wr; k++) put(k);
+    }
+};
+
+// Same walk as k_walk_two, with the rows of the CSR as its output.  Walker w < n walks sequence seq_ids[w] from its
+// start; with both_ends, walker n + k walks seq_ids[k] ^ 1 and fills row k from its end.  A walker stops once it has
+// emitted its share (first half rounded up / second half rounded down); the two-step loop can overshoot the share by up
+// to three nodes, which land on the positions the other walker writes too, with the same values.
+__global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
+    __shared__ uint32_t ring_lds[RING2 * WAVE];
+    __shared__ uint4 mailbox[WAVE];
+    __shared__ uint32_t mail_done;
+    const uint32_t lane = threadIdx.x % WAVE;
+    const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
+    if (!helper) {
+        mailbox[lane] = make_uint4(0, 0, 0, 0);
+        if (lane == 0) mail_done = 0;
+    }
+    __syncthreads();
+    if (helper) {
+        const uint32_t owners = a.paths_per_wave ? a.paths_per_wave : WAVE;
+        if (lane >= a.helper_lanes) return;
+        lookahead_helper2(ix.desc2, ix.cblocks, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane % owners])),
+                          static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mail_done)), (lane << 26) | (1u << 25));
+        return;
+    }
+    const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));
+    DirectSinkT<RING2> sink(ring_lds, lane);
+    const uint64_t walkers = a.both_ends ? 2 * a.n : a.n;
+    const uint64_t w = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
+    const bool owner = lane < a.paths_per_wave && w < walkers;
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, quota = 0;
+    if (owner) {
+        const uint64_t k = w < a.n ? w : w - a.n;
+        sink.backward = w >= a.n;
+        sink.len = a.out_offsets[k + 1] - a.out_offsets[k];
+        sink.row = a.out_nodes + a.out_offsets[k];
+        const uint64_t share = !a.both_ends ? sink.len : (sink.backward ? sink.len / 2 : sink.len - sink.len / 2);
+        quota = static_cast<uint32_t>(share);
+        const uint64_t id = a.seq_ids[k] ^ (sink.backward ? 1u : 0u);
+        if (quota > 0 && id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+            const uint2 e = ix.endmarker[id];
+            if (e.x != 0) {
+                sink.push(e.x, true);
+                offset = e.y;
+                if (quota <= 1 || !arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+    }
+    const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
+    uint32_t seq = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;
+    const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
+    while (__ballot(rec != 0) != 0) {
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, quota, rec, offset, bb, sink.wr, seq);
+        if (slow_exit) {
+            const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
+            if (slow) {
+                generic_step(ix, sink, rec, offset, bb);
+                if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+        while (sink.needs_flush()) sink.flush16(a);
+    }
+    if (lane == 0) *const_cast<volatile uint32_t *>(&mail_done) = 1;
+    if (owner) sink.finish();
+}
+
+// Arithmetic modulo the Mersenne prime 2^61 - 1 for the order-sensitive fingerprints below.
+constexpr uint64_t FP_P = (uint64_t(1) << 61) - 1;
+constexpr uint64_t FP_X = 0x1D4F5C6B7A891234ull % FP_P;           // base of the polynomial
+__host__ __device__ inline uint64_t fp_mul(uint64_t a, uint64_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint64_t hi = __umul64hi(a, b), lo = a * b;
+#else
+    const unsigned __int128 t = static_cast<unsigned __int128>(a) * b;
+    const uint64_t hi = static_cast<uint64_t>(t >> 64), lo = static_cast<uint64_t>(t);
+#endif
+    uint64_t r = (lo & FP_P) + ((lo >> 61) | (hi << 3));          // a, b < 2^61: hi < 2^58
+    r = (r & FP_P) + (r >> 61);
+    return r >= FP_P ? r - FP_P : r;
+}
+__host__ __device__ inline uint64_t fp_add(uint64_t a, uint64_t b) { const uint64_t r = a + b; return r >= FP_P ? r - FP_P : r; }
+__host__ __device__ inline uint64_t fp_pow(uint64_t base, uint64_t e) {
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = fp_mul(r, base); base = fp_mul(base, base); e >>= 1; }
+    return r;
+}
+__host__ __device__ inline uint64_t fp_hash(uint64_t v) {           // splitmix64 finaliser, reduced
+    v += 0x9E3779B97F4A7C15ull; v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull; v = (v ^ (v >> 27)) * 0x94D049BB133111EBull; v ^= v >> 31;
+    return v % FP_P;
+}
+
+// Sink that counts the nodes of a sequence (its length) and keeps two fingerprints of it:
+//   fwd = sum h(v_i) x^i          (the sequence as it is)
+//   rev = sum h(v_i ^ 1) x^-i     (times x^(len-1): the fingerprint `fwd` of the sequence reversed and flipped)
+// k_check_orientation_pairs uses them to prove that sequence 2k+1 is sequence 2k reversed before an extraction is
+// allowed to fill a row from both ends.
+struct CountSink {
+    uint32_t wr = 0;
+    uint64_t fwd = 0, rev = 0, xp = 1, xm = 1, xinv;
+    __device__ __forceinline__ explicit CountSink(uint64_t x_inverse) : xinv(x_inverse) {}
+    __device__ __forceinline__ void push(uint32_t node, bool counts) {
+        if (!counts) return;
+        fwd = fp_add(fwd, fp_mul(fp_hash(node), xp));
+        rev = fp_add(rev, fp_mul(fp_hash(node ^ 1u), xm));
+        xp = fp_mul(xp, FP_X); xm = fp_mul(xm, xinv);
+        wr++;
+    }
+};
+
+// One lane per sequence: the number of nodes SequenceIter would yield (src/gbwt.rs:557-568), by the two-step walk in
+// plain C++ without an output.  Runs once, at open.
+__global__ void __launch_bounds__(256) k_sequence_lengths(DeviceIndex ix, uint32_t *seq_len, uint64_t *prints, uint64_t x_inverse, uint32_t *overflow) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id >= ix.n_sequences) return;
+    CountSink sink(x_inverse);
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
+    if (id < ix.n_endmarker) {
+        const uint2 e = ix.endmarker[id];
+        if (e.x != 0) {
+            sink.push(e.x, true);
+            offset = e.y;
+            if (!arrive(ix, e.x, e.y, rec, bb)) rec = 0;
+        }
+    }
+    uint64_t guard = 0;
+    while (rec != 0) {
+        if (++guard > 0xFFFFFFF0ull || sink.wr > 0xFFFFFFF0u) { atomicOr(overflow, 1u); break; }
+        const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
+        const uint4 F1 = d[1];
+        if (F1.x & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); continue; }
+        const uint4 F0 = d[0];
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+        const uint4 K0 = ix.cblocks[2 * idx], K1 = ix.cblocks[2 * idx + 1];
+        const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+        const uint32_t bit = offset & 63u;
+        const uint64_t below = (uint64_t(1) << bit) - 1;
+        const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u;
+        const uint64_t m = a ? bits1 : ~bits1;
+        const uint32_t rank_a = a ? K1.x + __popcll(m & below) : (offset - bit) - K1.x + __popcll(m & below);
+        const uint32_t j = (a ? F0.w : F0.y) + rank_a;
+        const uint32_t b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+        const uint32_t ones_w = (a ? K1.z : K1.y) + __popcll(m & bits2 & below);
+        const uint4 leaf = d[2 + 2 * a + b];
+        const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
+        rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
+        sink.push(n1, n1 != 0);
+        sink.push((wword & REC_MASK) + ix.alphabet_offset, (wword & LEAF_EMIT2) != 0);
+        sink.push(leaf.x, leaf.x != 0);
+        sink.push(rec + ix.alphabet_offset, (leaf.z & LEAF_EMIT2) != 0);
+    }
+    seq_len[id] = sink.wr;
+    prints[2 * id] = sink.fwd; prints[2 * id + 1] = sink.rev;
+}
+
+// One lane per path of a bidirectional index: sequence 2k + 1 must be sequence 2k reversed with every node flipped
+// (support::reverse_path, src/support.rs:310-314) -- same length, and the fingerprint of each as it is equals the
+// fingerprint of the other one reversed and flipped.  Any failure clears the flag: rows are then filled from one end.
+__global__ void __launch_bounds__(256) k_check_orientation_pairs(const uint32_t *seq_len, const uint64_t *prints, uint64_t n_pairs, uint32_t *mismatch) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n_pairs) return;
+    const uint32_t lf = seq_len[2 * k], lr = seq_len[2 * k + 1];
+    bool good = lf == lr;
+    if (good && lf > 0) {
+        const uint64_t shift = fp_pow(FP_X, lf - 1);
+        good = prints[4 * k] == fp_mul(prints[4 * k + 3], shift) && prints[4 * k + 2] == fp_mul(prints[4 * k + 1], shift);
+    }
+    if (!good) atomicOr(mismatch, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_gather_lengths(const uint32_t *seq_len, const uint64_t *ids, uint64_t n, uint64_t *lengths) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k < n) lengths[k] = seq_len[ids[k]];
 }
 
 // Wave-cooperative walk (WALK_COOP): lanes 0..P-1 of each wave own one sequence each; long class 1 / 2 records are
@@ -860,8 +1095,27 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
         return;
     }
     // walking wave + look-ahead helper wave
+    if (args.out_nodes != nullptr) {   // lengths known: rows written in place, both ends at once
+        const uint64_t walkers = args.both_ends ? 2 * args.n : args.n;
+        hipLaunchKernelGGL(k_walk_direct, dim3(grid_for(walkers, p)), dim3(2 * WAVE), 0, stream, ix, args);
+        return;
+    }
     if (args.mode == WALK_ONE_STEP) { hipLaunchKernelGGL(k_walk_blocks, grid, dim3(2 * WAVE), 0, stream, ix, args); return; }
     hipLaunchKernelGGL(k_walk_two, grid, dim3(2 * WAVE), 0, stream, ix, args);
+}
+
+void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_t *d_prints, uint32_t *d_overflow, hipStream_t stream) {
+    if (ix.n_sequences == 0) return;
+    const uint64_t x_inverse = fp_pow(FP_X, FP_P - 2);   // Fermat
+    hipLaunchKernelGGL(k_sequence_lengths, dim3(grid_for(ix.n_sequences, 256)), dim3(256), 0, stream, ix, d_seq_len, d_prints, x_inverse, d_overflow);
+}
+
+void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d_prints, uint64_t n_pairs, uint32_t *d_mismatch, hipStream_t stream) {
+    if (n_pairs) hipLaunchKernelGGL(k_check_orientation_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, stream, d_seq_len, d_prints, n_pairs, d_mismatch);
+}
+
+void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_gather_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_seq_len, d_ids, n, d_lengths);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {
