@@ -372,7 +372,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.mode = ws->walk_mode;
             const uint64_t walkers = ix->orientation_pairs ? 2 * n : n;   // upper bound (GBWT_HIP_BOTH_ENDS=0 halves it)
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
-                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(32, (walkers + 1023) / 1024)));
+                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (walkers + 1023) / 1024)));
             a.helper_lanes = 64;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;

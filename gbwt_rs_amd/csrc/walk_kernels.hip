@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
 //     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
 __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
                                                    uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t &rec, uint32_t &offset,
-                                                   uint32_t &bb, uint32_t &wr, uint32_t &seq) {
+                                                   uint32_t &bb, uint32_t &wr) {
 #ifdef GBWT_HIP_CXX_LOOP
     // plain C++ statement of the loop (no pipelining)
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
@@ -473,8 +473,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         wr += leaf.x != 0 ? 1u : 0u;
         ring[(wr & (RING2 - 1)) * WAVE] = rec + alphabet_offset;
         wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
-        seq += 0x9E3779B1u;
-        mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = seq;
+        mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = wr;
         if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
         if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > RING2_URGENT) != 0) return 0;
     }
@@ -528,7 +527,6 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_mov_b32_e32 v42, %[offset]\n\t" \
         "v_mov_b32_e32 v43, %[bb]\n\t" \
         "v_mov_b32_e32 v44, %[wr]\n\t" \
-        "v_mov_b32_e32 v79, %[seq]\n\t" \
         "v_mov_b32_e32 v71, 0\n\t" \
         "s_mov_b32 %[reason], 0\n\t" \
         "s_mov_b64 s[44:45], -1\n\t" \
@@ -582,7 +580,6 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_cndmask_b32_e32 v43, v115, v119, vcc\n\t"        /* its block base */ \
         "v_add_u32_e32 v42, v113, v107\n\t"                 /* the new offset */ \
         "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
-        "v_add_u32_e32 v79, 0x9e3779b1, v79\n\t"            /* new sequence number for the look-ahead target of the record just left */ \
         "v_and_b32_e32 v92, 0x7f, v44\n\t"                  /* ring slot of the next node */ \
         "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
@@ -602,12 +599,12 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
         "v_and_b32_e32 v92, 0x7f, v44\n\t" \
-        "ds_write_b128 %[mail], v[76:79]\n\t" \
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
         "ds_write_b32 v92, v111\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks (both-ends walks) */ \
-        "s_nop 1\n\t" \
+        "v_mov_b32_e32 v79, v44\n\t"                        /* mailbox: look-ahead target of the record just left + nodes staged so far */ \
+        "ds_write_b128 %[mail], v[76:79]\n\t" \
         "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
         "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
         ISSUE \
@@ -625,8 +622,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_mov_b32_e32 %[offset], v42\n\t" \
         "v_mov_b32_e32 %[bb], v43\n\t" \
         "v_mov_b32_e32 %[wr], v44\n\t" \
-        "v_mov_b32_e32 %[seq], v79\n\t" \
-        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [seq] "+v"(seq), [reason] "=&s"(reason) \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
         : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
@@ -722,11 +718,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
         }
     }
     const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
-    uint32_t seq = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;
     // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, rec, offset, bb, sink.wr, seq);
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) generic_step(ix, sink, rec, offset, bb);
@@ -741,100 +736,161 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
 }
 
 // ---- extraction with known lengths ---------------------------------------------------------------------------
-// Output of a walker that knows where its row lives: the LDS ring as in RingSinkT, but 16 staged nodes go straight
-// into the CSR row -- front to back for the walker of the sequence itself, back to front with the nodes flipped for
-// the walker that comes from the other end (sequence id ^ 1 visits the same nodes reversed and flipped).
-template <uint32_t SLOTS>
-struct DirectSinkT {
-    uint32_t *stage;
-    uint32_t wr = 0, flushed = 0;
-    uint32_t *row = nullptr;     // first node of the row
+// With the lengths of the sequences known (device_index.hpp: seq_len) the CSR offsets exist before the walk starts, so
+// the nodes go straight into their rows -- and in a bidirectional index every row is filled from BOTH ends at once:
+// walker k walks sequence id from its start and writes front to back, walker n + k walks sequence id ^ 1 (the same
+// path reversed and flipped) and writes back to front, flipping the nodes.  Each stops at the middle.
+//
+// The walking wave never stores to global memory here.  Row starts are megabytes apart, so 10 000 write streams miss
+// the TLB all the time, and on gfx9 a store in flight delays every load behind it (one in-order vmcnt): with the walker
+// storing, filling rows from both ends gained 1.2x instead of 2x on the headline index.  The nodes therefore stay in
+// the LDS ring until the HELPER wave -- which already does the look-ahead touches and has a vmcnt of its own -- moves
+// them to the row, 64 bytes at a time.  The walker publishes how many nodes it has staged (mailbox word 3), the
+// helper publishes how many it has written (`drained`), and the walker only stalls when its ring is full.
+
+// Where the nodes of one walker go.
+struct RowTarget {
+    uint32_t *row = nullptr;     // first node of the CSR row
     uint64_t len = 0;            // nodes in the row
-    bool backward = false;
-    __device__ __forceinline__ DirectSinkT(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    bool backward = false;       // this walker comes from the other end: node k goes to row[len - 1 - k], flipped
+    uint32_t share = 0;          // nodes this walker has to deliver
+};
+
+__device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
+    RowTarget t;
+    const uint64_t k = w < a.n ? w : w - a.n;
+    t.backward = w >= a.n;
+    t.len = a.out_offsets[k + 1] - a.out_offsets[k];
+    t.row = a.out_nodes + a.out_offsets[k];
+    const uint64_t share = !a.both_ends ? t.len : (t.backward ? t.len / 2 : t.len - t.len / 2);
+    t.share = static_cast<uint32_t>(share);
+    return t;
+}
+
+// Staging only: the walking wave's side of the ring.
+struct StageSink {
+    uint32_t *stage;
+    uint32_t wr = 0;
+    __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
     __device__ __forceinline__ void push(uint32_t node, bool counts) {
-        stage[(wr & (SLOTS - 1)) * WAVE] = node;
+        stage[(wr & (RING2 - 1)) * WAVE] = node;
         wr += counts ? 1u : 0u;
     }
-    __device__ __forceinline__ bool needs_flush() const { return wr - flushed >= RING_FLUSH; }
-    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & (SLOTS - 1)) * WAVE]; }
-    __device__ __forceinline__ void put(uint32_t k) {   // node number k of this walker -> its place in the row
-        if (k >= len) return;                            // cannot happen in a consistent index; never write outside the row
-        if (backward) row[len - 1 - k] = slot(k) ^ 1u; else row[k] = slot(k);
+};
+
+// The helper's side: moves staged nodes [drained, upto) of one lane's ring column to the row.
+struct RowWriter {
+    const volatile uint32_t *stage;
+    RowTarget t;
+    uint32_t drained = 0;
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & (RING2 - 1)) * WAVE]; }
+    __device__ __forceinline__ void put(uint32_t k) {
+        if (k >= t.len) return;   // cannot happen in a consistent index; never write outside the row
+        if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
     }
-    __device__ __forceinline__ void flush16(const WalkArgs &) {
-        const uint32_t c = flushed;
-        if (static_cast<uint64_t>(c) + RING_FLUSH <= len) {
+    __device__ __forceinline__ void chunk() {   // 16 nodes = 64 bytes
+        const uint32_t c = drained;
+        if (static_cast<uint64_t>(c) + RING_FLUSH <= t.len) {
             uint32_t v[RING_FLUSH];
 #pragma unroll
-            for (uint32_t t = 0; t < RING_FLUSH; t++) v[t] = slot(c + t);
-            if (!backward) {
-                uint32_t *dst = row + c;
-                if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            for (uint32_t i = 0; i < RING_FLUSH; i++) v[i] = slot(c + i);
+            uint32_t *dst = t.backward ? t.row + (t.len - c - RING_FLUSH) : t.row + c;
+            const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+            if (!t.backward) {
+                if (aligned) {
 #pragma unroll
                     for (uint32_t q = 0; q < RING_FLUSH / 4; q++) reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 } else {
 #pragma unroll
-                    for (uint32_t t = 0; t < RING_FLUSH; t++) dst[t] = v[t];
+                    for (uint32_t i = 0; i < RING_FLUSH; i++) dst[i] = v[i];
                 }
-            } else {
-                uint32_t *dst = row + (len - c - RING_FLUSH);   // node c + t goes to dst[15 - t]
-                if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            } else {   // node c + i goes to dst[15 - i]
+                if (aligned) {
 #pragma unroll
                     for (uint32_t q = 0; q < RING_FLUSH / 4; q++)
                         reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[15 - 4 * q] ^ 1u, v[14 - 4 * q] ^ 1u, v[13 - 4 * q] ^ 1u, v[12 - 4 * q] ^ 1u);
                 } else {
 #pragma unroll
-                    for (uint32_t t = 0; t < RING_FLUSH; t++) dst[RING_FLUSH - 1 - t] = v[t] ^ 1u;
+                    for (uint32_t i = 0; i < RING_FLUSH; i++) dst[RING_FLUSH - 1 - i] = v[i] ^ 1u;
                 }
             }
         } else {
-            for (uint32_t t = 0; t < RING_FLUSH; t++) put(c + t);
+            for (uint32_t i = 0; i < RING_FLUSH; i++) put(c + i);
         }
-        flushed += RING_FLUSH;
-    }
-    __device__ __forceinline__ void finish() {
-        while (needs_flush()) flush16(WalkArgs{});
-        for (uint32_t k = flushed; k < wr; k++) put(k);
+        drained += RING_FLUSH;
     }
 };
 
-// Same walk as k_walk_two, with the rows of the CSR as its output.  Walker w < n walks sequence seq_ids[w] from its
-// start; with both_ends, walker n + k walks seq_ids[k] ^ 1 and fills row k from its end.  A walker stops once it has
-// emitted its share (first half rounded up / second half rounded down); the two-step loop can overshoot the share by up
-// to three nodes, which land on the positions the other walker writes too, with the same values.
+// One look-ahead touch from compiler-scheduled code: an LDS-direct load has no register destination, so nothing can be
+// corrupted by the data arriving late, and nobody ever waits for it.  `lds_dummy` = wave-uniform LDS byte address of a
+// 256-byte scratch area.
+__device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p), "s"(lds_dummy) : "memory");
+}
+
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
     __shared__ uint32_t ring_lds[RING2 * WAVE];
-    __shared__ uint4 mailbox[WAVE];
+    __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
+    __shared__ uint32_t drained_pub[WAVE];   // per walking lane: nodes the helper has moved to the row
+    __shared__ uint32_t touch_dummy[WAVE];
     __shared__ uint32_t mail_done;
     const uint32_t lane = threadIdx.x % WAVE;
     const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
     if (!helper) {
         mailbox[lane] = make_uint4(0, 0, 0, 0);
+        drained_pub[lane] = 0;
         if (lane == 0) mail_done = 0;
     }
     __syncthreads();
-    if (helper) {
-        const uint32_t owners = a.paths_per_wave ? a.paths_per_wave : WAVE;
-        if (lane >= a.helper_lanes) return;
-        lookahead_helper2(ix.desc2, ix.cblocks, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane % owners])),
-                          static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mail_done)), (lane << 26) | (1u << 25));
-        return;
-    }
-    const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));
-    DirectSinkT<RING2> sink(ring_lds, lane);
     const uint64_t walkers = a.both_ends ? 2 * a.n : a.n;
     const uint64_t w = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && w < walkers;
-    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, quota = 0;
+    RowTarget target;
+    if (owner) target = row_target(a, w);
+    volatile uint4 *vmail = mailbox;
+    volatile uint32_t *vdrained = drained_pub;
+    volatile uint32_t *vdone = &mail_done;
+
+    if (helper) {
+        // ---- helper wave: look-ahead touches for every slot, row writes for its own lane's column
+        const uint32_t owners = a.paths_per_wave ? a.paths_per_wave : WAVE;
+        const uint32_t serve = lane % owners;                        // the 64 lanes share the owners' look-ahead slots ...
+        const uint32_t spread = (lane << 26) | (1u << 25);           // ... and spread over the target's blocks
+        const uint32_t dummy = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(touch_dummy));
+        RowWriter writer{ring_lds + lane, target, 0};
+        uint32_t seen = 0;
+        for (;;) {
+            const uint32_t done = *vdone;                            // read before the counts: the final count is then complete
+            const uint32_t look_rec = vmail[serve].x, look_base = vmail[serve].y, look_count = vmail[serve].z, stamp = vmail[serve].w;
+            if (lane < a.helper_lanes && look_rec != 0 && stamp != seen) {
+                const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(look_rec);
+                touch_line(d, dummy);
+                touch_line(d + 4, dummy);
+                touch_line(ix.cblocks + 2 * (static_cast<uint64_t>(look_base) + __umulhi(spread, look_count)), dummy);
+            }
+            seen = stamp;
+            if (owner) {
+                const uint32_t staged = vmail[lane].w;
+                while (staged - writer.drained >= RING_FLUSH) writer.chunk();
+                if (done) { for (uint32_t k = writer.drained; k < staged; k++) writer.put(k); }
+                vdrained[lane] = writer.drained;
+            }
+            if (done) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        return;
+    }
+
+    // ---- walking wave
+    const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));
+    StageSink sink(ring_lds, lane);
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
+    const uint32_t quota = target.share;
     if (owner) {
         const uint64_t k = w < a.n ? w : w - a.n;
-        sink.backward = w >= a.n;
-        sink.len = a.out_offsets[k + 1] - a.out_offsets[k];
-        sink.row = a.out_nodes + a.out_offsets[k];
-        const uint64_t share = !a.both_ends ? sink.len : (sink.backward ? sink.len / 2 : sink.len - sink.len / 2);
-        quota = static_cast<uint32_t>(share);
-        const uint64_t id = a.seq_ids[k] ^ (sink.backward ? 1u : 0u);
+        const uint64_t id = a.seq_ids[k] ^ (target.backward ? 1u : 0u);
         if (quota > 0 && id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
             const uint2 e = ix.endmarker[id];
             if (e.x != 0) {
@@ -844,22 +900,25 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
         }
     }
+    vmail[lane].w = sink.wr;
     const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
-    uint32_t seq = (lane + WAVE * blockIdx.x) * 0x9E3779B1u;
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, quota, rec, offset, bb, sink.wr, seq);
+        const uint32_t drained = vdrained[lane];
+        if (__ballot(sink.wr - drained > RING2_URGENT) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) {
                 generic_step(ix, sink, rec, offset, bb);
                 if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
             }
+            vmail[lane].w = sink.wr;
         }
-        while (sink.needs_flush()) sink.flush16(a);
     }
-    if (lane == 0) *const_cast<volatile uint32_t *>(&mail_done) = 1;
-    if (owner) sink.finish();
+    vmail[lane].w = sink.wr;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *vdone = 1;
 }
 
 // Arithmetic modulo the Mersenne prime 2^61 - 1 for the order-sensitive fingerprints below.
