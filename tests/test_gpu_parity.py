@@ -528,6 +528,30 @@ def test_config_c3_search_bit_exact(model, haplotypes):
         assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
 
 
+@pytest.mark.parametrize("env", [{"GBWT_HIP_DIRECT": "0"}, {"GBWT_HIP_BOTH_ENDS": "0"}, {"GBWT_HIP_SEQ_LEN": "0"}, {}])
+def test_extraction_output_paths(monkeypatch, env):
+    """The extraction has three output paths: rows filled from both ends (default, bidirectional indexes whose sequence
+    pairs check out), rows filled from one end, and the pool of chained blocks + compaction (no sequence lengths).
+    Odd and even lengths, empty sequences, lengths below one ring chunk, duplicates, reverse sequences."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = random.Random(31)
+    paths = [[2 * rng.randint(1, 40) + rng.randint(0, 1) for _ in range(ln)] for ln in (0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 64, 65, 127, 700, 1001)]
+    s = S.Synth.from_paths(paths, bidirectional=True)
+    dev = open_synth(s)
+    ids = list(range(s.sequences)) + [5, 5, 28]
+    offsets, nodes = dev.sequences_csr(ids)
+    for k, i in enumerate(ids):
+        exp = paths[i // 2] if i % 2 == 0 else kat.reverse_path(paths[i // 2])
+        assert list(nodes[offsets[k]:offsets[k + 1]]) == exp, (i, env)
+    chain = S.Synth.chain(sites=900, haplotypes=200, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.02, seed=23)
+    cdev, coracle = open_synth(chain), oracle_of(chain)
+    cids = np.arange(0, chain.sequences, dtype=np.uint64)
+    o_off, o_nodes = coracle.extract(cids, threads=4)
+    c_off, c_nodes = cdev.sequences_csr(cids)
+    assert np.array_equal(c_off, o_off) and np.array_equal(c_nodes, o_nodes)
+
+
 def test_two_step_walk_with_64_bit_addresses(monkeypatch):
     """The two-step loop has two addressing variants (SGPR base + 32-bit offsets below 4 GiB, 64-bit addresses above);
     GBWT_HIP_WIDE_ADDRESSES forces the second one, which no test index is large enough to need."""
