@@ -181,6 +181,28 @@ void upload(gbwt_hip_index &ix) {
         if (!flags[0]) {
             d.seq_len = ix.seq_len.as<uint32_t>();
             ix.orientation_pairs = h.bidirectional && h.sequences % 2 == 0 && !flags[2];
+            // Sequence samples: where every sequence is about every `interval` nodes (second walk), so that extractions
+            // can fill a row with many walkers at once.  GBWT_HIP_SAMPLE_INTERVAL=0 switches them off.
+            uint32_t interval = 4096;
+            if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+            if (interval >= 8) {
+                DeviceBuffer counts, scan_tmp;
+                counts.reserve(h.sequences * sizeof(uint64_t));
+                ix.sample_base.reserve((h.sequences + 1) * sizeof(uint64_t));
+                launch_sample_counts(ix.seq_len.as<uint32_t>(), h.sequences, interval, counts.as<uint64_t>(), nullptr);
+                const size_t tb = scan_temp_bytes(h.sequences);
+                scan_tmp.reserve(std::max<size_t>(tb, 16));
+                launch_scan(counts.as<uint64_t>(), ix.sample_base.as<uint64_t>(), h.sequences, scan_tmp.ptr, tb, nullptr);
+                uint64_t total_samples = 0;
+                HIP_CHECK(hipMemcpy(&total_samples, ix.sample_base.as<uint64_t>() + h.sequences, sizeof(uint64_t), hipMemcpyDeviceToHost));
+                ix.samples.reserve(std::max<uint64_t>(total_samples, 1) * sizeof(uint4));
+                launch_record_samples(d, ix.sample_base.as<uint64_t>(), interval, ix.samples.as<uint4>(), nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+                HIP_CHECK(hipGetLastError());
+                d.samples = ix.samples.as<uint4>();
+                d.sample_base = ix.sample_base.as<uint64_t>();
+                d.sample_interval = interval;
+            }
         }
     }
 }
@@ -361,18 +383,27 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         if (n && ix->dev.seq_len && ws->walk_mode == WALK_TWO_STEP && !(no_direct && std::atoi(no_direct) == 0)) {
             // Lengths known: offsets first, then every lane writes into its row; in a bidirectional index two walkers per
             // sequence, one from each end.
-            launch_gather_lengths(ix->dev.seq_len, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), s);
+            HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
+            launch_gather_lengths(ix->dev.seq_len, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
             launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
             uint64_t total = 0;
+            uint32_t max_len = 0;
             HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(&max_len, ws->counters.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             ws->nodes.reserve(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
             WalkArgs a{};
             a.seq_ids = ws->seq_ids.as<uint64_t>(); a.n = n;
             a.mode = ws->walk_mode;
-            const uint64_t walkers = ix->orientation_pairs ? 2 * n : n;   // upper bound (GBWT_HIP_BOTH_ENDS=0 halves it)
+            // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
+            const char *seg = std::getenv("GBWT_HIP_SEGMENTS");
+            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && !(seg && std::atoi(seg) == 0);
+            a.segments = segmented ? (max_len - 1) / ix->dev.sample_interval + 1 : 0u;
+            const uint64_t walkers = segmented ? static_cast<uint64_t>(a.segments) * n : (ix->orientation_pairs ? 2 * n : n);
+            // many walkers: the walk is a throughput problem, full waves; few walkers (one or two per row): latency, and
+            // about one workgroup per four SIMDs keeps every workgroup resident (32 KB of LDS each)
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
-                                                   : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (walkers + 1023) / 1024)));
+                               : segmented ? 64u : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (walkers + 1023) / 1024)));
             a.helper_lanes = 64;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;

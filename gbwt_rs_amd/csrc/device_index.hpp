@@ -47,6 +47,11 @@
 //               ends at once -- sequence id from its start for the first half, sequence id ^ 1 (the same path
 //               reversed, src/support.rs:310-314) from ITS start for the second half, written back to front with the
 //               nodes flipped.  The LF steps are the same ones; the dependent chain per sequence is half as long.
+//   samples   : the position of every sequence about every `sample_interval` nodes (recorded by a second walk at open):
+//               {record, offset, block base, nodes emitted so far}.  An extraction starts one walker per sample, so a
+//               row is filled by many walkers at once and the dependent chain is one sample interval long instead of
+//               the whole sequence -- the walk stops being bound by the latency of one chain and becomes a
+//               throughput problem.  Every LF step is still taken, by exactly one walker.
 //   blocks    : the outdegree-2 records decoded once at open (k_fill_blocks) into RANK BLOCKS of 64 offsets, 16 bytes
 //               each: {values of offsets 64k .. 64k+63 as one bit each (two words), value-1 offsets before 64k, 0}.
 //               Record::lf (src/bwt.rs:480-496) at offset i becomes: value = bit i, rank = ones-before (value 1) or
@@ -85,6 +90,9 @@ struct DeviceIndex {
     const uint4 *desc2;        // 8 * n_records entries (two-step walk descriptors)
     const uint4 *tables;       // LF tables of the class 0 records (desc_raw C.z = first entry, C.w = 1), or null
     const uint32_t *seq_len;   // number of nodes of every sequence (counted once at open), or null
+    const uint4 *samples;      // sequence samples {record, offset, block base, nodes emitted so far}, or null
+    const uint64_t *sample_base;   // n_sequences + 1: first sample of every sequence
+    uint32_t sample_interval;  // a sample about every this many nodes
     const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
     uint64_t data_len;
     uint64_t n_records;

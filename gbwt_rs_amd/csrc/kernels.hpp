@@ -65,6 +65,7 @@ struct WalkArgs {
     uint32_t *out_nodes;       // [offsets[n]] CSR nodes, or null = pool output
     const uint64_t *out_offsets;   // [n + 1]
     uint32_t both_ends;        // 1: walkers n .. 2n-1 walk sequence id ^ 1 for the second half of row k = w - n
+    uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);
@@ -72,7 +73,11 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
 void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_t *d_prints, uint32_t *d_overflow, hipStream_t stream);
 // bidirectional indexes: is sequence 2k + 1 the reverse of sequence 2k for every k (fingerprints from the pass above)?
 void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d_prints, uint64_t n_pairs, uint32_t *d_mismatch, hipStream_t stream);
-void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, hipStream_t stream);
+// lengths[k] = seq_len[ids[k]]; *d_max_len = the largest of them (zeroed by the caller)
+void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
+// sequence samples: counts per sequence from the lengths, then the recording walk
+void launch_sample_counts(const uint32_t *d_seq_len, uint64_t n_sequences, uint32_t interval, uint64_t *d_counts, hipStream_t stream);
+void launch_record_samples(const DeviceIndex &ix, const uint64_t *d_sample_base, uint32_t interval, uint4 *d_samples, hipStream_t stream);
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 
 // per-path sum of node ids over CSR rows (checking hook)

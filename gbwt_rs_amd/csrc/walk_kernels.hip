@@ -767,6 +767,30 @@ __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
     return t;
 }
 
+// Segmented extraction (DeviceIndex::samples): walker w fills segment j = w / n of row k = w % n -- the nodes from
+// sample j of the sequence up to sample j + 1 (or the end of the row).  Walkers of one wave hold the same segment of
+// neighbouring rows, so they travel together like whole-sequence walkers do.
+struct WalkerStart { uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, first_node = 0; };
+
+__device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, const WalkArgs &a, uint64_t w, RowTarget &t) {
+    WalkerStart s;
+    const uint64_t j = w / a.n, k = w % a.n;
+    const uint64_t id = a.seq_ids[k];
+    const uint64_t base = ix.sample_base[id], count = ix.sample_base[id + 1] - base;
+    const uint64_t len = a.out_offsets[k + 1] - a.out_offsets[k];
+    if (j >= count) return s;                                 // this row has fewer segments: nothing to do
+    const uint4 here = ix.samples[base + j];
+    const uint64_t from = j == 0 ? 0 : here.w;                // segment 0 starts with the start node (sample 0 is the state after it)
+    const uint64_t to = j + 1 < count ? ix.samples[base + j + 1].w : len;
+    t.row = a.out_nodes + a.out_offsets[k] + from;
+    t.len = to > from ? to - from : 0;
+    t.backward = false;
+    t.share = static_cast<uint32_t>(t.len);
+    s.rec = here.x; s.offset = here.y; s.bb = here.z;
+    if (j == 0 && id < ix.n_endmarker) s.first_node = ix.endmarker[id].x;
+    return s;
+}
+
 // Staging only: the walking wave's side of the ring.
 struct StageSink {
     uint32_t *stage;
@@ -844,11 +868,15 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (lane == 0) mail_done = 0;
     }
     __syncthreads();
-    const uint64_t walkers = a.both_ends ? 2 * a.n : a.n;
+    const uint64_t walkers = a.segments ? static_cast<uint64_t>(a.segments) * a.n : (a.both_ends ? 2 * a.n : a.n);
     const uint64_t w = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && w < walkers;
     RowTarget target;
-    if (owner) target = row_target(a, w);
+    WalkerStart begin;
+    if (owner) {
+        if (a.segments) begin = segment_start(ix, a, w, target);
+        else target = row_target(a, w);
+    }
     volatile uint4 *vmail = mailbox;
     volatile uint32_t *vdrained = drained_pub;
     volatile uint32_t *vdone = &mail_done;
@@ -888,7 +916,12 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     StageSink sink(ring_lds, lane);
     uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
     const uint32_t quota = target.share;
-    if (owner) {
+    if (owner && a.segments) {
+        if (quota > 0) {
+            if (begin.first_node != 0) sink.push(begin.first_node, true);   // segment 0 also delivers the start node
+            if (sink.wr < quota) { rec = begin.rec; offset = begin.offset; bb = begin.bb; }
+        }
+    } else if (owner) {
         const uint64_t k = w < a.n ? w : w - a.n;
         const uint64_t id = a.seq_ids[k] ^ (target.backward ? 1u : 0u);
         if (quota > 0 && id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
@@ -962,29 +995,29 @@ struct CountSink {
         xp = fp_mul(xp, FP_X); xm = fp_mul(xm, xinv);
         wr++;
     }
+    __device__ __forceinline__ void checkpoint(uint32_t, uint32_t, uint32_t) {}
 };
 
-// One lane per sequence: the number of nodes SequenceIter would yield (src/gbwt.rs:557-568), by the two-step walk in
-// plain C++ without an output.  Runs once, at open.
-__global__ void __launch_bounds__(256) k_sequence_lengths(DeviceIndex ix, uint32_t *seq_len, uint64_t *prints, uint64_t x_inverse, uint32_t *overflow) {
-    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (id >= ix.n_sequences) return;
-    CountSink sink(x_inverse);
+// The two-step walk in plain C++ without an output, for the one-time passes at open: `sink.push` sees every node in
+// order, `sink.checkpoint` sees the position of the walk after every iteration (a state from which a walker can go on).
+template <class Sink>
+__device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, Sink &sink, uint32_t *overflow) {
     uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
     if (id < ix.n_endmarker) {
         const uint2 e = ix.endmarker[id];
         if (e.x != 0) {
             sink.push(e.x, true);
             offset = e.y;
-            if (!arrive(ix, e.x, e.y, rec, bb)) rec = 0;
+            if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            sink.checkpoint(rec, offset, bb);
         }
     }
     uint64_t guard = 0;
     while (rec != 0) {
-        if (++guard > 0xFFFFFFF0ull || sink.wr > 0xFFFFFFF0u) { atomicOr(overflow, 1u); break; }
+        if (++guard > 0xFFFFFFF0ull || sink.wr > 0xFFFFFFF0u) { if (overflow) atomicOr(overflow, 1u); break; }
         const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
         const uint4 F1 = d[1];
-        if (F1.x & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); continue; }
+        if (F1.x & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); sink.checkpoint(rec, offset, bb); continue; }
         const uint4 F0 = d[0];
         const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
         const uint4 K0 = ix.cblocks[2 * idx], K1 = ix.cblocks[2 * idx + 1];
@@ -1004,9 +1037,48 @@ __global__ void __launch_bounds__(256) k_sequence_lengths(DeviceIndex ix, uint32
         sink.push((wword & REC_MASK) + ix.alphabet_offset, (wword & LEAF_EMIT2) != 0);
         sink.push(leaf.x, leaf.x != 0);
         sink.push(rec + ix.alphabet_offset, (leaf.z & LEAF_EMIT2) != 0);
+        sink.checkpoint(rec, offset, bb);
     }
+}
+
+// One lane per sequence: the number of nodes SequenceIter would yield (src/gbwt.rs:557-568) and the two fingerprints.
+__global__ void __launch_bounds__(256) k_sequence_lengths(DeviceIndex ix, uint32_t *seq_len, uint64_t *prints, uint64_t x_inverse, uint32_t *overflow) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id >= ix.n_sequences) return;
+    CountSink sink(x_inverse);
+    quiet_walk(ix, id, sink, overflow);
     seq_len[id] = sink.wr;
     prints[2 * id] = sink.fwd; prints[2 * id + 1] = sink.rev;
+}
+
+// Sequence samples: sample 0 = the position after the start node, sample j = the first position at which at least
+// j * interval nodes have been emitted (an iteration emits at most four, so no boundary is skipped).
+__global__ void __launch_bounds__(256) k_sample_counts(const uint32_t *seq_len, uint64_t n_sequences, uint32_t interval, uint64_t *counts) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id < n_sequences) counts[id] = seq_len[id] == 0 ? 0 : (seq_len[id] - 1) / interval + 1;
+}
+
+struct SampleSink {
+    uint32_t wr = 0, next = 0, interval;
+    uint4 *out;
+    uint64_t written = 0, capacity;
+    __device__ __forceinline__ void push(uint32_t, bool counts) { wr += counts ? 1u : 0u; }
+    __device__ __forceinline__ void checkpoint(uint32_t rec, uint32_t offset, uint32_t bb) {
+        if (wr >= next && written < capacity) { out[written++] = make_uint4(rec, offset, bb, wr); next += interval; }
+    }
+};
+
+__global__ void __launch_bounds__(256) k_record_samples(DeviceIndex ix, const uint64_t *sample_base, uint32_t interval, uint4 *samples, uint32_t *overflow) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id >= ix.n_sequences) return;
+    SampleSink sink;
+    sink.interval = interval;
+    sink.out = samples + sample_base[id];
+    sink.capacity = sample_base[id + 1] - sample_base[id];
+    if (sink.capacity == 0) return;
+    quiet_walk(ix, id, sink, overflow);
+    // a sample that was never reached cannot exist (every boundary lies below the length); keep the table well-formed anyway
+    for (; sink.written < sink.capacity; sink.written++) sink.out[sink.written] = make_uint4(0u, 0u, BLOCK_NONE, sink.wr);
 }
 
 // One lane per path of a bidirectional index: sequence 2k + 1 must be sequence 2k reversed with every node flipped
@@ -1024,9 +1096,12 @@ __global__ void __launch_bounds__(256) k_check_orientation_pairs(const uint32_t 
     if (!good) atomicOr(mismatch, 1u);
 }
 
-__global__ void __launch_bounds__(256) k_gather_lengths(const uint32_t *seq_len, const uint64_t *ids, uint64_t n, uint64_t *lengths) {
+__global__ void __launch_bounds__(256) k_gather_lengths(const uint32_t *seq_len, const uint64_t *ids, uint64_t n, uint64_t *lengths, uint32_t *max_len) {
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (k < n) lengths[k] = seq_len[ids[k]];
+    if (k >= n) return;
+    const uint32_t len = seq_len[ids[k]];
+    lengths[k] = len;
+    atomicMax(max_len, len);
 }
 
 // Wave-cooperative walk (WALK_COOP): lanes 0..P-1 of each wave own one sequence each; long class 1 / 2 records are
@@ -1155,7 +1230,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
     }
     // walking wave + look-ahead helper wave
     if (args.out_nodes != nullptr) {   // lengths known: rows written in place, both ends at once
-        const uint64_t walkers = args.both_ends ? 2 * args.n : args.n;
+        const uint64_t walkers = args.segments ? static_cast<uint64_t>(args.segments) * args.n : (args.both_ends ? 2 * args.n : args.n);
         hipLaunchKernelGGL(k_walk_direct, dim3(grid_for(walkers, p)), dim3(2 * WAVE), 0, stream, ix, args);
         return;
     }
@@ -1173,8 +1248,18 @@ void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d
     if (n_pairs) hipLaunchKernelGGL(k_check_orientation_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, stream, d_seq_len, d_prints, n_pairs, d_mismatch);
 }
 
-void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_gather_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_seq_len, d_ids, n, d_lengths);
+void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_gather_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_seq_len, d_ids, n, d_lengths, d_max_len);
+}
+
+void launch_sample_counts(const uint32_t *d_seq_len, uint64_t n_sequences, uint32_t interval, uint64_t *d_counts, hipStream_t stream) {
+    if (n_sequences) hipLaunchKernelGGL(k_sample_counts, dim3(grid_for(n_sequences, 256)), dim3(256), 0, stream, d_seq_len, n_sequences, interval, d_counts);
+}
+
+void launch_record_samples(const DeviceIndex &ix, const uint64_t *d_sample_base, uint32_t interval, uint4 *d_samples, hipStream_t stream) {
+    if (ix.n_sequences == 0) return;
+    hipLaunchKernelGGL(k_record_samples, dim3(grid_for(ix.n_sequences, 256)), dim3(256), 0, stream, ix, d_sample_base, interval, d_samples,
+                       static_cast<uint32_t *>(nullptr));
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {
