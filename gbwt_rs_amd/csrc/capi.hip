@@ -407,6 +407,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.helper_lanes = 64;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
+            a.helper_naps = 1;
+            if (const char *v = std::getenv("GBWT_HIP_HELPER_NAPS")) a.helper_naps = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
             const char *both = std::getenv("GBWT_HIP_BOTH_ENDS");
             a.both_ends = ix->orientation_pairs && !(both && std::atoi(both) == 0) ? 1u : 0u;

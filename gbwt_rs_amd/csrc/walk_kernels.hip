@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 vdrained[lane] = writer.drained;
             }
             if (done) break;
-            __builtin_amdgcn_s_sleep(4);
+            for (uint32_t nap = 0; nap < a.helper_naps; nap++) __builtin_amdgcn_s_sleep(4);
         }
         return;
     }
