@@ -843,6 +843,22 @@ struct RowWriter {
         }
         drained += RING_FLUSH;
     }
+    // Everything that is staged and can go out in whole 64-byte pieces.  Segments start at arbitrary node counts, so a
+    // front-to-back writer first brings itself to a 64-byte boundary of the row with single stores; from there on every
+    // piece is one aligned cache-line half (unaligned pieces would go out as sixteen 4-byte stores each and reach HBM as
+    // partial lines: 22.7 GB written for 13.3 GB of node ids before this).
+    __device__ __forceinline__ void drain(uint32_t staged) {
+        if (!t.backward) {
+            const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(t.row + drained) >> 2) & (RING_FLUSH - 1));
+            if (mis != 0) {
+                const uint32_t need = RING_FLUSH - mis;
+                if (staged - drained < need) return;
+                for (uint32_t i = 0; i < need; i++) put(drained + i);
+                drained += need;
+            }
+        }
+        while (staged - drained >= RING_FLUSH) chunk();
+    }
 };
 
 // One look-ahead touch from compiler-scheduled code: an LDS-direct load has no register destination, so nothing can be
@@ -901,7 +917,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             seen = stamp;
             if (owner) {
                 const uint32_t staged = vmail[lane].w;
-                while (staged - writer.drained >= RING_FLUSH) writer.chunk();
+                writer.drain(staged);
                 if (done) { for (uint32_t k = writer.drained; k < staged; k++) writer.put(k); }
                 vdrained[lane] = writer.drained;
             }
