@@ -96,7 +96,7 @@ void upload(gbwt_hip_index &ix) {
         if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
         launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
         {
-            uint32_t hops = 3;
+            uint32_t hops = 7;
             if (const char *v = std::getenv("GBWT_HIP_LOOKAHEAD_HOPS")) hops = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             launch_link_lookahead(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), hops, nullptr);
             // two-step walk: composed descriptors + two-step blocks
@@ -407,6 +407,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.helper_lanes = 64;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
+            a.ring_slots = 128;
+            if (const char *v = std::getenv("GBWT_HIP_RING_SLOTS")) { const int r = std::atoi(v); if (r == 32 || r == 64 || r == 128) a.ring_slots = static_cast<uint32_t>(r); }
             a.helper_naps = 1;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_NAPS")) a.helper_naps = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();

@@ -65,6 +65,7 @@ struct WalkArgs {
     uint32_t *out_nodes;       // [offsets[n]] CSR nodes, or null = pool output
     const uint64_t *out_offsets;   // [n + 1]
     uint32_t both_ends;        // 1: walkers n .. 2n-1 walk sequence id ^ 1 for the second half of row k = w - n
+    uint32_t ring_slots;       // k_walk_direct: LDS ring slots per lane (32, 64 or 128)
     uint32_t helper_naps;      // helper wave of k_walk_direct: s_sleep 4 (256 cycles) this many times between polls
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };

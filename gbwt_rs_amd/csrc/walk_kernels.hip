@@ -109,7 +109,6 @@ constexpr uint32_t RING = 64;                // single-step walk: at most 2 node
 constexpr uint32_t RING2 = 128;              // two-step walk: at most 4 nodes per iteration
 constexpr uint32_t RING_FLUSH = 16;
 constexpr uint32_t RING_URGENT = RING - 4;   // the hot loop hands over to the flush code once a lane has more than this waiting
-constexpr uint32_t RING2_URGENT = RING2 - 8;
 static_assert(POOL_BLOCK_NODES % RING_FLUSH == 0, "a block must hold a whole number of flushes");
 
 template <uint32_t SLOTS>
@@ -439,8 +438,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
 //     leaf (a, b): rec = its landing record, offset = its base + rank_b
 //     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
 __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t &rec, uint32_t &offset,
-                                                   uint32_t &bb, uint32_t &wr) {
+                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t &rec,
+                                                   uint32_t &offset, uint32_t &bb, uint32_t &wr) {
 #ifdef GBWT_HIP_CXX_LOOP
     // plain C++ statement of the loop (no pipelining)
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
@@ -465,17 +464,17 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         const uint4 leaf = a ? (b ? L11 : L10) : (b ? L01 : L00);
         const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
         rec = leaf.z & REC_MASK; offset = leaf.y + rank_b; bb = leaf.w;
-        ring[(wr & (RING2 - 1)) * WAVE] = n1;
+        ring[(wr & ring_mask) * WAVE] = n1;
         wr += n1 != 0 ? 1u : 0u;
-        ring[(wr & (RING2 - 1)) * WAVE] = (wword & REC_MASK) + alphabet_offset;
+        ring[(wr & ring_mask) * WAVE] = (wword & REC_MASK) + alphabet_offset;
         wr += (wword & LEAF_EMIT2) ? 1u : 0u;
-        ring[(wr & (RING2 - 1)) * WAVE] = leaf.x;
+        ring[(wr & ring_mask) * WAVE] = leaf.x;
         wr += leaf.x != 0 ? 1u : 0u;
-        ring[(wr & (RING2 - 1)) * WAVE] = rec + alphabet_offset;
+        ring[(wr & ring_mask) * WAVE] = rec + alphabet_offset;
         wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
         mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = wr;
         if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
-        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > RING2_URGENT) != 0) return 0;
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > ring_mask + 1 - 8) != 0) return 0;
     }
 #else
     // The same loop in gfx950 assembly (see walk_hot_loop for the conventions: all lanes run everything, parked lanes sit
@@ -580,25 +579,25 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_cndmask_b32_e32 v43, v115, v119, vcc\n\t"        /* its block base */ \
         "v_add_u32_e32 v42, v113, v107\n\t"                 /* the new offset */ \
         "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
-        "v_and_b32_e32 v92, 0x7f, v44\n\t"                  /* ring slot of the next node */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t"                  /* ring slot of the next node */ \
         "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
         "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
         "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
-        "v_and_b32_e32 v92, 0x7f, v44\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
         "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
         "ds_write_b32 v92, v110\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
-        "v_and_b32_e32 v92, 0x7f, v44\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
         "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
         "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
-        "v_and_b32_e32 v92, 0x7f, v44\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
         "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
         "ds_write_b32 v92, v111\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
@@ -623,14 +622,14 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_mov_b32_e32 %[bb], v43\n\t" \
         "v_mov_b32_e32 %[wr], v44\n\t" \
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
-        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
           "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
           "v64", "v65", "v66", "v67", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
           "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
           "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
-    const uint32_t limit = flushed + RING2_URGENT;
+    const uint32_t limit = flushed + (ring_mask + 1 - 8);   // leave with more than slots - 8 nodes waiting
     if (narrow) { GBWT_WALK2_LOOP(GBWT_WALK2_ISSUE_NARROW) } else { GBWT_WALK2_LOOP(GBWT_WALK2_ISSUE_WIDE) }
 #undef GBWT_WALK2_LOOP
 #undef GBWT_WALK2_ISSUE_NARROW
@@ -721,7 +720,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, rec, offset, bb, sink.wr);
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, RING2 - 1, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) generic_step(ix, sink, rec, offset, bb);
@@ -794,10 +793,10 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
 // Staging only: the walking wave's side of the ring.
 struct StageSink {
     uint32_t *stage;
-    uint32_t wr = 0;
-    __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    uint32_t wr = 0, mask;
+    __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane, uint32_t ring_mask) : stage(lds + lane), mask(ring_mask) {}
     __device__ __forceinline__ void push(uint32_t node, bool counts) {
-        stage[(wr & (RING2 - 1)) * WAVE] = node;
+        stage[(wr & mask) * WAVE] = node;
         wr += counts ? 1u : 0u;
     }
 };
@@ -806,8 +805,8 @@ struct StageSink {
 struct RowWriter {
     const volatile uint32_t *stage;
     RowTarget t;
-    uint32_t drained = 0;
-    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & (RING2 - 1)) * WAVE]; }
+    uint32_t drained = 0, mask = RING2 - 1;
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * WAVE]; }
     __device__ __forceinline__ void put(uint32_t k) {
         if (k >= t.len) return;   // cannot happen in a consistent index; never write outside the row
         if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
@@ -871,7 +870,7 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
 }
 
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
-    __shared__ uint32_t ring_lds[RING2 * WAVE];
+    extern __shared__ uint32_t ring_lds[];   // a.ring_slots * WAVE entries (dynamic: the ring size sets how many workgroups fit a CU)
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
     __shared__ uint32_t drained_pub[WAVE];   // per walking lane: nodes the helper has moved to the row
     __shared__ uint32_t touch_dummy[WAVE];
@@ -887,6 +886,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     const uint64_t walkers = a.segments ? static_cast<uint64_t>(a.segments) * a.n : (a.both_ends ? 2 * a.n : a.n);
     const uint64_t w = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
     const bool owner = lane < a.paths_per_wave && w < walkers;
+    const uint32_t ring_mask = a.ring_slots - 1;
     RowTarget target;
     WalkerStart begin;
     if (owner) {
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t serve = lane % owners;                        // the 64 lanes share the owners' look-ahead slots ...
         const uint32_t spread = (lane << 26) | (1u << 25);           // ... and spread over the target's blocks
         const uint32_t dummy = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(touch_dummy));
-        RowWriter writer{ring_lds + lane, target, 0};
+        RowWriter writer{ring_lds + lane, target, 0, ring_mask};
         uint32_t seen = 0;
         for (;;) {
             const uint32_t done = *vdone;                            // read before the counts: the final count is then complete
@@ -929,7 +929,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
 
     // ---- walking wave
     const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));
-    StageSink sink(ring_lds, lane);
+    StageSink sink(ring_lds, lane, ring_mask);
     uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
     const uint32_t quota = target.share;
     if (owner && a.segments) {
@@ -954,8 +954,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = vdrained[lane];
-        if (__ballot(sink.wr - drained > RING2_URGENT) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, rec, offset, bb, sink.wr);
+        if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) {
@@ -1247,7 +1247,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
     // walking wave + look-ahead helper wave
     if (args.out_nodes != nullptr) {   // lengths known: rows written in place, both ends at once
         const uint64_t walkers = args.segments ? static_cast<uint64_t>(args.segments) * args.n : (args.both_ends ? 2 * args.n : args.n);
-        hipLaunchKernelGGL(k_walk_direct, dim3(grid_for(walkers, p)), dim3(2 * WAVE), 0, stream, ix, args);
+        hipLaunchKernelGGL(k_walk_direct, dim3(grid_for(walkers, p)), dim3(2 * WAVE), args.ring_slots * WAVE * sizeof(uint32_t), stream, ix, args);
         return;
     }
     if (args.mode == WALK_ONE_STEP) { hipLaunchKernelGGL(k_walk_blocks, grid, dim3(2 * WAVE), 0, stream, ix, args); return; }
