@@ -67,6 +67,8 @@ struct WalkArgs {
     uint32_t both_ends;        // 1: walkers n .. 2n-1 walk sequence id ^ 1 for the second half of row k = w - n
     uint32_t ring_slots;       // k_walk_direct: LDS ring slots per lane (32, 64 or 128)
     uint32_t helper_naps;      // helper wave of k_walk_direct: s_sleep 4 (256 cycles) this many times between polls
+    uint32_t row_piece;        // segmented extraction: nodes per cooperative row write (16 = 64 bytes, 32 = 128 bytes; 0 = every lane writes its own row)
+    uint32_t debug;            // measurement switches (never set by the library itself): 1 = k_walk_direct stores no rows
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;

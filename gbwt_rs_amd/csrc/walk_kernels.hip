@@ -790,11 +790,26 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     return s;
 }
 
+// LDS through pointers that say so.  A `volatile uint32_t *` into __shared__ memory is a generic pointer: hipcc turns
+// every access into flat_load / flat_store sc0 sc1, which travel through the vector-memory path (address coalescer,
+// vmcnt AND lgkmcnt) like a global access -- the helper's polling and its sixteen ring reads per 64 bytes written were
+// competing with the walk's own loads for the same unit.  The low 32 bits of a flat LDS address are the LDS offset.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lds_u32_t *lds_ptr(const void *p) { return (lds_u32_t *)static_cast<uintptr_t>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p))); }
+__device__ __forceinline__ uint32_t lds_peek(const lds_u32_t *p) { return *const_cast<const volatile lds_u32_t *>(p); }
+__device__ __forceinline__ void lds_poke(lds_u32_t *p, uint32_t v) { *const_cast<volatile lds_u32_t *>(p) = v; }
+__device__ __forceinline__ u32x4_t lds_peek4(const lds_u32_t *p) {   // one ds_read_b128 (16-byte aligned)
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // Staging only: the walking wave's side of the ring.
 struct StageSink {
-    uint32_t *stage;
+    lds_u32_t *stage;
     uint32_t wr = 0, mask;
-    __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane, uint32_t ring_mask) : stage(lds + lane), mask(ring_mask) {}
+    __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane, uint32_t ring_mask) : stage(lds_ptr(lds + lane)), mask(ring_mask) {}
     __device__ __forceinline__ void push(uint32_t node, bool counts) {
         stage[(wr & mask) * WAVE] = node;
         wr += counts ? 1u : 0u;
@@ -803,12 +818,13 @@ struct StageSink {
 
 // The helper's side: moves staged nodes [drained, upto) of one lane's ring column to the row.
 struct RowWriter {
-    const volatile uint32_t *stage;
+    const lds_u32_t *stage;      // not volatile: the caller puts a compiler barrier between polls, the reads of one piece can then go out together
     RowTarget t;
     uint32_t drained = 0, mask = RING2 - 1;
+    bool dry = false;            // measurement switch (GBWT_HIP_DEBUG_DRY_ROWS): read the ring, store nothing
     __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * WAVE]; }
     __device__ __forceinline__ void put(uint32_t k) {
-        if (k >= t.len) return;   // cannot happen in a consistent index; never write outside the row
+        if (k >= t.len || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row
         if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
     }
     __device__ __forceinline__ void chunk() {   // 16 nodes = 64 bytes
@@ -817,6 +833,7 @@ struct RowWriter {
             uint32_t v[RING_FLUSH];
 #pragma unroll
             for (uint32_t i = 0; i < RING_FLUSH; i++) v[i] = slot(c + i);
+            if (dry) { uint32_t x = 0; for (uint32_t i = 0; i < RING_FLUSH; i++) x ^= v[i]; asm volatile("" :: "v"(x)); drained += RING_FLUSH; return; }
             uint32_t *dst = t.backward ? t.row + (t.len - c - RING_FLUSH) : t.row + c;
             const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
             if (!t.backward) {
@@ -860,6 +877,69 @@ struct RowWriter {
     }
 };
 
+// Cooperative row writes (segmented extraction: front-to-back rows only).  LPR lanes share one row: each moves four
+// nodes of a piece of 4 * LPR nodes, so one store instruction writes WAVE / LPR whole pieces of 16 * LPR contiguous,
+// aligned bytes -- the memory system sees one request per piece instead of one 16-byte request per lane (with every
+// lane writing its own row, a wave's store touched 64 different cache lines with 16 bytes each, four times in a row).
+// A row first brings itself to a piece boundary with single stores (segments start anywhere), the tail goes out the
+// same way once the walk is over.  Row state lives in LDS: `staged` in the mailboxes, `drained` in drained_pub, and the
+// row addresses in row_lo / row_hi / row_len (written by the helper itself before the loop).
+struct CoopRows {
+    const lds_u32_t *ring;       // the whole ring: slot * WAVE + lane
+    const lds_u32_t *mail;       // mailbox[0].x; staged count of row r = word 4 r + 3
+    lds_u32_t *drained;          // drained_pub
+    const lds_u32_t *row_lo, *row_hi, *row_len;
+    uint32_t mask;
+    bool dry;
+};
+
+template <uint32_t LPR>
+__device__ __forceinline__ void coop_drain_group(const CoopRows &c, uint32_t group, uint32_t lane, uint32_t done) {
+    constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
+    const uint32_t r = group * ROWS + lane / LPR, p = lane % LPR;
+    const uint32_t staged = lds_peek(c.mail + 4 * r + 3), drained = lds_peek(c.drained + r);
+    const uint32_t lo = c.row_lo[r], hi = c.row_hi[r], len = c.row_len[r];
+    asm volatile("" ::: "memory");                                   // ring reads stay behind the counts
+    const uint32_t pend = staged - drained;
+    const uint32_t mis = ((lo >> 2) + drained) & (PIECE - 1);        // nodes past the last piece boundary of the row's memory
+    uint32_t n = PIECE - mis;                                        // nodes up to the next boundary
+    if (pend < n) { if (!done || pend == 0) return; n = pend; }      // short pieces only once the walk is over
+    uint32_t *dst = reinterpret_cast<uint32_t *>((static_cast<uint64_t>(hi) << 32) | lo) + drained;
+    const lds_u32_t *col = c.ring + r;
+    if (n == PIECE && static_cast<uint64_t>(drained) + PIECE <= len) {
+        const uint32_t k = drained + 4 * p;
+        const uint32_t v0 = col[((k + 0) & c.mask) * WAVE], v1 = col[((k + 1) & c.mask) * WAVE], v2 = col[((k + 2) & c.mask) * WAVE],
+                       v3 = col[((k + 3) & c.mask) * WAVE];
+        if (!c.dry) reinterpret_cast<uint4 *>(dst)[p] = make_uint4(v0, v1, v2, v3);
+        else asm volatile("" :: "v"(v0 ^ v1 ^ v2 ^ v3));
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t k = p + LPR * i;
+            if (k < n && static_cast<uint64_t>(drained) + k < len && !c.dry) dst[k] = col[((drained + k) & c.mask) * WAVE];   // never outside the row
+        }
+    }
+    if (p == 0) lds_poke(c.drained + r, drained + n);
+}
+
+// One round over the rows that have something to write.  Lane l looks at row l to find them; returns the rows that
+// still hold staged nodes afterwards (as seen before the round).
+template <uint32_t LPR>
+__device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane, uint32_t done) {
+    constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
+    const uint32_t staged = lds_peek(c.mail + 4 * lane + 3), drained = lds_peek(c.drained + lane);
+    const uint32_t pend = staged - drained;
+    const uint32_t mis = ((c.row_lo[lane] >> 2) + drained) & (PIECE - 1);
+    uint64_t todo = __ballot(pend >= PIECE - mis || (done && pend != 0));
+    const uint64_t left = __ballot(pend != 0);
+    while (todo != 0) {                                              // wave-uniform
+        const uint32_t group = static_cast<uint32_t>(__builtin_ctzll(todo)) / ROWS;
+        todo &= ~(((ROWS == 64 ? ~uint64_t(0) : ((uint64_t(1) << ROWS) - 1))) << (group * ROWS));
+        coop_drain_group<LPR>(c, group, lane, done);
+    }
+    return left;
+}
+
 // One look-ahead touch from compiler-scheduled code: an LDS-direct load has no register destination, so nothing can be
 // corrupted by the data arriving late, and nobody ever waits for it.  `lds_dummy` = wave-uniform LDS byte address of a
 // 256-byte scratch area.
@@ -874,6 +954,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
     __shared__ uint32_t drained_pub[WAVE];   // per walking lane: nodes the helper has moved to the row
     __shared__ uint32_t touch_dummy[WAVE];
+    __shared__ uint32_t row_lo[WAVE], row_hi[WAVE], row_len[WAVE];   // cooperative row writes: where row r is (helper's own table)
     __shared__ uint32_t mail_done;
     const uint32_t lane = threadIdx.x % WAVE;
     const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
@@ -893,9 +974,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (a.segments) begin = segment_start(ix, a, w, target);
         else target = row_target(a, w);
     }
-    volatile uint4 *vmail = mailbox;
-    volatile uint32_t *vdrained = drained_pub;
-    volatile uint32_t *vdone = &mail_done;
+    lds_u32_t *const my_mail = lds_ptr(&mailbox[lane]);          // word 3 = nodes staged so far
+    lds_u32_t *const my_drained = lds_ptr(&drained_pub[lane]);
+    lds_u32_t *const done_flag = lds_ptr(&mail_done);
 
     if (helper) {
         // ---- helper wave: look-ahead touches for every slot, row writes for its own lane's column
@@ -903,11 +984,23 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t serve = lane % owners;                        // the 64 lanes share the owners' look-ahead slots ...
         const uint32_t spread = (lane << 26) | (1u << 25);           // ... and spread over the target's blocks
         const uint32_t dummy = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(touch_dummy));
-        RowWriter writer{ring_lds + lane, target, 0, ring_mask};
+        RowWriter writer{lds_ptr(ring_lds + lane), target, 0, ring_mask, (a.debug & 1u) != 0};
+        const lds_u32_t *const served_mail = lds_ptr(&mailbox[serve]);
+        const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
+        const CoopRows rows{lds_ptr(ring_lds), lds_ptr(mailbox), lds_ptr(drained_pub), lds_ptr(row_lo), lds_ptr(row_hi), lds_ptr(row_len),
+                            ring_mask, (a.debug & 1u) != 0};
+        if (piece) {
+            const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
+            lds_poke(lds_ptr(row_lo) + lane, static_cast<uint32_t>(at));
+            lds_poke(lds_ptr(row_hi) + lane, static_cast<uint32_t>(at >> 32));
+            lds_poke(lds_ptr(row_len) + lane, static_cast<uint32_t>(target.len));
+        }
         uint32_t seen = 0;
         for (;;) {
-            const uint32_t done = *vdone;                            // read before the counts: the final count is then complete
-            const uint32_t look_rec = vmail[serve].x, look_base = vmail[serve].y, look_count = vmail[serve].z, stamp = vmail[serve].w;
+            asm volatile("" ::: "memory");                           // the ring and the mailboxes have changed since the last poll
+            const uint32_t done = lds_peek(done_flag);               // read before the counts: the final count is then complete
+            const u32x4_t mail = lds_peek4(served_mail);
+            const uint32_t look_rec = mail.x, look_base = mail.y, look_count = mail.z, stamp = mail.w;
             if (lane < a.helper_lanes && look_rec != 0 && stamp != seen) {
                 const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(look_rec);
                 touch_line(d, dummy);
@@ -915,13 +1008,18 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 touch_line(ix.cblocks + 2 * (static_cast<uint64_t>(look_base) + __umulhi(spread, look_count)), dummy);
             }
             seen = stamp;
-            if (owner) {
-                const uint32_t staged = vmail[lane].w;
+            if (piece) {
+                const uint64_t left = piece == 32 ? coop_drain<8>(rows, lane, done) : coop_drain<4>(rows, lane, done);
+                if (done && left == 0) break;
+                if (done) continue;
+            } else if (owner) {
+                const uint32_t staged = lds_peek(my_mail + 3);
+                asm volatile("" ::: "memory");                       // ring reads stay behind the count
                 writer.drain(staged);
                 if (done) { for (uint32_t k = writer.drained; k < staged; k++) writer.put(k); }
-                vdrained[lane] = writer.drained;
+                lds_poke(my_drained, writer.drained);
             }
-            if (done) break;
+            if (done && !piece) break;
             for (uint32_t nap = 0; nap < a.helper_naps; nap++) __builtin_amdgcn_s_sleep(4);
         }
         return;
@@ -949,11 +1047,11 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
         }
     }
-    vmail[lane].w = sink.wr;
-    const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sink.stage));
+    lds_poke(my_mail + 3, sink.wr);
+    const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring_lds + lane));
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t drained = vdrained[lane];
+        const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
         const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, rec, offset, bb, sink.wr);
         if (slow_exit) {
@@ -962,12 +1060,12 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 generic_step(ix, sink, rec, offset, bb);
                 if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
             }
-            vmail[lane].w = sink.wr;
+            lds_poke(my_mail + 3, sink.wr);
         }
     }
-    vmail[lane].w = sink.wr;
+    lds_poke(my_mail + 3, sink.wr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) *vdone = 1;
+    if (lane == 0) lds_poke(done_flag, 1);
 }
 
 // Arithmetic modulo the Mersenne prime 2^61 - 1 for the order-sensitive fingerprints below.
