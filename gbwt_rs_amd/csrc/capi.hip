@@ -412,9 +412,13 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.helper_naps = 1;
             if (const char *v = std::getenv("GBWT_HIP_HELPER_NAPS")) a.helper_naps = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
+            a.xcd_map = segmented ? 1u : 0u;
+            if (const char *v = std::getenv("GBWT_HIP_XCD_MAP")) a.xcd_map = std::atoi(v) ? 1u : 0u;
+            a.uniform_loop = 1;
+            if (const char *v = std::getenv("GBWT_HIP_UNIFORM_LOOP")) a.uniform_loop = std::atoi(v) ? 1u : 0u;
             a.row_piece = 32;
             if (const char *v = std::getenv("GBWT_HIP_ROW_PIECE")) { const int r = std::atoi(v); if (r == 0 || r == 16 || r == 32) a.row_piece = static_cast<uint32_t>(r); }
-            if (const char *v = std::getenv("GBWT_HIP_DEBUG_DRY_ROWS")) a.debug = std::atoi(v) ? 1u : 0u;   // timing experiments only: rows stay unwritten
+            if (const char *v = std::getenv("GBWT_HIP_DEBUG_DRY_ROWS")) a.debug = static_cast<uint32_t>(std::atoi(v));   // timing experiments only, see WalkArgs::debug   // timing experiments only: rows stay unwritten
             const char *both = std::getenv("GBWT_HIP_BOTH_ENDS");
             a.both_ends = ix->orientation_pairs && !(both && std::atoi(both) == 0) ? 1u : 0u;
             HIP_CHECK(hipEventRecord(ws->ev[0], s));

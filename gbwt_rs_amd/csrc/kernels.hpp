@@ -68,7 +68,10 @@ struct WalkArgs {
     uint32_t ring_slots;       // k_walk_direct: LDS ring slots per lane (32, 64 or 128)
     uint32_t helper_naps;      // helper wave of k_walk_direct: s_sleep 4 (256 cycles) this many times between polls
     uint32_t row_piece;        // segmented extraction: nodes per cooperative row write (16 = 64 bytes, 32 = 128 bytes; 0 = every lane writes its own row)
-    uint32_t debug;            // measurement switches (never set by the library itself): 1 = k_walk_direct stores no rows
+    uint32_t xcd_map;          // k_walk_direct: XCD x (workgroups x, x + 8, ...) takes the x-th eighth of the walkers
+    uint32_t uniform_loop;     // k_walk_direct: try the wave-uniform loop (scalar descriptor fetch) first
+    uint32_t debug;            // measurement switches of k_walk_direct (GBWT_HIP_DEBUG_DRY_ROWS; never set by the library itself; the output is
+                               // wrong with 1 and 2): 1 = no row stores, 2 = all rows written into one 64 MB window, 32 = row groups in row order
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;

@@ -438,8 +438,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
 //     leaf (a, b): rec = its landing record, offset = its base + rank_b
 //     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
 __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t &rec,
-                                                   uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
+                                                   uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
 #ifdef GBWT_HIP_CXX_LOOP
     // plain C++ statement of the loop (no pipelining)
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
@@ -464,13 +464,13 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         const uint4 leaf = a ? (b ? L11 : L10) : (b ? L01 : L00);
         const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
         rec = leaf.z & REC_MASK; offset = leaf.y + rank_b; bb = leaf.w;
-        ring[(wr & ring_mask) * WAVE] = n1;
+        ring[(wr & ring_mask) * ring_stride] = n1;
         wr += n1 != 0 ? 1u : 0u;
-        ring[(wr & ring_mask) * WAVE] = (wword & REC_MASK) + alphabet_offset;
+        ring[(wr & ring_mask) * ring_stride] = (wword & REC_MASK) + alphabet_offset;
         wr += (wword & LEAF_EMIT2) ? 1u : 0u;
-        ring[(wr & ring_mask) * WAVE] = leaf.x;
+        ring[(wr & ring_mask) * ring_stride] = leaf.x;
         wr += leaf.x != 0 ? 1u : 0u;
-        ring[(wr & ring_mask) * WAVE] = rec + alphabet_offset;
+        ring[(wr & ring_mask) * ring_stride] = rec + alphabet_offset;
         wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
         mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = wr;
         if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
@@ -581,24 +581,24 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
         "v_and_b32_e32 v92, %[ringmask], v44\n\t"                  /* ring slot of the next node */ \
         "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
         "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
         "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
         "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
         "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
         "ds_write_b32 v92, v110\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
         "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
         "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
         "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
         "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_lshl_add_u32 v92, v92, 8, %[ring]\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
         "ds_write_b32 v92, v111\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks (both-ends walks) */ \
@@ -622,7 +622,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_mov_b32_e32 %[bb], v43\n\t" \
         "v_mov_b32_e32 %[wr], v44\n\t" \
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
-        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
           "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
@@ -634,6 +634,177 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
 #undef GBWT_WALK2_LOOP
 #undef GBWT_WALK2_ISSUE_NARROW
 #undef GBWT_WALK2_ISSUE_WIDE
+    return reason;
+#endif
+}
+
+// ---- two-step walk, wave-uniform variant ----------------------------------------------------------------------
+// With sixty-four lanes walking, the vector-memory path is what the walk saturates (TA / TD busy 92-95 % of the kernel,
+// profiles/r01_coop_pmc_headline.txt): every lane fetches its own copy of the 104 descriptor bytes, 16 bytes per lane
+// per load instruction.  The walkers of a wave hold the same segment of neighbouring rows, and haplotypes travel
+// together, so very often ALL lanes sit on the same record: then the descriptor is one scalar fetch (s_load, 28 SGPRs)
+// and only the two-step rank block -- the one thing that differs between lanes -- goes through the vector path
+// (28 bytes per lane instead of 132).  gfx9 VALU instructions read at most one SGPR, so instead of v_cndmask the
+// per-lane choices are made by running the same `v_mov / v_add  vgpr, sgpr` under the exec mask of each choice.
+// Same registers and conventions as walk2_hot_loop.  Leaves with reason 2 -- nothing in flight, state intact -- as
+// soon as the lanes are not all on one record (or some are parked); the caller then continues with walk2_hot_loop.
+// SGPRs: s[48:63] F0 F1 L00 L01, s[64:71] L10 L11, s[72:75] look-ahead target, s[76:85] masks, s[88:89] descriptor
+// address, s90 the record.  Only for arrays below 4 GiB (`narrow`).
+__device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                       uint32_t mail_slot, uint32_t drained_addr, uint32_t quota, uint32_t ring_mask,
+                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    return 2;
+#else
+    uint32_t reason;
+    const uint32_t slack = ring_mask + 1 - 8;   // leave with more than slots - 8 nodes waiting in a ring
+    const uint32_t dlo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2)), dhi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2) >> 32);
+#define GBWT_WALK2U_ISSUE(REFRESH)                                                                                \
+    "v_readfirstlane_b32 s78, v40\n\t"                    /* the record of lane 0 */                       \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "s_lshl_b32 s76, s78, 7\n\t"                          /* two-step descriptors are 128 bytes */        \
+    "s_lshr_b32 s77, s78, 25\n\t"                                                                         \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "s_add_u32 s76, s76, %[dlo]\n\t"                                                                      \
+    "s_addc_u32 s77, s77, %[dhi]\n\t"                                                                     \
+    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
+    "v_cmp_ne_u32_e32 vcc, s78, v40\n\t"                  /* lanes on another record */                   \
+    "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* F0, F1, leaf (0, 0), leaf (0, 1) */          \
+    "s_load_dwordx8 s[64:71], s[76:77], 0x40\n\t"         /* leaf (1, 0), leaf (1, 1) */                  \
+    "s_load_dwordx4 s[72:75], s[76:77], 0x60\n\t"         /* look-ahead target */                         \
+    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
+    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */                \
+    REFRESH
+#define GBWT_WALK2U_LEAF(MASK, X, Y, Z, W)                                                                 \
+    MASK "\n\t"                                                                                           \
+    "v_mov_b32_e32 v112, " X "\n\t"                       /* node to emit */                              \
+    "v_add_u32_e32 v42, " Y ", v107\n\t"                  /* the new offset = offset base + rank_b */     \
+    "v_mov_b32_e32 v114, " Z "\n\t"                       /* landing record | flags */                    \
+    "v_mov_b32_e32 v43, " W "\n\t"                        /* its block base */
+#define GBWT_WALK2U_LOOP(REFRESH) \
+    asm volatile( \
+        "v_mov_b32_e32 v40, %[rec]\n\t" \
+        "v_mov_b32_e32 v42, %[offset]\n\t" \
+        "v_mov_b32_e32 v43, %[bb]\n\t" \
+        "v_mov_b32_e32 v44, %[wr]\n\t" \
+        "s_mov_b32 %[reason], 0\n\t" \
+        GBWT_WALK2U_ISSUE(REFRESH) \
+        "s_nop 1\n\t" \
+        "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
+        "s_cmp_eq_u32 s78, 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_loop_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "s_bitcmp1_b32 s52, 30\n\t"                         /* DESC2_SLOW */ \
+        "s_cbranch_scc1 .Lgbwt_walk2u_slow_%=\n\t" \
+        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
+        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
+        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
+        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v101, v81, v98\n\t" \
+        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v101, v97, 0, v101\n\t" \
+        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
+        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
+        "s_mov_b64 s[44:45], vcc\n\t"                       /* a */ \
+        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
+        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
+        "v_mov_b32_e32 v104, s48\n\t"                       /* edge 0: node */ \
+        "v_mov_b32_e32 v105, s52\n\t"                       /*         w_0 | flags */ \
+        "v_add_u32_e32 v103, s49, v99\n\t"                  /*         j = offset base + rank_a: offset in w_a */ \
+        "s_mov_b64 exec, s[44:45]\n\t"                      /* the lanes that take edge 1 */ \
+        "v_mov_b32_e32 v104, s50\n\t" \
+        "v_mov_b32_e32 v105, s53\n\t" \
+        "v_add_u32_e32 v103, s51, v99\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
+        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v101, v101, v83\n\t" \
+        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
+        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
+        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */ \
+        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
+        GBWT_WALK2U_LEAF("s_nor_b64 exec, s[44:45], s[46:47]", "s56", "s57", "s58", "s59")     /* lanes of leaf (0, 0) */ \
+        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[46:47], s[44:45]", "s60", "s61", "s62", "s63")   /*          leaf (0, 1) */ \
+        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[44:45], s[46:47]", "s64", "s65", "s66", "s67")   /*          leaf (1, 0) */ \
+        GBWT_WALK2U_LEAF("s_and_b64 exec, s[44:45], s[46:47]", "s68", "s69", "s70", "s71")     /*          leaf (1, 1) */ \
+        "s_mov_b64 exec, -1\n\t" \
+        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v110\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v111\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_mov_b32_e32 v76, s72\n\t"                        /* mailbox: look-ahead target of the record just left ... */ \
+        "v_mov_b32_e32 v77, s73\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"           /* a walker that has emitted its share parks */ \
+        "v_mov_b32_e32 v78, s74\n\t" \
+        "v_mov_b32_e32 v79, v44\n\t"                        /* ... + nodes staged so far */ \
+        "ds_write_b128 %[mail], v[76:79]\n\t" \
+        "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
+        "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
+        "v_sub_u32_e32 v92, v44, v45\n\t"                   /* nodes waiting in the ring (drained as of the last iteration) */ \
+        GBWT_WALK2U_ISSUE(REFRESH) \
+        "v_cmp_lt_u32_e64 s[46:47], %[slack], v92\n\t"      /* more than slots - 8 of them */ \
+        "s_nop 0\n\t" \
+        "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
+        "s_cmp_eq_u32 s78, 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t"           /* everyone has parked */ \
+        "s_cmp_eq_u64 s[46:47], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_loop_%=\n\t" \
+        "s_branch .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_slow_%=:\n\t" \
+        "s_mov_b32 %[reason], 1\n\t" \
+        "s_branch .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_mixed_%=:\n\t" \
+        "s_mov_b32 %[reason], 2\n\t" \
+        ".Lgbwt_walk2u_out_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "v_mov_b32_e32 %[rec], v40\n\t" \
+        "v_mov_b32_e32 %[offset], v42\n\t" \
+        "v_mov_b32_e32 %[bb], v43\n\t" \
+        "v_mov_b32_e32 %[wr], v44\n\t" \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
+        : [dlo] "s"(dlo), [dhi] "s"(dhi), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [drained] "v"(drained_addr), [slack] "s"(slack), [quota] "v"(quota), \
+          [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), "{s41}"(alphabet_offset) \
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
+          "v40", "v42", "v43", "v44", "v45", "v70", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v90", "v92", "v94", "v95", \
+          "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v114");
+    // the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered
+    // with, it had to leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted
+    // round of loads)
+    GBWT_WALK2U_LOOP("ds_read_b32 v45, %[drained]\n\t")
+#undef GBWT_WALK2U_LOOP
+#undef GBWT_WALK2U_LEAF
+#undef GBWT_WALK2U_ISSUE
     return reason;
 #endif
 }
@@ -720,7 +891,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, RING2 - 1, rec, offset, bb, sink.wr);
+        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, RING2 - 1, WAVE, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) generic_step(ix, sink, rec, offset, bb);
@@ -782,6 +953,7 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     const uint64_t from = j == 0 ? 0 : here.w;                // segment 0 starts with the start node (sample 0 is the state after it)
     const uint64_t to = j + 1 < count ? ix.samples[base + j + 1].w : len;
     t.row = a.out_nodes + a.out_offsets[k] + from;
+    if (a.debug & 2u) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
     t.len = to > from ? to - from : 0;
     t.backward = false;
     t.share = static_cast<uint32_t>(t.len);
@@ -805,13 +977,18 @@ __device__ __forceinline__ u32x4_t lds_peek4(const lds_u32_t *p) {   // one ds_r
     return v;
 }
 
+// k_walk_direct's ring: slot s of lane l at dword s * RING_PITCH + l.  The pitch is 65, not 64, so that the slots of one
+// lane fall into different LDS banks: the cooperative row writes read several slots of the same lane in one
+// instruction (with a pitch of 64 they were all in one bank: 60 % of the LDS cycles of the kernel were bank conflicts).
+constexpr uint32_t RING_PITCH = WAVE + 1;
+
 // Staging only: the walking wave's side of the ring.
 struct StageSink {
     lds_u32_t *stage;
     uint32_t wr = 0, mask;
     __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane, uint32_t ring_mask) : stage(lds_ptr(lds + lane)), mask(ring_mask) {}
     __device__ __forceinline__ void push(uint32_t node, bool counts) {
-        stage[(wr & mask) * WAVE] = node;
+        stage[(wr & mask) * RING_PITCH] = node;
         wr += counts ? 1u : 0u;
     }
 };
@@ -822,7 +999,7 @@ struct RowWriter {
     RowTarget t;
     uint32_t drained = 0, mask = RING2 - 1;
     bool dry = false;            // measurement switch (GBWT_HIP_DEBUG_DRY_ROWS): read the ring, store nothing
-    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * WAVE]; }
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * RING_PITCH]; }
     __device__ __forceinline__ void put(uint32_t k) {
         if (k >= t.len || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row
         if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
@@ -885,10 +1062,11 @@ struct RowWriter {
 // same way once the walk is over.  Row state lives in LDS: `staged` in the mailboxes, `drained` in drained_pub, and the
 // row addresses in row_lo / row_hi / row_len (written by the helper itself before the loop).
 struct CoopRows {
-    const lds_u32_t *ring;       // the whole ring: slot * WAVE + lane
+    const lds_u32_t *ring;       // the whole ring: slot * RING_PITCH + lane
     const lds_u32_t *mail;       // mailbox[0].x; staged count of row r = word 4 r + 3
     lds_u32_t *drained;          // drained_pub
     const lds_u32_t *row_lo, *row_hi, *row_len;
+    const lds_u32_t *order;      // the rows sorted by the phase of their addresses (row_order)
     uint32_t mask;
     bool dry;
 };
@@ -896,7 +1074,7 @@ struct CoopRows {
 template <uint32_t LPR>
 __device__ __forceinline__ void coop_drain_group(const CoopRows &c, uint32_t group, uint32_t lane, uint32_t done) {
     constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
-    const uint32_t r = group * ROWS + lane / LPR, p = lane % LPR;
+    const uint32_t r = c.order[group * ROWS + lane / LPR], p = lane % LPR;
     const uint32_t staged = lds_peek(c.mail + 4 * r + 3), drained = lds_peek(c.drained + r);
     const uint32_t lo = c.row_lo[r], hi = c.row_hi[r], len = c.row_len[r];
     asm volatile("" ::: "memory");                                   // ring reads stay behind the counts
@@ -904,32 +1082,44 @@ __device__ __forceinline__ void coop_drain_group(const CoopRows &c, uint32_t gro
     const uint32_t mis = ((lo >> 2) + drained) & (PIECE - 1);        // nodes past the last piece boundary of the row's memory
     uint32_t n = PIECE - mis;                                        // nodes up to the next boundary
     if (pend < n) { if (!done || pend == 0) return; n = pend; }      // short pieces only once the walk is over
-    uint32_t *dst = reinterpret_cast<uint32_t *>((static_cast<uint64_t>(hi) << 32) | lo) + drained;
+    // a pointer rebuilt from integers is a generic one: say that it is global memory, or the stores become flat_store
+    // (which also count in lgkmcnt, so that every LDS wait of the helper would wait for its row writes as well)
+    typedef __attribute__((address_space(1))) uint32_t global_u32_t;
+    typedef __attribute__((address_space(1))) u32x4_t global_u32x4_t;
+    global_u32_t *dst = (global_u32_t *)((static_cast<uint64_t>(hi) << 32) | lo) + drained;
     const lds_u32_t *col = c.ring + r;
     if (n == PIECE && static_cast<uint64_t>(drained) + PIECE <= len) {
         const uint32_t k = drained + 4 * p;
-        const uint32_t v0 = col[((k + 0) & c.mask) * WAVE], v1 = col[((k + 1) & c.mask) * WAVE], v2 = col[((k + 2) & c.mask) * WAVE],
-                       v3 = col[((k + 3) & c.mask) * WAVE];
-        if (!c.dry) reinterpret_cast<uint4 *>(dst)[p] = make_uint4(v0, v1, v2, v3);
+        const uint32_t v0 = col[((k + 0) & c.mask) * RING_PITCH], v1 = col[((k + 1) & c.mask) * RING_PITCH], v2 = col[((k + 2) & c.mask) * RING_PITCH],
+                       v3 = col[((k + 3) & c.mask) * RING_PITCH];
+        if (!c.dry) {
+            u32x4_t v; v.x = v0; v.y = v1; v.z = v2; v.w = v3;
+            ((global_u32x4_t *)dst)[p] = v;   // (non-temporal stores measure the same)
+        }
         else asm volatile("" :: "v"(v0 ^ v1 ^ v2 ^ v3));
     } else {
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
             const uint32_t k = p + LPR * i;
-            if (k < n && static_cast<uint64_t>(drained) + k < len && !c.dry) dst[k] = col[((drained + k) & c.mask) * WAVE];   // never outside the row
+            if (k < n && static_cast<uint64_t>(drained) + k < len && !c.dry) dst[k] = col[((drained + k) & c.mask) * RING_PITCH];   // never outside the row
         }
     }
     if (p == 0) lds_poke(c.drained + r, drained + n);
 }
 
-// One round over the rows that have something to write.  Lane l looks at row l to find them; returns the rows that
-// still hold staged nodes afterwards (as seen before the round).
+// One round over the rows that have something to write.  Lane l looks at row `mine` = order[l] to find them; returns
+// the rows that still hold staged nodes afterwards (as seen before the round).
+//
+// Rows are grouped by the phase of their addresses (row_order): walkers that travel together stage nodes at the same
+// rate, so rows whose memory has the same offset within a piece complete their pieces in the same iteration and
+// one store instruction then carries WAVE / LPR full pieces.  Grouped by row number, the rows of a group had eight
+// different phases, became ready one or two at a time, and the kernel issued 2.2 store instructions per kilobyte.
 template <uint32_t LPR>
-__device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane, uint32_t done) {
+__device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane, uint32_t mine, uint32_t done) {
     constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
-    const uint32_t staged = lds_peek(c.mail + 4 * lane + 3), drained = lds_peek(c.drained + lane);
+    const uint32_t staged = lds_peek(c.mail + 4 * mine + 3), drained = lds_peek(c.drained + mine);
     const uint32_t pend = staged - drained;
-    const uint32_t mis = ((c.row_lo[lane] >> 2) + drained) & (PIECE - 1);
+    const uint32_t mis = ((c.row_lo[mine] >> 2) + drained) & (PIECE - 1);
     uint64_t todo = __ballot(pend >= PIECE - mis || (done && pend != 0));
     const uint64_t left = __ballot(pend != 0);
     while (todo != 0) {                                              // wave-uniform
@@ -950,11 +1140,12 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
 }
 
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
-    extern __shared__ uint32_t ring_lds[];   // a.ring_slots * WAVE entries (dynamic: the ring size sets how many workgroups fit a CU)
+    extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
     __shared__ uint32_t drained_pub[WAVE];   // per walking lane: nodes the helper has moved to the row
     __shared__ uint32_t touch_dummy[WAVE];
     __shared__ uint32_t row_lo[WAVE], row_hi[WAVE], row_len[WAVE];   // cooperative row writes: where row r is (helper's own table)
+    __shared__ uint32_t row_order[WAVE];                             //                         the rows sorted by address phase
     __shared__ uint32_t mail_done;
     const uint32_t lane = threadIdx.x % WAVE;
     const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
@@ -965,7 +1156,13 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     }
     __syncthreads();
     const uint64_t walkers = a.segments ? static_cast<uint64_t>(a.segments) * a.n : (a.both_ends ? 2 * a.n : a.n);
-    const uint64_t w = blockIdx.x * static_cast<uint64_t>(a.paths_per_wave) + lane;
+    // Workgroup i runs on XCD i % 8 (round-robin dispatch), every XCD has an L2 of its own, and the walkers that pass
+    // through the same records at the same time are neighbours in w (the same segment of neighbouring rows).  With
+    // xcd_map the grid is a multiple of 8 and XCD x takes the x-th eighth of the walkers, in order, so that a record is
+    // fetched into ONE L2 instead of all eight.
+    uint64_t group = blockIdx.x;
+    if (a.xcd_map) group = (blockIdx.x % 8u) * static_cast<uint64_t>(gridDim.x / 8u) + blockIdx.x / 8u;
+    const uint64_t w = group * a.paths_per_wave + lane;
     const bool owner = lane < a.paths_per_wave && w < walkers;
     const uint32_t ring_mask = a.ring_slots - 1;
     RowTarget target;
@@ -988,12 +1185,24 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const lds_u32_t *const served_mail = lds_ptr(&mailbox[serve]);
         const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
         const CoopRows rows{lds_ptr(ring_lds), lds_ptr(mailbox), lds_ptr(drained_pub), lds_ptr(row_lo), lds_ptr(row_hi), lds_ptr(row_len),
-                            ring_mask, (a.debug & 1u) != 0};
+                            lds_ptr(row_order), ring_mask, (a.debug & 1u) != 0};
+        uint32_t mine = lane;                                        // the row this lane watches
         if (piece) {
             const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
             lds_poke(lds_ptr(row_lo) + lane, static_cast<uint32_t>(at));
             lds_poke(lds_ptr(row_hi) + lane, static_cast<uint32_t>(at >> 32));
             lds_poke(lds_ptr(row_len) + lane, static_cast<uint32_t>(target.len));
+            // order = the rows sorted by (address phase within a piece, row): rank by counting, once per workgroup
+            const uint32_t phase = (static_cast<uint32_t>(at) >> 2) & (piece - 1);
+            uint32_t rank = 0;
+            for (uint32_t other = 0; other < WAVE; other++) {
+                const uint32_t theirs = (lds_peek(lds_ptr(row_lo) + other) >> 2) & (piece - 1);
+                rank += (theirs < phase || (theirs == phase && other < lane)) ? 1u : 0u;
+            }
+            if (a.debug & 32u) rank = lane;                          // measurement switch: groups of consecutive rows
+            lds_poke(lds_ptr(row_order) + rank, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mine = lds_peek(lds_ptr(row_order) + lane);
         }
         uint32_t seen = 0;
         for (;;) {
@@ -1009,7 +1218,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
             seen = stamp;
             if (piece) {
-                const uint64_t left = piece == 32 ? coop_drain<8>(rows, lane, done) : coop_drain<4>(rows, lane, done);
+                const uint64_t left = piece == 32 ? coop_drain<8>(rows, lane, mine, done) : coop_drain<4>(rows, lane, mine, done);
                 if (done && left == 0) break;
                 if (done) continue;
             } else if (owner) {
@@ -1053,7 +1262,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
-        const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, rec, offset, bb, sink.wr);
+        // all lanes on one record: scalar descriptor fetch; otherwise (or above 4 GiB) every lane fetches its own
+        uint32_t slow_exit = narrow && a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&drained_pub[lane])), quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
+        if (slow_exit == 2) slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
             if (slow) {
@@ -1345,7 +1556,9 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
     // walking wave + look-ahead helper wave
     if (args.out_nodes != nullptr) {   // lengths known: rows written in place, both ends at once
         const uint64_t walkers = args.segments ? static_cast<uint64_t>(args.segments) * args.n : (args.both_ends ? 2 * args.n : args.n);
-        hipLaunchKernelGGL(k_walk_direct, dim3(grid_for(walkers, p)), dim3(2 * WAVE), args.ring_slots * WAVE * sizeof(uint32_t), stream, ix, args);
+        unsigned groups = grid_for(walkers, p);
+        if (args.xcd_map) groups = (groups + 7u) / 8u * 8u;   // whole eighths; the workgroups past the end own nothing
+        hipLaunchKernelGGL(k_walk_direct, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
         return;
     }
     if (args.mode == WALK_ONE_STEP) { hipLaunchKernelGGL(k_walk_blocks, grid, dim3(2 * WAVE), 0, stream, ix, args); return; }
