@@ -189,11 +189,11 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (profiles/*_hbm_traffic.json); it is only quoted when the workload is the one those passes ran.
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_segments_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_uniform_hbm_traffic.json")
         if os.path.exists(tpath) and (args.sites, args.haplotypes, args.model, args.seed) == (333334, 5000, "mosaic", 42):
             tj = json.load(open(tpath))
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_note = "profiles/r01_segments_hbm_traffic.json: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
+            traffic_note = "profiles/r01_uniform_hbm_traffic.json: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
         achieved = b_per_step * steps_done / (walk_avg_ms * 1e-3) / 1e9
         result = {
             "metric": "LF-steps/sec (batched path extract)",
@@ -225,7 +225,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_note": "algorithmic bytes are the reference's access pattern (record header + run scan up to the offset, SURVEY 8d); "
+                             "the rank-block index answers a step without touching them, so this fraction can exceed 1: "
+                             "see traffic / traffic_frac for what the kernel really moves",
                 "traffic": traffic,
+                "traffic_frac": None if traffic is None else traffic / (walk_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic_note": traffic_note,
                 "algorithmic_bytes_per_step": b_per_step,
                 "bytes_sample": f"exact H+P+4 over {sampled_steps} LF-steps of {min(args.bytes_sample, n_paths)} paths, scaled to {steps_done}",

@@ -552,6 +552,61 @@ def test_extraction_output_paths(monkeypatch, env):
     assert np.array_equal(c_off, o_off) and np.array_equal(c_nodes, o_nodes)
 
 
+SEGMENT_ENVS = [{},                                                             # defaults: 4096-node segments, 128-byte row pieces
+                {"GBWT_HIP_SAMPLE_INTERVAL": "8"},                              # the shortest segments there are
+                {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_ROW_PIECE": "16"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "37", "GBWT_HIP_RING_SLOTS": "128"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_UNIFORM_LOOP": "0"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ROW_PIECE": "0"},     # every lane writes its own row
+                {"GBWT_HIP_SAMPLE_INTERVAL": "250", "GBWT_HIP_XCD_MAP": "0"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "1000", "GBWT_HIP_PATHS_PER_WAVE": "13"},
+                {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
+
+
+def _skipping_haplotypes(sites, haplotypes, seed):
+    """Haplotypes over a bubble chain that skip whole stretches of sites: the rows of a wave have different lengths, so
+    walkers of the same segment number sit on different records (non-uniform waves, with uniform stretches in between)."""
+    rng = random.Random(seed)
+    paths = []
+    for h in range(haplotypes):
+        p, site = [], 0
+        while site < sites:
+            p.append(2 * (3 * site + 1))
+            p.append(2 * (3 * site + 2 + (rng.random() < 0.3)))
+            site += 1 if rng.random() < 0.97 else rng.randint(2, 9)
+        paths.append(p if h % 11 else p[:rng.randint(0, len(p))])
+    return paths
+
+
+@pytest.mark.parametrize("env", SEGMENT_ENVS, ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
+def test_segmented_extraction(monkeypatch, env):
+    """Segmented extraction (sequence samples at open, one walker per sample interval of every row, cooperative row
+    writes by the helper wave, wave-uniform loop with scalar descriptor fetch) against the oracle for every knob: rows of
+    every length around the piece and ring sizes, empty rows, duplicates, reverse sequences, lock-step bubble chains
+    (uniform waves), haplotypes that drift apart (mixed waves), and outdegree > 2 (slow records leave the hot loops)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = random.Random(41)
+    lengths = [0, 1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 700, 1001, 4097]
+    paths = [[2 * rng.randint(1, 40) + rng.randint(0, 1) for _ in range(ln)] for ln in lengths]
+    s = S.Synth.from_paths(paths, bidirectional=True)
+    dev = open_synth(s)
+    ids = list(range(s.sequences)) + [5, 5, 28, 43]
+    offsets, nodes = dev.sequences_csr(ids)
+    for k, i in enumerate(ids):
+        exp = paths[i // 2] if i % 2 == 0 else kat.reverse_path(paths[i // 2])
+        assert list(nodes[offsets[k]:offsets[k + 1]]) == exp, (i, env)
+    cases = [S.Synth.chain(sites=900, haplotypes=200, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.02, seed=23),
+             S.Synth.chain(sites=300, haplotypes=130, alleles=5, model=S.IID, zipf=0.5, seed=24),
+             S.Synth.from_paths(_skipping_haplotypes(400, 150, 25), bidirectional=True)]
+    for c in cases:
+        cdev, coracle = open_synth(c), oracle_of(c)
+        for cids in (np.arange(0, c.sequences, dtype=np.uint64), np.arange(0, c.sequences, 2, dtype=np.uint64)[::-1].copy()):
+            o_off, o_nodes = coracle.extract(cids, threads=4)
+            c_off, c_nodes = cdev.sequences_csr(cids)
+            assert np.array_equal(c_off, o_off) and np.array_equal(c_nodes, o_nodes), env
+
+
 def test_two_step_walk_with_64_bit_addresses(monkeypatch):
     """The two-step loop has two addressing variants (SGPR base + 32-bit offsets below 4 GiB, 64-bit addresses above);
     GBWT_HIP_WIDE_ADDRESSES forces the second one, which no test index is large enough to need."""
