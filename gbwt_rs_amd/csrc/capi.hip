@@ -183,7 +183,7 @@ void upload(gbwt_hip_index &ix) {
             ix.orientation_pairs = h.bidirectional && h.sequences % 2 == 0 && !flags[2];
             // Sequence samples: where every sequence is about every `interval` nodes (second walk), so that extractions
             // can fill a row with many walkers at once.  GBWT_HIP_SAMPLE_INTERVAL=0 switches them off.
-            uint32_t interval = 4096;
+            uint32_t interval = 2048;   // 16 bytes per 2 048 nodes; 1 024 .. 4 096 measure within 3 % of each other
             if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             if (interval >= 8) {
                 DeviceBuffer counts, scan_tmp;
@@ -409,7 +409,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
             a.ring_slots = segmented ? 64 : 128;   // many walkers: smaller rings, more workgroups per CU (7.4 vs 8.1 ms on the headline)
             if (const char *v = std::getenv("GBWT_HIP_RING_SLOTS")) { const int r = std::atoi(v); if (r == 32 || r == 64 || r == 128) a.ring_slots = static_cast<uint32_t>(r); }
-            a.helper_naps = 1;
+            a.helper_naps = segmented ? 6u : 1u;   // many walkers per CU: a helper that polls less leaves more issue slots and LDS cycles to them
             if (const char *v = std::getenv("GBWT_HIP_HELPER_NAPS")) a.helper_naps = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
             a.xcd_map = segmented ? 1u : 0u;

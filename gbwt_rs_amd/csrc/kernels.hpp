@@ -71,7 +71,8 @@ struct WalkArgs {
     uint32_t xcd_map;          // k_walk_direct: XCD x (workgroups x, x + 8, ...) takes the x-th eighth of the walkers
     uint32_t uniform_loop;     // k_walk_direct: try the wave-uniform loop (scalar descriptor fetch) first
     uint32_t debug;            // measurement switches of k_walk_direct (GBWT_HIP_DEBUG_DRY_ROWS; never set by the library itself; the output is
-                               // wrong with 1 and 2): 1 = no row stores, 2 = all rows written into one 64 MB window, 32 = row groups in row order
+                               // wrong with 1, 2 and 128): 1 = no row stores, 2 = all rows written into one 64 MB window, 128 = into 1 MB, 4 = plain
+                               // instead of non-temporal row stores, 32 = row groups in row order
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;

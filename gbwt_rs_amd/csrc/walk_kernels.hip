@@ -954,6 +954,7 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     const uint64_t to = j + 1 < count ? ix.samples[base + j + 1].w : len;
     t.row = a.out_nodes + a.out_offsets[k] + from;
     if (a.debug & 2u) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
+    if (a.debug & 128u) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
     t.len = to > from ? to - from : 0;
     t.backward = false;
     t.share = static_cast<uint32_t>(t.len);
@@ -1069,6 +1070,7 @@ struct CoopRows {
     const lds_u32_t *order;      // the rows sorted by the phase of their addresses (row_order)
     uint32_t mask;
     bool dry;
+    bool plain_stores;           // row pieces as ordinary stores instead of non-temporal ones (measurement switch)
 };
 
 template <uint32_t LPR>
@@ -1094,7 +1096,13 @@ __device__ __forceinline__ void coop_drain_group(const CoopRows &c, uint32_t gro
                        v3 = col[((k + 3) & c.mask) * RING_PITCH];
         if (!c.dry) {
             u32x4_t v; v.x = v0; v.y = v1; v.z = v2; v.w = v3;
-            ((global_u32x4_t *)dst)[p] = v;   // (non-temporal stores measure the same)
+            global_u32x4_t *at = (global_u32x4_t *)dst + p;
+            // Rows are written once and never read by this kernel: as plain stores they fill the L2s with dirty lines whose
+            // write-back gets in the way of the walk's own traffic (6.9 ms per headline pass; 4.1 ms when all rows are
+            // aimed at one megabyte that never leaves the L2s).  Non-temporal stores stream out: 5.1 ms.  Measured with
+            // every sc0 / sc1 / nt combination: nt and nt sc0 are equal, nt sc0 sc1 is halfway, the others change nothing.
+            if (c.plain_stores) *at = v;
+            else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(v) : "memory");
         }
         else asm volatile("" :: "v"(v0 ^ v1 ^ v2 ^ v3));
     } else {
@@ -1185,7 +1193,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const lds_u32_t *const served_mail = lds_ptr(&mailbox[serve]);
         const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
         const CoopRows rows{lds_ptr(ring_lds), lds_ptr(mailbox), lds_ptr(drained_pub), lds_ptr(row_lo), lds_ptr(row_hi), lds_ptr(row_len),
-                            lds_ptr(row_order), ring_mask, (a.debug & 1u) != 0};
+                            lds_ptr(row_order), ring_mask, (a.debug & 1u) != 0, (a.debug & 4u) != 0};
         uint32_t mine = lane;                                        // the row this lane watches
         if (piece) {
             const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
