@@ -183,7 +183,12 @@ void upload(gbwt_hip_index &ix) {
             ix.orientation_pairs = h.bidirectional && h.sequences % 2 == 0 && !flags[2];
             // Sequence samples: where every sequence is about every `interval` nodes (second walk), so that extractions
             // can fill a row with many walkers at once.  GBWT_HIP_SAMPLE_INTERVAL=0 switches them off.
-            uint32_t interval = 2048;   // 16 bytes per 2 048 nodes; 1 024 .. 4 096 measure within 3 % of each other
+            // 16 bytes per sample.  Large indexes: every 2 048 nodes (1 024 .. 4 096 measure within 3 % of each other on the
+            // headline); smaller ones get shorter intervals, down to 64 nodes, so that an extraction still has enough
+            // walkers to fill the GPU -- about four million samples per index at most.
+            const uint64_t all_nodes = h.size >= h.sequences ? h.size - h.sequences : 0;
+            uint32_t interval = 64;
+            while (interval < 2048 && (all_nodes >> 22) > interval) interval *= 2;
             if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             if (interval >= 8) {
                 DeviceBuffer counts, scan_tmp;
