@@ -111,6 +111,7 @@ void upload(gbwt_hip_index &ix) {
         }
         // LF tables for the class 0 records, while they fit the budget
         d.tables = nullptr;
+        d.wtables = nullptr;
         if (n_records > 0) {
             DeviceBuffer positions, sigmas, table_base, edge_base, edges;
             positions.reserve(n_records * sizeof(uint64_t)); sigmas.reserve(n_records * sizeof(uint64_t));
@@ -133,6 +134,15 @@ void upload(gbwt_hip_index &ix) {
                                    edges.as<uint2>(), nullptr);
                 HIP_CHECK(hipDeviceSynchronize());
                 HIP_CHECK(hipGetLastError());
+                // walk tables next to them while both fit (GBWT_HIP_WALK_TABLES=0: walks take one plain table step at a time)
+                const char *wt = std::getenv("GBWT_HIP_WALK_TABLES");
+                if (2 * total_positions * sizeof(uint4) <= budget && n_records <= 0x7FFFFFFFull && !(wt && std::atoi(wt) == 0)) {
+                    ix.wtables.reserve(total_positions * sizeof(uint4));
+                    launch_fill_wtables(d, ix.wtables.as<uint4>(), nullptr);
+                    HIP_CHECK(hipDeviceSynchronize());
+                    HIP_CHECK(hipGetLastError());
+                    d.wtables = ix.wtables.as<uint4>();
+                }
             }
         }
         HIP_CHECK(hipDeviceSynchronize());

@@ -34,6 +34,8 @@ void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t 
 void launch_table_counts(const DeviceIndex &ix, uint64_t *d_positions, uint64_t *d_sigmas, hipStream_t stream);
 void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t *d_table_base, const uint64_t *d_edge_base, uint4 *d_tables,
                         uint2 *d_edges, hipStream_t stream);
+// walk tables: the LF tables with the step through a unary successor and the landing record's base folded in (after fill_tables)
+void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t stream);
 // two-step walk (device_index.hpp): composed descriptors, two-step rank blocks, look-ahead targets
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream);
 void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream);

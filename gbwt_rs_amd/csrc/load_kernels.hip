@@ -258,6 +258,47 @@ __global__ void __launch_bounds__(64) k_fill_tables(DeviceIndex ix, uint4 *desc_
     desc_raw[4 * rec + 2] = C;
 }
 
+// Walk tables (DeviceIndex::wtables): the LF tables with what a WALK does next folded in, one block per table record.
+// Entry i of record v starts from the plain entry (successor n_u, offset y, landing record u):
+//  * u unary, not the end of the sequence, and the record w behind it exists with o0(u) + y < Record::len(w): the step
+//    through u is taken here -- emit n_u and the node of w, land on w at o0(u) + y (LEAF_EMIT2), exactly the two
+//    SequenceIter steps of the reference (src/gbwt.rs:557-568, src/bwt.rs:480-496 with outdegree 1: every position maps
+//    to (n0, o0 + i));
+//  * otherwise the plain step: emit n_u, land on u (0 = the walk ends behind n_u).
+// Either way word 3 is what the walk needs to go on without another lookup: the table base of the landing record when
+// that is a table record itself (WT_TABLE; the offset has been checked against its length, src/bwt.rs:481), else its
+// block base.  A chain of multi-allelic sites is then one 16-byte load per site.
+__global__ void __launch_bounds__(256) k_fill_wtables(DeviceIndex ix, uint4 *wtables) {
+    const uint64_t v = blockIdx.x;
+    if (v >= ix.n_records) return;
+    const uint4 *raw = ix.desc_raw;
+    const uint4 C = raw[4 * v + 2];
+    if (C.w != 1u) return;
+    for (uint32_t i = threadIdx.x; i < C.y; i += blockDim.x) {
+        const uint4 e = ix.tables[static_cast<uint64_t>(C.z) + i];
+        uint4 out = make_uint4(e.x, e.y, 0u, BLOCK_NONE);
+        uint64_t land = e.z;
+        uint32_t offset = e.y, flags = 0;
+        if (land != 0) {
+            const uint4 UA = raw[4 * land], UB = raw[4 * land + 1];
+            uint64_t w = 0;
+            if (UB.y == DESC_UNARY && UA.x != 0 && landing_record(ix, UA.x, w) && static_cast<uint64_t>(UA.y) + e.y <= 0xFFFFFFFFull) {
+                const uint4 WB = raw[4 * w + 1], WC = raw[4 * w + 2];
+                const uint64_t wlen = WB.y == 0 ? 0 : (desc_class(WB.z) == 0 ? (WC.w == 1u ? WC.y : 0) : WB.w);   // class 0 without a table: not taken here
+                if (static_cast<uint64_t>(UA.y) + e.y < wlen) { land = w; offset = UA.y + e.y; flags = LEAF_EMIT2; }
+            }
+            const uint4 LB = raw[4 * land + 1], LC = raw[4 * land + 2];
+            if (LB.y != 0 && desc_class(LB.z) == 0 && LC.w == 1u) {
+                if (offset < LC.y) out = make_uint4(e.x, offset, static_cast<uint32_t>(land) | flags | WT_TABLE, LC.z);
+                else out = make_uint4(e.x, offset, 0u, BLOCK_NONE);          // i >= Record::len -> None: the walk ends behind n_u (never with LEAF_EMIT2: checked above)
+            } else {
+                out = make_uint4(e.x, offset, static_cast<uint32_t>(land) | flags, flags ? ix.block_base[land] : e.w);
+            }
+        }
+        wtables[static_cast<uint64_t>(C.z) + i] = out;
+    }
+}
+
 // ---- two-step walk: descriptors and blocks -----------------------------------------------------------------
 // The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
 // The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
@@ -498,6 +539,11 @@ void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t
                         uint2 *d_edges, hipStream_t stream) {
     if (ix.n_records == 0) return;
     hipLaunchKernelGGL(k_fill_tables, dim3(grid_for(ix.n_records, 64)), dim3(64), 0, stream, ix, d_desc_raw, d_table_base, d_edge_base, d_tables, d_edges);
+}
+
+void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t stream) {
+    if (ix.n_records == 0 || ix.n_records > 0x7FFFFFFFull) return;
+    hipLaunchKernelGGL(k_fill_wtables, dim3(static_cast<unsigned>(ix.n_records)), dim3(256), 0, stream, ix, d_wtables);
 }
 
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream) {

@@ -1274,8 +1274,35 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         uint32_t slow_exit = narrow && a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&drained_pub[lane])), quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
         if (slow_exit == 2) slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
         if (slow_exit) {
-            const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
-            if (slow) {
+            bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;   // lanes on a slow record
+            if (ix.wtables != nullptr) {
+                // Lanes on a table record walk on the walk tables: one 16-byte entry per step says what to emit (the
+                // successor and, where a unary record follows, the node behind it), where the walk lands and -- when that
+                // is a table record again -- where its table is, so a chain of multi-allelic sites never goes back to the
+                // hot loops.  The others wait; the loop ends when fewer than half of the walking lanes are still in it.
+                bool in_table = false;
+                uint32_t tb = 0;
+                if (generic) {
+                    const uint4 C = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 2];
+                    if (C.w == 1u && offset < C.y) { in_table = true; tb = C.z; generic = false; }   // offset >= Record::len: generic_step ends the walk (src/bwt.rs:481)
+                }
+                while (__ballot(in_table) != 0) {
+                    if (in_table) {
+                        const uint4 e = ix.wtables[static_cast<uint64_t>(tb) + offset];
+                        sink.push(e.x, e.x != 0);
+                        sink.push((e.z & REC_MASK) + ix.alphabet_offset, (e.z & LEAF_EMIT2) != 0);
+                        rec = e.z & REC_MASK; offset = e.y;
+                        if (e.z & WT_TABLE) tb = e.w; else { bb = e.w; in_table = false; }
+                        if (rec == 0 || sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; in_table = false; }
+                    }
+                    lds_poke(my_mail + 3, sink.wr);
+                    const uint64_t still = __ballot(in_table);
+                    if (2 * __popcll(still) < __popcll(__ballot(rec != 0))) break;
+                    if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - 8) != 0) break;   // ring full: the outer loop waits for the helper
+                }
+                if (in_table) bb = BLOCK_NONE;     // left on a table record (it has no blocks): back here after the next look at the ring
+            }
+            if (generic) {   // no table (or no walk tables at all): one step of the generic decoder with all the reference's tests
                 generic_step(ix, sink, rec, offset, bb);
                 if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
             }
