@@ -189,11 +189,11 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (profiles/*_hbm_traffic.json); it is only quoted when the workload is the one those passes ran.
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_nt_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
         if os.path.exists(tpath) and (args.sites, args.haplotypes, args.model, args.seed) == (333334, 5000, "mosaic", 42):
             tj = json.load(open(tpath))
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_note = "profiles/r01_nt_hbm_traffic.json: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
+            traffic_note = "profiles/r01_final_hbm_traffic.json: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
         achieved = b_per_step * steps_done / (walk_avg_ms * 1e-3) / 1e9
         result = {
             "metric": "LF-steps/sec (batched path extract)",

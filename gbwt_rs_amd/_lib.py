@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgbwt_hip.so")
+LIB_PATH = os.environ.get("GBWT_HIP_LIB") or os.path.join(CSRC, "libgbwt_hip.so")   # GBWT_HIP_LIB: A/B runs of two builds (tools/)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "gbwt_hip.h")
 
 OK, INVALID_DATA, IO_ERROR, BAD_ARGUMENT, NO_DEVICE, DEVICE_ERROR, CAPACITY, UNSUPPORTED = range(8)
