@@ -608,6 +608,53 @@ def test_segmented_extraction(monkeypatch, env):
             assert np.array_equal(c_off, o_off) and np.array_equal(c_nodes, o_nodes), env
 
 
+def _layered_paths(layers, haplotypes, seed):
+    """Paths over a layered graph with layers 1 .. 6 nodes wide, some layers skipped by some haplotypes: outdegrees from 1
+    to 12, table records followed directly by table records, by unary records and by outdegree-2 records."""
+    rng = random.Random(seed)
+    widths = [rng.choice((1, 1, 2, 2, 3, 5, 6)) for _ in range(layers)]
+    first = [1]
+    for w in widths:
+        first.append(first[-1] + w)
+    paths = []
+    for h in range(haplotypes):
+        p = []
+        for layer, w in enumerate(widths):
+            if rng.random() < 0.05:
+                continue
+            node = first[layer] + min(w - 1, int(rng.random() ** 2 * w))
+            p.append(2 * node + (rng.random() < 0.02))
+        paths.append(p if h % 13 else p[:rng.randint(0, len(p))])
+    return paths
+
+
+@pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "9", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
+                                 {"GBWT_HIP_WALK_TABLES": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_DIRECT": "0"}],
+                         ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
+def test_walk_tables(monkeypatch, env):
+    """Walks over records with outdegree > 2 (walk tables: the plain LF entry with the step through a unary successor and
+    the landing record's table / block base folded in) in a graph where table records are followed by every kind of
+    record, with segment boundaries of every phase (a boundary can fall between the two nodes of a fused entry), against
+    the oracle; forward() on the same index still answers with the plain tables."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for seed, (layers, haplotypes) in enumerate([(60, 90), (300, 200), (37, 1500)]):
+        paths = _layered_paths(layers, haplotypes, 50 + seed)
+        s = S.Synth.from_paths(paths, bidirectional=True)
+        dev, oracle = open_synth(s), oracle_of(s)
+        assert dev.stats.max_outdegree > 2
+        ids = np.arange(0, s.sequences, dtype=np.uint64)
+        o_off, o_nodes = oracle.extract(ids, threads=4)
+        offsets, nodes = dev.sequences_csr(ids)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes), (env, seed)
+        some = np.array([rng_id for rng_id in random.Random(seed).sample(range(s.sequences), min(29, s.sequences))], dtype=np.uint64)
+        o_off, o_nodes = oracle.extract(some)
+        offsets, nodes = dev.sequences_csr(some)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes), (env, seed)
+        if seed == 0:
+            check_all_positions(dev, oracle)
+
+
 def test_two_step_walk_with_64_bit_addresses(monkeypatch):
     """The two-step loop has two addressing variants (SGPR base + 32-bit offsets below 4 GiB, 64-bit addresses above);
     GBWT_HIP_WIDE_ADDRESSES forces the second one, which no test index is large enough to need."""
