@@ -420,6 +420,28 @@ def test_headline_scale_properties():
     assert np.array_equal(r_nodes[r_off[1]:r_off[2]], (s.path(0) ^ 1)[::-1])
 
 
+def test_headline_full_size():
+    """BASELINE's headline index at its full size (5 000 paths x 1 000 002 nodes, 3.33 G LF-steps per pass), checked through
+    what does not need the oracle: every extracted path against the generator's ground truth (per-path checksums reduced
+    on the device, full rows for a few), uniform lengths, total = (size - sequences) / 2, reverse sequences = flipped
+    reversals, and the same answers from a second pass (the extraction is idempotent)."""
+    s = S.Synth.chain(sites=333334, haplotypes=5000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=42)
+    dev = open_synth(s)
+    ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
+    truth = np.array([s.path_checksum(h) for h in range(s.paths)], dtype=np.uint64)
+    for _ in range(2):
+        out = dev.extract_device(ids)
+        assert int(out.total) == (s.size - s.sequences) // 2 == 5000 * 2 * 333334
+        assert np.array_equal(dev.path_sums(s.paths), truth)
+    for h in (0, 1234, 4999):
+        row = dev.copy_path(h)
+        assert len(row) == 2 * s.sites and np.array_equal(row, s.path(h))
+    rev = np.array([2 * 1234 + 1, 1, 2 * 4999 + 1], dtype=np.uint64)
+    dev.extract_device(rev)
+    for k, h in enumerate((1234, 0, 4999)):
+        assert np.array_equal(dev.copy_path(k), (s.path(h) ^ 1)[::-1])
+
+
 # ---------------------------------------------------------------------------------------------
 # kernel variants: results never depend on the tuning
 

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""W-line text of all paths of a synthetic GBZ on one GPU (gbwt_hip_path_lines: extraction + formatting on the device,
+text copied to the host): bytes, wall time of the size query (walk + token widths) and of the full call."""
+import argparse
+import hashlib
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gbwt_rs_amd as G
+from gbwt_rs_amd import synth as S
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sites", type=int, default=20000)
+ap.add_argument("--haplotypes", type=int, default=5000)
+args = ap.parse_args()
+
+s = S.Synth.chain(args.sites, args.haplotypes, alleles=2, model=S.MOSAIC, seed=42)
+path = os.path.join(tempfile.mkdtemp(prefix="gfa_bench_"), "bench.gbz")
+s.save(path, as_gbz=True)
+gbz = G.GBZ.load(path)
+ids = np.arange(gbz.paths(), dtype=np.uint64)
+nodes = (gbz.len() - gbz.sequences()) // 2
+for rep in range(3):
+    t0 = time.perf_counter()
+    text = gbz.path_lines(ids, 1)
+    dt = time.perf_counter() - t0
+    print(f"W-lines of {len(ids)} paths, {nodes} nodes: {len(text)} bytes in {dt * 1e3:.1f} ms = {len(text) / dt / 1e9:.2f} GB/s of text, "
+          f"{nodes / dt / 1e9:.2f} G nodes/s   sha256 {hashlib.sha256(text).hexdigest()[:16]}", flush=True)
+os.remove(path)
