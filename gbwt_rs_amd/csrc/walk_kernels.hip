@@ -649,9 +649,9 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
 // Same registers and conventions as walk2_hot_loop.  Leaves with reason 2 -- nothing in flight, state intact -- as
 // soon as the lanes are not all on one record (or some are parked); the caller then continues with walk2_hot_loop.
 // SGPRs: s[48:63] F0 F1 L00 L01, s[64:71] L10 L11, s[72:75] look-ahead target, s[76:85] masks, s[88:89] descriptor
-// address, s90 the record.  Only for arrays below 4 GiB (`narrow`).
+// address, s78 the record.
 __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                       uint32_t mail_slot, uint32_t drained_addr, uint32_t quota, uint32_t ring_mask,
+                                                       uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
                                                        uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
 #ifdef GBWT_HIP_CXX_LOOP
     return 2;
@@ -659,7 +659,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
     uint32_t reason;
     const uint32_t slack = ring_mask + 1 - 8;   // leave with more than slots - 8 nodes waiting in a ring
     const uint32_t dlo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2)), dhi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2) >> 32);
-#define GBWT_WALK2U_ISSUE(REFRESH)                                                                                \
+#define GBWT_WALK2U_ISSUE(KLOAD, REFRESH)                                                                             \
     "v_readfirstlane_b32 s78, v40\n\t"                    /* the record of lane 0 */                       \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
     "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
@@ -674,23 +674,32 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
     "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* F0, F1, leaf (0, 0), leaf (0, 1) */          \
     "s_load_dwordx8 s[64:71], s[76:77], 0x40\n\t"         /* leaf (1, 0), leaf (1, 1) */                  \
     "s_load_dwordx4 s[72:75], s[76:77], 0x60\n\t"         /* look-ahead target */                         \
-    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
-    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */                \
+    KLOAD                                                                                                 \
     REFRESH
+// K0 = {bits1, bits2}, K1 = {ones1, R0, R1} of the lane's two-step block: SGPR base + 32-bit byte offset while the block
+// array is below 4 GiB, a 64-bit address per lane above
+#define GBWT_WALK2U_KLOAD_NARROW                                                                          \
+    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"                                                   \
+    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"
+#define GBWT_WALK2U_KLOAD_WIDE                                                                            \
+    "v_lshrrev_b32_e32 v91, 27, v70\n\t"                                                                  \
+    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
+    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"                                                     \
+    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"
 #define GBWT_WALK2U_LEAF(MASK, X, Y, Z, W)                                                                 \
     MASK "\n\t"                                                                                           \
     "v_mov_b32_e32 v112, " X "\n\t"                       /* node to emit */                              \
     "v_add_u32_e32 v42, " Y ", v107\n\t"                  /* the new offset = offset base + rank_b */     \
     "v_mov_b32_e32 v114, " Z "\n\t"                       /* landing record | flags */                    \
     "v_mov_b32_e32 v43, " W "\n\t"                        /* its block base */
-#define GBWT_WALK2U_LOOP(REFRESH) \
+#define GBWT_WALK2U_LOOP(KLOAD, REFRESH) \
     asm volatile( \
         "v_mov_b32_e32 v40, %[rec]\n\t" \
         "v_mov_b32_e32 v42, %[offset]\n\t" \
         "v_mov_b32_e32 v43, %[bb]\n\t" \
         "v_mov_b32_e32 v44, %[wr]\n\t" \
         "s_mov_b32 %[reason], 0\n\t" \
-        GBWT_WALK2U_ISSUE(REFRESH) \
+        GBWT_WALK2U_ISSUE(KLOAD, REFRESH) \
         "s_nop 1\n\t" \
         "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
         "s_cmp_eq_u32 s78, 0\n\t" \
@@ -771,7 +780,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
         "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
         "v_sub_u32_e32 v92, v44, v45\n\t"                   /* nodes waiting in the ring (drained as of the last iteration) */ \
-        GBWT_WALK2U_ISSUE(REFRESH) \
+        GBWT_WALK2U_ISSUE(KLOAD, REFRESH) \
         "v_cmp_lt_u32_e64 s[46:47], %[slack], v92\n\t"      /* more than slots - 8 of them */ \
         "s_nop 0\n\t" \
         "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
@@ -796,14 +805,17 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
           [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
-          "v40", "v42", "v43", "v44", "v45", "v70", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v90", "v92", "v94", "v95", \
+          "v40", "v42", "v43", "v44", "v45", "v70", "v91", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v90", "v92", "v94", "v95", \
           "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v114");
     // the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered
     // with, it had to leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted
     // round of loads)
-    GBWT_WALK2U_LOOP("ds_read_b32 v45, %[drained]\n\t")
+    if (narrow) { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_NARROW, "ds_read_b32 v45, %[drained]\n\t") }
+    else { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_WIDE, "ds_read_b32 v45, %[drained]\n\t") }
 #undef GBWT_WALK2U_LOOP
 #undef GBWT_WALK2U_LEAF
+#undef GBWT_WALK2U_KLOAD_WIDE
+#undef GBWT_WALK2U_KLOAD_NARROW
 #undef GBWT_WALK2U_ISSUE
     return reason;
 #endif
@@ -1270,8 +1282,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
-        // all lanes on one record: scalar descriptor fetch; otherwise (or above 4 GiB) every lane fetches its own
-        uint32_t slow_exit = narrow && a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&drained_pub[lane])), quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
+        // all lanes on one record: scalar descriptor fetch; otherwise every lane fetches its own
+        uint32_t slow_exit = a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&drained_pub[lane])), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
         if (slow_exit == 2) slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
         if (slow_exit) {
             bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;   // lanes on a slow record

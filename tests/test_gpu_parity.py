@@ -581,6 +581,7 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_UNIFORM_LOOP": "0"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ROW_PIECE": "0"},     # every lane writes its own row
                 {"GBWT_HIP_SAMPLE_INTERVAL": "250", "GBWT_HIP_XCD_MAP": "0"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "128", "GBWT_HIP_WIDE_ADDRESSES": "1"},   # both loops with 64-bit addresses
                 {"GBWT_HIP_SAMPLE_INTERVAL": "1000", "GBWT_HIP_PATHS_PER_WAVE": "13"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_WALK_TABLES": "0"},   # outdegree > 2: plain table steps, one at a time
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
