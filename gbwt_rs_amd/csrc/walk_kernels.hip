@@ -1072,40 +1072,45 @@ struct RowWriter {
 // aligned bytes -- the memory system sees one request per piece instead of one 16-byte request per lane (with every
 // lane writing its own row, a wave's store touched 64 different cache lines with 16 bytes each, four times in a row).
 // A row first brings itself to a piece boundary with single stores (segments start anywhere), the tail goes out the
-// same way once the walk is over.  Row state lives in LDS: `staged` in the mailboxes, `drained` in drained_pub, and the
-// row addresses in row_lo / row_hi / row_len (written by the helper itself before the loop).
+// same way once the walk is over.  Row state lives in LDS: `staged` in the mailboxes (word 3), and one uint4 per row
+// {address low, address high, length, drained} in row_state -- the helper writes all of it, the walker reads `drained`.
+// A visit costs two LDS round trips (state + count, then the four nodes) and about two dozen VALU instructions: the
+// helper's instructions compete with the walkers' for the same SIMDs (profiles/r01_final_pmc_headline.txt: VALU busy
+// 60 % of the kernel, 134 VALU instructions per walker iteration of which the walker's own are 83).
 struct CoopRows {
-    const lds_u32_t *ring;       // the whole ring: slot * RING_PITCH + lane
-    const lds_u32_t *mail;       // mailbox[0].x; staged count of row r = word 4 r + 3
-    lds_u32_t *drained;          // drained_pub
-    const lds_u32_t *row_lo, *row_hi, *row_len;
-    const lds_u32_t *order;      // the rows sorted by the phase of their addresses (row_order)
+    uint32_t ring;               // LDS byte address of the ring: slot * RING_PITCH + lane (dwords)
+    uint32_t mail;               //                  of mailbox[0]; staged count of row r = word 4 r + 3
+    uint32_t state;              //                  of row_state[0]
     uint32_t mask;
     bool dry;
     bool plain_stores;           // row pieces as ordinary stores instead of non-temporal ones (measurement switch)
+    bool skip_reads;             // measurement switch: nothing is read from the ring or stored
 };
+__device__ __forceinline__ uint32_t lds_word(uint32_t byte_address) { return *(const volatile lds_u32_t *)static_cast<uintptr_t>(byte_address); }
 
+// The lanes that serve row r (lane p of LPR): one piece, or what the rules above allow instead.
 template <uint32_t LPR>
-__device__ __forceinline__ void coop_drain_group(const CoopRows &c, uint32_t group, uint32_t lane, uint32_t done) {
-    constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
-    const uint32_t r = c.order[group * ROWS + lane / LPR], p = lane % LPR;
-    const uint32_t staged = lds_peek(c.mail + 4 * r + 3), drained = lds_peek(c.drained + r);
-    const uint32_t lo = c.row_lo[r], hi = c.row_hi[r], len = c.row_len[r];
-    asm volatile("" ::: "memory");                                   // ring reads stay behind the counts
+__device__ __forceinline__ void coop_visit(const CoopRows &c, uint32_t r, uint32_t p, uint32_t done) {
+    constexpr uint32_t PIECE = 4 * LPR;
+    const uint32_t staged = lds_word(c.mail + 16 * r + 12);
+    const u32x4_t st = lds_peek4((const lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r));   // waits for both
+    const uint32_t drained = st.w, len = st.z;
     const uint32_t pend = staged - drained;
-    const uint32_t mis = ((lo >> 2) + drained) & (PIECE - 1);        // nodes past the last piece boundary of the row's memory
+    const uint32_t mis = ((st.x >> 2) + drained) & (PIECE - 1);      // nodes past the last piece boundary of the row's memory
     uint32_t n = PIECE - mis;                                        // nodes up to the next boundary
     if (pend < n) { if (!done || pend == 0) return; n = pend; }      // short pieces only once the walk is over
+    volatile lds_u32_t *const publish = (volatile lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r + 12);   // only after the nodes have left the ring
+    if (c.skip_reads) { if (p == 0) *publish = drained + n; return; }   // measurement switch: the ring is emptied unread
     // a pointer rebuilt from integers is a generic one: say that it is global memory, or the stores become flat_store
     // (which also count in lgkmcnt, so that every LDS wait of the helper would wait for its row writes as well)
     typedef __attribute__((address_space(1))) uint32_t global_u32_t;
     typedef __attribute__((address_space(1))) u32x4_t global_u32x4_t;
-    global_u32_t *dst = (global_u32_t *)((static_cast<uint64_t>(hi) << 32) | lo) + drained;
-    const lds_u32_t *col = c.ring + r;
-    if (n == PIECE && static_cast<uint64_t>(drained) + PIECE <= len) {
+    global_u32_t *dst = (global_u32_t *)((static_cast<uint64_t>(st.y) << 32) | st.x) + drained;
+    const uint32_t col = c.ring + 4 * r;                             // slot s of the row at col + s * 4 * RING_PITCH (24-bit multiply: LDS is small)
+    if (n == PIECE && drained + PIECE <= len) {
         const uint32_t k = drained + 4 * p;
-        const uint32_t v0 = col[((k + 0) & c.mask) * RING_PITCH], v1 = col[((k + 1) & c.mask) * RING_PITCH], v2 = col[((k + 2) & c.mask) * RING_PITCH],
-                       v3 = col[((k + 3) & c.mask) * RING_PITCH];
+        const uint32_t v0 = lds_word(col + __umul24((k + 0) & c.mask, 4 * RING_PITCH)), v1 = lds_word(col + __umul24((k + 1) & c.mask, 4 * RING_PITCH)),
+                       v2 = lds_word(col + __umul24((k + 2) & c.mask, 4 * RING_PITCH)), v3 = lds_word(col + __umul24((k + 3) & c.mask, 4 * RING_PITCH));
         if (!c.dry) {
             u32x4_t v; v.x = v0; v.y = v1; v.z = v2; v.w = v3;
             global_u32x4_t *at = (global_u32x4_t *)dst + p;
@@ -1121,31 +1126,33 @@ __device__ __forceinline__ void coop_drain_group(const CoopRows &c, uint32_t gro
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
             const uint32_t k = p + LPR * i;
-            if (k < n && static_cast<uint64_t>(drained) + k < len && !c.dry) dst[k] = col[((drained + k) & c.mask) * RING_PITCH];   // never outside the row
+            if (k < n && drained + k < len && !c.dry) dst[k] = lds_word(col + __umul24((drained + k) & c.mask, 4 * RING_PITCH));   // never outside the row
         }
     }
-    if (p == 0) lds_poke(c.drained + r, drained + n);
+    if (p == 0) *publish = drained + n;
 }
 
-// One round over the rows that have something to write.  Lane l looks at row `mine` = order[l] to find them; returns
-// the rows that still hold staged nodes afterwards (as seen before the round).
+// One round over the rows that have something to write.  Lane l looks at row `mine` = order[l] to find them; rows[g] =
+// the row this lane serves in group g (both from the helper's sort of the rows by address phase); returns the rows that
+// still hold staged nodes afterwards (as seen before the round).
 //
-// Rows are grouped by the phase of their addresses (row_order): walkers that travel together stage nodes at the same
-// rate, so rows whose memory has the same offset within a piece complete their pieces in the same iteration and
-// one store instruction then carries WAVE / LPR full pieces.  Grouped by row number, the rows of a group had eight
-// different phases, became ready one or two at a time, and the kernel issued 2.2 store instructions per kilobyte.
+// Rows are grouped by the phase of their addresses: walkers that travel together stage nodes at the same rate, so rows
+// whose memory has the same offset within a piece complete their pieces in the same iteration and one store
+// instruction then carries WAVE / LPR full pieces.  Grouped by row number, the rows of a group had eight different
+// phases, became ready one or two at a time, and the kernel issued 2.2 store instructions per kilobyte.
 template <uint32_t LPR>
-__device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane, uint32_t mine, uint32_t done) {
+__device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane, uint32_t mine, const uint32_t (&rows)[8], uint32_t done) {
     constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
-    const uint32_t staged = lds_peek(c.mail + 4 * mine + 3), drained = lds_peek(c.drained + mine);
-    const uint32_t pend = staged - drained;
-    const uint32_t mis = ((c.row_lo[mine] >> 2) + drained) & (PIECE - 1);
-    uint64_t todo = __ballot(pend >= PIECE - mis || (done && pend != 0));
+    const uint32_t staged = lds_word(c.mail + 16 * mine + 12);
+    const u32x4_t st = lds_peek4((const lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * mine));
+    const uint32_t pend = staged - st.w;
+    const uint32_t mis = ((st.x >> 2) + st.w) & (PIECE - 1);
+    const uint64_t todo = __ballot(pend >= PIECE - mis || (done && pend != 0));
     const uint64_t left = __ballot(pend != 0);
-    while (todo != 0) {                                              // wave-uniform
-        const uint32_t group = static_cast<uint32_t>(__builtin_ctzll(todo)) / ROWS;
-        todo &= ~(((ROWS == 64 ? ~uint64_t(0) : ((uint64_t(1) << ROWS) - 1))) << (group * ROWS));
-        coop_drain_group<LPR>(c, group, lane, done);
+    if (todo != 0) {
+#pragma unroll
+        for (uint32_t g = 0; g < LPR; g++)                           // wave-uniform tests; rows[g] stays in a register
+            if (((todo >> (g * ROWS)) & ((uint64_t(1) << ROWS) - 1)) != 0) coop_visit<LPR>(c, rows[g], lane % LPR, done);
     }
     return left;
 }
@@ -1162,16 +1169,15 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
     extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
-    __shared__ uint32_t drained_pub[WAVE];   // per walking lane: nodes the helper has moved to the row
+    __shared__ uint4 row_state[WAVE];        // per walking lane: {row address low, high, length (cooperative row writes), nodes the helper has moved to the row}
     __shared__ uint32_t touch_dummy[WAVE];
-    __shared__ uint32_t row_lo[WAVE], row_hi[WAVE], row_len[WAVE];   // cooperative row writes: where row r is (helper's own table)
-    __shared__ uint32_t row_order[WAVE];                             //                         the rows sorted by address phase
+    __shared__ uint32_t row_order[WAVE];     // cooperative row writes: the rows sorted by address phase (helper's own table)
     __shared__ uint32_t mail_done;
     const uint32_t lane = threadIdx.x % WAVE;
     const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
     if (!helper) {
         mailbox[lane] = make_uint4(0, 0, 0, 0);
-        drained_pub[lane] = 0;
+        row_state[lane] = make_uint4(0, 0, 0, 0);
         if (lane == 0) mail_done = 0;
     }
     __syncthreads();
@@ -1192,7 +1198,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         else target = row_target(a, w);
     }
     lds_u32_t *const my_mail = lds_ptr(&mailbox[lane]);          // word 3 = nodes staged so far
-    lds_u32_t *const my_drained = lds_ptr(&drained_pub[lane]);
+    lds_u32_t *const my_drained = lds_ptr(&row_state[lane].w);
     lds_u32_t *const done_flag = lds_ptr(&mail_done);
 
     if (helper) {
@@ -1204,25 +1210,30 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         RowWriter writer{lds_ptr(ring_lds + lane), target, 0, ring_mask, (a.debug & 1u) != 0};
         const lds_u32_t *const served_mail = lds_ptr(&mailbox[serve]);
         const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
-        const CoopRows rows{lds_ptr(ring_lds), lds_ptr(mailbox), lds_ptr(drained_pub), lds_ptr(row_lo), lds_ptr(row_hi), lds_ptr(row_len),
-                            lds_ptr(row_order), ring_mask, (a.debug & 1u) != 0, (a.debug & 4u) != 0};
+        const auto lds_address = [](const void *q) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(q)); };
+        const CoopRows rows{lds_address(ring_lds), lds_address(mailbox), lds_address(row_state), ring_mask, (a.debug & 1u) != 0, (a.debug & 4u) != 0,
+                            (a.debug & 64u) != 0};
         uint32_t mine = lane;                                        // the row this lane watches
+        uint32_t served[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // the row this lane serves in group g
         if (piece) {
             const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
-            lds_poke(lds_ptr(row_lo) + lane, static_cast<uint32_t>(at));
-            lds_poke(lds_ptr(row_hi) + lane, static_cast<uint32_t>(at >> 32));
-            lds_poke(lds_ptr(row_len) + lane, static_cast<uint32_t>(target.len));
+            lds_poke(lds_ptr(&row_state[lane].x), static_cast<uint32_t>(at));
+            lds_poke(lds_ptr(&row_state[lane].y), static_cast<uint32_t>(at >> 32));
+            lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0xFFFFFFF0u)));
             // order = the rows sorted by (address phase within a piece, row): rank by counting, once per workgroup
             const uint32_t phase = (static_cast<uint32_t>(at) >> 2) & (piece - 1);
             uint32_t rank = 0;
             for (uint32_t other = 0; other < WAVE; other++) {
-                const uint32_t theirs = (lds_peek(lds_ptr(row_lo) + other) >> 2) & (piece - 1);
+                const uint32_t theirs = (lds_peek(lds_ptr(&row_state[other].x)) >> 2) & (piece - 1);
                 rank += (theirs < phase || (theirs == phase && other < lane)) ? 1u : 0u;
             }
             if (a.debug & 32u) rank = lane;                          // measurement switch: groups of consecutive rows
             lds_poke(lds_ptr(row_order) + rank, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             mine = lds_peek(lds_ptr(row_order) + lane);
+            const uint32_t lanes_per_row = piece / 4, rows_per_group = WAVE / lanes_per_row;
+#pragma unroll
+            for (uint32_t g = 0; g < 8; g++) served[g] = g < lanes_per_row ? lds_peek(lds_ptr(row_order) + g * rows_per_group + lane / lanes_per_row) : 0u;
         }
         uint32_t seen = 0;
         for (;;) {
@@ -1238,7 +1249,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
             seen = stamp;
             if (piece) {
-                const uint64_t left = piece == 32 ? coop_drain<8>(rows, lane, mine, done) : coop_drain<4>(rows, lane, mine, done);
+                const uint64_t left = piece == 32 ? coop_drain<8>(rows, lane, mine, served, done) : coop_drain<4>(rows, lane, mine, served, done);
                 if (done && left == 0) break;
                 if (done) continue;
             } else if (owner) {
@@ -1283,7 +1294,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
         // all lanes on one record: scalar descriptor fetch; otherwise every lane fetches its own
-        uint32_t slow_exit = a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&drained_pub[lane])), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
+        uint32_t slow_exit = a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
         if (slow_exit == 2) slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
         if (slow_exit) {
             bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;   // lanes on a slow record
