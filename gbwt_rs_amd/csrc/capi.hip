@@ -178,29 +178,35 @@ void upload(gbwt_hip_index &ix) {
     const char *want_len = std::getenv("GBWT_HIP_SEQ_LEN");
     if (h.sequences > 0 && !(want_len && std::atoi(want_len) == 0)) {
         ix.seq_len.reserve(h.sequences * sizeof(uint32_t));
+        // 16 bytes per sample.  Large indexes: every 2 048 nodes (1 024 .. 4 096 measure within 3 % of each other on the
+        // headline); smaller ones get shorter intervals, down to 64 nodes, so that an extraction still has enough
+        // walkers to fill the GPU -- about four million samples per index at most.  GBWT_HIP_SAMPLE_INTERVAL=0: none.
+        const uint64_t all_nodes = h.size >= h.sequences ? h.size - h.sequences : 0;
+        uint32_t interval = 64;
+        while (interval < 2048 && (all_nodes >> 22) > interval) interval *= 2;
+        if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+        const bool sampled = interval >= 8;
+        // Without samples an extraction fills every row from both ends, which needs the proof that sequence 2k + 1 is
+        // sequence 2k reversed (fingerprints); with samples nothing does, and the counting walk is twice as fast
+        // without them (0.42 -> 0.19 s on the headline index).  GBWT_HIP_ORIENTATION_CHECK=1 forces the proof.
+        const char *force = std::getenv("GBWT_HIP_ORIENTATION_CHECK");
+        const bool want_pairs = h.bidirectional && h.sequences % 2 == 0 && (!sampled || (force && std::atoi(force) != 0));
         DeviceBuffer prints;
-        prints.reserve(h.sequences * 2 * sizeof(uint64_t));
+        if (want_pairs) prints.reserve(h.sequences * 2 * sizeof(uint64_t));
         HIP_CHECK(hipMemset(d_stats, 0, 2 * sizeof(uint64_t)));
         uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_stats);   // [0] = a length overflowed, [2] = a pair does not match
-        launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), d_flags, nullptr);
-        if (h.bidirectional && h.sequences % 2 == 0)
+        launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), want_pairs ? prints.as<uint64_t>() : nullptr, d_flags, nullptr);
+        if (want_pairs)
             launch_check_orientation_pairs(ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), h.sequences / 2, d_flags + 2, nullptr);
         uint32_t flags[4] = {0, 0, 0, 0};
         HIP_CHECK(hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost));
         HIP_CHECK(hipGetLastError());
         if (!flags[0]) {
             d.seq_len = ix.seq_len.as<uint32_t>();
-            ix.orientation_pairs = h.bidirectional && h.sequences % 2 == 0 && !flags[2];
+            ix.orientation_pairs = want_pairs && !flags[2];
             // Sequence samples: where every sequence is about every `interval` nodes (second walk), so that extractions
-            // can fill a row with many walkers at once.  GBWT_HIP_SAMPLE_INTERVAL=0 switches them off.
-            // 16 bytes per sample.  Large indexes: every 2 048 nodes (1 024 .. 4 096 measure within 3 % of each other on the
-            // headline); smaller ones get shorter intervals, down to 64 nodes, so that an extraction still has enough
-            // walkers to fill the GPU -- about four million samples per index at most.
-            const uint64_t all_nodes = h.size >= h.sequences ? h.size - h.sequences : 0;
-            uint32_t interval = 64;
-            while (interval < 2048 && (all_nodes >> 22) > interval) interval *= 2;
-            if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
-            if (interval >= 8) {
+            // can fill a row with many walkers at once.
+            if (sampled) {
                 DeviceBuffer counts, scan_tmp;
                 counts.reserve(h.sequences * sizeof(uint64_t));
                 ix.sample_base.reserve((h.sequences + 1) * sizeof(uint64_t));

@@ -1424,10 +1424,24 @@ __device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, S
     }
 }
 
-// One lane per sequence: the number of nodes SequenceIter would yield (src/gbwt.rs:557-568) and the two fingerprints.
+// One lane per sequence: the number of nodes SequenceIter would yield (src/gbwt.rs:557-568) and, with `prints`, the two
+// fingerprints (two modular multiplications per node: more than half of the pass, so they are only computed when an
+// extraction could fill rows from both ends, i.e. when the index gets no sequence samples).
+struct LengthSink {
+    uint32_t wr = 0;
+    __device__ __forceinline__ void push(uint32_t, bool counts) { wr += counts ? 1u : 0u; }
+    __device__ __forceinline__ void checkpoint(uint32_t, uint32_t, uint32_t) {}
+};
+
 __global__ void __launch_bounds__(256) k_sequence_lengths(DeviceIndex ix, uint32_t *seq_len, uint64_t *prints, uint64_t x_inverse, uint32_t *overflow) {
     const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (id >= ix.n_sequences) return;
+    if (prints == nullptr) {
+        LengthSink sink;
+        quiet_walk(ix, id, sink, overflow);
+        seq_len[id] = sink.wr;
+        return;
+    }
     CountSink sink(x_inverse);
     quiet_walk(ix, id, sink, overflow);
     seq_len[id] = sink.wr;

@@ -550,7 +550,10 @@ def test_config_c3_search_bit_exact(model, haplotypes):
         assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
 
 
-@pytest.mark.parametrize("env", [{"GBWT_HIP_DIRECT": "0"}, {"GBWT_HIP_BOTH_ENDS": "0"}, {"GBWT_HIP_SEQ_LEN": "0"}, {}])
+@pytest.mark.parametrize("env", [{"GBWT_HIP_DIRECT": "0"}, {"GBWT_HIP_BOTH_ENDS": "0"}, {"GBWT_HIP_SEQ_LEN": "0"}, {},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "0"},                                   # no samples: rows filled from both ends
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "0", "GBWT_HIP_BOTH_ENDS": "0"},      #             ... from one end
+                                 {"GBWT_HIP_ORIENTATION_CHECK": "1", "GBWT_HIP_SEGMENTS": "0"}])    # samples present, both ends used
 def test_extraction_output_paths(monkeypatch, env):
     """The extraction has three output paths: rows filled from both ends (default, bidirectional indexes whose sequence
     pairs check out), rows filled from one end, and the pool of chained blocks + compaction (no sequence lengths).
