@@ -420,7 +420,21 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             const char *seg = std::getenv("GBWT_HIP_SEGMENTS");
             const bool segmented = ix->dev.samples != nullptr && max_len > 0 && !(seg && std::atoi(seg) == 0);
             a.segments = segmented ? (max_len - 1) / ix->dev.sample_interval + 1 : 0u;
-            const uint64_t walkers = segmented ? static_cast<uint64_t>(a.segments) * n : (ix->orientation_pairs ? 2 * n : n);
+            uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
+            if (segmented) {
+                // walker order: segment by segment over the rows that have the segment (rows sorted by their segment count)
+                const size_t ob = walker_order_temp_bytes(n), sb = scan_temp_bytes(a.segments);
+                ws->order_keys.reserve(2 * n * sizeof(uint32_t)); ws->order_rows.reserve(2 * n * sizeof(uint32_t));
+                ws->order_counts.reserve(a.segments * sizeof(uint64_t)); ws->order_level.reserve((a.segments + 1ull) * sizeof(uint64_t));
+                ws->order_temp.reserve(std::max<size_t>(std::max(ob, sb), 16));
+                const uint32_t *sorted_rows = nullptr;
+                launch_walker_order(ix->dev, ws->seq_ids.as<uint64_t>(), n, a.segments, ws->order_keys.as<uint32_t>(), ws->order_rows.as<uint32_t>(),
+                                    ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), ws->order_temp.ptr, ob, &sorted_rows, s);
+                launch_scan(ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), a.segments, ws->order_temp.ptr, sb, s);
+                HIP_CHECK(hipMemcpyAsync(&walkers, ws->order_level.as<uint64_t>() + a.segments, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                a.sorted_rows = sorted_rows; a.level = ws->order_level.as<uint64_t>(); a.walkers = walkers;
+            }
             // many walkers: the walk is a throughput problem, full waves; few walkers (one or two per row): latency, and
             // about one workgroup per four SIMDs keeps every workgroup resident (32 KB of LDS each)
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave

@@ -80,6 +80,7 @@ struct gbwt_hip_workspace {
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
     uint32_t walk_mode = gbwt_hip::WALK_TWO_STEP, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
+    gbwt_hip::DeviceBuffer order_keys, order_rows, order_counts, order_level, order_temp;   // walker order of a segmented extraction
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid, follow_off;  // search staging
     gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_valid;  // GFA line formatting
     ~gbwt_hip_workspace() {

@@ -75,6 +75,11 @@ struct WalkArgs {
     uint32_t debug;            // measurement switches of k_walk_direct (GBWT_HIP_DEBUG_DRY_ROWS; never set by the library itself; the output is
                                // wrong with 1, 2 and 128): 1 = no row stores, 2 = all rows written into one 64 MB window, 128 = into 1 MB, 4 = plain
                                // instead of non-temporal row stores, 32 = row groups in row order
+    // segmented extraction with rows of different lengths: walkers in (segment, row) order with the rows that have no such
+    // segment left out.  rows sorted by their number of segments (descending, stable); level[j] = walkers before segment j.
+    const uint32_t *sorted_rows;   // [n]
+    const uint64_t *level;         // [segments + 1]; level[segments] = number of walkers
+    uint64_t walkers;              // = level[segments] (host copy)
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
@@ -88,6 +93,11 @@ void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uin
 // sequence samples: counts per sequence from the lengths, then the recording walk
 void launch_sample_counts(const uint32_t *d_seq_len, uint64_t n_sequences, uint32_t interval, uint64_t *d_counts, hipStream_t stream);
 void launch_record_samples(const DeviceIndex &ix, const uint64_t *d_sample_base, uint32_t interval, uint4 *d_samples, hipStream_t stream);
+// walker order of a segmented extraction: per-row segment counts -> rows sorted by count (descending, stable) and
+// level[j] = number of walkers in segments < j.  d_keys / d_rows: 2 x n scratch each (double buffers of the sort).
+size_t walker_order_temp_bytes(uint64_t n);
+void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
+                         uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream);
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 
 // per-path sum of node ids over CSR rows (checking hook)

@@ -949,14 +949,22 @@ __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
     return t;
 }
 
-// Segmented extraction (DeviceIndex::samples): walker w fills segment j = w / n of row k = w % n -- the nodes from
-// sample j of the sequence up to sample j + 1 (or the end of the row).  Walkers of one wave hold the same segment of
-// neighbouring rows, so they travel together like whole-sequence walkers do.
+// Segmented extraction (DeviceIndex::samples): a walker fills one segment of one row -- the nodes from sample j of the
+// sequence up to sample j + 1 (or the end of the row).  Walkers are numbered segment by segment, within a segment over
+// the rows that have it (rows sorted by their number of segments, stable: with rows of one length simply w = j * n + k),
+// so the walkers of a wave hold the same segment of neighbouring rows and travel together like whole-sequence walkers
+// do, and a batch with one long row and many short ones has as many walkers as it has segments, not rows x longest.
 struct WalkerStart { uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, first_node = 0; };
 
 __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, const WalkArgs &a, uint64_t w, RowTarget &t) {
     WalkerStart s;
-    const uint64_t j = w / a.n, k = w % a.n;
+    // walker w -> segment j = the level it falls into, row = the (w - level[j])-th of the rows that have a segment j
+    uint32_t lo = 0, hi = a.segments;                             // level[lo] <= w < level[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (a.level[mid] <= w) lo = mid; else hi = mid;
+    }
+    const uint64_t j = lo, k = a.sorted_rows[w - a.level[lo]];
     const uint64_t id = a.seq_ids[k];
     const uint64_t base = ix.sample_base[id], count = ix.sample_base[id + 1] - base;
     const uint64_t len = a.out_offsets[k + 1] - a.out_offsets[k];
@@ -1181,7 +1189,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (lane == 0) mail_done = 0;
     }
     __syncthreads();
-    const uint64_t walkers = a.segments ? static_cast<uint64_t>(a.segments) * a.n : (a.both_ends ? 2 * a.n : a.n);
+    const uint64_t walkers = a.segments ? a.walkers : (a.both_ends ? 2 * a.n : a.n);
     // Workgroup i runs on XCD i % 8 (round-robin dispatch), every XCD has an L2 of its own, and the walkers that pass
     // through the same records at the same time are neighbours in w (the same segment of neighbouring rows).  With
     // xcd_map the grid is a multiple of 8 and XCD x takes the x-th eighth of the walkers, in order, so that a record is
@@ -1612,6 +1620,45 @@ __global__ void __launch_bounds__(256) k_path_sums(const uint64_t *offsets, cons
 
 }  // namespace
 
+// keys[k] = number of segments of row k = samples of its sequence (0 for an empty sequence), rows[k] = k
+__global__ void __launch_bounds__(256) k_segment_counts(const uint64_t *sample_base, const uint64_t *ids, uint64_t n, uint32_t *keys, uint32_t *rows) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t id = ids[k];
+    keys[k] = static_cast<uint32_t>(sample_base[id + 1] - sample_base[id]);
+    rows[k] = static_cast<uint32_t>(k);
+}
+
+// counts[j] = rows with more than j segments = the first position of the descending keys that is <= j
+__global__ void __launch_bounds__(256) k_level_counts(const uint32_t *sorted_keys, uint64_t n, uint32_t segments, uint64_t *counts) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= segments) return;
+    uint64_t lo = 0, hi = n;                                        // keys[< lo] > j, keys[>= hi] <= j
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (sorted_keys[mid] > j) lo = mid + 1; else hi = mid;
+    }
+    counts[j] = lo;
+}
+
+size_t walker_order_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    hipcub::DoubleBuffer<uint32_t> keys(nullptr, nullptr), rows(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, keys, rows, static_cast<int>(n));
+    return bytes;
+}
+
+void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
+                         uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream) {
+    hipLaunchKernelGGL(k_segment_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, d_ids, n, d_keys, d_rows);
+    hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + n), rows(d_rows, d_rows + n);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(d_temp, temp_bytes, keys, rows, static_cast<int>(n), 0, 32, stream);   // radix sort: stable
+    hipLaunchKernelGGL(k_level_counts, dim3(grid_for(segments, 256)), dim3(256), 0, stream, keys.Current(), n, segments, d_level_counts);
+    *d_sorted_rows = rows.Current();
+    // d_level[0] = 0, d_level[j + 1] = counts[0] + ... + counts[j]: the caller runs launch_scan on d_level_counts
+    (void)d_level;
+}
+
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream) {
     if (args.n == 0) return;
     if (args.mode == WALK_LANE_SERIAL) {
@@ -1627,7 +1674,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
     }
     // walking wave + look-ahead helper wave
     if (args.out_nodes != nullptr) {   // lengths known: rows written in place, both ends at once
-        const uint64_t walkers = args.segments ? static_cast<uint64_t>(args.segments) * args.n : (args.both_ends ? 2 * args.n : args.n);
+        const uint64_t walkers = args.segments ? args.walkers : (args.both_ends ? 2 * args.n : args.n);
         unsigned groups = grid_for(walkers, p);
         if (args.xcd_map) groups = (groups + 7u) / 8u * 8u;   // whole eighths; the workgroups past the end own nothing
         hipLaunchKernelGGL(k_walk_direct, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);

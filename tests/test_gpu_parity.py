@@ -634,6 +634,35 @@ def test_segmented_extraction(monkeypatch, env):
             assert np.array_equal(c_off, o_off) and np.array_equal(c_nodes, o_nodes), env
 
 
+@pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "50", "GBWT_HIP_XCD_MAP": "0"}],
+                         ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
+def test_walker_order_with_ragged_rows(monkeypatch, env):
+    """A few long haplotypes and thousands of short walks (a fragmented assembly): the walkers of a segmented extraction
+    are numbered segment by segment over the rows that HAVE the segment (rows sorted by segment count, level prefix
+    sums), in every batch order, with duplicates and empty rows; compared with the input paths."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = random.Random(77)
+
+    def walk(first, count):
+        p = []
+        for site in range(first, first + count):
+            p += [2 * (3 * site + 1), 2 * (3 * site + 2 + (rng.random() < 0.3))]
+        return p
+
+    sites = 5000
+    paths = [walk(0, sites), walk(100, sites - 100), walk(0, sites // 3)] + [walk(rng.randrange(0, sites - 60), rng.randint(0, 60)) for _ in range(3000)]
+    s = S.Synth.from_paths(paths, bidirectional=True)
+    dev = open_synth(s)
+    batches = [list(range(0, s.sequences, 2)), list(range(s.sequences - 1, -1, -1)), [rng.randrange(s.sequences) for _ in range(777)] + [0, 0, 1]]
+    for ids in batches:
+        offsets, nodes = dev.sequences_csr(ids)
+        assert len(offsets) == len(ids) + 1
+        for k, i in enumerate(ids):
+            exp = paths[i // 2] if i % 2 == 0 else kat.reverse_path(paths[i // 2])
+            assert np.array_equal(nodes[offsets[k]:offsets[k + 1]], np.array(exp, dtype=np.uint32)), (i, env)
+
+
 def _layered_paths(layers, haplotypes, seed):
     """Paths over a layered graph with layers 1 .. 6 nodes wide, some layers skipped by some haplotypes: outdegrees from 1
     to 12, table records followed directly by table records, by unary records and by outdegree-2 records."""
