@@ -408,10 +408,11 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             launch_gather_lengths(ix->dev.seq_len, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
             launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
             uint64_t total = 0;
-            uint32_t max_len = 0;
+            uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
             HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipMemcpyAsync(&max_len, ws->counters.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(extremes, ws->counters.ptr, sizeof(extremes), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
+            const uint32_t max_len = extremes[0], min_len = ~extremes[1];
             ws->nodes.reserve(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
             WalkArgs a{};
             a.seq_ids = ws->seq_ids.as<uint64_t>(); a.n = n;
@@ -421,7 +422,11 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             const bool segmented = ix->dev.samples != nullptr && max_len > 0 && !(seg && std::atoi(seg) == 0);
             a.segments = segmented ? (max_len - 1) / ix->dev.sample_interval + 1 : 0u;
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
-            if (segmented) {
+            const bool same_segments = segmented && min_len > 0 && (min_len - 1) / ix->dev.sample_interval + 1 == a.segments;
+            if (same_segments) {
+                walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
+                a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
+            } else if (segmented) {
                 // walker order: segment by segment over the rows that have the segment (rows sorted by their segment count)
                 const size_t ob = walker_order_temp_bytes(n), sb = scan_temp_bytes(a.segments);
                 ws->order_keys.reserve(2 * n * sizeof(uint32_t)); ws->order_rows.reserve(2 * n * sizeof(uint32_t));

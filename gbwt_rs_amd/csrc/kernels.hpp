@@ -78,7 +78,7 @@ struct WalkArgs {
     // segmented extraction with rows of different lengths: walkers in (segment, row) order with the rows that have no such
     // segment left out.  rows sorted by their number of segments (descending, stable); level[j] = walkers before segment j.
     const uint32_t *sorted_rows;   // [n]
-    const uint64_t *level;         // [segments + 1]; level[segments] = number of walkers
+    const uint64_t *level;         // [segments + 1]; level[segments] = number of walkers; null = every row has every segment (w = j * n + k)
     uint64_t walkers;              // = level[segments] (host copy)
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
@@ -88,7 +88,7 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
 void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_t *d_prints, uint32_t *d_overflow, hipStream_t stream);
 // bidirectional indexes: is sequence 2k + 1 the reverse of sequence 2k for every k (fingerprints from the pass above)?
 void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d_prints, uint64_t n_pairs, uint32_t *d_mismatch, hipStream_t stream);
-// lengths[k] = seq_len[ids[k]]; *d_max_len = the largest of them (zeroed by the caller)
+// lengths[k] = seq_len[ids[k]]; d_max_len[0] = the largest of them, d_max_len[1] = ~(the smallest) (both zeroed by the caller)
 void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
 // sequence samples: counts per sequence from the lengths, then the recording walk
 void launch_sample_counts(const uint32_t *d_seq_len, uint64_t n_sequences, uint32_t interval, uint64_t *d_counts, hipStream_t stream);

@@ -959,12 +959,14 @@ struct WalkerStart { uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, first_node =
 __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, const WalkArgs &a, uint64_t w, RowTarget &t) {
     WalkerStart s;
     // walker w -> segment j = the level it falls into, row = the (w - level[j])-th of the rows that have a segment j
-    uint32_t lo = 0, hi = a.segments;                             // level[lo] <= w < level[hi]
+    uint32_t lo = 0, hi = a.level == nullptr ? 1u : a.segments;   // level[lo] <= w < level[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) / 2;
         if (a.level[mid] <= w) lo = mid; else hi = mid;
     }
-    const uint64_t j = lo, k = a.sorted_rows[w - a.level[lo]];
+    uint64_t j = lo, k = 0;
+    if (a.level == nullptr) { j = w / a.n; k = w % a.n; }           // every row has every segment: w = j * n + k
+    else k = a.sorted_rows[w - a.level[lo]];
     const uint64_t id = a.seq_ids[k];
     const uint64_t base = ix.sample_base[id], count = ix.sample_base[id + 1] - base;
     const uint64_t len = a.out_offsets[k + 1] - a.out_offsets[k];
@@ -1507,6 +1509,7 @@ __global__ void __launch_bounds__(256) k_gather_lengths(const uint32_t *seq_len,
     const uint32_t len = seq_len[ids[k]];
     lengths[k] = len;
     atomicMax(max_len, len);
+    atomicMax(max_len + 1, ~len);      // max_len[1] = ~(the shortest)
 }
 
 // Wave-cooperative walk (WALK_COOP): lanes 0..P-1 of each wave own one sequence each; long class 1 / 2 records are
