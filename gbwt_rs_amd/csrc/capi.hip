@@ -419,7 +419,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.mode = ws->walk_mode;
             // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
             const char *seg = std::getenv("GBWT_HIP_SEGMENTS");
-            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && !(seg && std::atoi(seg) == 0);
+            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && !(seg && std::atoi(seg) == 0);   // (the walker order sorts 32-bit row numbers)
             a.segments = segmented ? (max_len - 1) / ix->dev.sample_interval + 1 : 0u;
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
             const bool same_segments = segmented && min_len > 0 && (min_len - 1) / ix->dev.sample_interval + 1 == a.segments;
