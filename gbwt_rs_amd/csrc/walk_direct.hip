@@ -1,0 +1,493 @@
+// walk_direct.hip -- extraction with known sequence lengths: rows of the CSR written in place (k_walk_direct: segmented
+// extraction from sequence samples, or one walker per end of every row), the cooperative row writes of the helper wave,
+// and the walker order of a segmented extraction.  Hot loops in walk_loops.hpp; launch wrappers declared in kernels.hpp.
+#include "kernels.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include "walk_loops.hpp"
+
+namespace gbwt_hip {
+
+namespace {
+
+// ---- extraction with known lengths ---------------------------------------------------------------------------
+// With the lengths of the sequences known (device_index.hpp: seq_len) the CSR offsets exist before the walk starts, so
+// the nodes go straight into their rows -- and in a bidirectional index every row is filled from BOTH ends at once:
+// walker k walks sequence id from its start and writes front to back, walker n + k walks sequence id ^ 1 (the same
+// path reversed and flipped) and writes back to front, flipping the nodes.  Each stops at the middle.
+//
+// The walking wave never stores to global memory here.  Row starts are megabytes apart, so 10 000 write streams miss
+// the TLB all the time, and on gfx9 a store in flight delays every load behind it (one in-order vmcnt): with the walker
+// storing, filling rows from both ends gained 1.2x instead of 2x on the headline index.  The nodes therefore stay in
+// the LDS ring until the HELPER wave -- which already does the look-ahead touches and has a vmcnt of its own -- moves
+// them to the row, 64 bytes at a time.  The walker publishes how many nodes it has staged (mailbox word 3), the
+// helper publishes how many it has written (`drained`), and the walker only stalls when its ring is full.
+
+// Where the nodes of one walker go.
+struct RowTarget {
+    uint32_t *row = nullptr;     // first node of the CSR row
+    uint64_t len = 0;            // nodes in the row
+    bool backward = false;       // this walker comes from the other end: node k goes to row[len - 1 - k], flipped
+    uint32_t share = 0;          // nodes this walker has to deliver
+};
+
+__device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
+    RowTarget t;
+    const uint64_t k = w < a.n ? w : w - a.n;
+    t.backward = w >= a.n;
+    t.len = a.out_offsets[k + 1] - a.out_offsets[k];
+    t.row = a.out_nodes + a.out_offsets[k];
+    const uint64_t share = !a.both_ends ? t.len : (t.backward ? t.len / 2 : t.len - t.len / 2);
+    t.share = static_cast<uint32_t>(share);
+    return t;
+}
+
+// Segmented extraction (DeviceIndex::samples): a walker fills one segment of one row -- the nodes from sample j of the
+// sequence up to sample j + 1 (or the end of the row).  Walkers are numbered segment by segment, within a segment over
+// the rows that have it (rows sorted by their number of segments, stable: with rows of one length simply w = j * n + k),
+// so the walkers of a wave hold the same segment of neighbouring rows and travel together like whole-sequence walkers
+// do, and a batch with one long row and many short ones has as many walkers as it has segments, not rows x longest.
+struct WalkerStart { uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, first_node = 0; };
+
+__device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, const WalkArgs &a, uint64_t w, RowTarget &t) {
+    WalkerStart s;
+    // walker w -> segment j = the level it falls into, row = the (w - level[j])-th of the rows that have a segment j
+    uint32_t lo = 0, hi = a.level == nullptr ? 1u : a.segments;   // level[lo] <= w < level[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (a.level[mid] <= w) lo = mid; else hi = mid;
+    }
+    uint64_t j = lo, k = 0;
+    if (a.level == nullptr) { j = w / a.n; k = w % a.n; }           // every row has every segment: w = j * n + k
+    else k = a.sorted_rows[w - a.level[lo]];
+    const uint64_t id = a.seq_ids[k];
+    const uint64_t base = ix.sample_base[id], count = ix.sample_base[id + 1] - base;
+    const uint64_t len = a.out_offsets[k + 1] - a.out_offsets[k];
+    if (j >= count) return s;                                 // this row has fewer segments: nothing to do
+    const uint4 here = ix.samples[base + j];
+    const uint64_t from = j == 0 ? 0 : here.w;                // segment 0 starts with the start node (sample 0 is the state after it)
+    const uint64_t to = j + 1 < count ? ix.samples[base + j + 1].w : len;
+    t.row = a.out_nodes + a.out_offsets[k] + from;
+    if (a.debug & 2u) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
+    if (a.debug & 128u) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
+    t.len = to > from ? to - from : 0;
+    t.backward = false;
+    t.share = static_cast<uint32_t>(t.len);
+    s.rec = here.x; s.offset = here.y; s.bb = here.z;
+    if (j == 0 && id < ix.n_endmarker) s.first_node = ix.endmarker[id].x;
+    return s;
+}
+
+// LDS through pointers that say so.  A `volatile uint32_t *` into __shared__ memory is a generic pointer: hipcc turns
+// every access into flat_load / flat_store sc0 sc1, which travel through the vector-memory path (address coalescer,
+// vmcnt AND lgkmcnt) like a global access -- the helper's polling and its sixteen ring reads per 64 bytes written were
+// competing with the walk's own loads for the same unit.  The low 32 bits of a flat LDS address are the LDS offset.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lds_u32_t *lds_ptr(const void *p) { return (lds_u32_t *)static_cast<uintptr_t>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p))); }
+__device__ __forceinline__ uint32_t lds_peek(const lds_u32_t *p) { return *const_cast<const volatile lds_u32_t *>(p); }
+__device__ __forceinline__ void lds_poke(lds_u32_t *p, uint32_t v) { *const_cast<volatile lds_u32_t *>(p) = v; }
+__device__ __forceinline__ u32x4_t lds_peek4(const lds_u32_t *p) {   // one ds_read_b128 (16-byte aligned)
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// k_walk_direct's ring: slot s of lane l at dword s * RING_PITCH + l.  The pitch is 65, not 64, so that the slots of one
+// lane fall into different LDS banks: the cooperative row writes read several slots of the same lane in one
+// instruction (with a pitch of 64 they were all in one bank: 60 % of the LDS cycles of the kernel were bank conflicts).
+constexpr uint32_t RING_PITCH = WAVE + 1;
+
+// Staging only: the walking wave's side of the ring.
+struct StageSink {
+    lds_u32_t *stage;
+    uint32_t wr = 0, mask;
+    __device__ __forceinline__ StageSink(uint32_t *lds, uint32_t lane, uint32_t ring_mask) : stage(lds_ptr(lds + lane)), mask(ring_mask) {}
+    __device__ __forceinline__ void push(uint32_t node, bool counts) {
+        stage[(wr & mask) * RING_PITCH] = node;
+        wr += counts ? 1u : 0u;
+    }
+};
+
+// The helper's side: moves staged nodes [drained, upto) of one lane's ring column to the row.
+struct RowWriter {
+    const lds_u32_t *stage;      // not volatile: the caller puts a compiler barrier between polls, the reads of one piece can then go out together
+    RowTarget t;
+    uint32_t drained = 0, mask = RING2 - 1;
+    bool dry = false;            // measurement switch (GBWT_HIP_DEBUG_DRY_ROWS): read the ring, store nothing
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * RING_PITCH]; }
+    __device__ __forceinline__ void put(uint32_t k) {
+        if (k >= t.len || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row
+        if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
+    }
+    __device__ __forceinline__ void chunk() {   // 16 nodes = 64 bytes
+        const uint32_t c = drained;
+        if (static_cast<uint64_t>(c) + RING_FLUSH <= t.len) {
+            uint32_t v[RING_FLUSH];
+#pragma unroll
+            for (uint32_t i = 0; i < RING_FLUSH; i++) v[i] = slot(c + i);
+            if (dry) { uint32_t x = 0; for (uint32_t i = 0; i < RING_FLUSH; i++) x ^= v[i]; asm volatile("" :: "v"(x)); drained += RING_FLUSH; return; }
+            uint32_t *dst = t.backward ? t.row + (t.len - c - RING_FLUSH) : t.row + c;
+            const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+            if (!t.backward) {
+                if (aligned) {
+#pragma unroll
+                    for (uint32_t q = 0; q < RING_FLUSH / 4; q++) reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < RING_FLUSH; i++) dst[i] = v[i];
+                }
+            } else {   // node c + i goes to dst[15 - i]
+                if (aligned) {
+#pragma unroll
+                    for (uint32_t q = 0; q < RING_FLUSH / 4; q++)
+                        reinterpret_cast<uint4 *>(dst)[q] = make_uint4(v[15 - 4 * q] ^ 1u, v[14 - 4 * q] ^ 1u, v[13 - 4 * q] ^ 1u, v[12 - 4 * q] ^ 1u);
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < RING_FLUSH; i++) dst[RING_FLUSH - 1 - i] = v[i] ^ 1u;
+                }
+            }
+        } else {
+            for (uint32_t i = 0; i < RING_FLUSH; i++) put(c + i);
+        }
+        drained += RING_FLUSH;
+    }
+    // Everything that is staged and can go out in whole 64-byte pieces.  Segments start at arbitrary node counts, so a
+    // front-to-back writer first brings itself to a 64-byte boundary of the row with single stores; from there on every
+    // piece is one aligned cache-line half (unaligned pieces would go out as sixteen 4-byte stores each and reach HBM as
+    // partial lines: 22.7 GB written for 13.3 GB of node ids before this).
+    __device__ __forceinline__ void drain(uint32_t staged) {
+        if (!t.backward) {
+            const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(t.row + drained) >> 2) & (RING_FLUSH - 1));
+            if (mis != 0) {
+                const uint32_t need = RING_FLUSH - mis;
+                if (staged - drained < need) return;
+                for (uint32_t i = 0; i < need; i++) put(drained + i);
+                drained += need;
+            }
+        }
+        while (staged - drained >= RING_FLUSH) chunk();
+    }
+};
+
+// Cooperative row writes (segmented extraction: front-to-back rows only).  LPR lanes share one row: each moves four
+// nodes of a piece of 4 * LPR nodes, so one store instruction writes WAVE / LPR whole pieces of 16 * LPR contiguous,
+// aligned bytes -- the memory system sees one request per piece instead of one 16-byte request per lane (with every
+// lane writing its own row, a wave's store touched 64 different cache lines with 16 bytes each, four times in a row).
+// A row first brings itself to a piece boundary with single stores (segments start anywhere), the tail goes out the
+// same way once the walk is over.  Row state lives in LDS: `staged` in the mailboxes (word 3), and one uint4 per row
+// {address low, address high, length, drained} in row_state -- the helper writes all of it, the walker reads `drained`.
+// A visit costs two LDS round trips (state + count, then the four nodes) and about two dozen VALU instructions: the
+// helper's instructions compete with the walkers' for the same SIMDs (profiles/r01_final_pmc_headline.txt: VALU busy
+// 60 % of the kernel, 134 VALU instructions per walker iteration of which the walker's own are 83).
+struct CoopRows {
+    uint32_t ring;               // LDS byte address of the ring: slot * RING_PITCH + lane (dwords)
+    uint32_t mail;               //                  of mailbox[0]; staged count of row r = word 4 r + 3
+    uint32_t state;              //                  of row_state[0]
+    uint32_t mask;
+    bool dry;
+    bool plain_stores;           // row pieces as ordinary stores instead of non-temporal ones (measurement switch)
+    bool skip_reads;             // measurement switch: nothing is read from the ring or stored
+};
+__device__ __forceinline__ uint32_t lds_word(uint32_t byte_address) { return *(const volatile lds_u32_t *)static_cast<uintptr_t>(byte_address); }
+
+// The lanes that serve row r (lane p of LPR): one piece, or what the rules above allow instead.
+template <uint32_t LPR>
+__device__ __forceinline__ void coop_visit(const CoopRows &c, uint32_t r, uint32_t p, uint32_t done) {
+    constexpr uint32_t PIECE = 4 * LPR;
+    const uint32_t staged = lds_word(c.mail + 16 * r + 12);
+    const u32x4_t st = lds_peek4((const lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r));   // waits for both
+    const uint32_t drained = st.w, len = st.z;
+    const uint32_t pend = staged - drained;
+    const uint32_t mis = ((st.x >> 2) + drained) & (PIECE - 1);      // nodes past the last piece boundary of the row's memory
+    uint32_t n = PIECE - mis;                                        // nodes up to the next boundary
+    if (pend < n) { if (!done || pend == 0) return; n = pend; }      // short pieces only once the walk is over
+    volatile lds_u32_t *const publish = (volatile lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r + 12);   // only after the nodes have left the ring
+    if (c.skip_reads) { if (p == 0) *publish = drained + n; return; }   // measurement switch: the ring is emptied unread
+    // a pointer rebuilt from integers is a generic one: say that it is global memory, or the stores become flat_store
+    // (which also count in lgkmcnt, so that every LDS wait of the helper would wait for its row writes as well)
+    typedef __attribute__((address_space(1))) uint32_t global_u32_t;
+    typedef __attribute__((address_space(1))) u32x4_t global_u32x4_t;
+    global_u32_t *dst = (global_u32_t *)((static_cast<uint64_t>(st.y) << 32) | st.x) + drained;
+    const uint32_t col = c.ring + 4 * r;                             // slot s of the row at col + s * 4 * RING_PITCH (24-bit multiply: LDS is small)
+    if (n == PIECE && drained + PIECE <= len) {
+        const uint32_t k = drained + 4 * p;
+        const uint32_t v0 = lds_word(col + __umul24((k + 0) & c.mask, 4 * RING_PITCH)), v1 = lds_word(col + __umul24((k + 1) & c.mask, 4 * RING_PITCH)),
+                       v2 = lds_word(col + __umul24((k + 2) & c.mask, 4 * RING_PITCH)), v3 = lds_word(col + __umul24((k + 3) & c.mask, 4 * RING_PITCH));
+        if (!c.dry) {
+            u32x4_t v; v.x = v0; v.y = v1; v.z = v2; v.w = v3;
+            global_u32x4_t *at = (global_u32x4_t *)dst + p;
+            // Rows are written once and never read by this kernel: as plain stores they fill the L2s with dirty lines whose
+            // write-back gets in the way of the walk's own traffic (6.9 ms per headline pass; 4.1 ms when all rows are
+            // aimed at one megabyte that never leaves the L2s).  Non-temporal stores stream out: 5.1 ms.  Measured with
+            // every sc0 / sc1 / nt combination: nt and nt sc0 are equal, nt sc0 sc1 is halfway, the others change nothing.
+            if (c.plain_stores) *at = v;
+            else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(v) : "memory");
+        }
+        else asm volatile("" :: "v"(v0 ^ v1 ^ v2 ^ v3));
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t k = p + LPR * i;
+            if (k < n && drained + k < len && !c.dry) dst[k] = lds_word(col + __umul24((drained + k) & c.mask, 4 * RING_PITCH));   // never outside the row
+        }
+    }
+    if (p == 0) *publish = drained + n;
+}
+
+// One round over the rows that have something to write.  Lane l looks at row `mine` = order[l] to find them; rows[g] =
+// the row this lane serves in group g (both from the helper's sort of the rows by address phase); returns the rows that
+// still hold staged nodes afterwards (as seen before the round).
+//
+// Rows are grouped by the phase of their addresses: walkers that travel together stage nodes at the same rate, so rows
+// whose memory has the same offset within a piece complete their pieces in the same iteration and one store
+// instruction then carries WAVE / LPR full pieces.  Grouped by row number, the rows of a group had eight different
+// phases, became ready one or two at a time, and the kernel issued 2.2 store instructions per kilobyte.
+template <uint32_t LPR>
+__device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane, uint32_t mine, const uint32_t (&rows)[8], uint32_t done) {
+    constexpr uint32_t PIECE = 4 * LPR, ROWS = WAVE / LPR;
+    const uint32_t staged = lds_word(c.mail + 16 * mine + 12);
+    const u32x4_t st = lds_peek4((const lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * mine));
+    const uint32_t pend = staged - st.w;
+    const uint32_t mis = ((st.x >> 2) + st.w) & (PIECE - 1);
+    const uint64_t todo = __ballot(pend >= PIECE - mis || (done && pend != 0));
+    const uint64_t left = __ballot(pend != 0);
+    if (todo != 0) {
+#pragma unroll
+        for (uint32_t g = 0; g < LPR; g++)                           // wave-uniform tests; rows[g] stays in a register
+            if (((todo >> (g * ROWS)) & ((uint64_t(1) << ROWS) - 1)) != 0) coop_visit<LPR>(c, rows[g], lane % LPR, done);
+    }
+    return left;
+}
+
+// One look-ahead touch from compiler-scheduled code: an LDS-direct load has no register destination, so nothing can be
+// corrupted by the data arriving late, and nobody ever waits for it.  `lds_dummy` = wave-uniform LDS byte address of a
+// 256-byte scratch area.
+__device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p), "s"(lds_dummy) : "memory");
+}
+
+__global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
+    extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
+    __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
+    __shared__ uint4 row_state[WAVE];        // per walking lane: {row address low, high, length (cooperative row writes), nodes the helper has moved to the row}
+    __shared__ uint32_t touch_dummy[WAVE];
+    __shared__ uint32_t row_order[WAVE];     // cooperative row writes: the rows sorted by address phase (helper's own table)
+    __shared__ uint32_t mail_done;
+    const uint32_t lane = threadIdx.x % WAVE;
+    const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x) >= WAVE;
+    if (!helper) {
+        mailbox[lane] = make_uint4(0, 0, 0, 0);
+        row_state[lane] = make_uint4(0, 0, 0, 0);
+        if (lane == 0) mail_done = 0;
+    }
+    __syncthreads();
+    const uint64_t walkers = a.segments ? a.walkers : (a.both_ends ? 2 * a.n : a.n);
+    // Workgroup i runs on XCD i % 8 (round-robin dispatch), every XCD has an L2 of its own, and the walkers that pass
+    // through the same records at the same time are neighbours in w (the same segment of neighbouring rows).  With
+    // xcd_map the grid is a multiple of 8 and XCD x takes the x-th eighth of the walkers, in order, so that a record is
+    // fetched into ONE L2 instead of all eight.
+    uint64_t group = blockIdx.x;
+    if (a.xcd_map) group = (blockIdx.x % 8u) * static_cast<uint64_t>(gridDim.x / 8u) + blockIdx.x / 8u;
+    const uint64_t w = group * a.paths_per_wave + lane;
+    const bool owner = lane < a.paths_per_wave && w < walkers;
+    const uint32_t ring_mask = a.ring_slots - 1;
+    RowTarget target;
+    WalkerStart begin;
+    if (owner) {
+        if (a.segments) begin = segment_start(ix, a, w, target);
+        else target = row_target(a, w);
+    }
+    lds_u32_t *const my_mail = lds_ptr(&mailbox[lane]);          // word 3 = nodes staged so far
+    lds_u32_t *const my_drained = lds_ptr(&row_state[lane].w);
+    lds_u32_t *const done_flag = lds_ptr(&mail_done);
+
+    if (helper) {
+        // ---- helper wave: look-ahead touches for every slot, row writes for its own lane's column
+        const uint32_t owners = a.paths_per_wave ? a.paths_per_wave : WAVE;
+        const uint32_t serve = lane % owners;                        // the 64 lanes share the owners' look-ahead slots ...
+        const uint32_t spread = (lane << 26) | (1u << 25);           // ... and spread over the target's blocks
+        const uint32_t dummy = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(touch_dummy));
+        RowWriter writer{lds_ptr(ring_lds + lane), target, 0, ring_mask, (a.debug & 1u) != 0};
+        const lds_u32_t *const served_mail = lds_ptr(&mailbox[serve]);
+        const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
+        const auto lds_address = [](const void *q) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(q)); };
+        const CoopRows rows{lds_address(ring_lds), lds_address(mailbox), lds_address(row_state), ring_mask, (a.debug & 1u) != 0, (a.debug & 4u) != 0,
+                            (a.debug & 64u) != 0};
+        uint32_t mine = lane;                                        // the row this lane watches
+        uint32_t served[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // the row this lane serves in group g
+        if (piece) {
+            const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
+            lds_poke(lds_ptr(&row_state[lane].x), static_cast<uint32_t>(at));
+            lds_poke(lds_ptr(&row_state[lane].y), static_cast<uint32_t>(at >> 32));
+            lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0xFFFFFFF0u)));
+            // order = the rows sorted by (address phase within a piece, row): rank by counting, once per workgroup
+            const uint32_t phase = (static_cast<uint32_t>(at) >> 2) & (piece - 1);
+            uint32_t rank = 0;
+            for (uint32_t other = 0; other < WAVE; other++) {
+                const uint32_t theirs = (lds_peek(lds_ptr(&row_state[other].x)) >> 2) & (piece - 1);
+                rank += (theirs < phase || (theirs == phase && other < lane)) ? 1u : 0u;
+            }
+            if (a.debug & 32u) rank = lane;                          // measurement switch: groups of consecutive rows
+            lds_poke(lds_ptr(row_order) + rank, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mine = lds_peek(lds_ptr(row_order) + lane);
+            const uint32_t lanes_per_row = piece / 4, rows_per_group = WAVE / lanes_per_row;
+#pragma unroll
+            for (uint32_t g = 0; g < 8; g++) served[g] = g < lanes_per_row ? lds_peek(lds_ptr(row_order) + g * rows_per_group + lane / lanes_per_row) : 0u;
+        }
+        uint32_t seen = 0;
+        for (;;) {
+            asm volatile("" ::: "memory");                           // the ring and the mailboxes have changed since the last poll
+            const uint32_t done = lds_peek(done_flag);               // read before the counts: the final count is then complete
+            const u32x4_t mail = lds_peek4(served_mail);
+            const uint32_t look_rec = mail.x, look_base = mail.y, look_count = mail.z, stamp = mail.w;
+            if (lane < a.helper_lanes && look_rec != 0 && stamp != seen) {
+                const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(look_rec);
+                touch_line(d, dummy);
+                touch_line(d + 4, dummy);
+                touch_line(ix.cblocks + 2 * (static_cast<uint64_t>(look_base) + __umulhi(spread, look_count)), dummy);
+            }
+            seen = stamp;
+            if (piece) {
+                const uint64_t left = piece == 32 ? coop_drain<8>(rows, lane, mine, served, done) : coop_drain<4>(rows, lane, mine, served, done);
+                if (done && left == 0) break;
+                if (done) continue;
+            } else if (owner) {
+                const uint32_t staged = lds_peek(my_mail + 3);
+                asm volatile("" ::: "memory");                       // ring reads stay behind the count
+                writer.drain(staged);
+                if (done) { for (uint32_t k = writer.drained; k < staged; k++) writer.put(k); }
+                lds_poke(my_drained, writer.drained);
+            }
+            if (done && !piece) break;
+            for (uint32_t nap = 0; nap < a.helper_naps; nap++) __builtin_amdgcn_s_sleep(4);
+        }
+        return;
+    }
+
+    // ---- walking wave
+    const uint32_t mail_slot = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&mailbox[lane]));
+    StageSink sink(ring_lds, lane, ring_mask);
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
+    const uint32_t quota = target.share;
+    if (owner && a.segments) {
+        if (quota > 0) {
+            if (begin.first_node != 0) sink.push(begin.first_node, true);   // segment 0 also delivers the start node
+            if (sink.wr < quota) { rec = begin.rec; offset = begin.offset; bb = begin.bb; }
+        }
+    } else if (owner) {
+        const uint64_t k = w < a.n ? w : w - a.n;
+        const uint64_t id = a.seq_ids[k] ^ (target.backward ? 1u : 0u);
+        if (quota > 0 && id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+            const uint2 e = ix.endmarker[id];
+            if (e.x != 0) {
+                sink.push(e.x, true);
+                offset = e.y;
+                if (quota <= 1 || !arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+    }
+    lds_poke(my_mail + 3, sink.wr);
+    const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring_lds + lane));
+    const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
+    while (__ballot(rec != 0) != 0) {
+        const uint32_t drained = lds_peek(my_drained);
+        if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
+        // all lanes on one record: scalar descriptor fetch; otherwise every lane fetches its own
+        uint32_t slow_exit = a.uniform_loop ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
+        if (slow_exit == 2) slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+        if (slow_exit) {
+            bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;   // lanes on a slow record
+            if (ix.wtables != nullptr) {
+                // Lanes on a table record walk on the walk tables: one 16-byte entry per step says what to emit (the
+                // successor and, where a unary record follows, the node behind it), where the walk lands and -- when that
+                // is a table record again -- where its table is, so a chain of multi-allelic sites never goes back to the
+                // hot loops.  The others wait; the loop ends when fewer than half of the walking lanes are still in it.
+                bool in_table = false;
+                uint32_t tb = 0;
+                if (generic) {
+                    const uint4 C = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 2];
+                    if (C.w == 1u && offset < C.y) { in_table = true; tb = C.z; generic = false; }   // offset >= Record::len: generic_step ends the walk (src/bwt.rs:481)
+                }
+                while (__ballot(in_table) != 0) {
+                    if (in_table) {
+                        const uint4 e = ix.wtables[static_cast<uint64_t>(tb) + offset];
+                        sink.push(e.x, e.x != 0);
+                        sink.push((e.z & REC_MASK) + ix.alphabet_offset, (e.z & LEAF_EMIT2) != 0);
+                        rec = e.z & REC_MASK; offset = e.y;
+                        if (e.z & WT_TABLE) tb = e.w; else { bb = e.w; in_table = false; }
+                        if (rec == 0 || sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; in_table = false; }
+                    }
+                    lds_poke(my_mail + 3, sink.wr);
+                    const uint64_t still = __ballot(in_table);
+                    if (2 * __popcll(still) < __popcll(__ballot(rec != 0))) break;
+                    if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - 8) != 0) break;   // ring full: the outer loop waits for the helper
+                }
+                if (in_table) bb = BLOCK_NONE;     // left on a table record (it has no blocks): back here after the next look at the ring
+            }
+            if (generic) {   // no table (or no walk tables at all): one step of the generic decoder with all the reference's tests
+                generic_step(ix, sink, rec, offset, bb);
+                if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+            }
+            lds_poke(my_mail + 3, sink.wr);
+        }
+    }
+    lds_poke(my_mail + 3, sink.wr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_poke(done_flag, 1);
+}
+
+}  // namespace
+
+// keys[k] = number of segments of row k = samples of its sequence (0 for an empty sequence), rows[k] = k
+__global__ void __launch_bounds__(256) k_segment_counts(const uint64_t *sample_base, const uint64_t *ids, uint64_t n, uint32_t *keys, uint32_t *rows) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t id = ids[k];
+    keys[k] = static_cast<uint32_t>(sample_base[id + 1] - sample_base[id]);
+    rows[k] = static_cast<uint32_t>(k);
+}
+
+// counts[j] = rows with more than j segments = the first position of the descending keys that is <= j
+__global__ void __launch_bounds__(256) k_level_counts(const uint32_t *sorted_keys, uint64_t n, uint32_t segments, uint64_t *counts) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= segments) return;
+    uint64_t lo = 0, hi = n;                                        // keys[< lo] > j, keys[>= hi] <= j
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (sorted_keys[mid] > j) lo = mid + 1; else hi = mid;
+    }
+    counts[j] = lo;
+}
+
+size_t walker_order_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    hipcub::DoubleBuffer<uint32_t> keys(nullptr, nullptr), rows(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, keys, rows, static_cast<int>(n));
+    return bytes;
+}
+
+void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
+                         uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream) {
+    hipLaunchKernelGGL(k_segment_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, d_ids, n, d_keys, d_rows);
+    hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + n), rows(d_rows, d_rows + n);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(d_temp, temp_bytes, keys, rows, static_cast<int>(n), 0, 32, stream);   // radix sort: stable
+    hipLaunchKernelGGL(k_level_counts, dim3(grid_for(segments, 256)), dim3(256), 0, stream, keys.Current(), n, segments, d_level_counts);
+    *d_sorted_rows = rows.Current();
+    // d_level[0] = 0, d_level[j + 1] = counts[0] + ... + counts[j]: the caller runs launch_scan on d_level_counts
+    (void)d_level;
+}
+
+void launch_walk_direct(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream) {
+    const unsigned p = args.paths_per_wave ? args.paths_per_wave : WAVE;
+    const uint64_t walkers = args.segments ? args.walkers : (args.both_ends ? 2 * args.n : args.n);
+    unsigned groups = grid_for(walkers, p);
+    if (args.xcd_map) groups = (groups + 7u) / 8u * 8u;   // whole eighths; the workgroups past the end own nothing
+    hipLaunchKernelGGL(k_walk_direct, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
+}
+
+}  // namespace gbwt_hip

@@ -1,0 +1,836 @@
+// walk_loops.hpp -- device code shared by the walk kernels (walk_kernels.hip, walk_direct.hip) and the one-time walks at
+// open (open_walks.hip): the output sinks of the pool walks, the arrival tests and the generic step, the hot loops in
+// gfx950 assembly (one LF step per iteration, two LF steps, two LF steps with a wave-uniform scalar descriptor fetch),
+// their look-ahead helpers, and the two-step walk in plain C++ (quiet_walk).  Everything lives in an anonymous
+// namespace: every translation unit gets its own copy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "coop_device.hpp"
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include "lf_device.hpp"
+
+namespace gbwt_hip {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Path extraction: one lane per sequence (GBWT::sequence + SequenceIter::next, src/gbwt.rs:253-261,
+// 557-568).  Lengths are unknown until a sequence ends, so every lane appends the nodes it visits
+// to a chain of 1 KiB blocks drawn from a shared pool; a second, bandwidth-bound kernel lays the
+// chains out as CSR once the lengths (and their prefix sums) exist.
+
+// Output sink of one lane: the nodes a sequence visits go to a chain of 1 KiB pool blocks.  Stores are staged in
+// LDS (SINK_STAGE entries per lane, entry-major so a wave's writes hit 64 distinct banks) and flushed as 64-byte
+// pieces: on gfx9 loads and stores share the in-order vmcnt counter, so a store issued every step would put its
+// ~700-cycle acknowledgement on the critical path of the next dependent load.
+constexpr uint32_t SINK_STAGE = 16;
+static_assert(POOL_BLOCK_NODES % SINK_STAGE == 0, "a block must hold a whole number of flushes");
+
+struct PathSink {
+    uint32_t *stage;             // this lane's column of the wave's LDS staging buffer (stride WAVE)
+    uint32_t *wp = nullptr;      // next slot in the current block
+    uint32_t left = 0;           // free slots in the current block
+    uint32_t staged = 0;         // entries waiting in LDS
+    uint32_t cur = POOL_NONE, head = POOL_NONE, blocks = 0;
+    bool overflow = false;
+    __device__ __forceinline__ explicit PathSink(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    __device__ __forceinline__ void flush(const WalkArgs &a) {
+        if (staged == 0 || overflow) { staged = 0; return; }
+        if (left == 0) {
+            uint32_t nb = atomicAdd(a.counter, 1u);
+            if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); overflow = true; staged = 0; return; }
+            a.next[nb] = POOL_NONE;
+            if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
+            cur = nb; blocks++;
+            wp = a.pool + static_cast<uint64_t>(nb) * POOL_BLOCK_NODES;
+            left = POOL_BLOCK_NODES;
+        }
+        if (staged == SINK_STAGE) {
+            uint4 *dst = reinterpret_cast<uint4 *>(wp);
+#pragma unroll
+            for (uint32_t q = 0; q < SINK_STAGE / 4; q++)
+                dst[q] = make_uint4(stage[(4 * q) * WAVE], stage[(4 * q + 1) * WAVE], stage[(4 * q + 2) * WAVE], stage[(4 * q + 3) * WAVE]);
+        } else {
+            for (uint32_t e = 0; e < staged; e++) wp[e] = stage[e * WAVE];
+        }
+        wp += staged; left -= staged; staged = 0;
+    }
+    // after a pool overflow the sink drops what it gets: the host grows the pool and walks again
+    __device__ __forceinline__ void push(const WalkArgs &a, uint32_t node) {
+        stage[staged * WAVE] = node;
+        staged++;
+        if (__builtin_expect(staged == SINK_STAGE, 0)) flush(a);
+    }
+    __device__ __forceinline__ uint64_t finish(const WalkArgs &a) {
+        flush(a);
+        return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left;
+    }
+};
+
+
+
+// Generic lane-serial Record::lf on the record bytes [start, start + bytes) (class 0 records, fallbacks).  Out of
+// line and by-value only, so that the hot loops stay small and nothing is forced into scratch.  Returns
+// (node, offset); node == 0 <=> None.
+__device__ __attribute__((noinline)) uint2 serial_record_lf(const uint8_t *data, uint64_t start, uint32_t bytes, uint32_t offset) {
+    ByteCursor c(data, start, start + bytes);
+    uint64_t sigma, nn, no;
+    if (c.varint(sigma) && sigma != 0 && record_lf(c, sigma, offset, nn, no)) return make_uint2(static_cast<uint32_t>(nn), static_cast<uint32_t>(no));
+    return make_uint2(0u, 0u);
+}
+
+// Output staging of the default walk: a ring of RING slots per lane in LDS.  Pushes are unconditional LDS writes
+// (the slot only advances when the node counts), and a lane moves 16 slots = 64 bytes to its pool block with four
+// dwordx4 stores whenever that many are waiting.  The pool is the same chain of POOL_BLOCK_NODES-sized blocks as
+// PathSink's.  After a pool overflow the sink drops what it gets: the host grows the pool and walks again.
+constexpr uint32_t RING = 64;                // single-step walk: at most 2 nodes per iteration
+constexpr uint32_t RING2 = 128;              // two-step walk: at most 4 nodes per iteration
+constexpr uint32_t RING_FLUSH = 16;
+constexpr uint32_t RING_URGENT = RING - 4;   // the hot loop hands over to the flush code once a lane has more than this waiting
+static_assert(POOL_BLOCK_NODES % RING_FLUSH == 0, "a block must hold a whole number of flushes");
+
+template <uint32_t SLOTS>
+struct RingSinkT {
+    uint32_t *stage;             // this lane's column of the ring: slot s at stage[s * WAVE]
+    uint32_t wr = 0, flushed = 0;   // nodes pushed / nodes written to the pool
+    uint32_t *wp = nullptr;
+    uint32_t left = 0;
+    uint32_t cur = POOL_NONE, head = POOL_NONE, blocks = 0;
+    bool overflow = false;
+    __device__ __forceinline__ RingSinkT(uint32_t *lds, uint32_t lane) : stage(lds + lane) {}
+    __device__ __forceinline__ void push(uint32_t node, bool counts) {
+        stage[(wr & (SLOTS - 1)) * WAVE] = node;
+        wr += counts ? 1u : 0u;
+    }
+    __device__ __forceinline__ bool needs_flush() const { return wr - flushed >= RING_FLUSH; }
+    __device__ __forceinline__ bool new_block(const WalkArgs &a) {
+        uint32_t nb = atomicAdd(a.counter, 1u);
+        if (nb >= a.pool_blocks) { atomicOr(a.flags, FLAG_POOL_OVERFLOW); overflow = true; return false; }
+        a.next[nb] = POOL_NONE;
+        if (cur == POOL_NONE) head = nb; else a.next[cur] = nb;
+        cur = nb; blocks++;
+        wp = a.pool + static_cast<uint64_t>(nb) * POOL_BLOCK_NODES;
+        left = POOL_BLOCK_NODES;
+        return true;
+    }
+    __device__ __forceinline__ void flush16(const WalkArgs &a) {
+        if (!overflow && (left != 0 || new_block(a))) {
+            const uint32_t *src = stage + (flushed & (SLOTS - 1)) * WAVE;   // slot 0, 16, 32 or 48
+            uint4 *dst = reinterpret_cast<uint4 *>(wp);
+#pragma unroll
+            for (uint32_t q = 0; q < RING_FLUSH / 4; q++)
+                dst[q] = make_uint4(src[(4 * q) * WAVE], src[(4 * q + 1) * WAVE], src[(4 * q + 2) * WAVE], src[(4 * q + 3) * WAVE]);
+            wp += RING_FLUSH; left -= RING_FLUSH;
+        }
+        flushed += RING_FLUSH;
+    }
+    __device__ __forceinline__ uint64_t finish(const WalkArgs &a) {
+        while (needs_flush()) flush16(a);
+        const uint32_t tail = wr - flushed;
+        if (tail != 0 && !overflow && (left != 0 || new_block(a))) {
+            for (uint32_t e = 0; e < tail; e++) wp[e] = stage[((flushed + e) & (SLOTS - 1)) * WAVE];
+            left -= tail;
+        }
+        return static_cast<uint64_t>(blocks) * POOL_BLOCK_NODES - left;
+    }
+};
+using RingSink = RingSinkT<RING>;
+
+// Arrival at (node, offset) from outside the linked descriptors (the start of a sequence, a generic step): the tests
+// of GBWT::forward / BWT::record / Record::lf (src/gbwt.rs:222-229, src/bwt.rs:124-130, 481) that k_link_desc
+// settles in advance for the linked edges.
+__device__ __forceinline__ bool arrive(const DeviceIndex &ix, uint32_t node, uint32_t offset, uint32_t &rec, uint32_t &bb) {
+    uint64_t r;
+    if (!landing_record(ix, node, r)) return false;
+    const uint4 LB = ix.desc_raw[4 * r + 1];
+    if (LB.y == 0 || (desc_class(LB.z) != 0 && offset >= LB.w)) return false;
+    rec = static_cast<uint32_t>(r); bb = ix.block_base[r];
+    return true;
+}
+
+// One generic step of a walk at a DESC_SLOW record: a lookup in the record's LF table when it has one, else Record::lf
+// on the record bytes followed by the arrival tests.
+template <class Sink>
+__device__ __forceinline__ void generic_step(const DeviceIndex &ix, Sink &sink, uint32_t &rec, uint32_t &offset, uint32_t &bb) {
+    const uint4 B = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 1], C = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 2];
+    if (C.w == 1u) {
+        uint4 e = make_uint4(0u, 0u, 0u, BLOCK_NONE);
+        if (offset < C.y) e = ix.tables[static_cast<uint64_t>(C.z) + offset];   // i >= Record::len -> None (src/bwt.rs:481)
+        sink.push(e.x, e.x != 0);
+        offset = e.y; rec = e.z; bb = e.w;
+        return;
+    }
+    const uint2 r = serial_record_lf(ix.data, desc_start(B.x, B.z), B.y, offset);
+    sink.push(r.x, r.x != 0);
+    offset = r.y;
+    if (r.x == 0 || !arrive(ix, r.x, r.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+}
+
+// The hot loop of the default walk, written in gfx950 assembly: hipcc's register shuffling around the cold paths and
+// its SGPR mask algebra more than doubled the instruction count of the loop, and the position of every load and wait
+// matters here.
+//
+// All 64 lanes run every instruction; lanes without a walk are PARKED on record 0, whose walk descriptor says
+// "nothing to emit, lands on record 0" and which reads the zero block, so a parked lane stays parked.
+// One iteration (Record::lf src/bwt.rs:480-496 + GBWT::forward src/gbwt.rs:222-229 for one or, fused, two nodes):
+//     wait for A, C, D (walk descriptor) and K (rank block)                      s_waitcnt vmcnt(0)
+//     any lane on a DESC_SLOW record -> leave BEFORE changing any state          (generic decode outside)
+//     value = bit `offset` of K, ones = K.z + popcount(K bits below `offset`)
+//     rank = value ? ones : offset - ones;  E = value ? C : A;  flags/look-ahead = value ? D.zw : D.xy
+//     rec = E.z; offset = E.y + rank; bb = E.w                                    (the new position)
+//     issue the four loads of the new position; post the look-ahead target in the helper wave's mailbox
+//     push E.x (counts if != 0), push rec + alphabet_offset (counts if EDGE_EMIT2) into the LDS ring
+//     leave if no lane is walking any more, or a lane has more than RING_URGENT nodes waiting in its ring
+// On exit nothing is in flight (vmcnt(0), lgkmcnt(0)).  Returns 1 when it left because of a DESC_SLOW record.
+// Hazards: a VALU write of VCC / an SGPR needs two wait states before a VALU reads it (gfx940+); the string keeps two
+// independent instructions (or an s_nop) in every such pair.  Registers v40-v89 and s41, s44-s45 are named literally
+// and listed as clobbers.
+__device__ __forceinline__ uint32_t walk_hot_loop(const uint4 *desc, const uint4 *blocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                  uint32_t mail_slot, uint32_t flushed, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t &hash) {
+#ifdef GBWT_HIP_CXX_LOOP
+    // the same loop in plain C++ (no pipelining, no look-ahead): what the assembly below must compute
+    for (;;) {
+        const uint4 *d = desc + 4 * static_cast<uint64_t>(rec);
+        const uint4 A = d[0], C = d[1], D = d[2];
+        const uint4 K = blocks[bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT)];
+        if (__ballot(static_cast<int32_t>(D.x) < 0) != 0) return 1;
+        const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+        const uint32_t bit = offset & 63u;
+        const uint32_t value = static_cast<uint32_t>(bits >> bit) & 1u;
+        const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << bit) - 1));
+        const uint32_t rank = value ? ones : offset - ones;
+        const uint4 E = value ? C : A;
+        const uint32_t flags = value ? D.w : D.y;
+        rec = E.z; offset = E.y + rank; bb = E.w;
+        __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
+        ring[(wr & (RING - 1)) * WAVE] = E.x;
+        wr += E.x != 0 ? 1u : 0u;
+        ring[(wr & (RING - 1)) * WAVE] = rec + alphabet_offset;
+        wr += static_cast<int32_t>(flags) < 0 ? 1u : 0u;
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > RING_URGENT) != 0) return 0;
+    }
+#else
+    uint32_t reason;
+#define GBWT_WALK_ISSUE                                                                                   \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "v_lshlrev_b32_e32 v82, 2, v40\n\t"                 /* v_lshl_add_u64 shifts by at most 4 */        \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "v_lshl_add_u64 v[68:69], v[70:71], 4, %[blocks]\n\t"                                                 \
+    "v_lshl_add_u64 v[66:67], v[82:83], 4, %[desc]\n\t"   /* descriptor of rec (64 bytes each) */        \
+    "s_mov_b64 exec, s[44:45]\n\t"                      /* only the lanes that were walking before this step load: a  */ \
+    "global_load_dwordx4 v[60:63], v[68:69], off\n\t"   /* lane that has just parked fetches the parking descriptor   */ \
+    "global_load_dwordx4 v[48:51], v[66:67], off\n\t"   /* once and keeps it; the texture path spends cycles on every */ \
+    "global_load_dwordx4 v[52:55], v[66:67], off offset:16\n\t" /* enabled lane                                       */ \
+    "global_load_dwordx4 v[56:59], v[66:67], off offset:32\n\t"                                           \
+    "global_load_dwordx2 v[90:91], v[66:67], off offset:48\n\t"                                           \
+    "s_mov_b64 exec, -1\n\t"                                                                              \
+    "v_add_u32_e32 v86, 0x9e3779b1, v86\n\t"              /* new sequence number = new pseudo-random number */ \
+    "ds_write_b128 %[mail], v[84:87]\n\t"                 /* look-ahead target for the helper wave */
+    asm volatile(
+        "v_mov_b32_e32 v40, %[rec]\n\t"
+        "v_mov_b32_e32 v83, 0\n\t"
+        "v_mov_b32_e32 v42, %[offset]\n\t"
+        "v_mov_b32_e32 v43, %[bb]\n\t"
+        "v_mov_b32_e32 v44, %[wr]\n\t"
+        "v_mov_b32_e32 v86, %[hash]\n\t"
+        "v_mov_b32_e32 v87, 0\n\t"
+        "v_mov_b32_e32 v71, 0\n\t"
+        "v_mov_b32_e32 v84, 0\n\t"
+        "v_mov_b32_e32 v85, 0\n\t"
+        "s_mov_b32 %[reason], 0\n\t"
+        "s_mov_b64 s[44:45], -1\n\t"
+        GBWT_WALK_ISSUE
+        ".Lgbwt_walk_loop_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_cmp_gt_i32_e32 vcc, 0, v56\n\t"                  /* DESC_SLOW = sign of D.x */
+        "v_lshrrev_b64 v[76:77], v42, v[60:61]\n\t"         /* bit `offset & 63` -> bit 0 */
+        "v_lshlrev_b64 v[78:79], v42, -1\n\t"               /* bits at and above it */
+        "s_cbranch_vccnz .Lgbwt_walk_slow_%=\n\t"
+        "v_and_b32_e32 v76, 1, v76\n\t"                     /* value */
+        "v_bfi_b32 v78, v78, 0, v60\n\t"                    /* K bits below */
+        "v_bfi_b32 v79, v79, 0, v61\n\t"
+        "v_cmp_eq_u32_e32 vcc, 1, v76\n\t"
+        "v_bcnt_u32_b32 v78, v78, v62\n\t"                  /* + value-1 positions before the block */
+        "v_bcnt_u32_b32 v78, v79, v78\n\t"                  /* ones */
+        "v_sub_u32_e32 v79, v42, v78\n\t"                   /* offset - ones */
+        "v_cndmask_b32_e32 v79, v79, v78, vcc\n\t"          /* rank */
+        "v_cndmask_b32_e32 v88, v48, v52, vcc\n\t"          /* E.x: node to emit */
+        "v_cndmask_b32_e32 v80, v49, v53, vcc\n\t"          /* E.y: offset base */
+        "v_cndmask_b32_e32 v40, v50, v54, vcc\n\t"          /* E.z: landing record */
+        "v_cndmask_b32_e32 v43, v51, v55, vcc\n\t"          /* E.w: its block base */
+        "v_cndmask_b32_e32 v84, v56, v58, vcc\n\t"          /* look-ahead base */
+        "v_cndmask_b32_e32 v85, v57, v59, vcc\n\t"          /* flags | look-ahead count */
+        "v_cndmask_b32_e32 v87, v90, v91, vcc\n\t"          /* look-ahead record */
+        "v_add_u32_e32 v42, v80, v79\n\t"                   /* offset in the landing record */
+        GBWT_WALK_ISSUE
+        "v_and_b32_e32 v76, 63, v44\n\t"                    /* ring slot of the next node */
+        "v_cmp_ne_u32_e32 vcc, 0, v88\n\t"
+        "v_lshl_add_u32 v76, v76, 8, %[ring]\n\t"
+        "v_add_u32_e32 v89, s41, v40\n\t"                   /* node of the landing record */
+        "ds_write_b32 v76, v88\n\t"
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */
+        "v_cmp_gt_i32_e32 vcc, 0, v85\n\t"                  /* EDGE_EMIT2 = sign of the flags */
+        "v_and_b32_e32 v76, 63, v44\n\t"
+        "v_lshl_add_u32 v76, v76, 8, %[ring]\n\t"
+        "ds_write_b32 v76, v89\n\t"
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"
+        "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */
+        "v_sub_u32_e32 v76, v44, %[flushed]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[urgent], v76\n\t"
+        "s_cmp_eq_u64 s[44:45], 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_walk_out_%=\n\t"
+        "s_cbranch_vccz .Lgbwt_walk_loop_%=\n\t"
+        "s_branch .Lgbwt_walk_out_%=\n\t"
+        ".Lgbwt_walk_slow_%=:\n\t"
+        "s_mov_b32 %[reason], 1\n\t"
+        ".Lgbwt_walk_out_%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "v_mov_b32_e32 %[rec], v40\n\t"
+        "v_mov_b32_e32 %[offset], v42\n\t"
+        "v_mov_b32_e32 %[bb], v43\n\t"
+        "v_mov_b32_e32 %[wr], v44\n\t"
+        "v_mov_b32_e32 %[hash], v86\n\t"
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [hash] "+v"(hash), [reason] "=&s"(reason)
+        : [desc] "s"(desc), [blocks] "s"(blocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [flushed] "v"(flushed), [urgent] "i"(RING_URGENT),
+          "{s41}"(alphabet_offset)
+        : "memory", "vcc", "scc", "s44", "s45",
+          "v40", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63", "v66", "v67", "v68", "v69", "v70", "v71", "v76", "v77", "v78",
+          "v79", "v80", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+#undef GBWT_WALK_ISSUE
+    return reason;
+#endif
+}
+
+// The look-ahead helper.  All walks of an XCD reach a record at about the same time, so the first one pays an L2
+// miss and the others wait on the same fill.  Touching the rank blocks a few records ahead fixes that, but not from
+// the walking wave: gfx9 returns a wave's loads in order, so a touch that misses holds back the demand loads issued
+// behind it, and the leader would still be paced by the miss.  The touches therefore come from a second wave of the
+// workgroup with a vmcnt of its own.  Every iteration a walking lane posts {first block, flags | block count, sequence
+// number, record} of the record it will reach a few iterations later (k_link_lookahead) in its LDS mailbox slot; the
+// helper polls the slots, and for every slot that changed loads the descriptor and one block of that record (lanes and
+// iterations follow one golden-ratio sequence, so together they cover the block array evenly) -- into registers nobody
+// reads, never waiting for them.  Leaves when the walking wave raises the done flag.
+__device__ __forceinline__ void lookahead_helper(const uint4 *desc, const uint4 *blocks, uint32_t mail_slot, uint32_t done_addr) {
+    asm volatile(
+        "v_mov_b32_e32 v40, 0\n\t"                          /* last sequence number seen */
+        "v_mov_b32_e32 v47, 0\n\t"
+        "s_mov_b32 s42, 0x1fffffff\n\t"
+        ".Lgbwt_helper_loop_%=:\n\t"
+        "ds_read_b128 v[48:51], %[mail]\n\t"
+        "ds_read_b32 v52, %[done]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ne_u32_e32 vcc, v50, v40\n\t"                /* slots with a new target */
+        "v_and_b32_e32 v53, s42, v49\n\t"                   /* number of blocks of the target */
+        "v_mov_b32_e32 v40, v50\n\t"
+        "v_cmp_ne_u32_e64 s[46:47], 0, v53\n\t"
+        "v_mul_hi_u32 v46, v50, v53\n\t"                    /* pseudo-random block of it */
+        "s_and_b64 vcc, vcc, s[46:47]\n\t"
+        "v_add_u32_e32 v46, v46, v48\n\t"
+        "v_lshlrev_b32_e32 v58, 2, v51\n\t"                /* descriptor of the target record: 64 bytes each */
+        "v_mov_b32_e32 v59, 0\n\t"
+        "s_and_saveexec_b64 s[44:45], vcc\n\t"
+        "v_lshl_add_u64 v[54:55], v[46:47], 4, %[blocks]\n\t"
+        "v_lshl_add_u64 v[58:59], v[58:59], 4, %[desc]\n\t"
+        "global_load_dword v56, v[54:55], off offset:12\n\t"
+        "global_load_dword v57, v[58:59], off\n\t"
+        "s_mov_b64 exec, s[44:45]\n\t"
+        "v_readfirstlane_b32 s46, v52\n\t"
+        "s_cmp_lg_u32 s46, 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_helper_out_%=\n\t"
+        "s_sleep 8\n\t"
+        "s_branch .Lgbwt_helper_loop_%=\n\t"
+        ".Lgbwt_helper_out_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        :
+        : [mail] "v"(mail_slot), [done] "v"(done_addr), [blocks] "s"(blocks), [desc] "s"(desc)
+        : "memory", "vcc", "scc", "s42", "s44", "s45", "s46", "s47", "v40", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+          "v57", "v58", "v59");
+}
+
+
+// ---- two-step walk --------------------------------------------------------------------------------------
+// Same frame as k_walk_blocks; an iteration of the hot loop composes two LF steps (k_link_desc2, k_fill_cblocks):
+//     a = bit `offset` of bits1;  rank_a = equal values of v before it;        j = base_a + rank_a  (offset in w_a)
+//     b = bit `offset` of bits2;  rank_b = equal values of w_a before j = R_a + (a-paths of this block before `offset`
+//                                          whose value in w_a is 1), or j minus that
+//     leaf (a, b): rec = its landing record, offset = its base + rank_b
+//     emit: node of edge a, node of w_a if that step was fused, node of the leaf, node of rec if that step was fused
+__device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                   uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
+                                                   uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    // plain C++ statement of the loop (no pipelining)
+    __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
+    __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
+    for (;;) {
+        const uint4 *d = desc2 + 8 * static_cast<uint64_t>(rec);
+        const uint4 F0 = d[0], F1 = d[1], L00 = d[2], L01 = d[3], L10 = d[4], L11 = d[5], look = d[6];
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+        const uint4 K0 = cblocks[2 * idx], K1 = cblocks[2 * idx + 1];
+        if (__ballot((F1.x & DESC2_SLOW) != 0) != 0) return 1;
+        const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+        const uint32_t bit = offset & 63u;
+        const uint64_t below = (uint64_t(1) << bit) - 1;
+        const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u;
+        const uint64_t m = a ? bits1 : ~bits1;
+        const uint32_t p = __popcll(m & below);
+        const uint32_t rank_a = a ? K1.x + p : (offset - bit) - K1.x + p;
+        const uint32_t j = (a ? F0.w : F0.y) + rank_a;
+        const uint32_t b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+        const uint32_t ones_w = (a ? K1.z : K1.y) + __popcll(m & bits2 & below);
+        const uint32_t rank_b = b ? ones_w : j - ones_w;
+        const uint4 leaf = a ? (b ? L11 : L10) : (b ? L01 : L00);
+        const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
+        rec = leaf.z & REC_MASK; offset = leaf.y + rank_b; bb = leaf.w;
+        ring[(wr & ring_mask) * ring_stride] = n1;
+        wr += n1 != 0 ? 1u : 0u;
+        ring[(wr & ring_mask) * ring_stride] = (wword & REC_MASK) + alphabet_offset;
+        wr += (wword & LEAF_EMIT2) ? 1u : 0u;
+        ring[(wr & ring_mask) * ring_stride] = leaf.x;
+        wr += leaf.x != 0 ? 1u : 0u;
+        ring[(wr & ring_mask) * ring_stride] = rec + alphabet_offset;
+        wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
+        mail[0] = look.x; mail[1] = look.y; mail[2] = look.z; mail[3] = wr;
+        if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > ring_mask + 1 - 8) != 0) return 0;
+    }
+#else
+    // The same loop in gfx950 assembly (see walk_hot_loop for the conventions: all lanes run everything, parked lanes sit
+    // on record 0, loads of the next position go out as early as possible, exits leave nothing in flight; a VALU write
+    // of VCC / an SGPR is kept two instructions away from the VALU that reads it).  Registers v40-v125, s41, s44-s47.
+    uint32_t reason;
+#define GBWT_WALK2_ISSUE_WIDE                                                                                  \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "v_lshlrev_b64 v[88:89], 7, v[40:41]\n\t"             /* two-step descriptors are 128 bytes */        \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "v_lshl_add_u64 v[88:89], v[88:89], 0, %[desc2]\n\t"                                                  \
+    "v_lshlrev_b64 v[90:91], 5, v[70:71]\n\t"             /* two-step blocks are 32 bytes */              \
+    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
+    "s_mov_b64 exec, s[44:45]\n\t"                        /* only lanes that were walking before this step */ \
+    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"             /* K0: bits1, bits2 */                  \
+    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"   /* K1: ones1, R0, R1 */                 \
+    "global_load_dwordx4 v[48:51], v[88:89], off\n\t"             /* F0 */                                \
+    "global_load_dwordx2 v[52:53], v[88:89], off offset:16\n\t"   /* F1 */                                \
+    "global_load_dwordx4 v[56:59], v[88:89], off offset:32\n\t"   /* leaf (0, 0) */                       \
+    "global_load_dwordx4 v[60:63], v[88:89], off offset:48\n\t"   /* leaf (0, 1) */                       \
+    "global_load_dwordx4 v[64:67], v[88:89], off offset:64\n\t"   /* leaf (1, 0) */                       \
+    "global_load_dwordx4 v[72:75], v[88:89], off offset:80\n\t"   /* leaf (1, 1) */                       \
+    "global_load_dwordx3 v[76:78], v[88:89], off offset:96\n\t"   /* look-ahead target */                 \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_WALK2_ISSUE_NARROW                                                                           \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "v_lshlrev_b32_e32 v88, 7, v40\n\t"                   /* two-step descriptors are 128 bytes */        \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
+    "s_mov_b64 exec, s[44:45]\n\t"                        /* only lanes that were walking before this step */ \
+    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
+    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
+    "global_load_dwordx4 v[48:51], v88, %[desc2]\n\t"               /* F0 */                              \
+    "global_load_dwordx2 v[52:53], v88, %[desc2] offset:16\n\t"     /* F1 */                              \
+    "global_load_dwordx4 v[56:59], v88, %[desc2] offset:32\n\t"     /* leaf (0, 0) */                     \
+    "global_load_dwordx4 v[60:63], v88, %[desc2] offset:48\n\t"     /* leaf (0, 1) */                     \
+    "global_load_dwordx4 v[64:67], v88, %[desc2] offset:64\n\t"     /* leaf (1, 0) */                     \
+    "global_load_dwordx4 v[72:75], v88, %[desc2] offset:80\n\t"     /* leaf (1, 1) */                     \
+    "global_load_dwordx3 v[76:78], v88, %[desc2] offset:96\n\t"     /* look-ahead target */               \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_WALK2_LOOP(ISSUE)                                                                             \
+    asm volatile( \
+        "v_mov_b32_e32 v40, %[rec]\n\t" \
+        "v_mov_b32_e32 v41, 0\n\t" \
+        "v_mov_b32_e32 v42, %[offset]\n\t" \
+        "v_mov_b32_e32 v43, %[bb]\n\t" \
+        "v_mov_b32_e32 v44, %[wr]\n\t" \
+        "v_mov_b32_e32 v71, 0\n\t" \
+        "s_mov_b32 %[reason], 0\n\t" \
+        "s_mov_b64 s[44:45], -1\n\t" \
+        ISSUE \
+        ".Lgbwt_walk2_loop_%=:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_lshlrev_b32_e32 v92, 1, v52\n\t"                 /* DESC2_SLOW (bit 30 of F1.x) -> sign */ \
+        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v92\n\t" \
+        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
+        "s_cbranch_vccnz .Lgbwt_walk2_slow_%=\n\t" \
+        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
+        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v101, v81, v98\n\t" \
+        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v101, v97, 0, v101\n\t" \
+        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
+        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v103, v49, v51, vcc\n\t"         /* offset base of edge a */ \
+        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
+        "v_cndmask_b32_e32 v104, v48, v50, vcc\n\t"         /* node of edge a */ \
+        "v_add_u32_e32 v103, v103, v99\n\t"                 /* j: offset in w_a */ \
+        "v_cndmask_b32_e32 v105, v52, v53, vcc\n\t"         /* w_a | flags */ \
+        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
+        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
+        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v101, v101, v83\n\t" \
+        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
+        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
+        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */ \
+        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
+        "v_cndmask_b32_e64 v112, v56, v60, s[46:47]\n\t"    /* leaf (0, b) */ \
+        "v_cndmask_b32_e64 v113, v57, v61, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v114, v58, v62, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v115, v59, v63, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v116, v64, v72, s[46:47]\n\t"    /* leaf (1, b) */ \
+        "v_cndmask_b32_e64 v117, v65, v73, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v118, v66, v74, s[46:47]\n\t" \
+        "v_cndmask_b32_e64 v119, v67, v75, s[46:47]\n\t" \
+        "v_cndmask_b32_e32 v112, v112, v116, vcc\n\t"       /* leaf (a, b): node to emit */ \
+        "v_cndmask_b32_e32 v113, v113, v117, vcc\n\t"       /* offset base */ \
+        "v_cndmask_b32_e32 v114, v114, v118, vcc\n\t"       /* landing record | flags */ \
+        "v_cndmask_b32_e32 v43, v115, v119, vcc\n\t"        /* its block base */ \
+        "v_add_u32_e32 v42, v113, v107\n\t"                 /* the new offset */ \
+        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t"                  /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v110\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v111\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks (both-ends walks) */ \
+        "v_mov_b32_e32 v79, v44\n\t"                        /* mailbox: look-ahead target of the record just left + nodes staged so far */ \
+        "ds_write_b128 %[mail], v[76:79]\n\t" \
+        "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
+        "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
+        ISSUE \
+        "v_cmp_ne_u32_e64 s[44:45], 0, v40\n\t"             /* lanes still walking */ \
+        "v_cmp_lt_u32_e32 vcc, %[limit], v44\n\t"             /* more than RING2_URGENT nodes waiting in a ring */ \
+        "s_cmp_eq_u64 s[44:45], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2_out_%=\n\t" \
+        "s_cbranch_vccz .Lgbwt_walk2_loop_%=\n\t" \
+        "s_branch .Lgbwt_walk2_out_%=\n\t" \
+        ".Lgbwt_walk2_slow_%=:\n\t" \
+        "s_mov_b32 %[reason], 1\n\t" \
+        ".Lgbwt_walk2_out_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "v_mov_b32_e32 %[rec], v40\n\t" \
+        "v_mov_b32_e32 %[offset], v42\n\t" \
+        "v_mov_b32_e32 %[bb], v43\n\t" \
+        "v_mov_b32_e32 %[wr], v44\n\t" \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
+          "{s41}"(alphabet_offset) \
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
+          "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
+          "v64", "v65", "v66", "v67", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
+          "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+    const uint32_t limit = flushed + (ring_mask + 1 - 8);   // leave with more than slots - 8 nodes waiting
+    if (narrow) { GBWT_WALK2_LOOP(GBWT_WALK2_ISSUE_NARROW) } else { GBWT_WALK2_LOOP(GBWT_WALK2_ISSUE_WIDE) }
+#undef GBWT_WALK2_LOOP
+#undef GBWT_WALK2_ISSUE_NARROW
+#undef GBWT_WALK2_ISSUE_WIDE
+    return reason;
+#endif
+}
+
+// ---- two-step walk, wave-uniform variant ----------------------------------------------------------------------
+// With sixty-four lanes walking, the vector-memory path is what the walk saturates (TA / TD busy 92-95 % of the kernel,
+// profiles/r01_coop_pmc_headline.txt): every lane fetches its own copy of the 104 descriptor bytes, 16 bytes per lane
+// per load instruction.  The walkers of a wave hold the same segment of neighbouring rows, and haplotypes travel
+// together, so very often ALL lanes sit on the same record: then the descriptor is one scalar fetch (s_load, 28 SGPRs)
+// and only the two-step rank block -- the one thing that differs between lanes -- goes through the vector path
+// (28 bytes per lane instead of 132).  gfx9 VALU instructions read at most one SGPR, so instead of v_cndmask the
+// per-lane choices are made by running the same `v_mov / v_add  vgpr, sgpr` under the exec mask of each choice.
+// Same registers and conventions as walk2_hot_loop.  Leaves with reason 2 -- nothing in flight, state intact -- as
+// soon as the lanes are not all on one record (or some are parked); the caller then continues with walk2_hot_loop.
+// SGPRs: s[48:63] F0 F1 L00 L01, s[64:71] L10 L11, s[72:75] look-ahead target, s[76:85] masks, s[88:89] descriptor
+// address, s78 the record.
+__device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                       uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
+                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    return 2;
+#else
+    uint32_t reason;
+    const uint32_t slack = ring_mask + 1 - 8;   // leave with more than slots - 8 nodes waiting in a ring
+    const uint32_t dlo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2)), dhi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2) >> 32);
+#define GBWT_WALK2U_ISSUE(KLOAD, REFRESH)                                                                             \
+    "v_readfirstlane_b32 s78, v40\n\t"                    /* the record of lane 0 */                       \
+    "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
+    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "s_lshl_b32 s76, s78, 7\n\t"                          /* two-step descriptors are 128 bytes */        \
+    "s_lshr_b32 s77, s78, 25\n\t"                                                                         \
+    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "s_add_u32 s76, s76, %[dlo]\n\t"                                                                      \
+    "s_addc_u32 s77, s77, %[dhi]\n\t"                                                                     \
+    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
+    "v_cmp_ne_u32_e32 vcc, s78, v40\n\t"                  /* lanes on another record */                   \
+    "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* F0, F1, leaf (0, 0), leaf (0, 1) */          \
+    "s_load_dwordx8 s[64:71], s[76:77], 0x40\n\t"         /* leaf (1, 0), leaf (1, 1) */                  \
+    "s_load_dwordx4 s[72:75], s[76:77], 0x60\n\t"         /* look-ahead target */                         \
+    KLOAD                                                                                                 \
+    REFRESH
+// K0 = {bits1, bits2}, K1 = {ones1, R0, R1} of the lane's two-step block: SGPR base + 32-bit byte offset while the block
+// array is below 4 GiB, a 64-bit address per lane above
+#define GBWT_WALK2U_KLOAD_NARROW                                                                          \
+    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"                                                   \
+    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"
+#define GBWT_WALK2U_KLOAD_WIDE                                                                            \
+    "v_lshrrev_b32_e32 v91, 27, v70\n\t"                                                                  \
+    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
+    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"                                                     \
+    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"
+#define GBWT_WALK2U_LEAF(MASK, X, Y, Z, W)                                                                 \
+    MASK "\n\t"                                                                                           \
+    "v_mov_b32_e32 v112, " X "\n\t"                       /* node to emit */                              \
+    "v_add_u32_e32 v42, " Y ", v107\n\t"                  /* the new offset = offset base + rank_b */     \
+    "v_mov_b32_e32 v114, " Z "\n\t"                       /* landing record | flags */                    \
+    "v_mov_b32_e32 v43, " W "\n\t"                        /* its block base */
+#define GBWT_WALK2U_LOOP(KLOAD, REFRESH) \
+    asm volatile( \
+        "v_mov_b32_e32 v40, %[rec]\n\t" \
+        "v_mov_b32_e32 v42, %[offset]\n\t" \
+        "v_mov_b32_e32 v43, %[bb]\n\t" \
+        "v_mov_b32_e32 v44, %[wr]\n\t" \
+        "s_mov_b32 %[reason], 0\n\t" \
+        GBWT_WALK2U_ISSUE(KLOAD, REFRESH) \
+        "s_nop 1\n\t" \
+        "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
+        "s_cmp_eq_u32 s78, 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_loop_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "s_bitcmp1_b32 s52, 30\n\t"                         /* DESC2_SLOW */ \
+        "s_cbranch_scc1 .Lgbwt_walk2u_slow_%=\n\t" \
+        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
+        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
+        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
+        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v101, v81, v98\n\t" \
+        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v101, v97, 0, v101\n\t" \
+        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
+        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
+        "s_mov_b64 s[44:45], vcc\n\t"                       /* a */ \
+        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
+        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
+        "v_mov_b32_e32 v104, s48\n\t"                       /* edge 0: node */ \
+        "v_mov_b32_e32 v105, s52\n\t"                       /*         w_0 | flags */ \
+        "v_add_u32_e32 v103, s49, v99\n\t"                  /*         j = offset base + rank_a: offset in w_a */ \
+        "s_mov_b64 exec, s[44:45]\n\t"                      /* the lanes that take edge 1 */ \
+        "v_mov_b32_e32 v104, s50\n\t" \
+        "v_mov_b32_e32 v105, s53\n\t" \
+        "v_add_u32_e32 v103, s51, v99\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
+        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v101, v101, v83\n\t" \
+        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
+        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
+        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */ \
+        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
+        GBWT_WALK2U_LEAF("s_nor_b64 exec, s[44:45], s[46:47]", "s56", "s57", "s58", "s59")     /* lanes of leaf (0, 0) */ \
+        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[46:47], s[44:45]", "s60", "s61", "s62", "s63")   /*          leaf (0, 1) */ \
+        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[44:45], s[46:47]", "s64", "s65", "s66", "s67")   /*          leaf (1, 0) */ \
+        GBWT_WALK2U_LEAF("s_and_b64 exec, s[44:45], s[46:47]", "s68", "s69", "s70", "s71")     /*          leaf (1, 1) */ \
+        "s_mov_b64 exec, -1\n\t" \
+        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v110\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v111\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_mov_b32_e32 v76, s72\n\t"                        /* mailbox: look-ahead target of the record just left ... */ \
+        "v_mov_b32_e32 v77, s73\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"           /* a walker that has emitted its share parks */ \
+        "v_mov_b32_e32 v78, s74\n\t" \
+        "v_mov_b32_e32 v79, v44\n\t"                        /* ... + nodes staged so far */ \
+        "ds_write_b128 %[mail], v[76:79]\n\t" \
+        "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
+        "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
+        "v_sub_u32_e32 v92, v44, v45\n\t"                   /* nodes waiting in the ring (drained as of the last iteration) */ \
+        GBWT_WALK2U_ISSUE(KLOAD, REFRESH) \
+        "v_cmp_lt_u32_e64 s[46:47], %[slack], v92\n\t"      /* more than slots - 8 of them */ \
+        "s_nop 0\n\t" \
+        "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
+        "s_cmp_eq_u32 s78, 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t"           /* everyone has parked */ \
+        "s_cmp_eq_u64 s[46:47], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_loop_%=\n\t" \
+        "s_branch .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_slow_%=:\n\t" \
+        "s_mov_b32 %[reason], 1\n\t" \
+        "s_branch .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_mixed_%=:\n\t" \
+        "s_mov_b32 %[reason], 2\n\t" \
+        ".Lgbwt_walk2u_out_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "v_mov_b32_e32 %[rec], v40\n\t" \
+        "v_mov_b32_e32 %[offset], v42\n\t" \
+        "v_mov_b32_e32 %[bb], v43\n\t" \
+        "v_mov_b32_e32 %[wr], v44\n\t" \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
+        : [dlo] "s"(dlo), [dhi] "s"(dhi), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [drained] "v"(drained_addr), [slack] "s"(slack), [quota] "v"(quota), \
+          [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), "{s41}"(alphabet_offset) \
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
+          "v40", "v42", "v43", "v44", "v45", "v70", "v91", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v90", "v92", "v94", "v95", \
+          "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v114");
+    // the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered
+    // with, it had to leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted
+    // round of loads)
+    if (narrow) { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_NARROW, "ds_read_b32 v45, %[drained]\n\t") }
+    else { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_WIDE, "ds_read_b32 v45, %[drained]\n\t") }
+#undef GBWT_WALK2U_LOOP
+#undef GBWT_WALK2U_LEAF
+#undef GBWT_WALK2U_KLOAD_WIDE
+#undef GBWT_WALK2U_KLOAD_NARROW
+#undef GBWT_WALK2U_ISSUE
+    return reason;
+#endif
+}
+
+// Look-ahead helper of the two-step walk: mailbox slot = {record, first block, number of blocks, sequence number} of
+// the record the walk reaches a few iterations later; touches its descriptor (128 bytes = two sectors) and one of its
+// two-step blocks.  Fire and forget, as lookahead_helper.
+__device__ __forceinline__ void lookahead_helper2(const uint4 *desc2, const uint4 *cblocks, uint32_t mail_slot, uint32_t done_addr, uint32_t spread) {
+    asm volatile(
+        "v_mov_b32_e32 v40, 0\n\t"                          /* last sequence number seen */
+        "v_mov_b32_e32 v47, 0\n\t"
+        "v_mov_b32_e32 v59, 0\n\t"
+        ".Lgbwt_helper2_loop_%=:\n\t"
+        "ds_read_b128 v[48:51], %[mail]\n\t"
+        "ds_read_b32 v52, %[done]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ne_u32_e32 vcc, v51, v40\n\t"                /* slots with a new target ... */
+        "v_mov_b32_e32 v58, v48\n\t"
+        "v_mov_b32_e32 v40, v51\n\t"
+        "v_cmp_ne_u32_e64 s[46:47], 0, v48\n\t"             /* ... that is a record */
+        "v_mov_b32_e32 v46, %[spread]\n\t"                  /* helper lane l takes the block (l + 1/2) / 64 of the way through */
+        "v_mul_hi_u32 v46, v46, v50\n\t"
+        "s_and_b64 vcc, vcc, s[46:47]\n\t"
+        "v_add_u32_e32 v46, v46, v49\n\t"
+        "s_and_saveexec_b64 s[44:45], vcc\n\t"
+        "v_lshlrev_b64 v[54:55], 5, v[46:47]\n\t"           /* two-step blocks are 32 bytes */
+        "v_lshlrev_b64 v[60:61], 7, v[58:59]\n\t"           /* two-step descriptors are 128 bytes */
+        "v_lshl_add_u64 v[54:55], v[54:55], 0, %[cblocks]\n\t"
+        "v_lshl_add_u64 v[60:61], v[60:61], 0, %[desc2]\n\t"
+        "global_load_dword v56, v[54:55], off\n\t"
+        "global_load_dword v57, v[60:61], off\n\t"
+        "global_load_dword v53, v[60:61], off offset:64\n\t"
+        "s_mov_b64 exec, s[44:45]\n\t"
+        "v_readfirstlane_b32 s46, v52\n\t"
+        "s_cmp_lg_u32 s46, 0\n\t"
+        "s_cbranch_scc1 .Lgbwt_helper2_out_%=\n\t"
+        "s_sleep 8\n\t"
+        "s_branch .Lgbwt_helper2_loop_%=\n\t"
+        ".Lgbwt_helper2_out_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        :
+        : [mail] "v"(mail_slot), [done] "v"(done_addr), [spread] "v"(spread), [cblocks] "s"(cblocks), [desc2] "s"(desc2)
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "v40", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+          "v57", "v58", "v59", "v60", "v61");
+}
+
+
+// The two-step walk in plain C++ without an output, for the one-time passes at open: `sink.push` sees every node in
+// order, `sink.checkpoint` sees the position of the walk after every iteration (a state from which a walker can go on).
+template <class Sink>
+__device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, Sink &sink, uint32_t *overflow) {
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
+    if (id < ix.n_endmarker) {
+        const uint2 e = ix.endmarker[id];
+        if (e.x != 0) {
+            sink.push(e.x, true);
+            offset = e.y;
+            if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            sink.checkpoint(rec, offset, bb);
+        }
+    }
+    uint64_t guard = 0;
+    while (rec != 0) {
+        if (++guard > 0xFFFFFFF0ull || sink.wr > 0xFFFFFFF0u) { if (overflow) atomicOr(overflow, 1u); break; }
+        const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
+        const uint4 F1 = d[1];
+        if (F1.x & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); sink.checkpoint(rec, offset, bb); continue; }
+        const uint4 F0 = d[0];
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+        const uint4 K0 = ix.cblocks[2 * idx], K1 = ix.cblocks[2 * idx + 1];
+        const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+        const uint32_t bit = offset & 63u;
+        const uint64_t below = (uint64_t(1) << bit) - 1;
+        const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u;
+        const uint64_t m = a ? bits1 : ~bits1;
+        const uint32_t rank_a = a ? K1.x + __popcll(m & below) : (offset - bit) - K1.x + __popcll(m & below);
+        const uint32_t j = (a ? F0.w : F0.y) + rank_a;
+        const uint32_t b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+        const uint32_t ones_w = (a ? K1.z : K1.y) + __popcll(m & bits2 & below);
+        const uint4 leaf = d[2 + 2 * a + b];
+        const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
+        rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
+        sink.push(n1, n1 != 0);
+        sink.push((wword & REC_MASK) + ix.alphabet_offset, (wword & LEAF_EMIT2) != 0);
+        sink.push(leaf.x, leaf.x != 0);
+        sink.push(rec + ix.alphabet_offset, (leaf.z & LEAF_EMIT2) != 0);
+        sink.checkpoint(rec, offset, bb);
+    }
+}
+
+}  // namespace
+
+}  // namespace gbwt_hip
