@@ -195,6 +195,20 @@ void upload(gbwt_hip_index &ix) {
         if (want_pairs) prints.reserve(h.sequences * 2 * sizeof(uint64_t));
         HIP_CHECK(hipMemset(d_stats, 0, 2 * sizeof(uint64_t)));
         uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_stats);   // [0] = a length overflowed, [2] = a pair does not match
+        // with samples and without fingerprints, lengths and samples come out of ONE walk (pooled samples, placed afterwards)
+        DeviceBuffer pool, tags;
+        uint64_t pooled = 0;
+        const uint64_t pool_capacity = all_nodes / std::max<uint32_t>(interval, 1) + 2 * h.sequences + 1024;
+        const char *two = std::getenv("GBWT_HIP_TWO_PASS_OPEN");
+        bool one_walk = sampled && !want_pairs && h.sequences <= 0xFFFFFFFFull && !(two && std::atoi(two) != 0);
+        if (one_walk) {
+            pool.reserve(pool_capacity * sizeof(uint4)); tags.reserve(pool_capacity * sizeof(uint2));
+            HIP_CHECK(hipMemset(d_stats + 2, 0, sizeof(uint64_t)));
+            launch_lengths_and_samples(d, interval, ix.seq_len.as<uint32_t>(), pool.as<uint4>(), tags.as<uint2>(), d_stats + 2, pool_capacity, d_flags, nullptr);
+            HIP_CHECK(hipMemcpy(&pooled, d_stats + 2, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            if (pooled > pool_capacity) one_walk = false;            // cannot happen (one sample per interval + one per sequence): walk twice
+        }
+        if (!one_walk)
         launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), want_pairs ? prints.as<uint64_t>() : nullptr, d_flags, nullptr);
         if (want_pairs)
             launch_check_orientation_pairs(ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), h.sequences / 2, d_flags + 2, nullptr);
@@ -217,7 +231,9 @@ void upload(gbwt_hip_index &ix) {
                 uint64_t total_samples = 0;
                 HIP_CHECK(hipMemcpy(&total_samples, ix.sample_base.as<uint64_t>() + h.sequences, sizeof(uint64_t), hipMemcpyDeviceToHost));
                 ix.samples.reserve(std::max<uint64_t>(total_samples, 1) * sizeof(uint4));
-                launch_record_samples(d, ix.sample_base.as<uint64_t>(), interval, ix.samples.as<uint4>(), nullptr);
+                if (one_walk) launch_place_samples(ix.seq_len.as<uint32_t>(), pool.as<uint4>(), tags.as<uint2>(), pooled, ix.sample_base.as<uint64_t>(), h.sequences,
+                                                   ix.samples.as<uint4>(), nullptr);
+                else launch_record_samples(d, ix.sample_base.as<uint64_t>(), interval, ix.samples.as<uint4>(), nullptr);
                 HIP_CHECK(hipDeviceSynchronize());
                 HIP_CHECK(hipGetLastError());
                 d.samples = ix.samples.as<uint4>();

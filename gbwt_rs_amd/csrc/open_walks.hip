@@ -108,6 +108,52 @@ __global__ void __launch_bounds__(256) k_record_samples(DeviceIndex ix, const ui
     for (; sink.written < sink.capacity; sink.written++) sink.out[sink.written] = make_uint4(0u, 0u, BLOCK_NONE, sink.wr);
 }
 
+// Lengths AND samples in one walk: a sequence does not know how many samples it will have until it ends, so the samples
+// go to a pool in the order they are met (one atomic per sample), tagged with (sequence, sample number); once the lengths
+// are there, k_place_samples puts them where k_record_samples would have.  Halves the open time of a large index.
+struct PooledSampleSink {
+    uint32_t wr = 0, next = 0, interval, number = 0, id;
+    uint4 *pool;
+    uint2 *tags;
+    unsigned long long *counter;
+    uint64_t capacity;
+    __device__ __forceinline__ void push(uint32_t, bool counts) { wr += counts ? 1u : 0u; }
+    __device__ __forceinline__ void checkpoint(uint32_t rec, uint32_t offset, uint32_t bb) {
+        if (wr < next) return;
+        const uint64_t at = atomicAdd(counter, 1ull);                // past the capacity: counted, not stored (the caller falls back)
+        if (at < capacity) { pool[at] = make_uint4(rec, offset, bb, wr); tags[at] = make_uint2(id, number); }
+        number++; next += interval;
+    }
+};
+
+__global__ void __launch_bounds__(256) k_lengths_and_samples(DeviceIndex ix, uint32_t interval, uint32_t *seq_len, uint4 *pool, uint2 *tags,
+                                                             unsigned long long *counter, uint64_t capacity, uint32_t *overflow) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id >= ix.n_sequences) return;
+    PooledSampleSink sink;
+    sink.interval = interval; sink.id = static_cast<uint32_t>(id);
+    sink.pool = pool; sink.tags = tags; sink.counter = counter; sink.capacity = capacity;
+    quiet_walk(ix, id, sink, overflow);
+    seq_len[id] = sink.wr;
+}
+
+// every sample slot starts as "never reached" (cannot happen: every boundary lies below the length) ...
+__global__ void __launch_bounds__(256) k_blank_samples(const uint32_t *seq_len, const uint64_t *sample_base, uint64_t n_sequences, uint4 *samples) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id >= n_sequences) return;
+    for (uint64_t k = sample_base[id]; k < sample_base[id + 1]; k++) samples[k] = make_uint4(0u, 0u, BLOCK_NONE, seq_len[id]);
+}
+
+// ... and the pooled ones move to their places (a walk can meet one boundary more than the sequence has samples: the
+// one at its very end)
+__global__ void __launch_bounds__(256) k_place_samples(const uint4 *pool, const uint2 *tags, uint64_t pooled, const uint64_t *sample_base, uint4 *samples) {
+    const uint64_t at = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (at >= pooled) return;
+    const uint2 t = tags[at];
+    const uint64_t base = sample_base[t.x], count = sample_base[t.x + 1] - base;
+    if (t.y < count) samples[base + t.y] = pool[at];
+}
+
 // One lane per path of a bidirectional index: sequence 2k + 1 must be sequence 2k reversed with every node flipped
 // (support::reverse_path, src/support.rs:310-314) -- same length, and the fingerprint of each as it is equals the
 // fingerprint of the other one reversed and flipped.  Any failure clears the flag: rows are then filled from one end.
@@ -133,6 +179,20 @@ void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_
 
 void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d_prints, uint64_t n_pairs, uint32_t *d_mismatch, hipStream_t stream) {
     if (n_pairs) hipLaunchKernelGGL(k_check_orientation_pairs, dim3(grid_for(n_pairs, 256)), dim3(256), 0, stream, d_seq_len, d_prints, n_pairs, d_mismatch);
+}
+
+void launch_lengths_and_samples(const DeviceIndex &ix, uint32_t interval, uint32_t *d_seq_len, uint4 *d_pool, uint2 *d_tags, uint64_t *d_counter,
+                                uint64_t capacity, uint32_t *d_overflow, hipStream_t stream) {
+    if (ix.n_sequences == 0) return;
+    hipLaunchKernelGGL(k_lengths_and_samples, dim3(grid_for(ix.n_sequences, 256)), dim3(256), 0, stream, ix, interval, d_seq_len, d_pool, d_tags,
+                       reinterpret_cast<unsigned long long *>(d_counter), capacity, d_overflow);
+}
+
+void launch_place_samples(const uint32_t *d_seq_len, const uint4 *d_pool, const uint2 *d_tags, uint64_t pooled, const uint64_t *d_sample_base,
+                          uint64_t n_sequences, uint4 *d_samples, hipStream_t stream) {
+    if (n_sequences == 0) return;
+    hipLaunchKernelGGL(k_blank_samples, dim3(grid_for(n_sequences, 256)), dim3(256), 0, stream, d_seq_len, d_sample_base, n_sequences, d_samples);
+    if (pooled) hipLaunchKernelGGL(k_place_samples, dim3(grid_for(pooled, 256)), dim3(256), 0, stream, d_pool, d_tags, pooled, d_sample_base, d_samples);
 }
 
 void launch_sample_counts(const uint32_t *d_seq_len, uint64_t n_sequences, uint32_t interval, uint64_t *d_counts, hipStream_t stream) {

@@ -587,6 +587,7 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "128", "GBWT_HIP_WIDE_ADDRESSES": "1"},   # both loops with 64-bit addresses
                 {"GBWT_HIP_SAMPLE_INTERVAL": "1000", "GBWT_HIP_PATHS_PER_WAVE": "13"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_WALK_TABLES": "0"},   # outdegree > 2: plain table steps, one at a time
+                {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_TWO_PASS_OPEN": "1"},  # lengths and samples from two walks at open instead of one
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
 
