@@ -206,7 +206,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": "u32",   # device arithmetic: record indices, offsets and node ids are 32-bit (the C ABI widens to u64 where the reference has usize)
             "data": "synthetic",
             "config": {
                 "workload": f"bubble-chain GBZ, {args.haplotypes} paths x {3 * args.sites} nodes per GPU "
