@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "capi_internal.hpp"
@@ -539,6 +541,46 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
     }
 }
 
+namespace {
+
+// Device -> pageable host memory for the large results (13 GB of node ids on the headline index).  A plain hipMemcpy
+// stages through one pinned buffer on one thread and also pays the first-touch page faults of a fresh destination on
+// that thread (0.5 - 1.1 s for 13.3 GB).  Here a few threads take alternate chunks, each with a pinned buffer and a
+// stream of its own: the copies over PCIe, the copies out of the pinned buffers and the page faults run side by side.
+void copy_to_host(int device, void *dst, const void *src, size_t bytes) {
+    constexpr size_t CHUNK = size_t(32) << 20;
+    const char *knob = std::getenv("GBWT_HIP_COPY_THREADS");
+    const unsigned threads = knob ? static_cast<unsigned>(std::max(1, std::atoi(knob))) : 4u;
+    if (bytes < 4 * CHUNK || threads < 2) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return; }
+    const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        void *pinned = nullptr;
+        hipStream_t stream = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pinned, CHUNK, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+            failed = 1;
+        } else {
+            for (size_t c = next++; c < chunks && !failed; c = next++) {
+                const size_t at = c * CHUNK, len = std::min(CHUNK, bytes - at);
+                if (hipMemcpyAsync(pinned, static_cast<const char *>(src) + at, len, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                    hipStreamSynchronize(stream) != hipSuccess) { failed = 1; break; }
+                std::memcpy(static_cast<char *>(dst) + at, pinned, len);
+            }
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        if (pinned) (void)hipHostFree(pinned);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t + 1 < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (failed) HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));   // whatever went wrong: the plain way, which reports it
+}
+
+}  // namespace
+
 gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                  uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity, uint64_t *total) {
     if (!out_offsets || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
@@ -550,7 +592,7 @@ gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *w
         *total = p.total;
         if (!out_nodes) return GBWT_HIP_OK;
         if (capacity < p.total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(p.total));
-        if (p.total) HIP_CHECK(hipMemcpy(out_nodes, p.d_nodes, p.total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (p.total) copy_to_host(ix->device, out_nodes, p.d_nodes, p.total * sizeof(uint32_t));
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
