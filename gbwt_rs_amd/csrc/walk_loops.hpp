@@ -673,6 +673,12 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         GBWT_WALK2U_LEAF("s_and_b64 exec, s[44:45], s[46:47]", "s68", "s69", "s70", "s71")     /*          leaf (1, 1) */ \
         "s_mov_b64 exec, -1\n\t" \
         "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
+        "v_mov_b32_e32 v76, s72\n\t"                        /* mailbox: look-ahead target of the record just left (before its SGPRs are reloaded) ... */ \
+        "v_mov_b32_e32 v77, s73\n\t" \
+        "v_mov_b32_e32 v78, s74\n\t" \
+        GBWT_WALK2U_ISSUE(KLOAD, "")                        /* the loads of the next position go out now; staging the nodes runs underneath them */ \
+        "s_nop 1\n\t" \
+        "s_mov_b64 s[44:45], vcc\n\t"                       /* lanes that are not on the record of lane 0 */ \
         "v_and_b32_e32 v92, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
         "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
         "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
@@ -695,19 +701,18 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
         "ds_write_b32 v92, v111\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
-        "v_mov_b32_e32 v76, s72\n\t"                        /* mailbox: look-ahead target of the record just left ... */ \
-        "v_mov_b32_e32 v77, s73\n\t" \
         "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"           /* a walker that has emitted its share parks */ \
-        "v_mov_b32_e32 v78, s74\n\t" \
         "v_mov_b32_e32 v79, v44\n\t"                        /* ... + nodes staged so far */ \
         "ds_write_b128 %[mail], v[76:79]\n\t" \
         "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
         "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
+        "s_andn2_b64 s[46:47], exec, vcc\n\t"               /* lanes that have just parked: their loads were for nothing, and the wave is no longer on one record */ \
         "v_sub_u32_e32 v92, v44, v45\n\t"                   /* nodes waiting in the ring (drained as of the last iteration) */ \
-        GBWT_WALK2U_ISSUE(KLOAD, REFRESH) \
+        "s_or_b64 s[44:45], s[44:45], s[46:47]\n\t" \
+        REFRESH \
         "v_cmp_lt_u32_e64 s[46:47], %[slack], v92\n\t"      /* more than slots - 8 of them */ \
-        "s_nop 0\n\t" \
-        "s_cbranch_vccnz .Lgbwt_walk2u_mixed_%=\n\t" \
+        "s_cmp_lg_u64 s[44:45], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_mixed_%=\n\t" \
         "s_cmp_eq_u32 s78, 0\n\t" \
         "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t"           /* everyone has parked */ \
         "s_cmp_eq_u64 s[46:47], 0\n\t" \
