@@ -1,5 +1,5 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01j; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01k; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
