@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <atomic>
 #include <string>
@@ -163,6 +164,7 @@ void upload(gbwt_hip_index &ix) {
     ix.stats.max_outdegree = hs[1];
     if (hs[2] != 0) throw InvalidData("BWT: record without a readable outdegree");
     if (hs[0] >= (uint64_t(1) << 32)) throw InvalidData("record longer than 2^32 positions is not supported");
+    d.max_walk = hs[3];
     const uint64_t end_len = hs[4], end_sigma = hs[5];
     ix.endmarker.reserve(std::max<uint64_t>(end_len, 1) * sizeof(uint2));
     if (end_len > 0) {
@@ -217,6 +219,7 @@ void upload(gbwt_hip_index &ix) {
         uint32_t flags[4] = {0, 0, 0, 0};
         HIP_CHECK(hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost));
         HIP_CHECK(hipGetLastError());
+        if (flags[0] & 2u) throw InvalidData("BWT: a sequence takes more LF steps than the records hold positions: the index is not consistent");
         if (!flags[0]) {
             d.seq_len = ix.seq_len.as<uint32_t>();
             ix.orientation_pairs = want_pairs && !flags[2];
@@ -246,25 +249,17 @@ void upload(gbwt_hip_index &ix) {
     }
 }
 
-gbwt_hip_status open_common(gbwt_hip_index *ix, gbwt_hip_index **out) {
-    try {
-        fill_stats(*ix);
-        int count = 0;
-        if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
-            delete ix;
-            return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
-        }
-        upload(*ix);
-        upload_label_lengths(*ix);
-        *out = ix;
-        return GBWT_HIP_OK;
-    } catch (const InvalidData &e) {
-        delete ix; return fail(GBWT_HIP_INVALID_DATA, e.what());
-    } catch (const HipError &e) {
-        delete ix; return status_of(e);
-    } catch (const std::bad_alloc &) {
-        delete ix; return fail(GBWT_HIP_DEVICE_ERROR, "out of host memory");
-    }
+// Takes ownership of `ix`; anything thrown on the way (corrupt sizes, HIP failures, allocation failures) destroys it and is
+// turned into a status by the guard of the calling entry point.
+gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index **out) {
+    fill_stats(*ix);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
+    upload(*ix);
+    upload_label_lengths(*ix);
+    *out = ix.release();
+    return GBWT_HIP_OK;
 }
 
 // Staging helper for the one-lane-per-query entry points.
@@ -313,92 +308,85 @@ int gbwt_hip_device_count(void) {
 }
 
 gbwt_hip_status gbwt_hip_parse_file(const char *path, gbwt_hip_stats *out) {
+    GBWT_HIP_GUARD_BEGIN
     if (!path || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
-    try {
-        gbwt_hip_index tmp;
-        tmp.host = load_index_file(path);
-        fill_stats(tmp);
-        *out = tmp.stats;
-        return GBWT_HIP_OK;
-    } catch (const InvalidData &e) {
-        return fail(GBWT_HIP_INVALID_DATA, e.what());
-    } catch (const IoError &e) {
-        return fail(GBWT_HIP_IO_ERROR, e.what());
-    }
+    gbwt_hip_index tmp;
+    tmp.host = load_index_file(path);
+    fill_stats(tmp);
+    *out = tmp.stats;
+    return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index **out) {
+    GBWT_HIP_GUARD_BEGIN
     if (!path || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = nullptr;
-    gbwt_hip_index *ix = new gbwt_hip_index;
+    std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
-    try {
-        ix->host = load_index_file(path);
-    } catch (const InvalidData &e) {
-        delete ix; return fail(GBWT_HIP_INVALID_DATA, e.what());
-    } catch (const IoError &e) {
-        delete ix; return fail(GBWT_HIP_IO_ERROR, e.what());
-    }
-    return open_common(ix, out);
+    ix->host = load_index_file(path);
+    return open_common(std::move(ix), out);
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
                                       uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,
                                       int bidirectional, int device, gbwt_hip_index **out) {
+    GBWT_HIP_GUARD_BEGIN
     if (!out || (data_len && !data) || (n_records && !starts)) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = nullptr;
-    gbwt_hip_index *ix = new gbwt_hip_index;
+    std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
-    try {
-        ix->host = index_from_records(data, data_len, starts, n_records, alphabet_offset, alphabet_size, n_sequences, size,
-                                      bidirectional != 0);
-    } catch (const InvalidData &e) {
-        delete ix; return fail(GBWT_HIP_INVALID_DATA, e.what());
-    }
-    return open_common(ix, out);
+    ix->host = index_from_records(data, data_len, starts, n_records, alphabet_offset, alphabet_size, n_sequences, size,
+                                  bidirectional != 0);
+    return open_common(std::move(ix), out);
+    GBWT_HIP_GUARD_END
 }
 
 void gbwt_hip_close(gbwt_hip_index *index) { delete index; }
 
 gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *out) {
+    GBWT_HIP_GUARD_BEGIN
     if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = index->stats;
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_workspace **out) {
+    GBWT_HIP_GUARD_BEGIN
     if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = nullptr;
-    gbwt_hip_workspace *ws = new gbwt_hip_workspace;
+    std::unique_ptr<gbwt_hip_workspace> ws(new gbwt_hip_workspace);
     ws->index = index;
-    try {
-        HIP_CHECK(hipSetDevice(index->device));
-        HIP_CHECK(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
-        for (auto &e : ws->ev) HIP_CHECK(hipEventCreate(&e));
-        ws->counters.reserve(4 * sizeof(uint32_t));
-    } catch (const HipError &e) {
-        delete ws; return status_of(e);
-    }
+    HIP_CHECK(hipSetDevice(index->device));
+    HIP_CHECK(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    for (auto &e : ws->ev) HIP_CHECK(hipEventCreate(&e));
+    ws->counters.reserve(4 * sizeof(uint32_t));
     // optional overrides for experiments / tests (same meaning as gbwt_hip_workspace_tune)
     if (const char *v = std::getenv("GBWT_HIP_WALK_MODE")) { int m = std::atoi(v); if (m >= 0 && m <= 3) ws->walk_mode = static_cast<uint32_t>(m); }
     if (const char *v = std::getenv("GBWT_HIP_PATHS_PER_WAVE")) { int p = std::atoi(v); if (p >= 0 && p <= 64) ws->paths_per_wave = static_cast<uint32_t>(p); }
     if (const char *v = std::getenv("GBWT_HIP_SMALL_RECORD")) { long r = std::atol(v); if (r >= 0) ws->small_record = static_cast<uint32_t>(r); }
-    *out = ws;
+    *out = ws.release();
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
 }
 
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws) { delete ws; }
 
 gbwt_hip_status gbwt_hip_workspace_tune(gbwt_hip_workspace *ws, uint32_t walk_mode, uint32_t paths_per_wave, uint32_t small_record) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ws || walk_mode > WALK_ONE_STEP || paths_per_wave > 64) return fail(GBWT_HIP_BAD_ARGUMENT, "bad tuning values");
     ws->walk_mode = walk_mode; ws->paths_per_wave = paths_per_wave; ws->small_record = small_record;
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
 }
 
 void *gbwt_hip_workspace_stream(gbwt_hip_workspace *ws) { return ws ? static_cast<void *>(ws->stream) : nullptr; }
 
 gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                         gbwt_hip_paths *out) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !seq_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null seq_ids");
     // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256)
@@ -539,6 +527,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
     } catch (const HipError &e) {
         return status_of(e);
     }
+    GBWT_HIP_GUARD_END
 }
 
 namespace {
@@ -583,6 +572,7 @@ void copy_to_host(int device, void *dst, const void *src, size_t bytes) {
 
 gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                  uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity, uint64_t *total) {
+    GBWT_HIP_GUARD_BEGIN
     if (!out_offsets || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
     gbwt_hip_paths p{};
     gbwt_hip_status st = gbwt_hip_extract_device(ix, ws, seq_ids, n, &p);
@@ -597,18 +587,22 @@ gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *w
     } catch (const HipError &e) {
         return status_of(e);
     }
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_extract_paths(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n,
                                        int reverse, uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity,
                                        uint64_t *total) {
+    GBWT_HIP_GUARD_BEGIN
     if (n && !path_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null path_ids");
     std::vector<uint64_t> ids(n);
     for (uint64_t k = 0; k < n; k++) ids[k] = 2 * path_ids[k] + (reverse ? 1 : 0);  // support::encode_path
     return gbwt_hip_extract(ix, ws, ids.data(), n, out_offsets, out_nodes, capacity, total);
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident extraction on this workspace");
     if (n != ws->last_n || (n && !out_sums)) return fail(GBWT_HIP_BAD_ARGUMENT, "n does not match the last extraction");
     if (n == 0) return GBWT_HIP_OK;
@@ -623,10 +617,12 @@ gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace 
     } catch (const HipError &e) {
         return status_of(e);
     }
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t k, uint32_t *out_nodes,
                                    uint64_t capacity, uint64_t *len) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !ws->timed || !len) return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident extraction on this workspace");
     if (k >= ws->last_n) return fail(GBWT_HIP_BAD_ARGUMENT, "row out of range");
     try {
@@ -640,9 +636,11 @@ gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *ix, gbwt_hip_workspace 
     } catch (const HipError &e) {
         return status_of(e);
     }
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ws || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no timed extraction on this workspace");
     float a = 0, b = 0;
     if (hipEventElapsedTime(&a, ws->ev[0], ws->ev[1]) != hipSuccess || hipEventElapsedTime(&b, ws->ev[0], ws->ev[2]) != hipSuccess)
@@ -650,83 +648,105 @@ gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *wal
     if (walk_ms) *walk_ms = a;
     if (total_ms) *total_ms = b;
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kernel_ms) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ws || !ws->query_timed || !kernel_ms) return fail(GBWT_HIP_BAD_ARGUMENT, "no timed query on this workspace");
     if (hipEventElapsedTime(kernel_ms, ws->qev[0], ws->qev[1]) != hipSuccess) return fail(GBWT_HIP_DEVICE_ERROR, "hipEventElapsedTime failed");
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_start(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                gbwt_hip_pos *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     return run_query(ix, ws, seq_ids, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
         launch_start(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_forward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
                                  gbwt_hip_pos *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     return run_query(ix, ws, in, n * sizeof(gbwt_hip_pos), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
         launch_forward(ix->dev, ws->in_a.as<gbwt_hip_pos>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_backward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
                                   gbwt_hip_pos *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Following sequences backward requires a bidirectional GBWT");
     return run_query(ix, ws, in, n * sizeof(gbwt_hip_pos), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
         launch_backward(ix->dev, ws->in_a.as<gbwt_hip_pos>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_find(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
                               gbwt_hip_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {
         launch_find(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_extend(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_state *states,
                                 const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     if (n && !nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null nodes");
     return run_query(ix, ws, states, n * sizeof(gbwt_hip_state), nodes, n * sizeof(uint64_t), out, n * sizeof(gbwt_hip_state), valid, n, [&] {
         launch_extend(ix->dev, ws->in_a.as<gbwt_hip_state>(), ws->in_b.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_state>(),
                       ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_bd_find(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
                                  gbwt_hip_bd_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     // the reference asserts here (src/gbwt.rs:312)
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
     return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
         launch_bd_find(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 static gbwt_hip_status bd_extend(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states,
                                  const uint64_t *nodes, uint64_t n, bool backward, gbwt_hip_bd_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
     if (n && !nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null nodes");
     return run_query(ix, ws, states, n * sizeof(gbwt_hip_bd_state), nodes, n * sizeof(uint64_t), out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
         launch_bd_extend(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), ws->in_b.as<uint64_t>(), n, backward,
                          ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_extend_forward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states,
                                         const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     return bd_extend(ix, ws, states, nodes, n, false, out, valid);
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_extend_backward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states,
                                          const uint64_t *nodes, uint64_t n, gbwt_hip_bd_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     return bd_extend(ix, ws, states, nodes, n, true, out, valid);
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_bd_state *states, uint64_t n, int backward,
                                 uint64_t *out_offsets, gbwt_hip_bd_state *out_states, uint64_t capacity, uint64_t *total, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (!ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
     if (!total || !out_offsets || (n && (!states || !valid))) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
@@ -762,21 +782,26 @@ gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *ix, gbwt_hip_workspace *ws
     } catch (const HipError &e) {
         return status_of(e);
     }
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *queries, uint64_t n,
                                 uint64_t len, gbwt_hip_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {
         launch_search(ix->dev, ws->in_a.as<uint64_t>(), n, len, ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *queries, uint64_t n,
                                    uint64_t len, uint64_t first, gbwt_hip_bd_state *out, uint8_t *valid) {
+    GBWT_HIP_GUARD_BEGIN
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
     return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
         launch_bd_search(ix->dev, ws->in_a.as<uint64_t>(), n, len, first, ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
     });
+    GBWT_HIP_GUARD_END
 }
 
 }  // extern "C"

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <new>
+#include <stdexcept>
 #include <string>
 
 #include "../../include/gbwt_hip.h"
@@ -51,6 +53,31 @@ inline gbwt_hip_status status_of(const HipError &e) {
     if (e.err == hipErrorNoDevice || e.err == hipErrorInvalidDevice) return fail(GBWT_HIP_NO_DEVICE, msg);
     return fail(GBWT_HIP_DEVICE_ERROR, msg);
 }
+
+// Lippincott function: the status of the exception in flight.  No exception may cross the C ABI (the caller is Rust / C /
+// ctypes: it would be std::terminate), so every extern "C" entry point that can throw wraps its body in
+// GBWT_HIP_GUARD_BEGIN / GBWT_HIP_GUARD_END, whatever it already catches inside.
+inline gbwt_hip_status status_of_current_exception() noexcept {
+    try {
+        throw;
+    } catch (const InvalidData &e) {
+        return fail(GBWT_HIP_INVALID_DATA, e.what());
+    } catch (const IoError &e) {
+        return fail(GBWT_HIP_IO_ERROR, e.what());
+    } catch (const HipError &e) {
+        return status_of(e);
+    } catch (const std::bad_alloc &) {
+        return fail(GBWT_HIP_DEVICE_ERROR, "out of host memory");
+    } catch (const std::length_error &e) {   // a size taken from a file that no container can hold
+        return fail(GBWT_HIP_INVALID_DATA, std::string("length error: ") + e.what());
+    } catch (const std::exception &e) {
+        return fail(GBWT_HIP_DEVICE_ERROR, std::string("unexpected exception: ") + e.what());
+    } catch (...) {
+        return fail(GBWT_HIP_DEVICE_ERROR, "unexpected exception");
+    }
+}
+#define GBWT_HIP_GUARD_BEGIN try {
+#define GBWT_HIP_GUARD_END } catch (...) { return gbwt_hip::status_of_current_exception(); }
 
 }  // namespace gbwt_hip
 

@@ -101,6 +101,7 @@ struct DeviceIndex {
     uint64_t n_sequences;      // header.sequences
     uint64_t n_endmarker;      // decompressed endmarker length
     uint64_t n_blocks;
+    uint64_t max_walk;         // BWT positions in all records together: no sequence of a consistent index visits more (bounds the walks at open)
     uint32_t alphabet_offset;
     uint32_t first_node;       // alphabet_offset + 1
 };

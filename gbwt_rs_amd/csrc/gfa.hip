@@ -456,10 +456,13 @@ extern "C" {
 
 gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
                                     char *out, uint64_t capacity, uint64_t *total) {
+    GBWT_HIP_GUARD_BEGIN
     return path_lines_impl(ix, ws, path_ids, n, mode, out, capacity, total, nullptr);
+    GBWT_HIP_GUARD_END
 }
 
 gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path) {
+    GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !path) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     try {
         require_gfa_capable(ix);
@@ -560,6 +563,7 @@ gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace 
     } catch (const HipError &e) {
         return status_of(e);
     }
+    GBWT_HIP_GUARD_END
 }
 
 }  // extern "C"

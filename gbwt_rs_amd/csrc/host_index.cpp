@@ -32,6 +32,7 @@ public:
         return p;
     }
     uint64_t pos() const { return pos_; }
+    uint64_t remaining() const { return n_ - pos_; }   // elements left: the bound of every length field that follows
     bool at_end() const { return pos_ == n_; }
     uint64_t peek() const { return pos_ < n_ ? w_[pos_] : 0; }
 
@@ -55,11 +56,14 @@ struct Packed {
 
 struct RawBits { uint64_t len = 0; const uint64_t *words = nullptr; uint64_t n_words = 0; };
 
+// Every length below comes from the file: it is compared with what is left of the file BEFORE it is rounded,
+// multiplied or used to allocate, so that a corrupt word is io::ErrorKind::InvalidData as in the reference and never an
+// overflow, a std::length_error or an out-of-bounds read.
 RawBits read_raw(Elements &in) {
     RawBits r;
     r.len = in.word();
     r.n_words = in.word();
-    if (r.n_words != (r.len + 63) / 64) throw InvalidData("RawVector: word count does not match length");
+    if (r.n_words != r.len / 64 + (r.len % 64 != 0 ? 1 : 0)) throw InvalidData("RawVector: word count does not match length");
     r.words = in.words(r.n_words);
     return r;
 }
@@ -69,7 +73,9 @@ Packed read_packed(Elements &in) {
     p.len = in.word();
     p.width = in.word();
     RawBits raw = read_raw(in);
-    if (p.width == 0 || p.width > 64 || raw.len != p.len * p.width) throw InvalidData("IntVector: invalid width / length");
+    uint64_t bits = 0;
+    if (p.width == 0 || p.width > 64 || __builtin_mul_overflow(p.len, p.width, &bits) || raw.len != bits)
+        throw InvalidData("IntVector: invalid width / length");
     p.words = raw.words;
     p.n_words = raw.n_words;
     return p;
@@ -77,7 +83,7 @@ Packed read_packed(Elements &in) {
 
 void skip_option(Elements &in) {
     uint64_t size = in.word();
-    in.words(size);
+    in.words(size);   // checked against the rest of the file
 }
 
 // SparseVector -> sorted values.  value_k = ((pos_k - k) << w) | low[k], pos_k = k-th set bit of high.
@@ -88,6 +94,7 @@ std::vector<uint64_t> read_sparse(Elements &in, uint64_t &universe) {
     skip_option(in); skip_option(in); skip_option(in);  // rank / select / select_zero supports
     Packed low = read_packed(in);
     if (low.len != ones) throw InvalidData("SparseVector: low length does not match the number of ones");
+    if (ones > high.len) throw InvalidData("SparseVector: more ones than bits in the high bitvector");   // also bounds the allocation
     std::vector<uint64_t> values;
     values.reserve(ones + 1);
     const uint64_t w = low.width;
@@ -98,7 +105,9 @@ std::vector<uint64_t> read_sparse(Elements &in, uint64_t &universe) {
             uint64_t pos = wi * 64 + static_cast<uint64_t>(__builtin_ctzll(word));
             word &= word - 1;
             if (k >= ones) throw InvalidData("SparseVector: too many ones in the high bitvector");
-            uint64_t hi = (w >= 64) ? 0 : ((pos - k) << w);
+            const uint64_t upper = pos - k;
+            if (w < 64 && upper != 0 && (upper >> (64 - w)) != 0) throw InvalidData("SparseVector: value does not fit 64 bits");
+            uint64_t hi = (w >= 64) ? 0 : (upper << w);
             values.push_back(hi | low.get(k));
             k++;
         }
@@ -109,7 +118,8 @@ std::vector<uint64_t> read_sparse(Elements &in, uint64_t &universe) {
 
 void read_bytes(Elements &in, std::vector<uint8_t> &out) {
     uint64_t len = in.word();
-    const uint8_t *p = reinterpret_cast<const uint8_t *>(in.words((len + 7) / 8));
+    if (len / 8 > in.remaining()) throw InvalidData("Vector<u8>: length exceeds the file");   // before rounding: (len + 7) / 8 wraps
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(in.words(len / 8 + (len % 8 != 0 ? 1 : 0)));
     out.assign(p, p + len);
 }
 
@@ -144,19 +154,54 @@ void read_strings_zstd(Elements &in, Strings &s) {
     uint64_t total = in.word();
     std::vector<uint8_t> compressed;
     read_bytes(in, compressed);
-    using decompress_fn = size_t (*)(void *, size_t, const void *, size_t);
+    // Streaming decompression into a buffer that grows with the data actually produced: `total` comes from the file and
+    // must not size an allocation before the stream has proved it (the reference reads to the end of the stream and then
+    // compares the lengths, src/support.rs:562-566).  Frames written by the reference's streaming encoder do not carry
+    // their content size, so there is nothing to check `total` against in advance.
+    struct InBuf { const void *src; size_t size, pos; };
+    struct OutBuf { void *dst; size_t size, pos; };
+    using create_fn = void *(*)();
+    using free_fn = size_t (*)(void *);
+    using stream_fn = size_t (*)(void *, OutBuf *, InBuf *);
     using iserror_fn = unsigned (*)(size_t);
     static void *lib = nullptr;
     if (!lib) lib = dlopen("libzstd.so.1", RTLD_NOW);
     if (!lib) lib = dlopen("libzstd.so", RTLD_NOW);
     if (!lib) throw IoError("zstd-compressed node labels need libzstd.so.1, which could not be loaded");
-    auto dec = reinterpret_cast<decompress_fn>(dlsym(lib, "ZSTD_decompress"));
+    auto create = reinterpret_cast<create_fn>(dlsym(lib, "ZSTD_createDStream"));
+    auto release = reinterpret_cast<free_fn>(dlsym(lib, "ZSTD_freeDStream"));
+    auto step = reinterpret_cast<stream_fn>(dlsym(lib, "ZSTD_decompressStream"));
     auto iserr = reinterpret_cast<iserror_fn>(dlsym(lib, "ZSTD_isError"));
-    if (!dec || !iserr) throw IoError("libzstd.so.1 lacks ZSTD_decompress");
+    if (!create || !release || !step || !iserr) throw IoError("libzstd.so.1 lacks the streaming decompression API");
+    std::unique_ptr<void, free_fn> stream(create(), release);
+    if (!stream) throw IoError("ZSTD_createDStream failed");
+    const char *mismatch = "StringArray: Decompressed string length does not match the expected length";
+    InBuf src{compressed.data(), compressed.size(), 0};
+    s.bytes.clear();
+    size_t produced = 0;
+    bool more = src.size != 0;   // one or more frames, like the reference's decoder reading to the end
+    while (more) {
+        if (produced == s.bytes.size()) {
+            if (produced > total) throw InvalidData(mismatch);
+            // at most one byte more than `total`: a longer stream shows itself by filling that byte
+            const uint64_t cap = total == ~uint64_t(0) ? total : total + 1;
+            const uint64_t room = std::min<uint64_t>(cap - produced, std::max<uint64_t>(produced, uint64_t(1) << 16));
+            s.bytes.resize(produced + std::max<uint64_t>(room, 1));
+        }
+        OutBuf dst{s.bytes.data(), s.bytes.size(), produced};
+        const size_t before_in = src.pos;
+        const size_t hint = step(stream.get(), &dst, &src);   // 0 = a frame is complete and flushed
+        if (iserr(hint)) throw InvalidData("StringArray: zstd stream is corrupt");
+        const bool full = dst.pos == s.bytes.size();
+        if (dst.pos == produced && src.pos == before_in) throw InvalidData("StringArray: zstd stream makes no progress");
+        produced = dst.pos;
+        if (src.pos == src.size && !(full && hint != 0)) {     // input used up and nothing left to flush
+            if (hint != 0) throw InvalidData("StringArray: zstd stream is truncated");
+            more = false;
+        }
+    }
+    if (produced != total) throw InvalidData(mismatch);
     s.bytes.resize(total);
-    size_t got = dec(s.bytes.data(), total, compressed.data(), compressed.size());
-    if (iserr(got) || got != total)
-        throw InvalidData("StringArray: Decompressed string length does not match the expected length");
     finish_strings(s, std::move(offsets));
 }
 
@@ -203,6 +248,7 @@ void read_metadata(Elements &in, HostIndex &h) {
     h.metadata_flags = in.word();
     check_header("MetadataHeader", word0, h.metadata_flags, METADATA_TAG, 2, 2, 0x7);
     uint64_t n_paths = in.word();
+    if (n_paths > in.remaining() / 2) throw InvalidData("Metadata: path name count exceeds the file");
     const uint64_t *pw = in.words(2 * n_paths);
     h.path_names.resize(n_paths);
     if (n_paths) std::memcpy(h.path_names.data(), pw, n_paths * sizeof(PathName));

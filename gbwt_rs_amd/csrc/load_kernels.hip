@@ -14,7 +14,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // Load-time passes
 
-// One lane per record: Record::len and outdegree maxima (sizes u32 offsets on device, feeds stats).
+// One lane per record: Record::len and outdegree maxima (sizes u32 offsets on device, feeds stats), and the sum of the lengths.
 __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *stats) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (rec >= ix.n_records) return;
@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *
     uint64_t len = record_len(c, sigma);
     atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(len));
     atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
+    atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(len));   // all BWT positions = GBWT::len of a consistent index
 }
 
 // 16 bytes of the stream at data[pos..], zero-filled past `limit`.

@@ -809,7 +809,10 @@ __device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, S
     }
     uint64_t guard = 0;
     while (rec != 0) {
-        if (++guard > 0xFFFFFFF0ull || sink.wr > 0xFFFFFFF0u) { if (overflow) atomicOr(overflow, 1u); break; }
+        // A sequence longer than 2^32 nodes is unsupported (bit 0); one that takes more steps than there are BWT positions
+        // never ends -- records of a corrupt file can send a walk in circles (bit 1).  Every iteration emits a node or ends.
+        if (sink.wr > 0xFFFFFFF0u) { if (overflow) atomicOr(overflow, 1u); break; }
+        if (++guard > ix.max_walk) { if (overflow) atomicOr(overflow, 2u); break; }
         const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
         const uint4 F1 = d[1];
         if (F1.x & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); sink.checkpoint(rec, offset, bb); continue; }

@@ -83,6 +83,82 @@ def test_parse_rejects_what_the_reference_rejects(tmp_path):
     assert e.value.status == _lib.INVALID_DATA and ("not bidirectional" in str(e.value) or "path count" in str(e.value))
 
 
+MUTATIONS = (0xFFFFFFFFFFFFFFFF, 0x8000000000000000, 0xFFFFFFFFFFFFFFC1, 1 << 40, 0x7FFFFFFFFFFFFFFF, 0, 1, 65)
+
+
+def mutated_files(tmp_path, names=None, values=MUTATIONS):
+    """Every 64-bit element of every golden file overwritten with each of `values` (length words near 2^64 wrap
+    (len + 7) / 8 and len * width; small ones truncate or shift every structure behind them)."""
+    import glob
+    target = str(tmp_path / "mutated.bin")
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "*.gb*"))):
+        if names is not None and os.path.basename(path) not in names:
+            continue
+        raw = open(path, "rb").read()
+        for value in values:
+            for w in range(len(raw) // 8):
+                if raw[8 * w:8 * w + 8] == value.to_bytes(8, "little"):
+                    continue
+                bad = bytearray(raw)
+                bad[8 * w:8 * w + 8] = value.to_bytes(8, "little")
+                with open(target, "wb") as f:
+                    f.write(bad)
+                yield os.path.basename(path), w, value, target
+
+
+def test_corrupt_words_are_invalid_data_never_an_abort(tmp_path):
+    """A corrupt length word must come back as GBWT_HIP_INVALID_DATA (io::ErrorKind::InvalidData in the reference's
+    loaders), not as an exception crossing the C ABI (std::terminate) or an out-of-bounds read.  Runs in-process: an
+    abort fails the whole suite, which is the point."""
+    accepted = rejected = 0
+    for name, w, value, path in mutated_files(tmp_path):
+        try:
+            G.parse_file(path)
+            accepted += 1
+        except G.GbwtHipError as e:
+            assert e.status == _lib.INVALID_DATA, (name, w, hex(value), str(e))
+            rejected += 1
+    assert rejected > 5000 and accepted > 1000, (accepted, rejected)   # payload words (names, record bytes) are free to change
+
+
+def test_zstd_labels_are_bounded_by_the_stream(tmp_path):
+    """The declared length of the zstd-compressed node labels (graph version 4) is checked against what the stream
+    produces, whatever the word says -- it never sizes an allocation on its own."""
+    raw = open(os.path.join(GOLDEN, "example.gbz"), "rb").read()
+    st = G.parse_file(os.path.join(GOLDEN, "example.gbz"))
+    assert st.is_gbz
+    hits = 0
+    for w in range(len(raw) // 8):
+        for value in (1 << 62, 1 << 36):
+            bad = bytearray(raw)
+            bad[8 * w:8 * w + 8] = value.to_bytes(8, "little")
+            p = tmp_path / "z.gbz"
+            p.write_bytes(bad)
+            try:
+                G.parse_file(str(p))
+            except G.GbwtHipError as e:
+                assert e.status == _lib.INVALID_DATA
+                hits += "Decompressed string length" in str(e)
+    assert hits >= 2
+
+
+def test_loader_under_sanitizers(tmp_path):
+    """The same mutations against the loader built with -fsanitize=address,undefined (host compiler, CPU only)."""
+    import glob
+    import shutil
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "mutate_loader"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([gxx, "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", _lib.CSRC,
+                    os.path.join(root, "tests", "cpp", "mutate_loader.cpp"), os.path.join(_lib.CSRC, "host_index.cpp"), "-ldl", "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe), str(tmp_path / "scratch.bin")] + sorted(glob.glob(os.path.join(GOLDEN, "*.gb*"))), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "accepted" in out.stdout
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product path fails loudly instead of computing on the host."""
     if G.device_count() > 0:
