@@ -40,6 +40,10 @@ class Paths(C.Structure):
     _fields_ = [("d_offsets", C.c_void_p), ("d_nodes", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
 
 
+class Lines(C.Structure):
+    _fields_ = [("d_text", C.c_void_p), ("d_line_offsets", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
+
+
 _p, _u64, _int = C.c_void_p, C.c_uint64, C.c_int
 
 SIGNATURES = {
@@ -56,6 +60,7 @@ SIGNATURES = {
     "gbwt_hip_workspace_tune": (_int, [_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "gbwt_hip_extract": (_int, [_p, _p, _p, _u64, _p, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_extract_device": (_int, [_p, _p, _p, _u64, C.POINTER(Paths)]),
+    "gbwt_hip_copy_result": (_int, [_p, _p, _p, _p, _u64]),
     "gbwt_hip_extract_paths": (_int, [_p, _p, _p, _u64, _int, _p, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_start": (_int, [_p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_forward": (_int, [_p, _p, _p, _u64, _p, _p]),
@@ -69,6 +74,7 @@ SIGNATURES = {
     "gbwt_hip_search": (_int, [_p, _p, _p, _u64, _u64, _p, _p]),
     "gbwt_hip_bd_search": (_int, [_p, _p, _p, _u64, _u64, _u64, _p, _p]),
     "gbwt_hip_path_lines": (_int, [_p, _p, _p, _u64, _int, _p, _u64, C.POINTER(_u64)]),
+    "gbwt_hip_path_lines_device": (_int, [_p, _p, _p, _u64, _int, C.POINTER(Lines)]),
     "gbwt_hip_write_gfa": (_int, [_p, _p, C.c_char_p]),
     "gbwt_hip_path_sums": (_int, [_p, _p, _p, _u64]),
     "gbwt_hip_copy_path": (_int, [_p, _p, _u64, _p, _u64, C.POINTER(_u64)]),

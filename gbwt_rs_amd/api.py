@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import BdState, GbwtHipError, Paths, Pos, State, Stats, check
+from ._lib import BdState, GbwtHipError, Lines, Paths, Pos, State, Stats, check
 
 FORWARD, REVERSE = 0, 1  # support::Orientation, src/support.rs:30-47
 
@@ -163,16 +163,20 @@ class GBWT:
         check(self._L.gbwt_hip_backward(self._h, self._ws, _ptr(pos), pos.size, _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 
-    def sequences_csr(self, ids):
-        """GBWT::sequence(id).collect() for every id -> (offsets[u64, n+1], nodes[u32])."""
+    def sequences_csr(self, ids, return_valid=False):
+        """GBWT::sequence(id).collect() for every id -> (offsets[u64, n+1], nodes[u32]) [, valid[bool]].
+
+        One walk of the sequences: they are extracted into HBM, the host array is sized from the result and filled by a
+        copy.  An id >= sequences() -- GBWT::sequence returns None, src/gbwt.rs:254-256 -- gets an empty row and
+        valid[k] = False; it never fails the batch."""
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = self.extract_device(ids)
         offsets = np.zeros(ids.size + 1, dtype=np.uint64)
-        total = C.c_uint64(0)
-        check(self._L.gbwt_hip_extract(self._h, self._ws, _ptr(ids), ids.size, _ptr(offsets), None, 0, C.byref(total)))
-        nodes = np.zeros(max(1, total.value), dtype=np.uint32)
-        check(self._L.gbwt_hip_extract(self._h, self._ws, _ptr(ids), ids.size, _ptr(offsets), _ptr(nodes), nodes.size,
-                                       C.byref(total)))
-        return offsets, nodes[: total.value]
+        nodes = np.empty(max(1, out.total), dtype=np.uint32)
+        check(self._L.gbwt_hip_copy_result(self._h, self._ws, _ptr(offsets), _ptr(nodes) if out.total else None, nodes.size))
+        if return_valid:
+            return offsets, nodes[: out.total], ids < np.uint64(self.sequences())
+        return offsets, nodes[: out.total]
 
     def sequence(self, seq_id):
         """GBWT::sequence(id): list of GBWT nodes, or None if there is no such sequence."""
@@ -316,16 +320,17 @@ class GBZ(GBWT):
         check(self._L.gbwt_hip_write_gfa(self._h, self._ws, os.fsencode(path)))
 
     def paths_csr(self, path_ids, orientation=FORWARD):
+        """GBZ::path(id, orientation) for every id, as CSR of GBWT-encoded nodes (support::encode_path, src/support.rs:229-231)."""
         ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
-        offsets = np.zeros(ids.size + 1, dtype=np.uint64)
-        total = C.c_uint64(0)
-        check(self._L.gbwt_hip_extract_paths(self._h, self._ws, _ptr(ids), ids.size, orientation, _ptr(offsets), None, 0,
-                                             C.byref(total)))
-        nodes = np.zeros(max(1, total.value), dtype=np.uint32)
-        check(self._L.gbwt_hip_extract_paths(self._h, self._ws, _ptr(ids), ids.size, orientation, _ptr(offsets), _ptr(nodes),
-                                             nodes.size, C.byref(total)))
-        return offsets, nodes[: total.value]
+        return self.sequences_csr(2 * ids + np.uint64(1 if orientation else 0))
+
+    def path_lines_device(self, path_ids, mode):
+        """The same lines left in HBM: a Lines struct (device pointers to the text and to the n + 1 line offsets)."""
+        ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
+        out = Lines()
+        check(self._L.gbwt_hip_path_lines_device(self._h, self._ws, _ptr(ids), ids.size, mode, C.byref(out)))
+        return out
 
 
-__all__ = ["GBWT", "GBZ", "GbwtHipError", "FORWARD", "REVERSE", "POS_DTYPE", "STATE_DTYPE", "BD_DTYPE", "encode_node",
+__all__ = ["GBWT", "GBZ", "GbwtHipError", "Lines", "Paths", "FORWARD", "REVERSE", "POS_DTYPE", "STATE_DTYPE", "BD_DTYPE", "encode_node",
            "decode_node", "flip_node", "encode_path", "device_count", "parse_file", "Pos", "State", "BdState"]

@@ -270,6 +270,7 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n == 0) return GBWT_HIP_OK;
     if (!in_a || !out || !valid) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
+    ws->follow_cached = false;   // the staging buffers are shared with gbwt_hip_follow
     try {
         HIP_CHECK(hipSetDevice(ix->device));
         ws->in_a.reserve(a_bytes);
@@ -389,9 +390,10 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
     GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !seq_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null seq_ids");
-    // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256)
-    for (uint64_t k = 0; k < n; k++)
-        if (seq_ids[k] >= ix->host.sequences) return fail(GBWT_HIP_BAD_ARGUMENT, "sequence id " + std::to_string(seq_ids[k]) + " >= sequences");
+    // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256).  "Not found" is a value here as well: such an id
+    // gets an empty row (the kernels test the id), the rest of the batch is extracted; callers tell None from an empty
+    // sequence by id < sequences.
+    ws->extract_cached = false;
     try {
         HIP_CHECK(hipSetDevice(ix->device));
         hipStream_t s = ws->stream;
@@ -411,7 +413,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             // Lengths known: offsets first, then every lane writes into its row; in a bidirectional index two walkers per
             // sequence, one from each end.
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
-            launch_gather_lengths(ix->dev.seq_len, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
+            launch_gather_lengths(ix->dev.seq_len, ix->dev.n_sequences, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
             launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
             uint64_t total = 0;
             uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
@@ -474,6 +476,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             HIP_CHECK(hipStreamSynchronize(s));
             HIP_CHECK(hipGetLastError());
             ws->timed = true; ws->last_n = n; ws->last_total = total;
+            ws->extract_key.assign(seq_ids, seq_ids + n); ws->extract_cached = true;
             out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = total; out->n = n;
             return GBWT_HIP_OK;
         }
@@ -519,6 +522,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         HIP_CHECK(hipGetLastError());
         ws->timed = true;
         ws->last_n = n; ws->last_total = total;
+        ws->extract_key.assign(seq_ids, seq_ids + n); ws->extract_cached = true;
         out->d_offsets = ws->offsets.as<uint64_t>();
         out->d_nodes = ws->nodes.as<uint32_t>();
         out->total = total;
@@ -575,9 +579,15 @@ gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *w
     GBWT_HIP_GUARD_BEGIN
     if (!out_offsets || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
     gbwt_hip_paths p{};
-    gbwt_hip_status st = gbwt_hip_extract_device(ix, ws, seq_ids, n, &p);
-    if (st != GBWT_HIP_OK) return st;
+    // the fill call after a size query (or after gbwt_hip_extract_device) with the same ids: the rows are still in the workspace
+    if (ix && ws && ws->index == ix && ws->extract_cached && ws->extract_key.size() == n && (n == 0 || (seq_ids && std::memcmp(ws->extract_key.data(), seq_ids, n * sizeof(uint64_t)) == 0))) {
+        p.d_offsets = ws->offsets.as<uint64_t>(); p.d_nodes = ws->nodes.as<uint32_t>(); p.total = ws->last_total; p.n = n;
+    } else {
+        gbwt_hip_status st = gbwt_hip_extract_device(ix, ws, seq_ids, n, &p);
+        if (st != GBWT_HIP_OK) return st;
+    }
     try {
+        HIP_CHECK(hipSetDevice(ix->device));
         HIP_CHECK(hipMemcpy(out_offsets, p.d_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
         *total = p.total;
         if (!out_nodes) return GBWT_HIP_OK;
@@ -598,6 +608,20 @@ gbwt_hip_status gbwt_hip_extract_paths(const gbwt_hip_index *ix, gbwt_hip_worksp
     std::vector<uint64_t> ids(n);
     for (uint64_t k = 0; k < n; k++) ids[k] = 2 * path_ids[k] + (reverse ? 1 : 0);  // support::encode_path
     return gbwt_hip_extract(ix, ws, ids.data(), n, out_offsets, out_nodes, capacity, total);
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_copy_result(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!ix || !ws || ws->index != ix || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident extraction on this workspace");
+    if (!out_offsets && !out_nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null outputs");
+    HIP_CHECK(hipSetDevice(ix->device));
+    if (out_offsets) HIP_CHECK(hipMemcpy(out_offsets, ws->offsets.ptr, (ws->last_n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (out_nodes) {
+        if (capacity < ws->last_total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ws->last_total));
+        if (ws->last_total) copy_to_host(ix->device, out_nodes, ws->nodes.ptr, ws->last_total * sizeof(uint32_t));
+    }
+    return GBWT_HIP_OK;
     GBWT_HIP_GUARD_END
 }
 
@@ -756,20 +780,30 @@ gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *ix, gbwt_hip_workspace *ws
     try {
         HIP_CHECK(hipSetDevice(ix->device));
         hipStream_t s = ws->stream;
-        ws->in_a.reserve(n * sizeof(gbwt_hip_bd_state));
-        ws->in_b.reserve(n * sizeof(uint64_t));
-        ws->out_valid.reserve(n);
-        ws->follow_off.reserve((n + 1) * sizeof(uint64_t));
-        const size_t temp_bytes = scan_temp_bytes(n);
-        ws->scan_temp.reserve(std::max<size_t>(temp_bytes, 16));
-        HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, states, n * sizeof(gbwt_hip_bd_state), hipMemcpyHostToDevice, s));
-        launch_follow_count(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), n, backward != 0, ws->in_b.as<uint64_t>(), ws->out_valid.as<uint8_t>(), s);
-        launch_scan(ws->in_b.as<uint64_t>(), ws->follow_off.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
-        HIP_CHECK(hipGetLastError());
+        // the fill call after a size query with the same states: counts and offsets are still in the workspace
+        const size_t key_bytes = n * sizeof(gbwt_hip_bd_state);
+        const bool hit = ws->follow_cached && ws->follow_backward == (backward != 0) && ws->follow_key.size() == key_bytes &&
+                         std::memcmp(ws->follow_key.data(), states, key_bytes) == 0;
+        if (!hit) {
+            ws->follow_cached = false;
+            ws->in_a.reserve(key_bytes);
+            ws->in_b.reserve(n * sizeof(uint64_t));
+            ws->out_valid.reserve(n);
+            ws->follow_off.reserve((n + 1) * sizeof(uint64_t));
+            const size_t temp_bytes = scan_temp_bytes(n);
+            ws->scan_temp.reserve(std::max<size_t>(temp_bytes, 16));
+            HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, states, key_bytes, hipMemcpyHostToDevice, s));
+            launch_follow_count(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), n, backward != 0, ws->in_b.as<uint64_t>(), ws->out_valid.as<uint8_t>(), s);
+            launch_scan(ws->in_b.as<uint64_t>(), ws->follow_off.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+            HIP_CHECK(hipGetLastError());
+            ws->follow_key.assign(reinterpret_cast<const uint8_t *>(states), reinterpret_cast<const uint8_t *>(states) + key_bytes);
+            ws->follow_backward = backward != 0;
+        }
         HIP_CHECK(hipMemcpyAsync(out_offsets, ws->follow_off.ptr, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         *total = out_offsets[n];
+        ws->follow_cached = true;
         if (!out_states) return GBWT_HIP_OK;
         if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the extensions");
         if (*total == 0) return GBWT_HIP_OK;

@@ -7,6 +7,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/gbwt_hip.h"
 #include "device_index.hpp"
@@ -110,6 +111,14 @@ struct gbwt_hip_workspace {
     gbwt_hip::DeviceBuffer order_keys, order_rows, order_counts, order_level, order_temp;   // walker order of a segmented extraction
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid, follow_off;  // search staging
     gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_valid;  // GFA line formatting
+    // What the device-resident results answer.  The C idiom "size query, then the same call with a buffer" (gbwt_hip_extract,
+    // _follow, _path_lines) must not compute twice: a call that repeats the request of the results still in the workspace
+    // copies them out.  Keys are host copies of the ids / states of the request.
+    bool extract_cached = false, follow_cached = false, lines_cached = false;
+    std::vector<uint64_t> extract_key, lines_key;
+    std::vector<uint8_t> follow_key;
+    int follow_backward = 0, lines_mode = 0;
+    uint64_t follow_total = 0, lines_total = 0;
     ~gbwt_hip_workspace() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : qev) if (e) (void)hipEventDestroy(e);

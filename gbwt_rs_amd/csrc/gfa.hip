@@ -340,20 +340,27 @@ void upload_label_lengths(gbwt_hip_index &ix) {
 
 }  // namespace gbwt_hip
 
-// Implementation of gbwt_hip_path_lines; with `grow` the text goes into that vector (sized here) instead of `out`.
-static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
-                                       char *out, uint64_t capacity, uint64_t *total, std::vector<char> *grow) {
-    if (!ix || !ws || ws->index != ix || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+// The lines of a batch of paths, formatted ONCE into device memory (ws->gfa_text, line k at [line_start[k], line_start[k + 1]),
+// offsets also on the device in ws->gfa_b).  The request is remembered in the workspace: the fill call that follows a size
+// query, and the copy-out of gbwt_hip_path_lines after gbwt_hip_path_lines_device, find the text there.
+static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode) {
+    if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !path_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null path_ids");
     if (mode != 0 && mode != 1) return fail(GBWT_HIP_BAD_ARGUMENT, "mode must be 0 (P-lines) or 1 (W-lines)");
+    if (ws->lines_cached && ws->lines_mode == mode && ws->lines_key.size() == n && (n == 0 || std::memcmp(ws->lines_key.data(), path_ids, n * sizeof(uint64_t)) == 0))
+        return GBWT_HIP_OK;
+    ws->lines_cached = false;
     try {
         require_gfa_capable(ix);
         const HostIndex &h = ix->host;
         const bool translated = h.has_translation && !h.segment_starts.empty();
         for (uint64_t k = 0; k < n; k++)
             if (path_ids[k] >= h.path_names.size()) return fail(GBWT_HIP_BAD_ARGUMENT, "path id out of range");
-        *total = 0;
-        if (n == 0) return GBWT_HIP_OK;
+        ws->lines_total = 0;
+        if (n == 0) {
+            ws->lines_key.clear(); ws->lines_mode = mode; ws->lines_cached = true;
+            return GBWT_HIP_OK;
+        }
         // 1. forward sequences of the paths (GBZ::path(id, Forward), src/bin/gbunzip.rs:462, 532)
         std::vector<uint64_t> seq_ids(n);
         for (uint64_t k = 0; k < n; k++) seq_ids[k] = 2 * path_ids[k];
@@ -420,14 +427,11 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
             header_off[k + 1] = headers.size();
             line_start[k + 1] = line_start[k] + (valid[k] ? (header_off[k + 1] - header_off[k]) + lens[k] + (mode == 0 ? 3 : 1) : host_lines[k].size());
         }
-        *total = line_start[n];
-        if (grow) { grow->resize(*total); out = grow->data(); capacity = *total; }
-        if (!out) return GBWT_HIP_OK;
-        if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the lines");
-        // 4. format on the device, copy back
+        const uint64_t total = line_start[n];
+        // 4. format on the device; the lines the host had to replay are copied into their places
         ws->gfa_b.reserve((2 * (n + 1)) * sizeof(uint64_t));
         ws->gfa_c.reserve(std::max<size_t>(headers.size(), 16));
-        ws->gfa_text.reserve(std::max<uint64_t>(*total, 16));
+        ws->gfa_text.reserve(std::max<uint64_t>(total, 16));
         uint64_t *d_line_start = ws->gfa_b.as<uint64_t>(), *d_header_off = d_line_start + (n + 1);
         HIP_CHECK(hipMemcpyAsync(d_line_start, line_start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_header_off, header_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -440,13 +444,38 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
             hipLaunchKernelGGL(k_format_lines, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
                                mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(out, ws->gfa_text.ptr, *total, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
         for (uint64_t k = 0; k < n; k++)
-            if (!valid[k]) std::memcpy(out + line_start[k], host_lines[k].data(), host_lines[k].size());
+            if (!valid[k] && !host_lines[k].empty())
+                HIP_CHECK(hipMemcpyAsync(ws->gfa_text.as<char>() + line_start[k], host_lines[k].data(), host_lines[k].size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));   // host_lines / headers / line_start go out of scope
+        ws->lines_total = total;
+        ws->lines_key.assign(path_ids, path_ids + n);
+        ws->lines_mode = mode;
+        ws->lines_cached = true;
         return GBWT_HIP_OK;
     } catch (const InvalidData &e) {
         return fail(GBWT_HIP_BAD_ARGUMENT, e.what());
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+// gbwt_hip_path_lines; with `grow` the text goes into that vector (sized here) instead of `out`.
+static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
+                                       char *out, uint64_t capacity, uint64_t *total, std::vector<char> *grow) {
+    if (!total) return fail(GBWT_HIP_BAD_ARGUMENT, "null total");
+    *total = 0;
+    const gbwt_hip_status st = path_lines_compute(ix, ws, path_ids, n, mode);
+    if (st != GBWT_HIP_OK) return st;
+    *total = ws->lines_total;
+    if (grow) { grow->resize(*total); out = grow->data(); capacity = *total; }
+    if (!out || *total == 0) return GBWT_HIP_OK;
+    if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the lines");
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        HIP_CHECK(hipMemcpyAsync(out, ws->gfa_text.ptr, *total, hipMemcpyDeviceToHost, ws->stream));
+        HIP_CHECK(hipStreamSynchronize(ws->stream));
+        return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
     }
@@ -458,6 +487,21 @@ gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *ix, gbwt_hip_workspace
                                     char *out, uint64_t capacity, uint64_t *total) {
     GBWT_HIP_GUARD_BEGIN
     return path_lines_impl(ix, ws, path_ids, n, mode, out, capacity, total, nullptr);
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
+                                           gbwt_hip_lines *out) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!out) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
+    *out = gbwt_hip_lines{nullptr, nullptr, 0, 0};
+    const gbwt_hip_status st = path_lines_compute(ix, ws, path_ids, n, mode);
+    if (st != GBWT_HIP_OK) return st;
+    out->d_text = n ? ws->gfa_text.as<char>() : nullptr;
+    out->d_line_offsets = n ? ws->gfa_b.as<uint64_t>() : nullptr;
+    out->total = ws->lines_total;
+    out->n = n;
+    return GBWT_HIP_OK;
     GBWT_HIP_GUARD_END
 }
 

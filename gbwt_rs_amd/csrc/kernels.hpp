@@ -89,7 +89,7 @@ void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_
 // bidirectional indexes: is sequence 2k + 1 the reverse of sequence 2k for every k (fingerprints from the pass above)?
 void launch_check_orientation_pairs(const uint32_t *d_seq_len, const uint64_t *d_prints, uint64_t n_pairs, uint32_t *d_mismatch, hipStream_t stream);
 // lengths[k] = seq_len[ids[k]]; d_max_len[0] = the largest of them, d_max_len[1] = ~(the smallest) (both zeroed by the caller)
-void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
+void launch_gather_lengths(const uint32_t *d_seq_len, uint64_t n_sequences, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
 // lengths and samples in one walk: samples into a pool of `capacity` entries (*d_counter = samples met, may exceed the
 // capacity: then nothing usable was recorded), then blank + place into the final table
 void launch_lengths_and_samples(const DeviceIndex &ix, uint32_t interval, uint32_t *d_seq_len, uint4 *d_pool, uint2 *d_tags, uint64_t *d_counter,

@@ -15,20 +15,31 @@ namespace {
 // Load-time passes
 
 // One lane per record: Record::len and outdegree maxima (sizes u32 offsets on device, feeds stats), and the sum of the lengths.
+// Reduced over the wave first: two million lanes on four addresses took 25 ms of atomics on the headline index.
 __global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *stats) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (rec >= ix.n_records) return;
-    uint64_t start, limit;
-    record_bounds(ix, rec, start, limit);
-    if (start >= limit) return;
-    ByteCursor c(ix.data, start, limit);
-    uint64_t sigma;
-    if (!c.varint(sigma)) { atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), 1ull); return; }
-    if (sigma == 0) return;
-    uint64_t len = record_len(c, sigma);
-    atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(len));
-    atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(sigma));
-    atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(len));   // all BWT positions = GBWT::len of a consistent index
+    uint64_t len = 0, sigma = 0, bad = 0;
+    if (rec < ix.n_records) {
+        uint64_t start, limit;
+        record_bounds(ix, rec, start, limit);
+        if (start < limit) {
+            ByteCursor c(ix.data, start, limit);
+            if (!c.varint(sigma)) { bad = 1; sigma = 0; }
+            else if (sigma != 0) len = record_len(c, sigma);
+        }
+    }
+    uint64_t max_len = len, max_sigma = sigma, sum = len;
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        max_len = max(max_len, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_len), d)));
+        max_sigma = max(max_sigma, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_sigma), d)));
+        sum += __shfl_down(static_cast<unsigned long long>(sum), d);
+        bad += __shfl_down(static_cast<unsigned long long>(bad), d);
+    }
+    if (threadIdx.x % WAVE != 0) return;
+    if (max_len) atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(max_len));
+    if (max_sigma) atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(max_sigma));
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), static_cast<unsigned long long>(bad));
+    if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(sum));   // all BWT positions = GBWT::len of a consistent index
 }
 
 // 16 bytes of the stream at data[pos..], zero-filled past `limit`.

@@ -62,6 +62,7 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     if (a.level == nullptr) { j = w / a.n; k = w % a.n; }           // every row has every segment: w = j * n + k
     else k = a.sorted_rows[w - a.level[lo]];
     const uint64_t id = a.seq_ids[k];
+    if (id >= ix.n_sequences) return s;                      // GBWT::sequence: no such sequence -> an empty row
     const uint64_t base = ix.sample_base[id], count = ix.sample_base[id + 1] - base;
     const uint64_t len = a.out_offsets[k + 1] - a.out_offsets[k];
     if (j >= count) return s;                                 // this row has fewer segments: nothing to do
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     } else if (owner) {
         const uint64_t k = w < a.n ? w : w - a.n;
         const uint64_t id = a.seq_ids[k] ^ (target.backward ? 1u : 0u);
-        if (quota > 0 && id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+        if (quota > 0 && id < ix.n_endmarker && id < ix.n_sequences) {  // GBWT::start, src/gbwt.rs:213-219
             const uint2 e = ix.endmarker[id];
             if (e.x != 0) {
                 sink.push(e.x, true);
@@ -444,11 +445,11 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
 }  // namespace
 
 // keys[k] = number of segments of row k = samples of its sequence (0 for an empty sequence), rows[k] = k
-__global__ void __launch_bounds__(256) k_segment_counts(const uint64_t *sample_base, const uint64_t *ids, uint64_t n, uint32_t *keys, uint32_t *rows) {
+__global__ void __launch_bounds__(256) k_segment_counts(const uint64_t *sample_base, uint64_t n_sequences, const uint64_t *ids, uint64_t n, uint32_t *keys, uint32_t *rows) {
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (k >= n) return;
     const uint64_t id = ids[k];
-    keys[k] = static_cast<uint32_t>(sample_base[id + 1] - sample_base[id]);
+    keys[k] = id < n_sequences ? static_cast<uint32_t>(sample_base[id + 1] - sample_base[id]) : 0u;
     rows[k] = static_cast<uint32_t>(k);
 }
 
@@ -473,7 +474,7 @@ size_t walker_order_temp_bytes(uint64_t n) {
 
 void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
                          uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream) {
-    hipLaunchKernelGGL(k_segment_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, d_ids, n, d_keys, d_rows);
+    hipLaunchKernelGGL(k_segment_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, ix.n_sequences, d_ids, n, d_keys, d_rows);
     hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + n), rows(d_rows, d_rows + n);
     (void)hipcub::DeviceRadixSort::SortPairsDescending(d_temp, temp_bytes, keys, rows, static_cast<int>(n), 0, 32, stream);   // radix sort: stable
     hipLaunchKernelGGL(k_level_counts, dim3(grid_for(segments, 256)), dim3(256), 0, stream, keys.Current(), n, segments, d_level_counts);

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(WAVE) k_walk(DeviceIndex ix, WalkArgs a) {
     const uint64_t id = a.seq_ids[k];
     uint64_t node = 0, offset = 0;
     bool valid = false;
-    if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+    if (id < ix.n_endmarker && id < ix.n_sequences) {  // GBWT::start, src/gbwt.rs:213-219
         uint2 e = ix.endmarker[id];
         node = e.x; offset = e.y;
         valid = node != 0;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_blocks(DeviceIndex ix, WalkAr
     uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;   // position of the walk (record index; 0 = parked) + block base of the record
     if (owner) {
         const uint64_t id = a.seq_ids[k];
-        if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+        if (id < ix.n_endmarker && id < ix.n_sequences) {  // GBWT::start, src/gbwt.rs:213-219
             const uint2 e = ix.endmarker[id];
             if (e.x != 0) {
                 sink.push(e.x, true);
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;   // position of the walk (record index; 0 = parked) + block base of the record
     if (owner) {
         const uint64_t id = a.seq_ids[k];
-        if (id < ix.n_endmarker) {  // GBWT::start, src/gbwt.rs:213-219
+        if (id < ix.n_endmarker && id < ix.n_sequences) {  // GBWT::start, src/gbwt.rs:213-219
             const uint2 e = ix.endmarker[id];
             if (e.x != 0) {
                 sink.push(e.x, true);
@@ -150,10 +150,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     }
 }
 
-__global__ void __launch_bounds__(256) k_gather_lengths(const uint32_t *seq_len, const uint64_t *ids, uint64_t n, uint64_t *lengths, uint32_t *max_len) {
+__global__ void __launch_bounds__(256) k_gather_lengths(const uint32_t *seq_len, uint64_t n_sequences, const uint64_t *ids, uint64_t n, uint64_t *lengths, uint32_t *max_len) {
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (k >= n) return;
-    const uint32_t len = seq_len[ids[k]];
+    const uint32_t len = ids[k] < n_sequences ? seq_len[ids[k]] : 0u;   // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256): an empty row
     lengths[k] = len;
     atomicMax(max_len, len);
     atomicMax(max_len + 1, ~len);      // max_len[1] = ~(the shortest)
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(WAVE) k_walk_coop(DeviceIndex ix, WalkArgs a) 
     bool active = false;
     if (owner) {
         const uint64_t id = a.seq_ids[k];
-        if (id < ix.n_endmarker) {
+        if (id < ix.n_endmarker && id < ix.n_sequences) {
             uint2 e = ix.endmarker[id];
             node = e.x; offset = e.y;
             active = node != 0;
@@ -289,8 +289,8 @@ void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream
     hipLaunchKernelGGL(k_walk_two, grid, dim3(2 * WAVE), 0, stream, ix, args);
 }
 
-void launch_gather_lengths(const uint32_t *d_seq_len, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_gather_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_seq_len, d_ids, n, d_lengths, d_max_len);
+void launch_gather_lengths(const uint32_t *d_seq_len, uint64_t n_sequences, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_gather_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_seq_len, n_sequences, d_ids, n, d_lengths, d_max_len);
 }
 
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream) {

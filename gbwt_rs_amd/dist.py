@@ -2,13 +2,17 @@
 
 The path set shards by sequence: every rank walks its own shard against its own replica (or its own contig) of the
 index, and there is NO collective inside the walk.  The only exchange is the one the reference's writer mutex
-stands for (src/bin/gbunzip.rs:421-434): putting the extracted rows back into path order on one rank.  That is
+stands for (src/bin/gbunzip.rs:421-434): putting the extracted rows -- node ids or finished GFA lines -- back into
+path order on one rank.  That is
 
-    1. all_gather of the per-rank row lengths                        (8 B per row)
-    2. variable-size gather of the row data to the destination rank  (point-to-point sends: every peer has its own
-       xGMI link to the root, so a direct gather beats a ring all-gather, which is bound by one link)
+    1. all_gather of the per-rank row and value counts                (16 B per rank)
+    2. variable-size gather of lengths and values to the destination  (ONE group of point-to-point operations:
+       dist.batch_isend_irecv, i.e. ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd on RCCL, so that all
+       peers stream at once, each over its own xGMI link to the root; a ring all-gather would be bound by one link)
+    3. with interleaved sharding, one scatter per peer into the path-ordered layout (index arithmetic on the device,
+       no per-row loop)
 
-Works on CUDA/HIP tensors over RCCL and on CPU tensors over gloo (the CPU form is what the tests run).
+Works on HIP tensors over RCCL and on CPU tensors over gloo (the CPU form is what the tests run).
 """
 import torch
 import torch.distributed as dist
@@ -30,55 +34,113 @@ def shard_ids(ids, rank, world, interleaved=False):
     return ids[lo:hi]
 
 
+def _exchange(lengths, values, rows, sizes, dst, group):
+    """Step 2: one batch of point-to-point operations.  Returns (len_parts, val_parts) on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = lengths.device
+    ops, len_parts, val_parts = [], None, None
+    if rank == dst:
+        len_parts = [lengths if r == rank else torch.empty(rows[r], dtype=torch.int64, device=device) for r in range(world)]
+        val_parts = [values if r == rank else torch.empty(sizes[r], dtype=values.dtype, device=device) for r in range(world)]
+        for r in range(world):
+            if r == rank:
+                continue
+            peer = r if group is None else dist.get_global_rank(group, r)
+            if rows[r]:
+                ops.append(dist.P2POp(dist.irecv, len_parts[r], peer, group))
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, val_parts[r], peer, group))
+    else:
+        peer = dst if group is None else dist.get_global_rank(group, dst)
+        if lengths.numel():
+            ops.append(dist.P2POp(dist.isend, lengths, peer, group))
+        if values.numel():
+            ops.append(dist.P2POp(dist.isend, values, peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return len_parts, val_parts
+
+
 def gather_rows(lengths, values, dst=0, group=None, interleaved=False):
     """Gathers this rank's CSR rows (lengths[k] values each, concatenated in `values`) on rank `dst`.
 
     Returns (offsets, values) of all rows in global path order on `dst`, (None, None) elsewhere.  `lengths` is an
-    int64 tensor, `values` any 1-D tensor; both on the same device."""
+    int64 tensor, `values` any 1-D tensor; both on the same device.  With `interleaved`, row k of rank r is global
+    row k * world + r (the layout of shard_ids(..., interleaved=True))."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     device = lengths.device
-    counts = torch.tensor([lengths.numel(), int(lengths.sum().item())], dtype=torch.int64, device=device)
-    all_counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_counts, counts, group=group)
-    rows = [int(c[0]) for c in all_counts]
-    sizes = [int(c[1]) for c in all_counts]
-    if rank == dst:
-        len_parts = [lengths if r == rank else torch.empty(rows[r], dtype=torch.int64, device=device) for r in range(world)]
-        val_parts = [values if r == rank else torch.empty(sizes[r], dtype=values.dtype, device=device) for r in range(world)]
-        reqs = []
-        for r in range(world):
-            if r == rank:
-                continue
-            if rows[r]:
-                reqs.append(dist.irecv(len_parts[r], src=r, group=group))
-            if sizes[r]:
-                reqs.append(dist.irecv(val_parts[r], src=r, group=group))
-        for q in reqs:
-            q.wait()
-        if not interleaved:
-            all_len = torch.cat(len_parts)
-            all_val = torch.cat(val_parts)
-        else:  # row k of rank r is global row k * world + r
-            total_rows = sum(rows)
-            all_len = torch.zeros(total_rows, dtype=torch.int64, device=device)
-            for r in range(world):
-                all_len[r::world] = len_parts[r]
-            offsets = torch.zeros(total_rows + 1, dtype=torch.int64, device=device)
-            torch.cumsum(all_len, 0, out=offsets[1:])
-            all_val = torch.empty(int(offsets[-1].item()), dtype=values.dtype, device=device)
-            for r in range(world):
-                src_off = torch.zeros(rows[r] + 1, dtype=torch.int64, device=device)
-                torch.cumsum(len_parts[r], 0, out=src_off[1:])
-                for k in range(rows[r]):   # host loop: gather order only matters for the (small) tests and GFA assembly
-                    g = k * world + r
-                    all_val[offsets[g]:offsets[g + 1]] = val_parts[r][src_off[k]:src_off[k + 1]]
-            return offsets, all_val
+    counts = torch.tensor([lengths.numel(), values.numel()], dtype=torch.int64, device=device)
+    all_counts = torch.zeros(2 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_counts, counts, group=group)
+    all_counts = all_counts.cpu().tolist()      # the one host synchronisation: the receive buffers are sized from it
+    rows, sizes = all_counts[0::2], all_counts[1::2]
+    len_parts, val_parts = _exchange(lengths, values, rows, sizes, dst, group)
+    if rank != dst:
+        return None, None
+    if not interleaved:
+        all_len = torch.cat(len_parts)
+        all_val = torch.cat(val_parts)
         offsets = torch.zeros(all_len.numel() + 1, dtype=torch.int64, device=device)
         torch.cumsum(all_len, 0, out=offsets[1:])
         return offsets, all_val
-    if lengths.numel():
-        dist.send(lengths, dst=dst, group=group)
-    if values.numel():
-        dist.send(values, dst=dst, group=group)
-    return None, None
+    total_rows, total = sum(rows), sum(sizes)
+    all_len = torch.zeros(total_rows, dtype=torch.int64, device=device)
+    for r in range(world):
+        all_len[r::world] = len_parts[r]
+    offsets = torch.zeros(total_rows + 1, dtype=torch.int64, device=device)
+    torch.cumsum(all_len, 0, out=offsets[1:])
+    all_val = torch.empty(total, dtype=values.dtype, device=device)
+    for r in range(world):
+        if sizes[r] == 0:
+            continue
+        # element e of the peer's row k goes to offsets[k * world + r] + (e - first element of row k)
+        src_start = torch.cumsum(len_parts[r], 0) - len_parts[r]
+        shift = offsets[r:total_rows:world] - src_start
+        where = torch.arange(sizes[r], dtype=torch.int64, device=device) + torch.repeat_interleave(shift, len_parts[r], output_size=sizes[r])
+        all_val.index_copy_(0, where, val_parts[r])
+    return offsets, all_val
+
+
+def gather_lines(line_offsets, text, dst=0, group=None, interleaved=False):
+    """The final GFA concatenation: this rank's finished lines (`text`, uint8; line k at line_offsets[k] ..
+    line_offsets[k + 1], int64) gathered on `dst` in path order.  Returns (offsets, text) there, (None, None) elsewhere.
+    With contiguous shards the lines of a rank travel as ONE row (their order is already final)."""
+    if interleaved:
+        return gather_rows(line_offsets[1:] - line_offsets[:-1], text, dst=dst, group=group, interleaved=True)
+    whole = torch.tensor([text.numel()], dtype=torch.int64, device=text.device)
+    offsets, all_text = gather_rows(whole, text, dst=dst, group=group)
+    return offsets, all_text
+
+
+class _DeviceMemory:
+    """A span of HBM owned by a libgbwt_hip workspace, described the way torch.as_tensor understands."""
+
+    def __init__(self, pointer, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (int(pointer), False), "version": 3}
+
+
+def device_view(pointer, count, dtype, device):
+    """A torch tensor over `count` elements of device memory at `pointer` (no copy).  The memory belongs to the
+    workspace that produced it and is valid until the next call on that workspace: clone() what must outlive it."""
+    typestr = {torch.uint8: "|u1", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+    if count == 0 or not pointer:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_DeviceMemory(pointer, count, typestr), device=device)
+
+
+def lines_tensors(lines, device):
+    """(line_offsets int64[n + 1], text uint8[total]) views of a gbwt_hip_lines result (api.GBZ.path_lines_device)."""
+    offsets = device_view(lines.d_line_offsets, lines.n + 1 if lines.n else 0, torch.int64, device)   # u64 offsets < 2^63
+    text = device_view(lines.d_text, lines.total, torch.uint8, device)
+    if lines.n == 0:
+        offsets = torch.zeros(1, dtype=torch.int64, device=device)
+    return offsets, text
+
+
+def paths_tensors(paths, device):
+    """(offsets int64[n + 1], nodes int32[total]) views of a gbwt_hip_paths result (api.GBWT.extract_device); node ids
+    are u32 on the device and < 2^31 whenever alphabet_size is."""
+    return device_view(paths.d_offsets, paths.n + 1, torch.int64, device), device_view(paths.d_nodes, paths.total, torch.int32, device)

@@ -114,10 +114,13 @@ void *gbwt_hip_workspace_stream(gbwt_hip_workspace *ws);
 /* ---- path extraction ---------------------------------------------------------------------------
  * gbwt_hip_extract: GBWT::sequence(id).collect::<Vec<_>>() for every id (src/gbwt.rs:253-261,
  * SequenceIter::next 557-568).  CSR output: out_offsets[n+1], nodes of sequence k at
- * out_nodes[out_offsets[k] .. out_offsets[k+1]).  id >= sequences -> GBWT_HIP_BAD_ARGUMENT (the
- * reference returns no iterator); an empty sequence gives a zero-length row.  `*total` always receives
- * the number of nodes (= LF steps); with out_nodes == NULL it is a size query; if capacity < total the
- * call returns GBWT_HIP_CAPACITY.  Host buffers. */
+ * out_nodes[out_offsets[k] .. out_offsets[k+1]).  id >= sequences (the reference returns no iterator) and
+ * an empty sequence both give a zero-length row: "not found" never fails the batch, and the caller tells
+ * the two apart by id < sequences.  `*total` always receives the number of nodes (= LF steps); with
+ * out_nodes == NULL it is a size query; if capacity < total the call returns GBWT_HIP_CAPACITY.  Host
+ * buffers.  The sequences are walked ONCE per request: the rows stay in the workspace, and the call that
+ * repeats the ids of the previous gbwt_hip_extract / gbwt_hip_extract_device on it (the fill call after a
+ * size query) only copies them out.  gbwt_hip_follow and gbwt_hip_path_lines do the same. */
 gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *seq_ids,
                                  uint64_t n, uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity,
                                  uint64_t *total);
@@ -127,6 +130,12 @@ gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *index, gbwt_hip_workspace
 typedef struct { const uint64_t *d_offsets; const uint32_t *d_nodes; uint64_t total; uint64_t n; } gbwt_hip_paths;
 gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws,
                                         const uint64_t *seq_ids, uint64_t n, gbwt_hip_paths *out);
+
+/* Copies the last device-resident extraction of `ws` to host buffers: out_offsets[n + 1] and/or out_nodes[total]
+ * (either may be NULL; capacity < total -> GBWT_HIP_CAPACITY).  With gbwt_hip_extract_device this is "extract once,
+ * size the buffer from gbwt_hip_paths.total, copy". */
+gbwt_hip_status gbwt_hip_copy_result(const gbwt_hip_index *index, gbwt_hip_workspace *ws, uint64_t *out_offsets,
+                                     uint32_t *out_nodes, uint64_t capacity);
 
 /* GBZ::path(path_id, orientation) (src/gbz.rs:461-466, PathIter 1053-1059): sequence id =
  * 2*path_id + orientation (support::encode_path, src/support.rs:229-231); output nodes stay GBWT-encoded
@@ -192,6 +201,12 @@ gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspa
  * translation print segment names (GBZ::segment_path / SegmentPathIter, src/gbz.rs:477-486, 1098-1169). */
 gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n,
                                     int mode, char *out, uint64_t capacity, uint64_t *total);
+/* Device-resident form: the text stays in HBM inside the workspace (valid until the next GFA call on it); line k is
+ * d_text[d_line_offsets[k] .. d_line_offsets[k + 1]).  This is what a multi-GPU extraction hands to the RCCL gather
+ * (gbwt_rs_amd/dist.py) and what gbwt_hip_path_lines copies out. */
+typedef struct { const char *d_text; const uint64_t *d_line_offsets; uint64_t total; uint64_t n; } gbwt_hip_lines;
+gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *path_ids,
+                                           uint64_t n, int mode, gbwt_hip_lines *out);
 /* gbwt_hip_write_gfa: the whole file `gbunzip -t 1` writes (write_gfa_impl, src/bin/gbunzip.rs:205-226, default
  * path mode): H, S and L lines from the host copy of the graph, then P-lines and W-lines in ascending path id. */
 gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const char *path);

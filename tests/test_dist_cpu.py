@@ -50,6 +50,72 @@ def test_shard_and_gather_world2(tmp_path, interleaved):
     assert (tmp_path / "ok").exists()
 
 
+def _lines_worker(rank, world, port, interleaved, out_dir):
+    """The final GFA concatenation: every rank formats the W-lines of its shard of the paths (oracle here, the device
+    formatter on a GPU box) and rank 0 must end up with the bytes of one pass over all paths, in path order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gbz = O.OracleGBZ(os.path.join(O.GOLDEN, "example.gbz"))
+        ids = np.arange(6, dtype=np.uint64)
+        mine = D.shard_ids(ids, rank, world, interleaved=interleaved)
+        lines = [gbz.path_lines([int(p)], 1) for p in mine]
+        text = torch.frombuffer(bytearray(b"".join(lines)), dtype=torch.uint8) if lines and sum(map(len, lines)) else torch.empty(0, dtype=torch.uint8)
+        offsets = torch.zeros(len(lines) + 1, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(torch.tensor([len(x) for x in lines], dtype=torch.int64), 0) if lines else offsets[1:]
+        g_off, g_text = D.gather_lines(offsets, text, dst=0, interleaved=interleaved)
+        if rank == 0:
+            assert bytes(g_text.numpy().tobytes()) == gbz.path_lines([int(p) for p in ids], 1)
+            assert int(g_off[-1]) == g_text.numel()
+            if interleaved:
+                assert g_off.numel() == 7     # one row per line, in path order
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+        else:
+            assert g_off is None and g_text is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,interleaved", [(2, False), (2, True), (4, True), (3, False)])
+def test_gather_gfa_lines(tmp_path, world, interleaved):
+    port = _free_port()
+    mp.spawn(_lines_worker, args=(world, port, interleaved, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        n = 23                                                    # not a multiple of the world size; some rows empty
+        lens = rng.integers(0, 9, n)
+        lens[[0, 7, 22]] = 0
+        rows = [np.arange(l, dtype=np.int64) + 1000 * k for k, l in enumerate(lens)]
+        for interleaved in (False, True):
+            mine = D.shard_ids(np.arange(n), rank, world, interleaved=interleaved)
+            lengths = torch.tensor([len(rows[k]) for k in mine], dtype=torch.int64)
+            values = torch.from_numpy(np.concatenate([rows[k] for k in mine]) if len(mine) else np.zeros(0, dtype=np.int64))
+            g_off, g_val = D.gather_rows(lengths, values, dst=1, interleaved=interleaved)   # a root that is not rank 0
+            if rank == 1:
+                assert np.array_equal(np.diff(g_off.numpy()), lens)
+                assert np.array_equal(g_val.numpy(), np.concatenate(rows))
+            else:
+                assert g_off is None
+        if rank == 1:
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_ragged_rows_world3(tmp_path):
+    port = _free_port()
+    mp.spawn(_ragged_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 5000, 5001):
         for world in (1, 2, 3, 8):

@@ -117,3 +117,50 @@ def test_synthetic_gfa_matches_oracle(tmp_path, alleles, sites, haps):
     ids = [haps - 1, 1, 7]
     assert dev.path_lines(ids, 1) == oracle.path_lines(ids, 1)
     assert dev.path_lines([0], 0) == oracle.path_lines([0], 0)
+
+
+def test_device_resident_lines_and_rccl_gather(tmp_path):
+    """gbwt_hip_path_lines_device leaves the text in HBM; dist.lines_tensors wraps it without a copy and
+    dist.gather_lines moves it over RCCL (backend "nccl", world size 1 on this box: the collective and the tensor
+    plumbing are the real ones, the peers are missing).  Runs in a child process: a process group is per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import gbwt_rs_amd as G
+from gbwt_rs_amd import dist as D
+import oracle_lib as O
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=PORT, RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+path = os.path.join(O.GOLDEN, "example.gbz")
+dev, oracle = G.GBZ.load(path), O.OracleGBZ(path)
+ids = [5, 2, 3]
+want = oracle.path_lines(ids, 1)
+lines = dev.path_lines_device(ids, 1)
+off, text = D.lines_tensors(lines, torch.device("cuda", 0))
+assert text.is_cuda and bytes(text.cpu().numpy().tobytes()) == want and int(off[-1]) == len(want) and off.numel() == 4
+assert dev.path_lines(ids, 1) == want                     # the copy-out of the same request
+for interleaved in (False, True):
+    g_off, g_text = D.gather_lines(off, text, dst=0, interleaved=interleaved)
+    assert bytes(g_text.cpu().numpy().tobytes()) == want and int(g_off[-1]) == len(want)
+# node ids the same way
+p = dev.extract_device(np.array([0, 2, 4], dtype=np.uint64))
+o, n = D.paths_tensors(p, torch.device("cuda", 0))
+oo, nn = oracle.gbwt().extract(np.array([0, 2, 4], dtype=np.uint64))
+assert np.array_equal(o.cpu().numpy(), oo.astype(np.int64)) and np.array_equal(n.cpu().numpy().astype(np.uint32), nn)
+g_off, g_val = D.gather_rows(o[1:] - o[:-1], n, dst=0)
+assert np.array_equal(g_val.cpu().numpy().astype(np.uint32), nn)
+dist.destroy_process_group()
+print("RCCL_GATHER_OK")
+'''
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}; PORT = '{port}'\n" + code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "RCCL_GATHER_OK" in out.stdout, out.stderr[-3000:]

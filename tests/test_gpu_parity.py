@@ -174,10 +174,57 @@ def test_fixture_extract(name, with_empty):
         assert list(nodes[offsets[2 * i + 1]:offsets[2 * i + 2]]) == kat.reverse_path(t)
         assert dev.sequence(2 * i) == t
     assert dev.sequence(dev.sequences()) is None
-    with pytest.raises(G.GbwtHipError):
-        dev.sequences_csr([dev.sequences()])
+    # GBWT::sequence(id >= sequences) is None (src/gbwt/tests.rs:227): a value, not an error -- the id gets an empty row
+    # and a False in the mask, the rest of the batch is extracted
+    mixed = np.array([dev.sequences(), 0, 2 ** 40, 3, dev.sequences() + 1], dtype=np.uint64)
+    m_off, m_nodes, m_valid = dev.sequences_csr(mixed, return_valid=True)
+    assert list(m_valid) == [False, True, False, True, False]
+    assert list(np.diff(m_off.astype(np.int64))) == [0, len(truth[0]), 0, len(truth[1]), 0]
+    assert list(m_nodes) == truth[0] + kat.reverse_path(truth[1])
     if with_empty:
         assert dev.sequence(8) == [] and dev.sequence(9) == []
+
+
+def test_size_then_fill_computes_once():
+    """The C idiom -- size query, then the same call with buffers -- must not walk the sequences twice: the second call
+    finds the rows of the same request in the workspace.  A different request in between is computed afresh."""
+    import ctypes as C
+    dev = G.GBWT.load(os.path.join(GOLDEN, "example.gbwt"))
+    L = dev._L
+    truth = kat.true_paths(False)
+    ids = np.array([0, 2, 6, 99, 1], dtype=np.uint64)
+    offsets = np.zeros(ids.size + 1, dtype=np.uint64)
+    total = C.c_uint64(0)
+    G._lib.check(L.gbwt_hip_extract(dev._h, dev._ws, ids.ctypes.data, ids.size, offsets.ctypes.data, None, 0, C.byref(total)))
+    walk_ms = dev.last_kernel_ms()
+    nodes = np.zeros(total.value, dtype=np.uint32)
+    G._lib.check(L.gbwt_hip_extract(dev._h, dev._ws, ids.ctypes.data, ids.size, offsets.ctypes.data, nodes.ctypes.data, nodes.size, C.byref(total)))
+    assert dev.last_kernel_ms() == walk_ms            # same events: no second walk
+    want = truth[0] + truth[1] + truth[3] + kat.reverse_path(truth[0])
+    assert list(nodes) == want and list(np.diff(offsets.astype(np.int64))) == [5, 4, 5, 0, 5]
+    # another request, then the first one again with buffers only
+    other = np.array([4], dtype=np.uint64)
+    o2 = np.zeros(2, dtype=np.uint64)
+    n2 = np.zeros(16, dtype=np.uint32)
+    G._lib.check(L.gbwt_hip_extract(dev._h, dev._ws, other.ctypes.data, 1, o2.ctypes.data, n2.ctypes.data, n2.size, C.byref(total)))
+    assert list(n2[:total.value]) == truth[2]
+    nodes[:] = 0
+    G._lib.check(L.gbwt_hip_extract(dev._h, dev._ws, ids.ctypes.data, ids.size, offsets.ctypes.data, nodes.ctypes.data, nodes.size, C.byref(total)))
+    assert list(nodes) == want
+    # too small a buffer: CAPACITY, and the total is still reported
+    st = L.gbwt_hip_extract(dev._h, dev._ws, ids.ctypes.data, ids.size, offsets.ctypes.data, nodes.ctypes.data, 3, C.byref(total))
+    assert st == G._lib.CAPACITY and total.value == len(want)
+    # GBZ::path through the C entry point (sequence id = 2 * path + orientation)
+    pids = np.array([1, 0], dtype=np.uint64)
+    po = np.zeros(3, dtype=np.uint64)
+    pn = np.zeros(16, dtype=np.uint32)
+    G._lib.check(L.gbwt_hip_extract_paths(dev._h, dev._ws, pids.ctypes.data, 2, 1, po.ctypes.data, pn.ctypes.data, pn.size, C.byref(total)))
+    assert list(pn[:total.value]) == kat.reverse_path(truth[1]) + kat.reverse_path(truth[0])
+    # follow: size query + fill
+    st8, ok = dev.bd_find([28, 24])
+    off, ext, valid = dev.follow(st8)
+    off2, ext2, valid2 = dev.follow(st8)
+    assert ok.all() and valid.all() and np.array_equal(off, off2) and np.array_equal(ext, ext2) and len(ext) == int(off[-1]) > 0
 
 
 def test_fixture_statistics():
@@ -774,3 +821,52 @@ def test_cpp_mirror_of_the_reference_tests(tmp_path):
     out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+def test_corrupt_files_never_take_the_device_down(tmp_path):
+    """Every 64-bit element of the small fixtures overwritten with hostile values: whatever the host parser accepts is
+    opened on the GPU and queried (extract everything, find + forward over all nodes).  Records full of garbage may give
+    garbage, or GBWT_HIP_INVALID_DATA when a walk never ends -- never a fault, a hang or an abort (the reference panics
+    on malformed records, src/bwt.rs:374-377; the C side returns a status).  Runs in a child process with a deadline."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import gbwt_rs_amd as G
+from test_capi_cpu import mutated_files
+import pathlib
+opened = rejected = 0
+for name, w, value, path in mutated_files(pathlib.Path(TMP), names=("example.gbwt", "with-empty.gbwt", "translation.gbz"), values=(0xFFFFFFFFFFFFFFFF, 0, 65, 1 << 40, 0x0101010101010101)):
+    try:
+        dev = G.GBZ.load(path)
+    except G.GbwtHipError as e:
+        assert e.status in (G._lib.INVALID_DATA, G._lib.DEVICE_ERROR, G._lib.UNSUPPORTED), (name, w, hex(value), str(e))
+        rejected += 1
+        continue
+    opened += 1
+    n_seq = min(dev.sequences(), 1 << 12)
+    off, nodes = dev.sequences_csr(np.arange(n_seq + 2, dtype=np.uint64))
+    assert int(off[-1]) == len(nodes)
+    hi = min(dev.alphabet_size() + 2, 1 << 12)
+    st, ok = dev.find(np.arange(hi, dtype=np.uint64))
+    pos = np.zeros(hi, dtype=G.POS_DTYPE); pos["node"] = np.arange(hi); pos["offset"] = 1
+    dev.forward(pos)
+    if dev.is_bidirectional():
+        dev.backward(pos)
+        bd, ok = dev.bd_find(np.arange(hi, dtype=np.uint64))
+        dev.follow(bd[ok][:64])
+    if dev.stats.is_gbz and dev.has_metadata() and dev.stats.paths:
+        try:
+            dev.path_lines(np.arange(min(dev.stats.paths, 8), dtype=np.uint64), 1)
+        except G.GbwtHipError as e:
+            assert e.status in (G._lib.BAD_ARGUMENT, G._lib.INVALID_DATA), str(e)
+    dev.close()
+print("opened", opened, "rejected", rejected)
+assert opened > 300 and rejected > 300
+print("MUTATIONS_OK")
+'''
+    out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}; TMP = {str(tmp_path)!r}\n" + code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "MUTATIONS_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
