@@ -407,6 +407,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         // (src/gbwt.rs:108-122), and every path wastes less than one block.
         const uint64_t all_nodes = ix->host.size >= ix->host.sequences ? ix->host.size - ix->host.sequences : 0;
         uint64_t pool_blocks = all_nodes / POOL_BLOCK_NODES + n + 1;
+        HIP_CHECK(hipEventRecord(ws->ev[3], s));   // everything the extraction puts on the stream lies between ev[3] and ev[2]
         if (n) HIP_CHECK(hipMemcpyAsync(ws->seq_ids.ptr, seq_ids, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         const char *no_direct = std::getenv("GBWT_HIP_DIRECT");
         if (n && ix->dev.seq_len && ws->walk_mode == WALK_TWO_STEP && !(no_direct && std::atoi(no_direct) == 0)) {
@@ -667,7 +668,7 @@ gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *wal
     GBWT_HIP_GUARD_BEGIN
     if (!ws || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no timed extraction on this workspace");
     float a = 0, b = 0;
-    if (hipEventElapsedTime(&a, ws->ev[0], ws->ev[1]) != hipSuccess || hipEventElapsedTime(&b, ws->ev[0], ws->ev[2]) != hipSuccess)
+    if (hipEventElapsedTime(&a, ws->ev[0], ws->ev[1]) != hipSuccess || hipEventElapsedTime(&b, ws->ev[3], ws->ev[2]) != hipSuccess)
         return fail(GBWT_HIP_DEVICE_ERROR, "hipEventElapsedTime failed");
     if (walk_ms) *walk_ms = a;
     if (total_ms) *total_ms = b;

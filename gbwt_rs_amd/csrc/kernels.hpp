@@ -74,7 +74,7 @@ struct WalkArgs {
     uint32_t uniform_loop;     // k_walk_direct: try the wave-uniform loop (scalar descriptor fetch) first
     uint32_t debug;            // measurement switches of k_walk_direct (GBWT_HIP_DEBUG_DRY_ROWS; never set by the library itself; the output is
                                // wrong with 1, 2 and 128): 1 = no row stores, 2 = all rows written into one 64 MB window, 128 = into 1 MB, 4 = plain
-                               // instead of non-temporal row stores, 32 = row groups in row order
+                               // instead of non-temporal row stores, 32 = row groups in row order, 16384 = XCDs 0-3 only (with XCD_MAP=0)
     // segmented extraction with rows of different lengths: walkers in (segment, row) order with the rows that have no such
     // segment left out.  rows sorted by their number of segments (descending, stable); level[j] = walkers before segment j.
     const uint32_t *sorted_rows;   // [n]

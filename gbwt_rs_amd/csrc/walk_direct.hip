@@ -293,6 +293,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     // fetched into ONE L2 instead of all eight.
     uint64_t group = blockIdx.x;
     if (a.xcd_map) group = (blockIdx.x % 8u) * static_cast<uint64_t>(gridDim.x / 8u) + blockIdx.x / 8u;
+    if (a.debug & 16384u) {   // measurement switch (tools/occupancy_probe.py): the same work on XCDs 0-3 only -- the grid is twice as large, XCDs 4-7 leave at once
+        if (blockIdx.x % 8u >= 4u) return;
+        group = (blockIdx.x / 8u) * 4ull + blockIdx.x % 8u;
+    }
     const uint64_t w = group * a.paths_per_wave + lane;
     const bool owner = lane < a.paths_per_wave && w < walkers;
     const uint32_t ring_mask = a.ring_slots - 1;
@@ -488,6 +492,7 @@ void launch_walk_direct(const DeviceIndex &ix, const WalkArgs &args, hipStream_t
     const uint64_t walkers = args.segments ? args.walkers : (args.both_ends ? 2 * args.n : args.n);
     unsigned groups = grid_for(walkers, p);
     if (args.xcd_map) groups = (groups + 7u) / 8u * 8u;   // whole eighths; the workgroups past the end own nothing
+    if (args.debug & 16384u) groups = grid_for(walkers, p) * 2u + 8u;
     hipLaunchKernelGGL(k_walk_direct, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
 }
 

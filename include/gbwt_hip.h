@@ -220,8 +220,9 @@ gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *index, gbwt_hip_workspa
                                    uint64_t capacity, uint64_t *len);
 
 /* ---- measurement hooks -------------------------------------------------------------------------
- * Name and average duration (ms, from HIP events on the workspace stream) of the dominant kernel of
- * the last gbwt_hip_extract_device call, for bench.py's roofline object. */
+ * From HIP events on the workspace stream, for the last gbwt_hip_extract_device call: *walk_ms = duration of its
+ * dominant kernel (the walk; bench.py's roofline object), *total_ms = everything the call put on the stream, from the
+ * upload of the ids to the last kernel (lengths, offsets, walker order, walk; host waits in between included). */
 gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms);
 /* Kernel time (ms, HIP events on the workspace stream, host staging excluded) of the last navigation / search call
  * (start, forward, backward, find, extend, bd_*, search, bd_search) on `ws`. */

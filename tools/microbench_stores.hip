@@ -27,6 +27,29 @@ __global__ void __launch_bounds__(64) k_pieces(uint8_t *out, uint64_t segments, 
     }
 }
 
+// (d) the REAL address pattern of the segmented extraction: 5 000 rows of 666 668 nodes, 326 segments of 2 048 nodes; workgroup g
+// (one wave here) holds segment g / 79 of rows 64 (g % 79) .. + 63 and writes, round after round, the next 128-byte piece of
+// every one of its 64 rows: eight store instructions of eight pieces each (rows 2.67 MB apart), `nap` sleeps between rounds.
+// Pieces are whole 128-byte lines, as the row writer of the kernel aligns them (unaligned pieces under nt: 1.2 TB/s).
+template <bool NT>
+__global__ void __launch_bounds__(64) k_rows(uint8_t *out, uint32_t rows, uint32_t row_nodes, uint32_t seg_nodes, uint32_t groups, uint32_t nap) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t j = blockIdx.x / groups, first = (blockIdx.x % groups) * 64u;
+    for (uint32_t round = 0; round < seg_nodes / 32; round++) {
+        for (uint32_t g = 0; g < 8; g++) {
+            const uint32_t row = first + 8 * g + lane / 8;
+            if (row >= rows) continue;
+            const uint64_t node = static_cast<uint64_t>(row) * row_nodes + static_cast<uint64_t>(j) * seg_nodes + round * 32ull + (lane % 8) * 4;
+            if (static_cast<uint64_t>(j) * seg_nodes + round * 32ull + 32 > row_nodes) continue;
+            u32x4 *at = reinterpret_cast<u32x4 *>(out + (((node - (lane % 8) * 4) * 4) & ~127ull) + (lane % 8) * 16);   // whole lines, as the row writer aligns them
+            const u32x4 v = u32x4{1u, 2u, 3u, round};
+            if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(v) : "memory");
+            else *at = v;
+        }
+        for (uint32_t k = 0; k < nap; k++) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 int main(int argc, char **argv) {
     const uint64_t bytes = 13333360000ull / 16384 * 16384;
     uint8_t *buf;
@@ -53,6 +76,20 @@ int main(int argc, char **argv) {
             snprintf(what, sizeof what, "8 x 128 B pieces per wave store, 16 KB segments, %u naps of 1024 cycles", nap);
             report(what);
         }
+    }
+    {
+        const uint32_t rows = 5000, row_nodes = 666668, seg_nodes = 2048, groups = (rows + 63) / 64, segs = (row_nodes + seg_nodes - 1) / seg_nodes;
+        for (int nt = 1; nt >= 0; nt--)
+            for (uint32_t nap : {0u, 1u, 2u, 4u}) {
+                for (int rep = 0; rep < 2; rep++) {
+                    CHECK(hipEventRecord(e0));
+                    if (nt) hipLaunchKernelGGL(k_rows<true>, dim3(groups * segs), dim3(64), 0, 0, buf, rows, row_nodes, seg_nodes, groups, nap);
+                    else hipLaunchKernelGGL(k_rows<false>, dim3(groups * segs), dim3(64), 0, 0, buf, rows, row_nodes, seg_nodes, groups, nap);
+                    char what[160];
+                    snprintf(what, sizeof what, "real pattern: 64 rows x 128 B per round, rows 2.67 MB apart, %s, %u naps", nt ? "nt" : "plain", nap);
+                    report(what);
+                }
+            }
     }
     CHECK(hipFree(buf));
     return 0;
