@@ -37,47 +37,90 @@ __device__ __forceinline__ uint32_t decimal_digits(uint32_t v) {
            (v >= 100000000u) + (v >= 1000000000u);
 }
 
-// One wave per path: text bytes of the node tokens and the summed label lengths (W-line end coordinate,
+// Lines are formatted in chunks of LINE_CHUNK path positions, so that the work is as parallel for ninety haplotypes of two
+// million nodes as it is for fifty thousand short walks (one workgroup per LINE had 0.6 G nodes/s on the former, 50 on the
+// latter).  Chunk c belongs to the path with chunk_first[path] <= c < chunk_first[path + 1] (every path has at least one
+// chunk: an empty path still has a header and a trailer).
+constexpr uint32_t LINE_CHUNK = 4096;
+
+__global__ void __launch_bounds__(256) k_chunk_counts(const uint64_t *offsets, uint64_t n, uint64_t *counts) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t len = offsets[p + 1] - offsets[p];
+    counts[p] = len == 0 ? 1 : (len + LINE_CHUNK - 1) / LINE_CHUNK;
+}
+
+struct ChunkRange { uint64_t path, begin, lo, hi; bool first, last; };
+
+__device__ __forceinline__ ChunkRange chunk_range(const uint64_t *chunk_first, uint64_t n, const uint64_t *offsets, uint64_t c) {
+    uint64_t lo = 0, hi = n;                                        // chunk_first[lo] <= c < chunk_first[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (chunk_first[mid] <= c) lo = mid; else hi = mid;
+    }
+    ChunkRange r;
+    r.path = lo;
+    r.begin = offsets[lo];
+    const uint64_t end = offsets[lo + 1];
+    r.lo = r.begin + (c - chunk_first[lo]) * LINE_CHUNK;
+    r.hi = r.lo + LINE_CHUNK < end ? r.lo + LINE_CHUNK : end;
+    r.first = c == chunk_first[lo];
+    r.last = c + 1 == chunk_first[lo + 1];
+    return r;
+}
+
+// One wave per chunk: text bytes of its node tokens and the summed label lengths (W-line end coordinate,
 // src/bin/gbunzip.rs:532-536: sequence_len(node).unwrap_or(0)).
-__global__ void __launch_bounds__(256) k_line_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint32_t *label_len,
-                                                     uint64_t n_labels, uint32_t first_node, int p_lines, uint64_t *text_len, uint64_t *seq_len) {
-    const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+__global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, uint64_t chunks,
+                                                      const uint32_t *label_len, uint64_t n_labels, uint32_t first_node, int p_lines, uint64_t *chunk_text,
+                                                      uint64_t *chunk_seq) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
-    if (path >= n) return;
-    const uint64_t begin = offsets[path], end = offsets[path + 1];
+    if (c >= chunks) return;
+    const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
     uint64_t text = 0, labels = 0;
-    for (uint64_t k = begin + lane; k < end; k += WAVE) {
+    for (uint64_t k = r.lo + lane; k < r.hi; k += WAVE) {
         const uint32_t node = nodes[k], id = node >> 1;
-        text += decimal_digits(id) + 1 + ((p_lines && k > begin) ? 1 : 0);
+        text += decimal_digits(id) + 1 + ((p_lines && k > r.begin) ? 1 : 0);
         const uint64_t seq = (static_cast<uint64_t>(node & ~1u) - first_node) / 2;   // GBZ::graph_node_to_sequence, src/gbz.rs:246-255
         if ((node & ~1u) >= first_node && seq < n_labels) labels += label_len[seq];
     }
     for (int d = WAVE / 2; d > 0; d >>= 1) { text += __shfl_down(text, d, WAVE); labels += __shfl_down(labels, d, WAVE); }
-    if (lane == 0) { text_len[path] = text; seq_len[path] = labels; }
+    if (lane == 0) { chunk_text[c] = text; chunk_seq[c] = labels; }
 }
 
-// One workgroup per line: header bytes, node tokens, trailer.
-__global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, int p_lines,
-                                                                  const uint64_t *line_start, const uint8_t *headers, const uint64_t *header_off,
-                                                                  uint8_t *out) {
+// Per path, from the scans over the chunks: text bytes of the tokens, summed label lengths, and -- translation graphs --
+// whether every position fitted a whole segment (bad_before = scan of the chunks' bad flags, or null).
+__global__ void __launch_bounds__(256) k_path_totals(const uint64_t *chunk_first, uint64_t n, const uint64_t *text_before, const uint64_t *seq_before,
+                                                      const uint64_t *bad_before, uint64_t *text_len, uint64_t *seq_len, uint8_t *valid) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t a = chunk_first[p], b = chunk_first[p + 1];
+    text_len[p] = text_before[b] - text_before[a];
+    seq_len[p] = seq_before[b] - seq_before[a];
+    if (valid) valid[p] = bad_before[b] == bad_before[a] ? 1 : 0;
+}
+
+// One workgroup per chunk: the header (first chunk of a line), the node tokens of the chunk, the trailer (last chunk).
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
+                                                                   const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint8_t *headers,
+                                                                   const uint64_t *header_off, uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
-    const uint64_t path = blockIdx.x;
-    if (path >= n) return;
+    const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
     const uint32_t t = threadIdx.x;
-    uint8_t *line = out + line_start[path];
-    const uint64_t h0 = header_off[path], h1 = header_off[path + 1];
-    for (uint64_t k = t; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
-    uint64_t cursor = h1 - h0;
-    const uint64_t begin = offsets[path], end = offsets[path + 1];
-    for (uint64_t base = begin; base < end; base += FORMAT_THREADS) {
+    uint8_t *line = out + line_start[r.path];
+    const uint64_t h0 = header_off[r.path], h1 = header_off[r.path + 1];
+    if (r.first) for (uint64_t k = t; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
+    uint64_t cursor = (h1 - h0) + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS) {
         const uint64_t k = base + t;
         char tok[13];
         uint32_t len = 0;
-        if (k < end) {
+        if (k < r.hi) {
             const uint32_t node = nodes[k], id = node >> 1, digits = decimal_digits(id);
             if (p_lines) {
-                if (k > begin) tok[len++] = ',';
+                if (k > r.begin) tok[len++] = ',';
             } else tok[len++] = (node & 1u) ? '<' : '>';
             uint32_t v = id;
             for (uint32_t d = 0; d < digits; d++) { tok[len + digits - 1 - d] = static_cast<char>('0' + v % 10u); v /= 10u; }
@@ -91,7 +134,7 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines(const uint64_t 
         __syncthreads();
     }
     // trailer: "\t*\n" for P-lines (src/bin/gbunzip.rs:476), "\n" for W-lines (:548)
-    if (t == 0) {
+    if (r.last && t == 0) {
         if (p_lines) { line[cursor] = '\t'; line[cursor + 1] = '*'; line[cursor + 2] = '\n'; }
         else line[cursor] = '\n';
     }
@@ -130,59 +173,60 @@ __device__ __forceinline__ uint32_t classify_position(const SegmentTables &t, co
     return 2;
 }
 
-// One wave per path, translation graphs: text bytes of the segment tokens, summed segment lengths, validity.
-__global__ void __launch_bounds__(256) k_line_stats_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, SegmentTables t, int p_lines,
-                                                              uint64_t *text_len, uint64_t *seq_len, uint8_t *valid) {
-    const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+// One wave per chunk, translation graphs: text bytes of the segment tokens, summed segment lengths, positions that fit no segment.
+__global__ void __launch_bounds__(256) k_chunk_stats_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
+                                                               uint64_t chunks, SegmentTables t, int p_lines, uint64_t *chunk_text, uint64_t *chunk_seq,
+                                                               uint64_t *chunk_bad) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
-    if (path >= n) return;
-    const uint64_t begin = offsets[path], end = offsets[path + 1];
+    if (c >= chunks) return;
+    const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
     uint64_t text = 0, labels = 0;
     uint32_t bad = 0;
-    for (uint64_t k = begin + lane; k < end; k += WAVE) {
+    for (uint64_t k = r.lo + lane; k < r.hi; k += WAVE) {
         uint32_t s;
-        const uint32_t kind = classify_position(t, nodes, begin, k, s);
+        const uint32_t kind = classify_position(t, nodes, r.begin, k, s);
         if (kind == 2) bad = 1;
         if (kind == 1) {
-            text += (t.name_off[s + 1] - t.name_off[s]) + 1 + ((p_lines && k > begin) ? 1 : 0);
+            text += (t.name_off[s + 1] - t.name_off[s]) + 1 + ((p_lines && k > r.begin) ? 1 : 0);
             labels += t.seq_len[s];
         }
     }
     for (int d = WAVE / 2; d > 0; d >>= 1) { text += __shfl_down(text, d, WAVE); labels += __shfl_down(labels, d, WAVE); bad |= __shfl_down(bad, d, WAVE); }
-    if (lane == 0) { text_len[path] = text; seq_len[path] = labels; valid[path] = bad ? 0 : 1; }
+    if (lane == 0) { chunk_text[c] = text; chunk_seq[c] = labels; chunk_bad[c] = bad; }
 }
 
-// One workgroup per line, translation graphs.  Lines of flagged paths are left to the host.
-__global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, SegmentTables t,
-                                                                           int p_lines, const uint8_t *valid, const uint64_t *line_start,
-                                                                           const uint8_t *headers, const uint64_t *header_off, uint8_t *out) {
+// One workgroup per chunk, translation graphs.  Lines of flagged paths are left to the host.
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
+                                                                            const uint64_t *text_before, SegmentTables t, int p_lines, const uint8_t *valid,
+                                                                            const uint64_t *line_start, const uint8_t *headers, const uint64_t *header_off,
+                                                                            uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
-    const uint64_t path = blockIdx.x;
-    if (path >= n || !valid[path]) return;
+    const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
+    if (!valid[r.path]) return;
     const uint32_t tid = threadIdx.x;
-    uint8_t *line = out + line_start[path];
-    const uint64_t h0 = header_off[path], h1 = header_off[path + 1];
-    for (uint64_t k = tid; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
-    uint64_t cursor = h1 - h0;
-    const uint64_t begin = offsets[path], end = offsets[path + 1];
-    for (uint64_t base = begin; base < end; base += FORMAT_THREADS) {
+    uint8_t *line = out + line_start[r.path];
+    const uint64_t h0 = header_off[r.path], h1 = header_off[r.path + 1];
+    if (r.first) for (uint64_t k = tid; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
+    uint64_t cursor = (h1 - h0) + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS) {
         const uint64_t k = base + tid;
         uint32_t len = 0, s = 0, name_len = 0;
         bool token = false, rev = false;
-        if (k < end) {
-            token = classify_position(t, nodes, begin, k, s) == 1;
+        if (k < r.hi) {
+            token = classify_position(t, nodes, r.begin, k, s) == 1;
             if (token) {
                 rev = (nodes[k] & 1u) != 0;
                 name_len = static_cast<uint32_t>(t.name_off[s + 1] - t.name_off[s]);
-                len = name_len + 1 + ((p_lines && k > begin) ? 1 : 0);
+                len = name_len + 1 + ((p_lines && k > r.begin) ? 1 : 0);
             }
         }
         uint32_t pos, total;
         BlockScan(scan_storage).ExclusiveSum(len, pos, total);
         if (token) {
             uint8_t *w = line + cursor + pos;
-            if (p_lines) { if (k > begin) *w++ = ','; }
+            if (p_lines) { if (k > r.begin) *w++ = ','; }
             else *w++ = rev ? '<' : '>';
             const uint8_t *name = t.names + t.name_off[s];
             for (uint32_t j = 0; j < name_len; j++) w[j] = name[j];
@@ -191,7 +235,7 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_lines_segments(const 
         cursor += total;
         __syncthreads();
     }
-    if (tid == 0) {
+    if (r.last && tid == 0) {
         if (p_lines) { line[cursor] = '\t'; line[cursor + 1] = '*'; line[cursor + 2] = '\n'; }
         else line[cursor] = '\n';
     }
@@ -369,20 +413,41 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         if (st != GBWT_HIP_OK) return st;
         HIP_CHECK(hipSetDevice(ix->device));
         hipStream_t s = ws->stream;
-        // 2. size of every line
+        // 2. size of every line: chunks of LINE_CHUNK positions, a wave per chunk, scans over the chunks
+        const size_t tb_n = scan_temp_bytes(n);
         ws->gfa_a.reserve(2 * n * sizeof(uint64_t));
+        ws->gfa_chunk_first.reserve(2 * (n + 1) * sizeof(uint64_t));
+        ws->scan_temp.reserve(std::max<size_t>(tb_n, 16));
         uint64_t *d_text_len = ws->gfa_a.as<uint64_t>(), *d_seq_len = d_text_len + n;
+        uint64_t *d_chunk_first = ws->gfa_chunk_first.as<uint64_t>(), *d_chunk_counts = d_chunk_first + (n + 1);
+        hipLaunchKernelGGL(k_chunk_counts, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_counts);
+        launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb_n, s);
+        uint64_t chunks = 0;
+        HIP_CHECK(hipMemcpyAsync(&chunks, d_chunk_first + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (chunks > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "too many line chunks in one batch: format fewer paths per call");
+        const size_t tb_c = scan_temp_bytes(chunks);
+        ws->gfa_chunks.reserve((3 * chunks + 3 * (chunks + 1)) * sizeof(uint64_t));
+        ws->scan_temp.reserve(std::max<size_t>(tb_c, 16));
+        uint64_t *d_chunk_text = ws->gfa_chunks.as<uint64_t>(), *d_chunk_seq = d_chunk_text + chunks, *d_chunk_bad = d_chunk_seq + chunks;
+        uint64_t *d_text_before = d_chunk_bad + chunks, *d_seq_before = d_text_before + (chunks + 1), *d_bad_before = d_seq_before + (chunks + 1);
         std::vector<uint8_t> valid(n, 1);
+        const unsigned stat_blocks = static_cast<unsigned>((chunks + 3) / 4);
         if (translated) {
             ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
-            hipLaunchKernelGGL(k_line_stats_segments, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               segment_tables(ix), mode == 0 ? 1 : 0, d_text_len, d_seq_len, ws->gfa_valid.as<uint8_t>());
-            HIP_CHECK(hipMemcpyAsync(valid.data(), ws->gfa_valid.ptr, n, hipMemcpyDeviceToHost, s));
+            hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks,
+                               segment_tables(ix), mode == 0 ? 1 : 0, d_chunk_text, d_chunk_seq, d_chunk_bad);
+            launch_scan(d_chunk_bad, d_bad_before, chunks, ws->scan_temp.ptr, tb_c, s);
         } else {
-            hipLaunchKernelGGL(k_line_stats, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n,
+            hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks,
                                ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
-                               static_cast<uint32_t>(h.alphabet_offset + 1), mode == 0 ? 1 : 0, d_text_len, d_seq_len);
+                               static_cast<uint32_t>(h.alphabet_offset + 1), mode == 0 ? 1 : 0, d_chunk_text, d_chunk_seq);
         }
+        launch_scan(d_chunk_text, d_text_before, chunks, ws->scan_temp.ptr, tb_c, s);
+        launch_scan(d_chunk_seq, d_seq_before, chunks, ws->scan_temp.ptr, tb_c, s);
+        hipLaunchKernelGGL(k_path_totals, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_chunk_first, n, d_text_before, d_seq_before,
+                           translated ? d_bad_before : nullptr, d_text_len, d_seq_len, translated ? ws->gfa_valid.as<uint8_t>() : nullptr);
+        if (translated) HIP_CHECK(hipMemcpyAsync(valid.data(), ws->gfa_valid.ptr, n, hipMemcpyDeviceToHost, s));
         std::vector<uint64_t> lens(2 * n);
         HIP_CHECK(hipMemcpyAsync(lens.data(), d_text_len, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -437,12 +502,13 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         HIP_CHECK(hipMemcpyAsync(d_header_off, header_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(ws->gfa_c.ptr, headers.data(), headers.size(), hipMemcpyHostToDevice, s));
         if (translated)
-            hipLaunchKernelGGL(k_format_lines_segments, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               segment_tables(ix), mode == 0 ? 1 : 0, ws->gfa_valid.as<uint8_t>(), d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off,
-                               ws->gfa_text.as<uint8_t>());
+            hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               d_chunk_first, d_text_before, segment_tables(ix), mode == 0 ? 1 : 0, ws->gfa_valid.as<uint8_t>(), d_line_start,
+                               ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
         else
-            hipLaunchKernelGGL(k_format_lines, dim3(static_cast<unsigned>(n)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
+            hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               d_chunk_first, d_text_before, mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off,
+                               ws->gfa_text.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
         for (uint64_t k = 0; k < n; k++)
             if (!valid[k] && !host_lines[k].empty())

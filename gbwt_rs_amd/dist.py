@@ -9,8 +9,9 @@ path order on one rank.  That is
     2. variable-size gather of lengths and values to the destination  (ONE group of point-to-point operations:
        dist.batch_isend_irecv, i.e. ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd on RCCL, so that all
        peers stream at once, each over its own xGMI link to the root; a ring all-gather would be bound by one link)
-    3. with interleaved sharding, one scatter per peer into the path-ordered layout (index arithmetic on the device,
-       no per-row loop)
+    3. with interleaved sharding, either one scatter per peer into the path-ordered layout (gather_rows: index
+       arithmetic on the device, no per-row loop; an int64 index per element, so for node ids and small texts), or no
+       copy at all: gather_parts + rows_in_path_order hand a writer the rows in path order where they arrived
 
 Works on HIP tensors over RCCL and on CPU tensors over gloo (the CPU form is what the tests run).
 """
@@ -63,6 +64,33 @@ def _exchange(lengths, values, rows, sizes, dst, group):
     return len_parts, val_parts
 
 
+def gather_parts(lengths, values, dst=0, group=None):
+    """Steps 1 and 2 only: on `dst` the lists (len_parts, val_parts) with one entry per rank (this rank's own tensors at
+    its place, no copy), (None, None) elsewhere.  For payloads that are consumed row by row -- a file writer -- this
+    is all that is needed: see rows_in_path_order."""
+    world = dist.get_world_size(group)
+    device = lengths.device
+    counts = torch.tensor([lengths.numel(), values.numel()], dtype=torch.int64, device=device)
+    all_counts = torch.zeros(2 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_counts, counts, group=group)
+    all_counts = all_counts.cpu().tolist()      # the one host synchronisation: the receive buffers are sized from it
+    return _exchange(lengths, values, all_counts[0::2], all_counts[1::2], dst, group)
+
+
+def rows_in_path_order(len_parts):
+    """(rank, begin, end) of every gathered row in global path order for interleaved shards (row k of rank r is global
+    row k * world + r): the slice val_parts[rank][begin:end] is that row.  Host-side bookkeeping from one copy of the
+    lengths; what a writer iterates over instead of building the interleaved array (which would cost an index per
+    element -- eight bytes per byte of GFA text)."""
+    world = len(len_parts)
+    ends = [torch.cumsum(p, 0).cpu().tolist() for p in len_parts]
+    rows = max((len(e) for e in ends), default=0)
+    for k in range(rows):
+        for r in range(world):
+            if k < len(ends[r]):
+                yield r, (ends[r][k - 1] if k else 0), ends[r][k]
+
+
 def gather_rows(lengths, values, dst=0, group=None, interleaved=False):
     """Gathers this rank's CSR rows (lengths[k] values each, concatenated in `values`) on rank `dst`.
 
@@ -72,12 +100,9 @@ def gather_rows(lengths, values, dst=0, group=None, interleaved=False):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     device = lengths.device
-    counts = torch.tensor([lengths.numel(), values.numel()], dtype=torch.int64, device=device)
-    all_counts = torch.zeros(2 * world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(all_counts, counts, group=group)
-    all_counts = all_counts.cpu().tolist()      # the one host synchronisation: the receive buffers are sized from it
-    rows, sizes = all_counts[0::2], all_counts[1::2]
-    len_parts, val_parts = _exchange(lengths, values, rows, sizes, dst, group)
+    len_parts, val_parts = gather_parts(lengths, values, dst, group)
+    rows = [int(p.numel()) for p in len_parts] if len_parts is not None else None
+    sizes = [int(p.numel()) for p in val_parts] if val_parts is not None else None
     if rank != dst:
         return None, None
     if not interleaved:
@@ -107,7 +132,9 @@ def gather_rows(lengths, values, dst=0, group=None, interleaved=False):
 def gather_lines(line_offsets, text, dst=0, group=None, interleaved=False):
     """The final GFA concatenation: this rank's finished lines (`text`, uint8; line k at line_offsets[k] ..
     line_offsets[k + 1], int64) gathered on `dst` in path order.  Returns (offsets, text) there, (None, None) elsewhere.
-    With contiguous shards the lines of a rank travel as ONE row (their order is already final)."""
+    With contiguous shards the lines of a rank travel as ONE row (their order is already final).  With interleaved
+    shards the dense result costs an index per byte on `dst`: for gigabytes of text use gather_parts + rows_in_path_order
+    (tools/gfa_sharded.py)."""
     if interleaved:
         return gather_rows(line_offsets[1:] - line_offsets[:-1], text, dst=dst, group=group, interleaved=True)
     whole = torch.tensor([text.numel()], dtype=torch.int64, device=text.device)

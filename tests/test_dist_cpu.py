@@ -65,6 +65,13 @@ def _lines_worker(rank, world, port, interleaved, out_dir):
         offsets = torch.zeros(len(lines) + 1, dtype=torch.int64)
         offsets[1:] = torch.cumsum(torch.tensor([len(x) for x in lines], dtype=torch.int64), 0) if lines else offsets[1:]
         g_off, g_text = D.gather_lines(offsets, text, dst=0, interleaved=interleaved)
+        if interleaved:   # the copy-free form a file writer uses: rows in path order where they arrived
+            len_parts, text_parts = D.gather_parts(offsets[1:] - offsets[:-1], text, dst=0)
+            if rank == 0:
+                streamed = b"".join(text_parts[r][a:b].numpy().tobytes() for r, a, b in D.rows_in_path_order(len_parts))
+                assert streamed == gbz.path_lines([int(p) for p in ids], 1)
+            else:
+                assert len_parts is None and text_parts is None
         if rank == 0:
             assert bytes(g_text.numpy().tobytes()) == gbz.path_lines([int(p) for p in ids], 1)
             assert int(g_off[-1]) == g_text.numel()

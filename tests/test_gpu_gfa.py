@@ -60,7 +60,7 @@ def test_synthetic_translation_valid_paths(tmp_path):
     fwd = lambda a, b: [2 * v for v in range(a, b + 1)]
     rev = lambda a, b: [2 * v + 1 for v in range(b, a - 1, -1)]
     unit = fwd(1, 3) + fwd(4, 4) + rev(5, 6) + fwd(7, 7) + fwd(8, 11) + rev(12, 12)
-    paths = [unit, fwd(1, 3) + fwd(5, 6) + fwd(8, 11), rev(8, 11) + fwd(4, 4) + rev(1, 3), unit * 60, [], fwd(12, 12)]
+    paths = [unit, fwd(1, 3) + fwd(5, 6) + fwd(8, 11), rev(8, 11) + fwd(4, 4) + rev(1, 3), unit * 60, [], fwd(12, 12), unit * 800]   # the last one: three chunks of 4 096 positions, segments straddle them
     dev, oracle = translated_graph(tmp_path, paths, starts, "segments.gbz")
     out = tmp_path / "segments.gfa"
     dev.write_gfa(str(out))
@@ -101,7 +101,7 @@ def test_bare_gbwt_has_no_gfa():
         dev.path_lines([0], 1)
 
 
-@pytest.mark.parametrize("alleles,sites,haps", [(2, 700, 300), (5, 90, 120)])
+@pytest.mark.parametrize("alleles,sites,haps", [(2, 700, 300), (5, 90, 120), (2, 4500, 12)])   # the last one: 9 000 nodes per line = three chunks
 def test_synthetic_gfa_matches_oracle(tmp_path, alleles, sites, haps):
     """Whole-file parity on generated GBZ files: node ids with 1-4 digits, single P-line, many W-lines, chunked lines
     (paths longer than one formatting chunk)."""

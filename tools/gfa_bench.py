@@ -31,4 +31,13 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     print(f"W-lines of {len(ids)} paths, {nodes} nodes: {len(text)} bytes in {dt * 1e3:.1f} ms = {len(text) / dt / 1e9:.2f} GB/s of text, "
           f"{nodes / dt / 1e9:.2f} G nodes/s   sha256 {hashlib.sha256(text).hexdigest()[:16]}", flush=True)
+for rep in range(3):
+    t0 = time.perf_counter()
+    lines = gbz.path_lines_device(ids[::-1].copy(), 1)   # another request: nothing of the calls above is reused
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lines = gbz.path_lines_device(ids, 1)
+    dt2 = time.perf_counter() - t0
+    print(f"the same lines left in HBM (gbwt_hip_path_lines_device): {lines.total} bytes in {dt2 * 1e3:.1f} ms = {lines.total / dt2 / 1e9:.1f} GB/s of text, "
+          f"{nodes / dt2 / 1e9:.1f} G nodes/s (reversed order: {dt * 1e3:.1f} ms)", flush=True)
 os.remove(path)

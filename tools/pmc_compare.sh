@@ -6,6 +6,7 @@ set -u
 out=$1; configs=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$out"
+case "$out" in /*) ;; *) out="$PWD/$out" ;; esac
 cd /tmp && export TMPDIR=/tmp
 IFS=';' read -ra CFGS <<< "$configs"
 for cfg in "${CFGS[@]}"; do
@@ -17,7 +18,7 @@ for cfg in "${CFGS[@]}"; do
         d="$out/$tag/pass$i"
         rm -rf "$d"; mkdir -p "$out/$tag"
         # shellcheck disable=SC2086
-        timeout 150 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$d" -- python3 "$root/tools/sweep_env.py" --reps 2 --configs "$cfg" > "$d.log" 2>&1
+        timeout --foreground 120 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$d" -- python3 "$root/tools/sweep_env.py" --reps 2 --configs "$cfg" > "$d.log" 2>&1
         echo "## pass $i: $group"
         python3 "$root/tools/pmc_summary.py" "$d" k_walk
     done

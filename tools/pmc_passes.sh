@@ -13,7 +13,7 @@ for group in "$@"; do
     d="$out/pass$i"
     rm -rf "$d"
     # shellcheck disable=SC2086
-    timeout 300 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$d" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$d.log" 2>&1
+    timeout --foreground 300 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$d" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$d.log" 2>&1
     echo "## pass $i: $group"
     python3 "$root/tools/pmc_summary.py" "$d" k_walk
 done
