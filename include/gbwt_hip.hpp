@@ -96,7 +96,8 @@ public:
     // panics in the reference when the index is not bidirectional: throws Error here
     std::vector<std::optional<Pos>> backward(const std::vector<Pos> &pos) const { return step(pos, gbwt_hip_backward); }
     std::optional<Pos> backward(Pos pos) const { return backward(std::vector<Pos>{pos})[0]; }
-    // GBWT::sequence(id).collect() for every id; an id >= sequences() is an Error (the reference returns no iterator)
+    // GBWT::sequence(id).collect() for every id; an id >= sequences() (no iterator in the reference) gets an empty row.
+    // Size query + fill call: the sequences are walked once, the second call finds the rows in the workspace.
     Rows sequences(const std::vector<uint64_t> &ids) const {
         Rows r;
         r.offsets.assign(ids.size() + 1, 0);
