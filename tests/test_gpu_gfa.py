@@ -27,6 +27,11 @@ def test_example_gbz_to_gfa(tmp_path, name):
     assert dev.path_lines([0, 1], 0) + dev.path_lines([2, 3, 4, 5], 1) == kat.EXAMPLE_PW_LINES
     assert dev.path_lines([5, 2], 1) == O.OracleGBZ(path).path_lines([5, 2], 1)
     assert dev.path_lines([], 1) == b""
+    empty = dev.path_lines_device([], 1)
+    assert empty.total == 0 and empty.n == 0
+    lines = dev.path_lines_device([5, 2], 1)                 # device-resident: the copy-out of the same request finds it there
+    assert lines.n == 2 and lines.total == len(O.OracleGBZ(path).path_lines([5, 2], 1))
+    assert dev.path_lines([5, 2], 1) == O.OracleGBZ(path).path_lines([5, 2], 1)
 
 
 @pytest.mark.parametrize("name", ["translation.gbz", "translation-v1.gbz"])

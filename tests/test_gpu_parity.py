@@ -225,6 +225,27 @@ def test_size_then_fill_computes_once():
     off, ext, valid = dev.follow(st8)
     off2, ext2, valid2 = dev.follow(st8)
     assert ok.all() and valid.all() and np.array_equal(off, off2) and np.array_equal(ext, ext2) and len(ext) == int(off[-1]) > 0
+    # follow: a size query, then another query on the same workspace (it reuses the staging buffers), then the fill call
+    st6 = np.ascontiguousarray(st8, dtype=G.BD_DTYPE)
+    f_off = np.zeros(st6.size + 1, dtype=np.uint64)
+    f_valid = np.zeros(st6.size, dtype=np.uint8)
+    G._lib.check(L.gbwt_hip_follow(dev._h, dev._ws, st6.ctypes.data, st6.size, 0, f_off.ctypes.data, None, 0, C.byref(total), f_valid.ctypes.data))
+    dev.find([22, 42, 30])
+    f_out = np.zeros(total.value, dtype=G.BD_DTYPE)
+    G._lib.check(L.gbwt_hip_follow(dev._h, dev._ws, st6.ctypes.data, st6.size, 0, f_off.ctypes.data, f_out.ctypes.data, f_out.size, C.byref(total), f_valid.ctypes.data))
+    assert np.array_equal(f_off, off) and np.array_equal(f_out, ext)
+    # gbwt_hip_copy_result: offsets only, nodes only, too small a buffer
+    p = dev.extract_device(ids)
+    only_off = np.zeros(ids.size + 1, dtype=np.uint64)
+    G._lib.check(L.gbwt_hip_copy_result(dev._h, dev._ws, only_off.ctypes.data, None, 0))
+    assert list(np.diff(only_off.astype(np.int64))) == [5, 4, 5, 0, 5] and int(only_off[-1]) == p.total
+    only_nodes = np.zeros(p.total, dtype=np.uint32)
+    G._lib.check(L.gbwt_hip_copy_result(dev._h, dev._ws, None, only_nodes.ctypes.data, only_nodes.size))
+    assert list(only_nodes) == want
+    assert L.gbwt_hip_copy_result(dev._h, dev._ws, None, only_nodes.ctypes.data, 3) == G._lib.CAPACITY
+    assert L.gbwt_hip_copy_result(dev._h, dev._ws, None, None, 0) == G._lib.BAD_ARGUMENT
+    fresh = G.GBWT.load(os.path.join(GOLDEN, "example.gbwt"))
+    assert L.gbwt_hip_copy_result(fresh._h, fresh._ws, only_off.ctypes.data, None, 0) == G._lib.BAD_ARGUMENT   # nothing extracted yet
 
 
 def test_fixture_statistics():
