@@ -1,0 +1,55 @@
+"""Host logic of bench.py that needs no GPU: the fingerprint that ties a PMC profile to a build, and the rank launcher."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_fingerprint_follows_sources_and_knobs(monkeypatch):
+    for k in list(os.environ):
+        if k.startswith("GBWT_HIP_"):
+            monkeypatch.delenv(k)
+    a = bench.source_fingerprint()
+    assert a == bench.source_fingerprint() and len(a) == 16
+    monkeypatch.setenv("GBWT_HIP_RING_SLOTS", "32")
+    b = bench.source_fingerprint()
+    assert b != a                                   # another knob setting is another measurement
+    monkeypatch.setenv("GBWT_HIP_LIB", "/somewhere/else.so")
+    assert bench.source_fingerprint() == b          # where the library is loaded from is not a knob of the kernel
+
+
+def test_committed_traffic_profile_names_its_build_and_workload():
+    """profiles/*_hbm_traffic.json of this round carry the fingerprint and the workload bench.py matches them by."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    t = json.load(open(path))
+    assert len(t["source_fingerprint"]) == 16 and t["workload_key"] == "sites=333334 haplotypes=5000 model=mosaic seed=42"
+    assert t["traffic_bytes_per_launch"] == 2 * t["fetch_bytes_raw"] + t["write_bytes"]
+    assert 13.3e9 < t["write_bytes"] < 13.5e9       # every node id once
+
+
+def test_gpus_without_a_launcher_starts_the_ranks(monkeypatch):
+    """--gpus N > 1 outside torchrun: the ranks are children of this (GPU-free) process, started over 127.0.0.1."""
+    calls = []
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_world_size_must_match_gpus(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value)
