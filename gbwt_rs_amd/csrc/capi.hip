@@ -223,6 +223,12 @@ void upload(gbwt_hip_index &ix) {
         if (!flags[0]) {
             d.seq_len = ix.seq_len.as<uint32_t>();
             ix.orientation_pairs = want_pairs && !flags[2];
+            {   // all sequences of one length?  (haplotypes over one reference frame: the headline's shape)
+                std::vector<uint32_t> lens(h.sequences);
+                HIP_CHECK(hipMemcpy(lens.data(), ix.seq_len.ptr, h.sequences * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                const auto mm = std::minmax_element(lens.begin(), lens.end());
+                ix.uniform_len = (*mm.first == *mm.second) ? *mm.first : 0u;
+            }
             // Sequence samples: where every sequence is about every `interval` nodes (second walk), so that extractions
             // can fill a row with many walkers at once.
             if (sampled) {
@@ -418,9 +424,18 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
             uint64_t total = 0;
             uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
-            HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipMemcpyAsync(extremes, ws->counters.ptr, sizeof(extremes), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            bool all_valid = ix->uniform_len != 0;
+            for (uint64_t k = 0; k < n && all_valid; k++) all_valid = seq_ids[k] < ix->host.sequences;
+            if (all_valid) {
+                // every row has the same, known length: total and extremes without a round trip to the device (the offsets are
+                // still scanned there, behind which the walk is simply enqueued)
+                total = n * static_cast<uint64_t>(ix->uniform_len);
+                extremes[0] = ix->uniform_len; extremes[1] = ~ix->uniform_len;
+            } else {
+                HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(extremes, ws->counters.ptr, sizeof(extremes), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+            }
             const uint32_t max_len = extremes[0], min_len = ~extremes[1];
             ws->nodes.reserve(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
             WalkArgs a{};
