@@ -315,8 +315,8 @@ __global__ void __launch_bounds__(256) k_fill_wtables(DeviceIndex ix, uint4 *wta
 // The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
 // The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
 // memory -- takes TWO LF steps (up to four nodes with fused unary successors):
-//   desc2[8 * v + 0] = F0 = {node to emit for edge 0, offset base in w_0, node to emit for edge 1, offset base in w_1}
-//   desc2[8 * v + 1] = F1 = {w_0 | LEAF_EMIT2 | DESC2_SLOW, w_1 | LEAF_EMIT2, 0, 0}      (first step; DESC2_SLOW: whole record)
+//   desc2[8 * v + a] = E_a = {node to emit for edge a, offset base in w_a, w_a | LEAF_EMIT2 | DESC2_SLOW, 0}   (first step, a = 0, 1;
+//                            DESC2_SLOW: whole record, set in both; one 12-byte load per edge, so that a walker that knows a needs one)
 //   desc2[8 * v + 2 + 2 * a + b] = leaf (a, b) = {node to emit, offset base, landing record | LEAF_EMIT2, block base}
 //   desc2[8 * v + 6] = look-ahead {record, first block, number of blocks, 0};  [7] unused
 // The second step exists (is "real") when w_a is unary (descriptor only: its value is always 0) or when both v and w_a
@@ -356,8 +356,8 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out) 
         }
     }
     uint4 *o = out + 8 * v;
-    o[0] = make_uint4(n1[0], base[0], n1[1], base[1]);
-    o[1] = make_uint4(wword[0] | (slow ? DESC2_SLOW : 0u), wword[1], 0u, 0u);
+    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), 0u);
+    o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), 0u);
     o[2] = leaf[0]; o[3] = leaf[1]; o[4] = leaf[2]; o[5] = leaf[3];
     o[6] = make_uint4(0u, 0u, 0u, 0u);
     o[7] = make_uint4(0u, 0u, 0u, 0u);
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_link_lookahead2(DeviceIndex ix, uint4 *
     uint64_t r = v;
     bool good = true;
     for (uint32_t h = 0; h < hops && good; h++) {
-        if (desc2[8 * r + 1].x & DESC2_SLOW) { good = false; break; }
+        if (desc2[8 * r].z & DESC2_SLOW) { good = false; break; }
         const uint32_t x = desc2[8 * r + 2].z & REC_MASK;
         if (x == 0) good = false; else r = x;
     }

@@ -271,6 +271,9 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
                  : "=&s"(keep) : "v"(p), "s"(lds_dummy) : "memory");
 }
 
+#ifdef GBWT_HIP_PROBE_WAVES   // measurement only (with GBWT_HIP_CXX_LOOP): the register budget that lets this many waves share a SIMD
+__attribute__((amdgpu_waves_per_eu(GBWT_HIP_PROBE_WAVES, GBWT_HIP_PROBE_WAVES)))
+#endif
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
     extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
@@ -399,6 +402,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     lds_poke(my_mail + 3, sink.wr);
     const uint32_t ring_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring_lds + lane));
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
+#ifdef GBWT_HIP_PROBE_LOOP_SHARE   // measurement only: nodes staged by each of the two loops, for a few workgroups (profiles/r02_walk_bounds.txt #16)
+    uint32_t probe_uniform = 0, probe_vector = 0, probe_entries = 0, probe_mixed_entries = 0, probe_fell_out = 0;
+#endif
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
@@ -406,10 +412,24 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         // (the uniform loop finds out by itself, but only after it has issued a round of loads for nothing: in graphs whose rows do
         // not move in lock-step the waves are mixed at almost every entry)
         const bool together = __ballot(rec != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rec))) == 0;
+#ifdef GBWT_HIP_PROBE_LOOP_SHARE
+        const uint32_t wr0 = sink.wr;
+        probe_entries++;
+#endif
         uint32_t slow_exit = a.uniform_loop && together ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
-        if (slow_exit == 2) slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+#ifdef GBWT_HIP_PROBE_LOOP_SHARE
+        const uint32_t wr1 = sink.wr;
+        probe_uniform += wr1 - wr0;
+        if (!together) probe_mixed_entries++;
+        if (slow_exit == 2 && together) probe_fell_out++;
+#endif
+        if (slow_exit == 2) slow_exit = a.gather_loop ? walk2_gather_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr)
+                                                      : walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+#ifdef GBWT_HIP_PROBE_LOOP_SHARE
+        probe_vector += sink.wr - wr1;
+#endif
         if (slow_exit) {
-            bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;   // lanes on a slow record
+            bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec)].z & DESC2_SLOW) != 0;   // lanes on a slow record
             if (ix.wtables != nullptr) {
                 // Lanes on a table record walk on the walk tables: one 16-byte entry per step says what to emit (the
                 // successor and, where a unary record follows, the node behind it), where the walk lands and -- when that
@@ -445,6 +465,11 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         }
     }
     lds_poke(my_mail + 3, sink.wr);
+#ifdef GBWT_HIP_PROBE_LOOP_SHARE
+    if ((lane == 0 || lane == 37) && blockIdx.x % 20011u == 7u)
+        printf("workgroup %u lane %u: %u nodes in the uniform loop, %u in the vector loop; %u entries, %u of them mixed, %u fell out at once\n", blockIdx.x, lane,
+               probe_uniform, probe_vector, probe_entries, probe_mixed_entries, probe_fell_out);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) lds_poke(done_flag, 1);
 }

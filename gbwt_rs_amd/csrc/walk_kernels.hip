@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     while (__ballot(rec != 0) != 0) {
         const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, RING2 - 1, WAVE, rec, offset, bb, sink.wr);
         if (slow_exit) {
-            const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec) + 1].x & DESC2_SLOW) != 0;
+            const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec)].z & DESC2_SLOW) != 0;
             if (slow) generic_step(ix, sink, rec, offset, bb);
         }
         while (sink.needs_flush()) sink.flush16(a);

@@ -370,10 +370,10 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
     for (;;) {
         const uint4 *d = desc2 + 8 * static_cast<uint64_t>(rec);
-        const uint4 F0 = d[0], F1 = d[1], L00 = d[2], L01 = d[3], L10 = d[4], L11 = d[5], look = d[6];
+        const uint4 E0 = d[0], E1 = d[1], L00 = d[2], L01 = d[3], L10 = d[4], L11 = d[5], look = d[6];
         const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
         const uint4 K0 = cblocks[2 * idx], K1 = cblocks[2 * idx + 1];
-        if (__ballot((F1.x & DESC2_SLOW) != 0) != 0) return 1;
+        if (__ballot((E0.z & DESC2_SLOW) != 0) != 0) return 1;
         const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
         const uint32_t bit = offset & 63u;
         const uint64_t below = (uint64_t(1) << bit) - 1;
@@ -381,12 +381,12 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         const uint64_t m = a ? bits1 : ~bits1;
         const uint32_t p = __popcll(m & below);
         const uint32_t rank_a = a ? K1.x + p : (offset - bit) - K1.x + p;
-        const uint32_t j = (a ? F0.w : F0.y) + rank_a;
+        const uint32_t j = (a ? E1.y : E0.y) + rank_a;
         const uint32_t b = static_cast<uint32_t>(bits2 >> bit) & 1u;
         const uint32_t ones_w = (a ? K1.z : K1.y) + __popcll(m & bits2 & below);
         const uint32_t rank_b = b ? ones_w : j - ones_w;
         const uint4 leaf = a ? (b ? L11 : L10) : (b ? L01 : L00);
-        const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
+        const uint32_t n1 = a ? E1.x : E0.x, wword = a ? E1.z : E0.z;
         rec = leaf.z & REC_MASK; offset = leaf.y + rank_b; bb = leaf.w;
         ring[(wr & ring_mask) * ring_stride] = n1;
         wr += n1 != 0 ? 1u : 0u;
@@ -405,6 +405,15 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     // on record 0, loads of the next position go out as early as possible, exits leave nothing in flight; a VALU write
     // of VCC / an SGPR is kept two instructions away from the VALU that reads it).  Registers v40-v125, s41, s44-s47.
     uint32_t reason;
+#ifdef GBWT_HIP_PROBE_MORE_LOADS   // measurement only: two more loads per lane and step from the descriptor's line (profiles/r02_walk_bounds.txt #16)
+#define GBWT_WALK2_PROBE_WIDE "global_load_dwordx2 v[46:47], v[88:89], off offset:112\n\t" "global_load_dwordx2 v[54:55], v[88:89], off offset:24\n\t"
+#define GBWT_WALK2_PROBE_NARROW "global_load_dwordx2 v[46:47], v88, %[desc2] offset:112\n\t" "global_load_dwordx2 v[54:55], v88, %[desc2] offset:24\n\t"
+#define GBWT_WALK2_PROBE_CLOBBERS "v46", "v47", "v54", "v55",
+#else
+#define GBWT_WALK2_PROBE_WIDE
+#define GBWT_WALK2_PROBE_NARROW
+#define GBWT_WALK2_PROBE_CLOBBERS
+#endif
 #define GBWT_WALK2_ISSUE_WIDE                                                                                  \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
     "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
@@ -417,13 +426,14 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     "s_mov_b64 exec, s[44:45]\n\t"                        /* only lanes that were walking before this step */ \
     "global_load_dwordx4 v[80:83], v[90:91], off\n\t"             /* K0: bits1, bits2 */                  \
     "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"   /* K1: ones1, R0, R1 */                 \
-    "global_load_dwordx4 v[48:51], v[88:89], off\n\t"             /* F0 */                                \
-    "global_load_dwordx2 v[52:53], v[88:89], off offset:16\n\t"   /* F1 */                                \
+    "global_load_dwordx3 v[48:50], v[88:89], off\n\t"             /* E_0 */                               \
+    "global_load_dwordx3 v[52:54], v[88:89], off offset:16\n\t"   /* E_1 */                                \
     "global_load_dwordx4 v[56:59], v[88:89], off offset:32\n\t"   /* leaf (0, 0) */                       \
     "global_load_dwordx4 v[60:63], v[88:89], off offset:48\n\t"   /* leaf (0, 1) */                       \
     "global_load_dwordx4 v[64:67], v[88:89], off offset:64\n\t"   /* leaf (1, 0) */                       \
     "global_load_dwordx4 v[72:75], v[88:89], off offset:80\n\t"   /* leaf (1, 1) */                       \
     "global_load_dwordx3 v[76:78], v[88:89], off offset:96\n\t"   /* look-ahead target */                 \
+    GBWT_WALK2_PROBE_WIDE \
     "s_mov_b64 exec, -1\n\t"
 #define GBWT_WALK2_ISSUE_NARROW                                                                           \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
@@ -435,13 +445,14 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     "s_mov_b64 exec, s[44:45]\n\t"                        /* only lanes that were walking before this step */ \
     "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
     "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
-    "global_load_dwordx4 v[48:51], v88, %[desc2]\n\t"               /* F0 */                              \
-    "global_load_dwordx2 v[52:53], v88, %[desc2] offset:16\n\t"     /* F1 */                              \
+    "global_load_dwordx3 v[48:50], v88, %[desc2]\n\t"               /* E_0 */                             \
+    "global_load_dwordx3 v[52:54], v88, %[desc2] offset:16\n\t"     /* E_1 */                              \
     "global_load_dwordx4 v[56:59], v88, %[desc2] offset:32\n\t"     /* leaf (0, 0) */                     \
     "global_load_dwordx4 v[60:63], v88, %[desc2] offset:48\n\t"     /* leaf (0, 1) */                     \
     "global_load_dwordx4 v[64:67], v88, %[desc2] offset:64\n\t"     /* leaf (1, 0) */                     \
     "global_load_dwordx4 v[72:75], v88, %[desc2] offset:80\n\t"     /* leaf (1, 1) */                     \
     "global_load_dwordx3 v[76:78], v88, %[desc2] offset:96\n\t"     /* look-ahead target */               \
+    GBWT_WALK2_PROBE_NARROW \
     "s_mov_b64 exec, -1\n\t"
 #define GBWT_WALK2_LOOP(ISSUE)                                                                             \
     asm volatile( \
@@ -456,7 +467,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         ISSUE \
         ".Lgbwt_walk2_loop_%=:\n\t" \
         "s_waitcnt vmcnt(0)\n\t" \
-        "v_lshlrev_b32_e32 v92, 1, v52\n\t"                 /* DESC2_SLOW (bit 30 of F1.x) -> sign */ \
+        "v_lshlrev_b32_e32 v92, 1, v50\n\t"                 /* DESC2_SLOW (bit 30 of E_0.z) -> sign */ \
         "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
         "v_cmp_gt_i32_e32 vcc, 0, v92\n\t" \
         "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
@@ -473,11 +484,11 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         "v_bcnt_u32_b32 v102, v100, 0\n\t" \
         "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
         "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
-        "v_cndmask_b32_e32 v103, v49, v51, vcc\n\t"         /* offset base of edge a */ \
+        "v_cndmask_b32_e32 v103, v49, v53, vcc\n\t"         /* offset base of edge a */ \
         "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
-        "v_cndmask_b32_e32 v104, v48, v50, vcc\n\t"         /* node of edge a */ \
+        "v_cndmask_b32_e32 v104, v48, v52, vcc\n\t"         /* node of edge a */ \
         "v_add_u32_e32 v103, v103, v99\n\t"                 /* j: offset in w_a */ \
-        "v_cndmask_b32_e32 v105, v52, v53, vcc\n\t"         /* w_a | flags */ \
+        "v_cndmask_b32_e32 v105, v50, v54, vcc\n\t"         /* w_a | flags */ \
         "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
         "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
         "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
@@ -548,8 +559,8 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
         : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
           "{s41}"(alphabet_offset) \
-        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", \
-          "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
+        : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", GBWT_WALK2_PROBE_CLOBBERS \
+          "v40", "v41", "v42", "v43", "v44", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", \
           "v64", "v65", "v66", "v67", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
           "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
           "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
@@ -558,6 +569,214 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
 #undef GBWT_WALK2_LOOP
 #undef GBWT_WALK2_ISSUE_NARROW
 #undef GBWT_WALK2_ISSUE_WIDE
+    return reason;
+#endif
+}
+
+// ---- two-step walk, gather variant -------------------------------------------------------------------------------
+// For waves whose lanes sit on DIFFERENT records (graphs with indels: rows of a batch leave lock step after the first
+// site).  There every vector-memory instruction costs the address path a pass over sixty-four distinct lines -- about
+// sixteen cycles per instruction and wave whatever its width -- and that, not latency, bounds the walk
+// (profiles/r02_walk_bounds.txt #16: time follows the number of load instructions per step, 12 with the helper's
+// touches in walk2_hot_loop).  So this loop fetches only what the step needs, in four instructions: the lane's two-step
+// block (2), then -- once a and b are known -- E_a (12 bytes) and leaf (a, b) (16 bytes), and posts no look-ahead
+// target.  The price is a second round trip per iteration; the other waves of the CU cover it.
+// Same contract as walk2_hot_loop.
+__device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                      uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
+                                                      uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
+    __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
+    mail[0] = 0;                                             // no look-ahead target: the helper's touches would cost what they save
+    for (;;) {
+        bool slow = false;
+        if (rec != 0) {
+            const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+            const uint4 K0 = cblocks[2 * idx];
+            const uint32_t *k1 = reinterpret_cast<const uint32_t *>(cblocks + 2 * idx + 1);
+            const uint32_t ones1 = k1[0], R0 = k1[1], R1 = k1[2];
+            const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+            const uint32_t bit = offset & 63u;
+            const uint64_t below = (uint64_t(1) << bit) - 1;
+            const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u, b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+            const uint4 *d = desc2 + 8 * static_cast<uint64_t>(rec);
+            const uint32_t *e = reinterpret_cast<const uint32_t *>(d + a);
+            const uint32_t n1 = e[0], base_a = e[1], wword = e[2];
+            const uint4 leaf = d[2 + 2 * a + b];
+            slow = (wword & DESC2_SLOW) != 0;
+            if (!slow) {
+                const uint64_t m = a ? bits1 : ~bits1;
+                const uint32_t p = __popcll(m & below);
+                const uint32_t rank_a = a ? ones1 + p : (offset - bit) - ones1 + p;
+                const uint32_t j = base_a + rank_a;
+                const uint32_t ones_w = (a ? R1 : R0) + __popcll(m & bits2 & below);
+                rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
+                ring[(wr & ring_mask) * ring_stride] = n1;
+                wr += n1 != 0 ? 1u : 0u;
+                ring[(wr & ring_mask) * ring_stride] = (wword & REC_MASK) + alphabet_offset;
+                wr += (wword & LEAF_EMIT2) ? 1u : 0u;
+                ring[(wr & ring_mask) * ring_stride] = leaf.x;
+                wr += leaf.x != 0 ? 1u : 0u;
+                ring[(wr & ring_mask) * ring_stride] = rec + alphabet_offset;
+                wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
+                mail[3] = wr;
+                if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+        if (__ballot(slow) != 0) return 1;
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > ring_mask + 1 - 8) != 0) return 0;
+    }
+#else
+    // gfx950 assembly: exactly four vector loads per iteration in two rounds (the compiler's version of the C++ above splits them into
+    // seven in three).  Conventions of walk2_hot_loop; s[44:45] = the lanes that load (those walking at the start of the PREVIOUS
+    // iteration, so that a lane that parks fetches record 0 once and keeps emitting nothing), s[42:43] = the lanes walking now.
+    uint32_t reason;
+    const uint32_t limit = flushed + (ring_mask + 1 - 8);   // leave with more than slots - 8 nodes waiting
+#define GBWT_GATHER_K_NARROW                                                                              \
+    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
+    "v_lshlrev_b32_e32 v88, 7, v40\n\t"                   /* two-step descriptors are 128 bytes */        \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
+    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_GATHER_K_WIDE                                                                                \
+    "v_lshlrev_b64 v[90:91], 5, v[70:71]\n\t"                                                             \
+    "v_lshlrev_b64 v[88:89], 7, v[40:41]\n\t"                                                             \
+    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
+    "v_lshl_add_u64 v[88:89], v[88:89], 0, %[desc2]\n\t"                                                  \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"                                                     \
+    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"                                           \
+    "s_mov_b64 exec, -1\n\t"
+// E_a at 16 a, leaf (a, b) at 32 + 16 (2 a + b) of the descriptor; v94 = a, v108 = b
+#define GBWT_GATHER_D_NARROW                                                                              \
+    "v_lshl_add_u32 v46, v94, 4, v88\n\t"                                                                 \
+    "v_lshl_add_u32 v47, v94, 1, v108\n\t"                                                                \
+    "v_lshl_add_u32 v47, v47, 4, v88\n\t"                                                                 \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx3 v[48:50], v46, %[desc2]\n\t"               /* E_a: node, offset base, w_a | flags */ \
+    "global_load_dwordx4 v[56:59], v47, %[desc2] offset:32\n\t"     /* leaf (a, b) */                     \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_GATHER_D_WIDE                                                                                \
+    "v_lshl_add_u32 v60, v94, 1, v108\n\t"                                                                \
+    "v_mov_b32_e32 v95, 0\n\t"                                                                            \
+    "v_mov_b32_e32 v61, 0\n\t"                                                                            \
+    "v_lshl_add_u64 v[46:47], v[94:95], 4, v[88:89]\n\t"                                                  \
+    "v_lshl_add_u64 v[60:61], v[60:61], 4, v[88:89]\n\t"                                                  \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx3 v[48:50], v[46:47], off\n\t"                                                     \
+    "global_load_dwordx4 v[56:59], v[60:61], off offset:32\n\t"                                           \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_GATHER_LOOP(KLOAD, DLOAD) \
+    asm volatile( \
+        "v_mov_b32_e32 v40, %[rec]\n\t" \
+        "v_mov_b32_e32 v41, 0\n\t" \
+        "v_mov_b32_e32 v42, %[offset]\n\t" \
+        "v_mov_b32_e32 v43, %[bb]\n\t" \
+        "v_mov_b32_e32 v44, %[wr]\n\t" \
+        "v_mov_b32_e32 v71, 0\n\t" \
+        "s_mov_b32 %[reason], 0\n\t" \
+        "s_mov_b64 s[44:45], -1\n\t"                        /* everybody loads in the first round (parked lanes: record 0) */ \
+        "v_cmp_ne_u32_e64 s[42:43], 0, v40\n\t" \
+        "ds_write_b32 %[mail], v41\n\t"                     /* no look-ahead target */ \
+        ".Lgbwt_gather_loop_%=:\n\t" \
+        "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                 /* bb != BLOCK_NONE */ \
+        "v_lshrrev_b32_e32 v70, 6, v42\n\t" \
+        "v_add_u32_e32 v70, v70, v43\n\t" \
+        "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"            /* block bb + offset / 64, or the zero block */ \
+        KLOAD \
+        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
+        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
+        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
+        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
+        DLOAD \
+        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
+        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v101, v81, v98\n\t" \
+        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v101, v97, 0, v101\n\t" \
+        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
+        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
+        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
+        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v101, v101, v83\n\t" \
+        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
+        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_lshlrev_b32_e32 v92, 1, v50\n\t"                 /* DESC2_SLOW (bit 30 of E_a.z) -> sign */ \
+        "v_add_u32_e32 v103, v49, v99\n\t"                  /* j: offset in w_a */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v92\n\t" \
+        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v110, 0x3fffffff, v50\n\t"           /* w_a */ \
+        "s_cbranch_vccnz .Lgbwt_gather_slow_%=\n\t" \
+        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
+        "v_mov_b32_e32 v43, v59\n\t"                        /* block base of the landing record */ \
+        "v_add_u32_e32 v42, v57, v107\n\t"                  /* the new offset */ \
+        "v_and_b32_e32 v40, 0x3fffffff, v58\n\t"            /* the new record */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v48\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v48\n\t"                         /* node of edge a */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v50\n\t"                  /* first step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v110\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_ne_u32_e32 vcc, 0, v56\n\t" \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v56\n\t"                         /* node of the leaf */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v58\n\t"                  /* second step fused? */ \
+        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v92, v111\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks */ \
+        "s_mov_b64 s[44:45], s[42:43]\n\t"                  /* the next round of loads: everybody who walked in this one */ \
+        "ds_write_b32 %[mail], v44 offset:12\n\t"           /* mailbox: nodes staged so far */ \
+        "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
+        "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
+        "v_cmp_lt_u32_e32 vcc, %[limit], v44\n\t"           /* more than slots - 8 nodes waiting in a ring */ \
+        "v_cmp_ne_u32_e64 s[42:43], 0, v40\n\t"             /* lanes still walking */ \
+        "s_nop 1\n\t" \
+        "s_cmp_eq_u64 s[42:43], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_gather_out_%=\n\t" \
+        "s_cbranch_vccz .Lgbwt_gather_loop_%=\n\t" \
+        "s_branch .Lgbwt_gather_out_%=\n\t" \
+        ".Lgbwt_gather_slow_%=:\n\t" \
+        "s_mov_b32 %[reason], 1\n\t" \
+        ".Lgbwt_gather_out_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "v_mov_b32_e32 %[rec], v40\n\t" \
+        "v_mov_b32_e32 %[offset], v42\n\t" \
+        "v_mov_b32_e32 %[bb], v43\n\t" \
+        "v_mov_b32_e32 %[wr], v44\n\t" \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
+          "{s41}"(alphabet_offset) \
+        : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", \
+          "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v49", "v50", "v56", "v57", "v58", "v59", "v60", "v61", "v70", "v71", \
+          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+          "v106", "v107", "v108", "v109", "v110", "v111");
+    if (narrow) { GBWT_GATHER_LOOP(GBWT_GATHER_K_NARROW, GBWT_GATHER_D_NARROW) } else { GBWT_GATHER_LOOP(GBWT_GATHER_K_WIDE, GBWT_GATHER_D_WIDE) }
+#undef GBWT_GATHER_LOOP
+#undef GBWT_GATHER_K_NARROW
+#undef GBWT_GATHER_K_WIDE
+#undef GBWT_GATHER_D_NARROW
+#undef GBWT_GATHER_D_WIDE
     return reason;
 #endif
 }
@@ -572,7 +791,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
 // per-lane choices are made by running the same `v_mov / v_add  vgpr, sgpr` under the exec mask of each choice.
 // Same registers and conventions as walk2_hot_loop.  Leaves with reason 2 -- nothing in flight, state intact -- as
 // soon as the lanes are not all on one record (or some are parked); the caller then continues with walk2_hot_loop.
-// SGPRs: s[48:63] F0 F1 L00 L01, s[64:71] L10 L11, s[72:75] look-ahead target, s[76:85] masks, s[88:89] descriptor
+// SGPRs: s[48:63] E_0 E_1 L00 L01, s[64:71] L10 L11, s[72:75] look-ahead target, s[76:85] masks, s[88:89] descriptor
 // address, s78 the record.
 __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
                                                        uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
@@ -595,7 +814,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
     "s_addc_u32 s77, s77, %[dhi]\n\t"                                                                     \
     "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
     "v_cmp_ne_u32_e32 vcc, s78, v40\n\t"                  /* lanes on another record */                   \
-    "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* F0, F1, leaf (0, 0), leaf (0, 1) */          \
+    "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* E_0, E_1, leaf (0, 0), leaf (0, 1) */         \
     "s_load_dwordx8 s[64:71], s[76:77], 0x40\n\t"         /* leaf (1, 0), leaf (1, 1) */                  \
     "s_load_dwordx4 s[72:75], s[76:77], 0x60\n\t"         /* look-ahead target */                         \
     KLOAD                                                                                                 \
@@ -630,7 +849,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t" \
         ".Lgbwt_walk2u_loop_%=:\n\t" \
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
-        "s_bitcmp1_b32 s52, 30\n\t"                         /* DESC2_SLOW */ \
+        "s_bitcmp1_b32 s50, 30\n\t"                         /* DESC2_SLOW */ \
         "s_cbranch_scc1 .Lgbwt_walk2u_slow_%=\n\t" \
         "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
         "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
@@ -651,12 +870,12 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
         "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
         "v_mov_b32_e32 v104, s48\n\t"                       /* edge 0: node */ \
-        "v_mov_b32_e32 v105, s52\n\t"                       /*         w_0 | flags */ \
+        "v_mov_b32_e32 v105, s50\n\t"                       /*         w_0 | flags */ \
         "v_add_u32_e32 v103, s49, v99\n\t"                  /*         j = offset base + rank_a: offset in w_a */ \
         "s_mov_b64 exec, s[44:45]\n\t"                      /* the lanes that take edge 1 */ \
-        "v_mov_b32_e32 v104, s50\n\t" \
-        "v_mov_b32_e32 v105, s53\n\t" \
-        "v_add_u32_e32 v103, s51, v99\n\t" \
+        "v_mov_b32_e32 v104, s52\n\t" \
+        "v_mov_b32_e32 v105, s54\n\t" \
+        "v_add_u32_e32 v103, s53, v99\n\t" \
         "s_mov_b64 exec, -1\n\t" \
         "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
         "v_and_b32_e32 v101, v101, v83\n\t" \
@@ -814,9 +1033,8 @@ __device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, S
         if (sink.wr > 0xFFFFFFF0u) { if (overflow) atomicOr(overflow, 1u); break; }
         if (++guard > ix.max_walk) { if (overflow) atomicOr(overflow, 2u); break; }
         const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
-        const uint4 F1 = d[1];
-        if (F1.x & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); sink.checkpoint(rec, offset, bb); continue; }
-        const uint4 F0 = d[0];
+        const uint4 E0 = d[0];
+        if (E0.z & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); sink.checkpoint(rec, offset, bb); continue; }
         const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
         const uint4 K0 = ix.cblocks[2 * idx], K1 = ix.cblocks[2 * idx + 1];
         const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
@@ -825,11 +1043,12 @@ __device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, S
         const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u;
         const uint64_t m = a ? bits1 : ~bits1;
         const uint32_t rank_a = a ? K1.x + __popcll(m & below) : (offset - bit) - K1.x + __popcll(m & below);
-        const uint32_t j = (a ? F0.w : F0.y) + rank_a;
+        const uint4 E = a ? d[1] : E0;
+        const uint32_t j = E.y + rank_a;
         const uint32_t b = static_cast<uint32_t>(bits2 >> bit) & 1u;
         const uint32_t ones_w = (a ? K1.z : K1.y) + __popcll(m & bits2 & below);
         const uint4 leaf = d[2 + 2 * a + b];
-        const uint32_t n1 = a ? F0.z : F0.x, wword = a ? F1.y : F1.x;
+        const uint32_t n1 = E.x, wword = E.z;
         rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
         sink.push(n1, n1 != 0);
         sink.push((wword & REC_MASK) + ix.alphabet_offset, (wword & LEAF_EMIT2) != 0);

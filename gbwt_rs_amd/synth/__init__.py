@@ -21,6 +21,8 @@ def lib():
         p, u64 = C.c_void_p, C.c_uint64
         L.gbwt_synth_chain.restype = p
         L.gbwt_synth_chain.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64]
+        L.gbwt_synth_chain_indel.restype = p
+        L.gbwt_synth_chain_indel.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32]
         L.gbwt_synth_from_paths.restype = p
         L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
         L.gbwt_synth_from_file.restype = p
@@ -60,8 +62,12 @@ class Synth:
         self.bidirectional = bool(bd)
 
     @classmethod
-    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42):
-        return cls(lib().gbwt_synth_chain(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed))
+    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0):
+        """`extra` > 0: alleles >= 1 are insertions of `extra` more nodes (paths of different lengths; gbwt_synth.h)."""
+        h = lib().gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra)
+        if not h:
+            raise ValueError("gbwt_synth_chain: parameters out of range")
+        return cls(h)
 
     @classmethod
     def from_paths(cls, paths, bidirectional=True):

@@ -33,6 +33,14 @@ enum { GBWT_SYNTH_MOSAIC = 0, GBWT_SYNTH_IID = 1 };
 gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                              double switch_rate, double zipf, uint64_t seed);
 
+/* The same chain with insertion alleles: every allele a >= 1 is the allele node followed by `extra` more nodes
+ * (allele 0 stays one node), so paths differ in length and the walks of a batch leave lock step after the first
+ * site: the regime of graphs with indels.  Node ids of site s (stride = alleles + 1 + (alleles - 1) * extra):
+ * anchor s*stride+1, allele nodes s*stride+2+a, tail e of allele a >= 1 at s*stride+2+alleles+(a-1)*extra+e.
+ * extra == 0 is gbwt_synth_chain. */
+gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                                   double switch_rate, double zipf, uint64_t seed, uint32_t extra);
+
 /* Paths as CSR over GBWT-encoded nodes (2 * id + orientation, id >= 1).  bidirectional != 0 adds the
  * reverse sequence of every path (src/support.rs:310-314).  No metadata, no graph. */
 gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, int bidirectional);

@@ -79,6 +79,7 @@ struct gbwt_synth {
     HostIndex index;
     // chain truth
     uint64_t sites = 0, haplotypes = 0, alleles = 0;
+    uint64_t extra = 0;             // alleles >= 1 are insertions: `extra` more nodes behind the allele node
     std::vector<uint64_t> bits;     // alleles == 2: site-major bit rows
     uint64_t row_words = 0;
     std::vector<uint16_t> choices;  // alleles > 2: site-major
@@ -94,8 +95,12 @@ struct gbwt_synth {
         if (alleles == 2) { if (a) bits[s * row_words + (h >> 6)] |= uint64_t(1) << (h & 63); }
         else choices[s * haplotypes + h] = static_cast<uint16_t>(a);
     }
-    inline uint64_t anchor_id(uint64_t s) const { return s * (alleles + 1) + 1; }
-    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * (alleles + 1) + 2 + a; }
+    // node ids of site s, ascending: anchor, the A allele nodes, then the `extra` tail nodes of allele 1, of allele 2, ...
+    inline uint64_t stride() const { return alleles + 1 + (alleles - 1) * extra; }
+    inline uint64_t anchor_id(uint64_t s) const { return s * stride() + 1; }
+    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * stride() + 2 + a; }
+    inline uint64_t tail_id(uint64_t s, uint32_t a, uint64_t e) const { return s * stride() + 2 + alleles + (a - 1) * extra + e; }
+    inline uint64_t last_id(uint64_t s, uint32_t a) const { return (a == 0 || extra == 0) ? allele_id(s, a) : tail_id(s, a, extra - 1); }
 };
 
 namespace {
@@ -177,24 +182,25 @@ void partition(const gbwt_synth &g, uint64_t s, const SiteStats &st, const std::
     for (uint32_t h : ord) out[cursor[g.allele(s, h)]++] = h;
 }
 
-// Pool of records produced by one sweep: slot (s, k) with k = 0 anchor, 1 + a = allele a.
+// Pool of records produced by one sweep: slot (s, k) with k = node id - anchor id (0 anchor, 1 + a = allele a, then the tails).
 struct Pool {
     std::vector<uint8_t> bytes;
-    std::vector<uint64_t> start;  // (S * (A + 1) + 1) entries, in generation order
+    std::vector<uint64_t> start;  // (S * stride + 1) entries, in generation order
 };
 
 void forward_sweep(const gbwt_synth &g, Pool &pool) {
-    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
-    pool.start.assign(S * (A + 1) + 1, 0);
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, X = g.extra, W = g.stride();
+    pool.start.assign(S * W + 1, 0);
     pool.bytes.reserve(S * 24);
     std::vector<uint32_t> ord(n), nxt, cursor;
     for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
     SiteStats st;
     std::vector<std::pair<uint64_t, uint64_t>> edges;
+    std::vector<uint64_t> before(A);
     RecordWriter rw(pool.bytes);
     for (uint64_t s = 0; s < S; s++) {
         st.compute(g, s);
-        const uint64_t base = s * (A + 1);
+        const uint64_t base = s * W;
         // anchor, forward orientation: successors are the allele nodes of this site
         pool.start[base] = pool.bytes.size();
         edges.clear();
@@ -204,27 +210,44 @@ void forward_sweep(const gbwt_synth &g, Pool &pool) {
         rw.end();
         partition(g, s, st, ord, nxt, cursor);
         ord.swap(nxt);
-        // allele nodes, forward: one edge to the next anchor (or the ENDMARKER at the last site)
-        uint64_t before = 0;
+        uint64_t acc = 0;
+        for (uint64_t a = 0; a < A; a++) { before[a] = acc; acc += st.cnt[a]; }
+        // the last node of an allele has one edge to the next anchor (or the ENDMARKER at the last site); the next
+        // anchor's visits are ordered by predecessor = last node of the allele, ascending with the allele
+        auto leave = [&](uint64_t a) {
+            edges.clear();
+            if (s + 1 < S) edges.emplace_back(2 * g.anchor_id(s + 1), before[a]); else edges.emplace_back(0, 0);
+        };
         for (uint64_t a = 0; a < A; a++) {
             pool.start[base + 1 + a] = pool.bytes.size();
             if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
-            edges.clear();
-            if (s + 1 < S) edges.emplace_back(2 * g.anchor_id(s + 1), before); else edges.emplace_back(0, 0);
+            if (a == 0 || X == 0) leave(a);
+            else { edges.clear(); edges.emplace_back(2 * g.tail_id(s, static_cast<uint32_t>(a), 0), 0); }
             rw.begin(edges);
             rw.push(0, st.cnt[a]);
             rw.end();
-            before += st.cnt[a];
+        }
+        // tails of the insertion alleles: unary records, every visit comes from the one predecessor
+        for (uint64_t a = 1; a < A; a++) {
+            for (uint64_t e = 0; e < X; e++) {
+                pool.start[base + 1 + A + (a - 1) * X + e] = pool.bytes.size();
+                if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
+                if (e + 1 == X) leave(a);
+                else { edges.clear(); edges.emplace_back(2 * g.tail_id(s, static_cast<uint32_t>(a), e + 1), 0); }
+                rw.begin(edges);
+                rw.push(0, st.cnt[a]);
+                rw.end();
+            }
         }
     }
-    pool.start[S * (A + 1)] = pool.bytes.size();
+    pool.start[S * W] = pool.bytes.size();
 }
 
 // Reverse orientation, generated from the last site down; slots are stored in generation order:
-// slot index for site s = (S - 1 - s) * (A + 1) + k.
+// slot index for site s = (S - 1 - s) * stride + k.
 void reverse_sweep(const gbwt_synth &g, Pool &pool) {
-    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
-    pool.start.assign(S * (A + 1) + 1, 0);
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, X = g.extra, W = g.stride();
+    pool.start.assign(S * W + 1, 0);
     pool.bytes.reserve(S * 24);
     std::vector<uint32_t> ord(n), nxt, cursor;
     for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
@@ -233,15 +256,15 @@ void reverse_sweep(const gbwt_synth &g, Pool &pool) {
     RecordWriter rw(pool.bytes);
     for (uint64_t s = S; s-- > 0;) {
         st.compute(g, s);
-        const uint64_t base = (S - 1 - s) * (A + 1);
+        const uint64_t base = (S - 1 - s) * W;
         partition(g, s, st, ord, nxt, cursor);
         ord.swap(nxt);  // order of the visits in the reverse anchor record
-        // anchor, reverse orientation: successors are the reverse allele nodes of site s - 1
+        // anchor, reverse orientation: successors are the reverse last nodes of the alleles of site s - 1
         pool.start[base] = pool.bytes.size();
         edges.clear();
         if (s > 0) {
             prev.compute(g, s - 1);
-            for (uint64_t a = 0; a < A; a++) if (prev.cnt[a]) edges.emplace_back(2 * g.allele_id(s - 1, static_cast<uint32_t>(a)) + 1, 0);
+            for (uint64_t a = 0; a < A; a++) if (prev.cnt[a]) edges.emplace_back(2 * g.last_id(s - 1, static_cast<uint32_t>(a)) + 1, 0);
             rw.begin(edges);
             for (uint32_t h : ord) rw.push(prev.rank[g.allele(s - 1, h)]);
             rw.end();
@@ -263,8 +286,20 @@ void reverse_sweep(const gbwt_synth &g, Pool &pool) {
             rw.end();
             before += st.cnt[a];
         }
+        // tails, reverse: back towards the allele node
+        for (uint64_t a = 1; a < A; a++) {
+            for (uint64_t e = 0; e < X; e++) {
+                pool.start[base + 1 + A + (a - 1) * X + e] = pool.bytes.size();
+                if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
+                edges.clear();
+                edges.emplace_back(2 * (e == 0 ? g.allele_id(s, static_cast<uint32_t>(a)) : g.tail_id(s, static_cast<uint32_t>(a), e - 1)) + 1, 0);
+                rw.begin(edges);
+                rw.push(0, st.cnt[a]);
+                rw.end();
+            }
+        }
     }
-    pool.start[S * (A + 1)] = pool.bytes.size();
+    pool.start[S * W] = pool.bytes.size();
 }
 
 void add_string(gbwt_hip::Strings &s, const std::string &x) {
@@ -273,23 +308,23 @@ void add_string(gbwt_hip::Strings &s, const std::string &x) {
 }
 
 void build_chain(gbwt_synth &g, uint64_t seed) {
-    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles;
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, W = g.stride();
     HostIndex &ix = g.index;
     Pool fwd, rev;
     std::thread t([&] { reverse_sweep(g, rev); });
     forward_sweep(g, fwd);
     t.join();
 
-    // endmarker record: sequence 2h starts at the first anchor, sequence 2h + 1 at the reverse of the last allele
+    // endmarker record: sequence 2h starts at the first anchor, sequence 2h + 1 at the reverse of the last allele's last node
     SiteStats last;
     last.compute(g, S - 1);
     std::vector<std::pair<uint64_t, uint64_t>> edges;
     edges.emplace_back(2 * g.anchor_id(0), 0);
-    for (uint64_t a = 0; a < A; a++) if (last.cnt[a]) edges.emplace_back(2 * g.allele_id(S - 1, static_cast<uint32_t>(a)) + 1, 0);
+    for (uint64_t a = 0; a < A; a++) if (last.cnt[a]) edges.emplace_back(2 * g.last_id(S - 1, static_cast<uint32_t>(a)) + 1, 0);
     ix.data.clear();
     ix.data.reserve(fwd.bytes.size() + rev.bytes.size() + 4 * n + 64);
     ix.starts.clear();
-    ix.starts.reserve(2 * S * (A + 1) + 2);
+    ix.starts.reserve(2 * S * W + 2);
     ix.starts.push_back(0);
     {
         RecordWriter rw(ix.data);
@@ -299,8 +334,8 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     }
     // interleave: node id ascending, forward record then reverse record
     for (uint64_t s = 0; s < S; s++) {
-        for (uint64_t k = 0; k <= A; k++) {
-            uint64_t fs = s * (A + 1) + k, rs = (S - 1 - s) * (A + 1) + k;
+        for (uint64_t k = 0; k < W; k++) {
+            uint64_t fs = s * W + k, rs = (S - 1 - s) * W + k;
             ix.starts.push_back(ix.data.size());
             ix.data.insert(ix.data.end(), fwd.bytes.begin() + fwd.start[fs], fwd.bytes.begin() + fwd.start[fs + 1]);
             ix.starts.push_back(ix.data.size());
@@ -310,14 +345,14 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     // alphabet_size = largest visited GBWT node + 1: drop the records of unused trailing allele nodes
     uint32_t top = 0;
     for (uint64_t a = 0; a < A; a++) if (last.cnt[a]) top = static_cast<uint32_t>(a);
-    const uint64_t max_node = 2 * g.allele_id(S - 1, top) + 1;
+    const uint64_t max_node = 2 * g.last_id(S - 1, top) + 1;
     if (max_node < ix.starts.size()) {   // records 0 .. max_node - 1 (record r <-> node r + 1)
         ix.data.resize(ix.starts[max_node]);
         ix.starts.resize(max_node);
     }
     ix.starts.push_back(ix.data.size());
     ix.sequences = 2 * n;
-    ix.size = 2 * n * (2 * S) + 2 * n;
+    ix.size = 0;   // set below, once the insertion visits are counted
     ix.alphabet_offset = 1;
     ix.alphabet_size = max_node + 1;
     ix.bidirectional = true;
@@ -340,18 +375,21 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     ix.is_gbz = true; ix.has_translation = false;
     Rng rng(seed ^ 0xACDCACDCull);
     SiteStats st;
-    uint64_t real = 0;
-    ix.sequences_labels.bytes.reserve(S * (A + 1));
-    ix.sequences_labels.offsets.reserve(S * (A + 1) + 1);
+    uint64_t real = 0, inserted = 0;
+    ix.sequences_labels.bytes.reserve(S * W);
+    ix.sequences_labels.offsets.reserve(S * W + 1);
     for (uint64_t s = 0; s < S; s++) {
         st.compute(g, s);
-        for (uint64_t k = 0; k <= A; k++) {
-            if (s * (A + 1) + k + 1 > g.allele_id(S - 1, top)) break;  // ids past the largest visited node
-            if (k == 0 || st.cnt[k - 1]) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
+        inserted += n - st.cnt[0];
+        for (uint64_t k = 0; k < W; k++) {
+            if (s * W + k + 1 > g.last_id(S - 1, top)) break;  // ids past the largest visited node
+            const uint64_t a = k == 0 ? 0 : (k <= A ? k - 1 : 1 + (k - 1 - A) / g.extra);
+            if (k == 0 || st.cnt[a]) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
             ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
         }
     }
     ix.graph_nodes = real;
+    ix.size = 2 * (n * 2 * S + inserted * g.extra) + 2 * n;
 }
 
 // ---- general path sets: brute-force reverse-prefix sort ------------------------------------------
@@ -435,9 +473,14 @@ extern "C" {
 
 gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                              double switch_rate, double zipf, uint64_t seed) {
-    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000) return nullptr;
+    return gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, 0);
+}
+
+gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                                   double switch_rate, double zipf, uint64_t seed, uint32_t extra) {
+    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64) return nullptr;
     gbwt_synth *g = new gbwt_synth;
-    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles;
+    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra;
     if (alleles == 2) { g->row_words = (haplotypes + 63) / 64; g->bits.assign(sites * g->row_words, 0); }
     else g->choices.assign(sites * haplotypes, 0);
     draw_alleles(*g, model, founders, switch_rate, zipf, seed);
@@ -537,10 +580,13 @@ int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz) {
 uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, uint64_t cap) {
     if (s->sites) {
         if (path_id >= s->haplotypes) return 0;
-        uint64_t len = 2 * s->sites;
-        for (uint64_t site = 0; site < s->sites && 2 * site < cap; site++) {
-            out[2 * site] = static_cast<uint32_t>(2 * s->anchor_id(site));
-            if (2 * site + 1 < cap) out[2 * site + 1] = static_cast<uint32_t>(2 * s->allele_id(site, s->allele(site, path_id)));
+        uint64_t len = 0;
+        auto put = [&](uint64_t node) { if (len < cap) out[len] = static_cast<uint32_t>(2 * node); len++; };
+        for (uint64_t site = 0; site < s->sites; site++) {
+            const uint32_t a = s->allele(site, path_id);
+            put(s->anchor_id(site));
+            put(s->allele_id(site, a));
+            if (a) for (uint64_t e = 0; e < s->extra; e++) put(s->tail_id(site, a, e));
         }
         return len;
     }
@@ -554,8 +600,11 @@ uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id) {
     uint64_t sum = 0;
     if (s->sites) {
         if (path_id >= s->haplotypes) return 0;
-        for (uint64_t site = 0; site < s->sites; site++)
-            sum += 2 * s->anchor_id(site) + 2 * s->allele_id(site, s->allele(site, path_id));
+        for (uint64_t site = 0; site < s->sites; site++) {
+            const uint32_t a = s->allele(site, path_id);
+            sum += 2 * s->anchor_id(site) + 2 * s->allele_id(site, a);
+            if (a) for (uint64_t e = 0; e < s->extra; e++) sum += 2 * s->tail_id(site, a, e);
+        }
         return sum;
     }
     if (path_id + 1 >= s->path_offsets.size()) return 0;

@@ -468,6 +468,41 @@ def test_config_c2_bit_exact(tmp_path):
         assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
 
 
+@pytest.mark.parametrize("alleles,extra,model", [(2, 1, S.MOSAIC), (2, 3, S.IID), (4, 2, S.MOSAIC)])
+def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
+    """Insertion alleles: paths of different lengths whose walks leave lock step after the first site (the wave-uniform
+    loop hardly ever applies).  Forward and reverse sequences against the oracle, via a .gbz file."""
+    s = S.Synth.chain(sites=2500, haplotypes=600, alleles=alleles, model=model, founders=16, switch_rate=5e-3, zipf=0.7, seed=31, extra=extra)
+    path = tmp_path / "indel.gbz"
+    s.save(str(path), as_gbz=True)
+    dev = G.GBZ.load(str(path))
+    oracle = O.OracleGBZ(str(path)).gbwt()
+    for first in (0, 1):
+        ids = np.arange(first, 1200, 2, dtype=np.uint64)
+        offsets, nodes = dev.sequences_csr(ids)
+        o_off, o_nodes = oracle.extract(ids, threads=8)
+        assert len(set(np.diff(offsets).tolist())) > 1
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    assert dev.path_lines(np.arange(1, 40, dtype=np.uint64), 1) == O.OracleGBZ(str(path)).path_lines(list(range(1, 40)), 1)
+
+
+def test_indel_chain_scale_properties():
+    """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix."""
+    s = S.Synth.chain(sites=60000, haplotypes=3000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=9, extra=2)
+    dev = open_synth(s)
+    ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
+    out = dev.extract_device(ids)
+    assert int(out.total) == (s.size - s.sequences) // 2
+    sums = dev.path_sums(len(ids))
+    for h in range(s.paths):
+        assert int(sums[h]) == s.path_checksum(h)
+    for h in (0, 1, 1500, 2999):
+        assert np.array_equal(dev.copy_path(h), s.path(h))
+    r_off, r_nodes = dev.sequences_csr([2 * 1500 + 1, 1])
+    assert np.array_equal(r_nodes[r_off[0]:r_off[1]], (s.path(1500) ^ 1)[::-1])
+    assert np.array_equal(r_nodes[r_off[1]:r_off[2]], (s.path(0) ^ 1)[::-1])
+
+
 def test_headline_scale_properties():
     """Size-independent checks at a large size (paths x sites well beyond what the oracle finishes quickly):
     every extracted path equals the generator's ground truth, lengths are uniform, the total equals

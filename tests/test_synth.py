@@ -96,6 +96,35 @@ def test_chain_generator_matches_bruteforce_builder(alleles, model):
     assert (s.sequences, s.size, s.alphabet_offset, s.alphabet_size) == (b.sequences, b.size, b.alphabet_offset, b.alphabet_size)
 
 
+@pytest.mark.parametrize("alleles,model,extra", [(2, S.MOSAIC, 1), (2, S.IID, 3), (5, S.MOSAIC, 2), (40, S.IID, 1)])
+def test_indel_chain_matches_bruteforce_builder(alleles, model, extra):
+    """Insertion alleles (paths of different lengths): the sweep generator still agrees with the brute-force builder
+    byte for byte, and its checksums and header follow the longer paths."""
+    s = S.Synth.chain(sites=9, haplotypes=21, alleles=alleles, model=model, founders=4, switch_rate=0.2, seed=8, extra=extra)
+    paths = [[int(x) for x in s.path(h)] for h in range(s.paths)]
+    assert len({len(p) for p in paths}) > 1
+    for h, p in enumerate(paths):
+        assert sum(p) == s.path_checksum(h)
+    b = S.Synth.from_paths(paths, bidirectional=True)
+    assert bytes(s.data()) == bytes(b.data())
+    assert list(s.starts()) == list(b.starts())
+    assert (s.sequences, s.size, s.alphabet_offset, s.alphabet_size) == (b.sequences, b.size, b.alphabet_offset, b.alphabet_size)
+
+
+def test_indel_chain_gbz_loads_in_the_oracle(tmp_path):
+    s = S.Synth.chain(sites=150, haplotypes=40, alleles=2, model=S.MOSAIC, founders=6, switch_rate=0.05, seed=3, extra=2)
+    path = tmp_path / "indel.gbz"
+    s.save(str(path), as_gbz=True)
+    z = O.OracleGBZ(str(path))
+    g = z.gbwt()
+    for h in (0, 7, 39):
+        truth = [int(x) for x in s.path(h)]
+        assert g.sequence(2 * h) == truth
+        assert g.sequence(2 * h + 1) == kat.reverse_path(truth)
+    w = [l for l in z.gfa().split(b"\n") if l.startswith(b"W\t")]
+    assert len(w) == 39 and int(w[0].split(b"\t")[5]) == len(s.path(1))   # 1 bp labels: walk length in bases = nodes
+
+
 def test_chain_generator_oracle_extraction(tmp_path):
     """Config C2 shape at reduced size: file -> oracle loader -> extraction == generator ground truth; GFA lines parse."""
     s = S.Synth.chain(sites=200, haplotypes=64, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.02, seed=42)

@@ -23,9 +23,10 @@ ap.add_argument("--haplotypes", type=int, default=5000)
 ap.add_argument("--model", default="mosaic")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--configs", default="")
+ap.add_argument("--extra", type=int, default=0, help="allele 1 is an insertion of this many more nodes (walks leave lock step)")
 args = ap.parse_args()
 
-s = S.Synth.chain(args.sites, args.haplotypes, alleles=2, model=S.MOSAIC if args.model == "mosaic" else S.IID, seed=42)
+s = S.Synth.chain(args.sites, args.haplotypes, alleles=2, model=S.MOSAIC if args.model == "mosaic" else S.IID, seed=42, extra=args.extra)
 ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
 truth = np.array([s.path_checksum(h) for h in range(s.paths)], dtype=np.uint64)
 steps = (s.size - s.sequences) // 2
