@@ -271,8 +271,12 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
                  : "=&s"(keep) : "v"(p), "s"(lds_dummy) : "memory");
 }
 
-#ifdef GBWT_HIP_PROBE_WAVES   // measurement only (with GBWT_HIP_CXX_LOOP): the register budget that lets this many waves share a SIMD
-__attribute__((amdgpu_waves_per_eu(GBWT_HIP_PROBE_WAVES, GBWT_HIP_PROBE_WAVES)))
+// Register budget: the two assembly loops live in v40-v87 (walk_loops.hpp) and the compiler takes what it likes of the rest: 128
+// VGPRs = four waves per SIMD = eight workgroups per CU, which is also what the LDS allows (64 ring slots x 65 lanes x 4 bytes + 2.5
+// KB per workgroup).  -DGBWT_HIP_WALK_WAVES=5 fits the kernel into 96 VGPRs (3 spilled outside the loops); it changes nothing while
+// the rings are this size, and smaller rings cannot hold a 128-byte row piece (profiles/r02_walk_bounds.txt #17).
+#ifdef GBWT_HIP_WALK_WAVES
+__attribute__((amdgpu_waves_per_eu(GBWT_HIP_WALK_WAVES, GBWT_HIP_WALK_WAVES)))
 #endif
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
     extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
@@ -423,8 +427,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (!together) probe_mixed_entries++;
         if (slow_exit == 2 && together) probe_fell_out++;
 #endif
-        if (slow_exit == 2) slow_exit = a.gather_loop ? walk2_gather_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr)
-                                                      : walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+        if (slow_exit == 2) slow_exit = walk2_gather_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif

@@ -634,39 +634,39 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
     uint32_t reason;
     const uint32_t limit = flushed + (ring_mask + 1 - 8);   // leave with more than slots - 8 nodes waiting
 #define GBWT_GATHER_K_NARROW                                                                              \
-    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
-    "v_lshlrev_b32_e32 v88, 7, v40\n\t"                   /* two-step descriptors are 128 bytes */        \
+    "v_lshlrev_b32_e32 v70, 5, v58\n\t"                   /* two-step blocks are 32 bytes */              \
+    "v_lshlrev_b32_e32 v68, 7, v40\n\t"                   /* two-step descriptors are 128 bytes */        \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
-    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
-    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
+    "global_load_dwordx4 v[60:63], v70, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
+    "global_load_dwordx3 v[64:66], v70, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
     "s_mov_b64 exec, -1\n\t"
 #define GBWT_GATHER_K_WIDE                                                                                \
-    "v_lshlrev_b64 v[90:91], 5, v[70:71]\n\t"                                                             \
-    "v_lshlrev_b64 v[88:89], 7, v[40:41]\n\t"                                                             \
-    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
-    "v_lshl_add_u64 v[88:89], v[88:89], 0, %[desc2]\n\t"                                                  \
+    "v_lshlrev_b64 v[70:71], 5, v[58:59]\n\t"                                                             \
+    "v_lshlrev_b64 v[68:69], 7, v[40:41]\n\t"                                                             \
+    "v_lshl_add_u64 v[70:71], v[70:71], 0, %[cblocks]\n\t"                                                \
+    "v_lshl_add_u64 v[68:69], v[68:69], 0, %[desc2]\n\t"                                                  \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
-    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"                                                     \
-    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"                                           \
+    "global_load_dwordx4 v[60:63], v[70:71], off\n\t"                                                     \
+    "global_load_dwordx3 v[64:66], v[70:71], off offset:16\n\t"                                           \
     "s_mov_b64 exec, -1\n\t"
-// E_a at 16 a, leaf (a, b) at 32 + 16 (2 a + b) of the descriptor; v94 = a, v108 = b
+// E_a at 16 a, leaf (a, b) at 32 + 16 (2 a + b) of the descriptor; v72 = a, v84 = b
 #define GBWT_GATHER_D_NARROW                                                                              \
-    "v_lshl_add_u32 v46, v94, 4, v88\n\t"                                                                 \
-    "v_lshl_add_u32 v47, v94, 1, v108\n\t"                                                                \
-    "v_lshl_add_u32 v47, v47, 4, v88\n\t"                                                                 \
+    "v_lshl_add_u32 v46, v72, 4, v68\n\t"                                                                 \
+    "v_lshl_add_u32 v47, v72, 1, v84\n\t"                                                                \
+    "v_lshl_add_u32 v47, v47, 4, v68\n\t"                                                                 \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
     "global_load_dwordx3 v[48:50], v46, %[desc2]\n\t"               /* E_a: node, offset base, w_a | flags */ \
-    "global_load_dwordx4 v[56:59], v47, %[desc2] offset:32\n\t"     /* leaf (a, b) */                     \
+    "global_load_dwordx4 v[52:55], v47, %[desc2] offset:32\n\t"     /* leaf (a, b) */                     \
     "s_mov_b64 exec, -1\n\t"
 #define GBWT_GATHER_D_WIDE                                                                                \
-    "v_lshl_add_u32 v60, v94, 1, v108\n\t"                                                                \
-    "v_mov_b32_e32 v95, 0\n\t"                                                                            \
-    "v_mov_b32_e32 v61, 0\n\t"                                                                            \
-    "v_lshl_add_u64 v[46:47], v[94:95], 4, v[88:89]\n\t"                                                  \
-    "v_lshl_add_u64 v[60:61], v[60:61], 4, v[88:89]\n\t"                                                  \
+    "v_lshl_add_u32 v56, v72, 1, v84\n\t"                                                                \
+    "v_mov_b32_e32 v73, 0\n\t"                                                                            \
+    "v_mov_b32_e32 v57, 0\n\t"                                                                            \
+    "v_lshl_add_u64 v[46:47], v[72:73], 4, v[68:69]\n\t"                                                  \
+    "v_lshl_add_u64 v[56:57], v[56:57], 4, v[68:69]\n\t"                                                  \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
     "global_load_dwordx3 v[48:50], v[46:47], off\n\t"                                                     \
-    "global_load_dwordx4 v[56:59], v[60:61], off offset:32\n\t"                                           \
+    "global_load_dwordx4 v[52:55], v[56:57], off offset:32\n\t"                                           \
     "s_mov_b64 exec, -1\n\t"
 #define GBWT_GATHER_LOOP(KLOAD, DLOAD) \
     asm volatile( \
@@ -675,74 +675,74 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
         "v_mov_b32_e32 v42, %[offset]\n\t" \
         "v_mov_b32_e32 v43, %[bb]\n\t" \
         "v_mov_b32_e32 v44, %[wr]\n\t" \
-        "v_mov_b32_e32 v71, 0\n\t" \
+        "v_mov_b32_e32 v59, 0\n\t" \
         "s_mov_b32 %[reason], 0\n\t" \
         "s_mov_b64 s[44:45], -1\n\t"                        /* everybody loads in the first round (parked lanes: record 0) */ \
         "v_cmp_ne_u32_e64 s[42:43], 0, v40\n\t" \
         "ds_write_b32 %[mail], v41\n\t"                     /* no look-ahead target */ \
         ".Lgbwt_gather_loop_%=:\n\t" \
         "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                 /* bb != BLOCK_NONE */ \
-        "v_lshrrev_b32_e32 v70, 6, v42\n\t" \
-        "v_add_u32_e32 v70, v70, v43\n\t" \
-        "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"            /* block bb + offset / 64, or the zero block */ \
+        "v_lshrrev_b32_e32 v58, 6, v42\n\t" \
+        "v_add_u32_e32 v58, v58, v43\n\t" \
+        "v_cndmask_b32_e32 v58, 0, v58, vcc\n\t"            /* block bb + offset / 64, or the zero block */ \
         KLOAD \
-        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
-        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_lshlrev_b64 v[74:75], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v77, 0xffffffc0, v42\n\t"            /* offset - bit */ \
         "s_waitcnt vmcnt(0)\n\t" \
-        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
-        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
-        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
-        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
+        "v_lshrrev_b64 v[72:73], v42, v[60:61]\n\t"         /* bits1 >> bit */ \
+        "v_lshrrev_b64 v[84:85], v42, v[62:63]\n\t"       /* bits2 >> bit */ \
+        "v_and_b32_e32 v72, 1, v72\n\t"                     /* a */ \
+        "v_and_b32_e32 v84, 1, v84\n\t"                   /* b */ \
         DLOAD \
-        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
-        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
-        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
-        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
-        "v_xor_b32_e32 v101, v81, v98\n\t" \
-        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
-        "v_bfi_b32 v101, v97, 0, v101\n\t" \
-        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
-        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
-        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
-        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
-        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
-        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
-        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
-        "v_and_b32_e32 v101, v101, v83\n\t" \
-        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
-        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
+        "v_add_u32_e32 v76, -1, v72\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v72\n\t"                  /* vcc = a */ \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v84\n\t"            /* s[46:47] = b */ \
+        "v_xor_b32_e32 v78, v60, v76\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v79, v61, v76\n\t" \
+        "v_bfi_b32 v78, v74, 0, v78\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v79, v75, 0, v79\n\t" \
+        "v_sub_u32_e32 v77, v77, v64\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v80, v78, 0\n\t" \
+        "v_cndmask_b32_e32 v77, v77, v64, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v80, v79, v80\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v82, v65, v66, vcc\n\t"         /* R_a */ \
+        "v_add_u32_e32 v77, v77, v80\n\t"                  /* rank_a */ \
+        "v_and_b32_e32 v78, v78, v62\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v79, v79, v63\n\t" \
+        "v_bcnt_u32_b32 v82, v78, v82\n\t" \
+        "v_bcnt_u32_b32 v82, v79, v82\n\t"               /* ones of w_a before j */ \
         "s_waitcnt vmcnt(0)\n\t" \
-        "v_lshlrev_b32_e32 v92, 1, v50\n\t"                 /* DESC2_SLOW (bit 30 of E_a.z) -> sign */ \
-        "v_add_u32_e32 v103, v49, v99\n\t"                  /* j: offset in w_a */ \
-        "v_cmp_gt_i32_e32 vcc, 0, v92\n\t" \
-        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
-        "v_and_b32_e32 v110, 0x3fffffff, v50\n\t"           /* w_a */ \
+        "v_lshlrev_b32_e32 v67, 1, v50\n\t"                 /* DESC2_SLOW (bit 30 of E_a.z) -> sign */ \
+        "v_add_u32_e32 v81, v49, v77\n\t"                  /* j: offset in w_a */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v67\n\t" \
+        "v_sub_u32_e32 v83, v81, v82\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v86, 0x3fffffff, v50\n\t"           /* w_a */ \
         "s_cbranch_vccnz .Lgbwt_gather_slow_%=\n\t" \
-        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
-        "v_mov_b32_e32 v43, v59\n\t"                        /* block base of the landing record */ \
-        "v_add_u32_e32 v42, v57, v107\n\t"                  /* the new offset */ \
-        "v_and_b32_e32 v40, 0x3fffffff, v58\n\t"            /* the new record */ \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
+        "v_cndmask_b32_e64 v83, v83, v82, s[46:47]\n\t"  /* rank_b */ \
+        "v_mov_b32_e32 v43, v55\n\t"                        /* block base of the landing record */ \
+        "v_add_u32_e32 v42, v53, v83\n\t"                  /* the new offset */ \
+        "v_and_b32_e32 v40, 0x3fffffff, v54\n\t"            /* the new record */ \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
         "v_cmp_ne_u32_e32 vcc, 0, v48\n\t" \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v48\n\t"                         /* node of edge a */ \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v48\n\t"                         /* node of edge a */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
         "v_cmp_gt_i32_e32 vcc, 0, v50\n\t"                  /* first step fused? */ \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v110\n\t" \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v86, s41, v86\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v86\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
-        "v_cmp_ne_u32_e32 vcc, 0, v56\n\t" \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v56\n\t"                         /* node of the leaf */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v52\n\t" \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v87, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v52\n\t"                         /* node of the leaf */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
-        "v_cmp_gt_i32_e32 vcc, 0, v58\n\t"                  /* second step fused? */ \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v111\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v54\n\t"                  /* second step fused? */ \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v87\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks */ \
         "s_mov_b64 s[44:45], s[42:43]\n\t"                  /* the next round of loads: everybody who walked in this one */ \
@@ -768,9 +768,9 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
         : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", \
-          "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v49", "v50", "v56", "v57", "v58", "v59", "v60", "v61", "v70", "v71", \
-          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v88", "v89", "v90", "v91", "v92", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
-          "v106", "v107", "v108", "v109", "v110", "v111");
+          "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v49", "v50", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", \
+          "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v68", "v69", "v70", "v71", "v67", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", \
+          "v82", "v83", "v84", "v85", "v86", "v87");
     if (narrow) { GBWT_GATHER_LOOP(GBWT_GATHER_K_NARROW, GBWT_GATHER_D_NARROW) } else { GBWT_GATHER_LOOP(GBWT_GATHER_K_WIDE, GBWT_GATHER_D_WIDE) }
 #undef GBWT_GATHER_LOOP
 #undef GBWT_GATHER_K_NARROW
@@ -805,14 +805,14 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
 #define GBWT_WALK2U_ISSUE(KLOAD, REFRESH)                                                                             \
     "v_readfirstlane_b32 s78, v40\n\t"                    /* the record of lane 0 */                       \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
-    "v_lshrrev_b32_e32 v70, 6, v42\n\t"                                                                   \
-    "v_add_u32_e32 v70, v70, v43\n\t"                                                                     \
+    "v_lshrrev_b32_e32 v46, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v46, v46, v43\n\t"                                                                     \
     "s_lshl_b32 s76, s78, 7\n\t"                          /* two-step descriptors are 128 bytes */        \
     "s_lshr_b32 s77, s78, 25\n\t"                                                                         \
-    "v_cndmask_b32_e32 v70, 0, v70, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
+    "v_cndmask_b32_e32 v46, 0, v46, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
     "s_add_u32 s76, s76, %[dlo]\n\t"                                                                      \
     "s_addc_u32 s77, s77, %[dhi]\n\t"                                                                     \
-    "v_lshlrev_b32_e32 v90, 5, v70\n\t"                   /* two-step blocks are 32 bytes */              \
+    "v_lshlrev_b32_e32 v60, 5, v46\n\t"                   /* two-step blocks are 32 bytes */              \
     "v_cmp_ne_u32_e32 vcc, s78, v40\n\t"                  /* lanes on another record */                   \
     "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* E_0, E_1, leaf (0, 0), leaf (0, 1) */         \
     "s_load_dwordx8 s[64:71], s[76:77], 0x40\n\t"         /* leaf (1, 0), leaf (1, 1) */                  \
@@ -822,18 +822,18 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
 // K0 = {bits1, bits2}, K1 = {ones1, R0, R1} of the lane's two-step block: SGPR base + 32-bit byte offset while the block
 // array is below 4 GiB, a 64-bit address per lane above
 #define GBWT_WALK2U_KLOAD_NARROW                                                                          \
-    "global_load_dwordx4 v[80:83], v90, %[cblocks]\n\t"                                                   \
-    "global_load_dwordx3 v[84:86], v90, %[cblocks] offset:16\n\t"
+    "global_load_dwordx4 v[52:55], v60, %[cblocks]\n\t"                                                   \
+    "global_load_dwordx3 v[56:58], v60, %[cblocks] offset:16\n\t"
 #define GBWT_WALK2U_KLOAD_WIDE                                                                            \
-    "v_lshrrev_b32_e32 v91, 27, v70\n\t"                                                                  \
-    "v_lshl_add_u64 v[90:91], v[90:91], 0, %[cblocks]\n\t"                                                \
-    "global_load_dwordx4 v[80:83], v[90:91], off\n\t"                                                     \
-    "global_load_dwordx3 v[84:86], v[90:91], off offset:16\n\t"
+    "v_lshrrev_b32_e32 v61, 27, v46\n\t"                                                                  \
+    "v_lshl_add_u64 v[60:61], v[60:61], 0, %[cblocks]\n\t"                                                \
+    "global_load_dwordx4 v[52:55], v[60:61], off\n\t"                                                     \
+    "global_load_dwordx3 v[56:58], v[60:61], off offset:16\n\t"
 #define GBWT_WALK2U_LEAF(MASK, X, Y, Z, W)                                                                 \
     MASK "\n\t"                                                                                           \
-    "v_mov_b32_e32 v112, " X "\n\t"                       /* node to emit */                              \
-    "v_add_u32_e32 v42, " Y ", v107\n\t"                  /* the new offset = offset base + rank_b */     \
-    "v_mov_b32_e32 v114, " Z "\n\t"                       /* landing record | flags */                    \
+    "v_mov_b32_e32 v80, " X "\n\t"                       /* node to emit */                              \
+    "v_add_u32_e32 v42, " Y ", v75\n\t"                  /* the new offset = offset base + rank_b */     \
+    "v_mov_b32_e32 v81, " Z "\n\t"                       /* landing record | flags */                    \
     "v_mov_b32_e32 v43, " W "\n\t"                        /* its block base */
 #define GBWT_WALK2U_LOOP(KLOAD, REFRESH) \
     asm volatile( \
@@ -851,85 +851,85 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
         "s_bitcmp1_b32 s50, 30\n\t"                         /* DESC2_SLOW */ \
         "s_cbranch_scc1 .Lgbwt_walk2u_slow_%=\n\t" \
-        "v_lshrrev_b64 v[94:95], v42, v[80:81]\n\t"         /* bits1 >> bit */ \
-        "v_lshlrev_b64 v[96:97], v42, -1\n\t"               /* bits at and above `bit` */ \
-        "v_and_b32_e32 v94, 1, v94\n\t"                     /* a */ \
-        "v_and_b32_e32 v99, 0xffffffc0, v42\n\t"            /* offset - bit */ \
-        "v_add_u32_e32 v98, -1, v94\n\t"                    /* a ? 0 : ~0 */ \
-        "v_cmp_eq_u32_e32 vcc, 1, v94\n\t"                  /* vcc = a */ \
-        "v_xor_b32_e32 v100, v80, v98\n\t"                  /* m = a ? bits1 : ~bits1 */ \
-        "v_xor_b32_e32 v101, v81, v98\n\t" \
-        "v_bfi_b32 v100, v96, 0, v100\n\t"                  /* m below `bit` */ \
-        "v_bfi_b32 v101, v97, 0, v101\n\t" \
-        "v_sub_u32_e32 v99, v99, v84\n\t"                   /* (offset - bit) - ones1 */ \
-        "v_bcnt_u32_b32 v102, v100, 0\n\t" \
-        "v_cndmask_b32_e32 v99, v99, v84, vcc\n\t"          /* a ? ones1 : that */ \
-        "v_bcnt_u32_b32 v102, v101, v102\n\t"               /* p */ \
-        "v_cndmask_b32_e32 v106, v85, v86, vcc\n\t"         /* R_a */ \
+        "v_lshrrev_b64 v[62:63], v42, v[52:53]\n\t"         /* bits1 >> bit */ \
+        "v_lshlrev_b64 v[64:65], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v62, 1, v62\n\t"                     /* a */ \
+        "v_and_b32_e32 v67, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_add_u32_e32 v66, -1, v62\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v62\n\t"                  /* vcc = a */ \
+        "v_xor_b32_e32 v68, v52, v66\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v69, v53, v66\n\t" \
+        "v_bfi_b32 v68, v64, 0, v68\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v69, v65, 0, v69\n\t" \
+        "v_sub_u32_e32 v67, v67, v56\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v70, v68, 0\n\t" \
+        "v_cndmask_b32_e32 v67, v67, v56, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v70, v69, v70\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v74, v57, v58, vcc\n\t"         /* R_a */ \
         "s_mov_b64 s[44:45], vcc\n\t"                       /* a */ \
-        "v_add_u32_e32 v99, v99, v102\n\t"                  /* rank_a */ \
-        "v_lshrrev_b64 v[108:109], v42, v[82:83]\n\t"       /* bits2 >> bit */ \
-        "v_mov_b32_e32 v104, s48\n\t"                       /* edge 0: node */ \
-        "v_mov_b32_e32 v105, s50\n\t"                       /*         w_0 | flags */ \
-        "v_add_u32_e32 v103, s49, v99\n\t"                  /*         j = offset base + rank_a: offset in w_a */ \
+        "v_add_u32_e32 v67, v67, v70\n\t"                  /* rank_a */ \
+        "v_lshrrev_b64 v[76:77], v42, v[54:55]\n\t"       /* bits2 >> bit */ \
+        "v_mov_b32_e32 v72, s48\n\t"                       /* edge 0: node */ \
+        "v_mov_b32_e32 v73, s50\n\t"                       /*         w_0 | flags */ \
+        "v_add_u32_e32 v71, s49, v67\n\t"                  /*         j = offset base + rank_a: offset in w_a */ \
         "s_mov_b64 exec, s[44:45]\n\t"                      /* the lanes that take edge 1 */ \
-        "v_mov_b32_e32 v104, s52\n\t" \
-        "v_mov_b32_e32 v105, s54\n\t" \
-        "v_add_u32_e32 v103, s53, v99\n\t" \
+        "v_mov_b32_e32 v72, s52\n\t" \
+        "v_mov_b32_e32 v73, s54\n\t" \
+        "v_add_u32_e32 v71, s53, v67\n\t" \
         "s_mov_b64 exec, -1\n\t" \
-        "v_and_b32_e32 v100, v100, v82\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
-        "v_and_b32_e32 v101, v101, v83\n\t" \
-        "v_and_b32_e32 v108, 1, v108\n\t"                   /* b */ \
-        "v_bcnt_u32_b32 v106, v100, v106\n\t" \
-        "v_cmp_eq_u32_e64 s[46:47], 1, v108\n\t"            /* s[46:47] = b */ \
-        "v_bcnt_u32_b32 v106, v101, v106\n\t"               /* ones of w_a before j */ \
-        "v_sub_u32_e32 v107, v103, v106\n\t"                /* j - ones */ \
-        "v_and_b32_e32 v110, 0x3fffffff, v105\n\t"          /* w_a */ \
-        "v_cndmask_b32_e64 v107, v107, v106, s[46:47]\n\t"  /* rank_b */ \
+        "v_and_b32_e32 v68, v68, v54\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v69, v69, v55\n\t" \
+        "v_and_b32_e32 v76, 1, v76\n\t"                   /* b */ \
+        "v_bcnt_u32_b32 v74, v68, v74\n\t" \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v76\n\t"            /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v74, v69, v74\n\t"               /* ones of w_a before j */ \
+        "v_sub_u32_e32 v75, v71, v74\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v78, 0x3fffffff, v73\n\t"          /* w_a */ \
+        "v_cndmask_b32_e64 v75, v75, v74, s[46:47]\n\t"  /* rank_b */ \
         GBWT_WALK2U_LEAF("s_nor_b64 exec, s[44:45], s[46:47]", "s56", "s57", "s58", "s59")     /* lanes of leaf (0, 0) */ \
         GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[46:47], s[44:45]", "s60", "s61", "s62", "s63")   /*          leaf (0, 1) */ \
         GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[44:45], s[46:47]", "s64", "s65", "s66", "s67")   /*          leaf (1, 0) */ \
         GBWT_WALK2U_LEAF("s_and_b64 exec, s[44:45], s[46:47]", "s68", "s69", "s70", "s71")     /*          leaf (1, 1) */ \
         "s_mov_b64 exec, -1\n\t" \
-        "v_and_b32_e32 v40, 0x3fffffff, v114\n\t"           /* the new record */ \
-        "v_mov_b32_e32 v76, s72\n\t"                        /* mailbox: look-ahead target of the record just left (before its SGPRs are reloaded) ... */ \
-        "v_mov_b32_e32 v77, s73\n\t" \
-        "v_mov_b32_e32 v78, s74\n\t" \
+        "v_and_b32_e32 v40, 0x3fffffff, v81\n\t"           /* the new record */ \
+        "v_mov_b32_e32 v48, s72\n\t"                        /* mailbox: look-ahead target of the record just left (before its SGPRs are reloaded) ... */ \
+        "v_mov_b32_e32 v49, s73\n\t" \
+        "v_mov_b32_e32 v50, s74\n\t" \
         GBWT_WALK2U_ISSUE(KLOAD, "")                        /* the loads of the next position go out now; staging the nodes runs underneath them */ \
         "s_nop 1\n\t" \
         "s_mov_b64 s[44:45], vcc\n\t"                       /* lanes that are not on the record of lane 0 */ \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
-        "v_cmp_ne_u32_e32 vcc, 0, v104\n\t" \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v104\n\t"                        /* node of edge a */ \
+        "v_and_b32_e32 v47, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v72\n\t" \
+        "v_mad_u32_u24 v47, v47, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v47, v72\n\t"                        /* node of edge a */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
-        "v_cmp_gt_i32_e32 vcc, 0, v105\n\t"                 /* first step fused? */ \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_add_u32_e32 v110, s41, v110\n\t"                 /* node of w_a */ \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v110\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v73\n\t"                 /* first step fused? */ \
+        "v_and_b32_e32 v47, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v78, s41, v78\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v47, v47, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v47, v78\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
-        "v_cmp_ne_u32_e32 vcc, 0, v112\n\t" \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_add_u32_e32 v111, s41, v40\n\t"                  /* node of the landing record */ \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v112\n\t"                        /* node of the leaf */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v80\n\t" \
+        "v_and_b32_e32 v47, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v79, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v47, v47, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v47, v80\n\t"                        /* node of the leaf */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
-        "v_cmp_gt_i32_e32 vcc, 0, v114\n\t"                 /* second step fused? */ \
-        "v_and_b32_e32 v92, %[ringmask], v44\n\t" \
-        "v_mad_u32_u24 v92, v92, %[stride], %[ring]\n\t" \
-        "ds_write_b32 v92, v111\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v81\n\t"                 /* second step fused? */ \
+        "v_and_b32_e32 v47, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v47, v47, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v47, v79\n\t" \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"           /* a walker that has emitted its share parks */ \
-        "v_mov_b32_e32 v79, v44\n\t"                        /* ... + nodes staged so far */ \
-        "ds_write_b128 %[mail], v[76:79]\n\t" \
+        "v_mov_b32_e32 v51, v44\n\t"                        /* ... + nodes staged so far */ \
+        "ds_write_b128 %[mail], v[48:51]\n\t" \
         "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
         "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
         "s_andn2_b64 s[46:47], exec, vcc\n\t"               /* lanes that have just parked: their loads were for nothing, and the wave is no longer on one record */ \
-        "v_sub_u32_e32 v92, v44, v45\n\t"                   /* nodes waiting in the ring (drained as of the last iteration) */ \
+        "v_sub_u32_e32 v47, v44, v45\n\t"                   /* nodes waiting in the ring (drained as of the last iteration) */ \
         "s_or_b64 s[44:45], s[44:45], s[46:47]\n\t" \
         REFRESH \
-        "v_cmp_lt_u32_e64 s[46:47], %[slack], v92\n\t"      /* more than slots - 8 of them */ \
+        "v_cmp_lt_u32_e64 s[46:47], %[slack], v47\n\t"      /* more than slots - 8 of them */ \
         "s_cmp_lg_u64 s[44:45], 0\n\t" \
         "s_cbranch_scc1 .Lgbwt_walk2u_mixed_%=\n\t" \
         "s_cmp_eq_u32 s78, 0\n\t" \
@@ -953,8 +953,8 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
           [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
-          "v40", "v42", "v43", "v44", "v45", "v70", "v91", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v90", "v92", "v94", "v95", \
-          "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v114");
+          "v40", "v42", "v43", "v44", "v45", "v46", "v61", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v47", "v62", "v63", \
+          "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81");
     // the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered
     // with, it had to leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted
     // round of loads)

@@ -19,7 +19,7 @@ for cfg in "${CFGS[@]}"; do
         d="$out/$tag/pass$i"
         rm -rf "$d"; mkdir -p "$out/$tag"
         # shellcheck disable=SC2086
-        timeout --foreground 120 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$d" -- python3 "$root/tools/sweep_env.py" --reps 2 ${SWEEP_ARGS:-} --configs "$cfg" > "$d.log" 2>&1
+        timeout --foreground -k 10 120 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$d" -- python3 "$root/tools/sweep_env.py" --reps 2 ${SWEEP_ARGS:-} --configs "$cfg" > "$d.log" 2>&1
         echo "## pass $i: $group"
         python3 "$root/tools/pmc_summary.py" "$d" k_walk
     done
