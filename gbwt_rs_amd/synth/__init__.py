@@ -22,7 +22,7 @@ def lib():
         L.gbwt_synth_chain.restype = p
         L.gbwt_synth_chain.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64]
         L.gbwt_synth_chain_indel.restype = p
-        L.gbwt_synth_chain_indel.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32]
+        L.gbwt_synth_chain_indel.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32]
         L.gbwt_synth_from_paths.restype = p
         L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
         L.gbwt_synth_from_file.restype = p
@@ -62,9 +62,10 @@ class Synth:
         self.bidirectional = bool(bd)
 
     @classmethod
-    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0):
-        """`extra` > 0: alleles >= 1 are insertions of `extra` more nodes (paths of different lengths; gbwt_synth.h)."""
-        h = lib().gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra)
+    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0, indel_every=1):
+        """`extra` > 0: alleles >= 1 are insertions of `extra` more nodes at every `indel_every`-th site (paths of
+        different lengths; gbwt_synth.h)."""
+        h = lib().gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every)
         if not h:
             raise ValueError("gbwt_synth_chain: parameters out of range")
         return cls(h)

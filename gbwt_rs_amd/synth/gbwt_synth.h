@@ -37,9 +37,10 @@ gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t allel
  * (allele 0 stays one node), so paths differ in length and the walks of a batch leave lock step after the first
  * site: the regime of graphs with indels.  Node ids of site s (stride = alleles + 1 + (alleles - 1) * extra):
  * anchor s*stride+1, allele nodes s*stride+2+a, tail e of allele a >= 1 at s*stride+2+alleles+(a-1)*extra+e.
+ * Only the sites s with s % indel_every == 0 carry insertions (the others are plain bubbles; their tail ids stay unused).
  * extra == 0 is gbwt_synth_chain. */
 gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
-                                   double switch_rate, double zipf, uint64_t seed, uint32_t extra);
+                                   double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every);
 
 /* Paths as CSR over GBWT-encoded nodes (2 * id + orientation, id >= 1).  bidirectional != 0 adds the
  * reverse sequence of every path (src/support.rs:310-314).  No metadata, no graph. */

@@ -79,7 +79,8 @@ struct gbwt_synth {
     HostIndex index;
     // chain truth
     uint64_t sites = 0, haplotypes = 0, alleles = 0;
-    uint64_t extra = 0;             // alleles >= 1 are insertions: `extra` more nodes behind the allele node
+    uint64_t extra = 0;             // alleles >= 1 are insertions: `extra` more nodes behind the allele node ...
+    uint64_t indel_every = 1;       // ... at the sites s with s % indel_every == 0 (the tail ids of the other sites stay unused)
     std::vector<uint64_t> bits;     // alleles == 2: site-major bit rows
     uint64_t row_words = 0;
     std::vector<uint16_t> choices;  // alleles > 2: site-major
@@ -100,7 +101,8 @@ struct gbwt_synth {
     inline uint64_t anchor_id(uint64_t s) const { return s * stride() + 1; }
     inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * stride() + 2 + a; }
     inline uint64_t tail_id(uint64_t s, uint32_t a, uint64_t e) const { return s * stride() + 2 + alleles + (a - 1) * extra + e; }
-    inline uint64_t last_id(uint64_t s, uint32_t a) const { return (a == 0 || extra == 0) ? allele_id(s, a) : tail_id(s, a, extra - 1); }
+    inline uint64_t extra_at(uint64_t s) const { return s % indel_every == 0 ? extra : 0; }
+    inline uint64_t last_id(uint64_t s, uint32_t a) const { return (a == 0 || extra_at(s) == 0) ? allele_id(s, a) : tail_id(s, a, extra - 1); }
 };
 
 namespace {
@@ -221,7 +223,7 @@ void forward_sweep(const gbwt_synth &g, Pool &pool) {
         for (uint64_t a = 0; a < A; a++) {
             pool.start[base + 1 + a] = pool.bytes.size();
             if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
-            if (a == 0 || X == 0) leave(a);
+            if (a == 0 || g.extra_at(s) == 0) leave(a);
             else { edges.clear(); edges.emplace_back(2 * g.tail_id(s, static_cast<uint32_t>(a), 0), 0); }
             rw.begin(edges);
             rw.push(0, st.cnt[a]);
@@ -231,7 +233,7 @@ void forward_sweep(const gbwt_synth &g, Pool &pool) {
         for (uint64_t a = 1; a < A; a++) {
             for (uint64_t e = 0; e < X; e++) {
                 pool.start[base + 1 + A + (a - 1) * X + e] = pool.bytes.size();
-                if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
+                if (!st.cnt[a] || g.extra_at(s) == 0) { pool.bytes.push_back(0); continue; }
                 if (e + 1 == X) leave(a);
                 else { edges.clear(); edges.emplace_back(2 * g.tail_id(s, static_cast<uint32_t>(a), e + 1), 0); }
                 rw.begin(edges);
@@ -290,7 +292,7 @@ void reverse_sweep(const gbwt_synth &g, Pool &pool) {
         for (uint64_t a = 1; a < A; a++) {
             for (uint64_t e = 0; e < X; e++) {
                 pool.start[base + 1 + A + (a - 1) * X + e] = pool.bytes.size();
-                if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
+                if (!st.cnt[a] || g.extra_at(s) == 0) { pool.bytes.push_back(0); continue; }
                 edges.clear();
                 edges.emplace_back(2 * (e == 0 ? g.allele_id(s, static_cast<uint32_t>(a)) : g.tail_id(s, static_cast<uint32_t>(a), e - 1)) + 1, 0);
                 rw.begin(edges);
@@ -380,11 +382,11 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     ix.sequences_labels.offsets.reserve(S * W + 1);
     for (uint64_t s = 0; s < S; s++) {
         st.compute(g, s);
-        inserted += n - st.cnt[0];
+        if (g.extra_at(s)) inserted += n - st.cnt[0];
         for (uint64_t k = 0; k < W; k++) {
             if (s * W + k + 1 > g.last_id(S - 1, top)) break;  // ids past the largest visited node
             const uint64_t a = k == 0 ? 0 : (k <= A ? k - 1 : 1 + (k - 1 - A) / g.extra);
-            if (k == 0 || st.cnt[a]) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
+            if (k == 0 || (st.cnt[a] && (k <= A || g.extra_at(s)))) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
             ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
         }
     }
@@ -473,14 +475,14 @@ extern "C" {
 
 gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                              double switch_rate, double zipf, uint64_t seed) {
-    return gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, 0);
+    return gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, 0, 1);
 }
 
 gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
-                                   double switch_rate, double zipf, uint64_t seed, uint32_t extra) {
-    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64) return nullptr;
+                                   double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every) {
+    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64 || indel_every == 0) return nullptr;
     gbwt_synth *g = new gbwt_synth;
-    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra;
+    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra; g->indel_every = indel_every;
     if (alleles == 2) { g->row_words = (haplotypes + 63) / 64; g->bits.assign(sites * g->row_words, 0); }
     else g->choices.assign(sites * haplotypes, 0);
     draw_alleles(*g, model, founders, switch_rate, zipf, seed);
@@ -586,7 +588,7 @@ uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, u
             const uint32_t a = s->allele(site, path_id);
             put(s->anchor_id(site));
             put(s->allele_id(site, a));
-            if (a) for (uint64_t e = 0; e < s->extra; e++) put(s->tail_id(site, a, e));
+            if (a) for (uint64_t e = 0; e < s->extra_at(site); e++) put(s->tail_id(site, a, e));
         }
         return len;
     }
@@ -603,7 +605,7 @@ uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id) {
         for (uint64_t site = 0; site < s->sites; site++) {
             const uint32_t a = s->allele(site, path_id);
             sum += 2 * s->anchor_id(site) + 2 * s->allele_id(site, a);
-            if (a) for (uint64_t e = 0; e < s->extra; e++) sum += 2 * s->tail_id(site, a, e);
+            if (a) for (uint64_t e = 0; e < s->extra_at(site); e++) sum += 2 * s->tail_id(site, a, e);
         }
         return sum;
     }

@@ -96,11 +96,12 @@ def test_chain_generator_matches_bruteforce_builder(alleles, model):
     assert (s.sequences, s.size, s.alphabet_offset, s.alphabet_size) == (b.sequences, b.size, b.alphabet_offset, b.alphabet_size)
 
 
-@pytest.mark.parametrize("alleles,model,extra", [(2, S.MOSAIC, 1), (2, S.IID, 3), (5, S.MOSAIC, 2), (40, S.IID, 1)])
-def test_indel_chain_matches_bruteforce_builder(alleles, model, extra):
+@pytest.mark.parametrize("alleles,model,extra,every", [(2, S.MOSAIC, 1, 1), (2, S.IID, 3, 1), (5, S.MOSAIC, 2, 1), (40, S.IID, 1, 1),
+                                                       (2, S.MOSAIC, 2, 3), (4, S.IID, 1, 4), (2, S.IID, 1, 9)])
+def test_indel_chain_matches_bruteforce_builder(alleles, model, extra, every):
     """Insertion alleles (paths of different lengths): the sweep generator still agrees with the brute-force builder
     byte for byte, and its checksums and header follow the longer paths."""
-    s = S.Synth.chain(sites=9, haplotypes=21, alleles=alleles, model=model, founders=4, switch_rate=0.2, seed=8, extra=extra)
+    s = S.Synth.chain(sites=9, haplotypes=21, alleles=alleles, model=model, founders=4, switch_rate=0.2, seed=8, extra=extra, indel_every=every)
     paths = [[int(x) for x in s.path(h)] for h in range(s.paths)]
     assert len({len(p) for p in paths}) > 1
     for h, p in enumerate(paths):
