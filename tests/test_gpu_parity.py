@@ -486,6 +486,26 @@ def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
     assert dev.path_lines(np.arange(1, 40, dtype=np.uint64), 1) == O.OracleGBZ(str(path)).path_lines(list(range(1, 40)), 1)
 
 
+@pytest.mark.parametrize("env", [{"GBWT_HIP_WIDE_ADDRESSES": "1"}, {"GBWT_HIP_RING_SLOTS": "32"}, {"GBWT_HIP_UNIFORM_LOOP": "0"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_HELPER_LANES": "0"}])
+def test_gather_loop_variants(monkeypatch, env):
+    """The loop for mixed waves with 64-bit addresses, with a ring asked for that is smaller than two row pieces (the library
+    raises it: a 32-slot ring never holds a 128-byte piece and the walk would not end), as the only loop, and with short
+    segments; sparse and dense insertions, every path against the generator's allele matrix."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for every in (1, 37):
+        s = S.Synth.chain(sites=6000, haplotypes=700, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=77, extra=1, indel_every=every)
+        dev = open_synth(s)
+        ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
+        out = dev.extract_device(ids)
+        assert int(out.total) == (s.size - s.sequences) // 2
+        sums = dev.path_sums(len(ids))
+        assert all(int(sums[h]) == s.path_checksum(h) for h in range(s.paths))
+        for h in (0, 350, 699):
+            assert np.array_equal(dev.copy_path(h), s.path(h))
+
+
 def test_indel_chain_scale_properties():
     """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix."""
     s = S.Synth.chain(sites=60000, haplotypes=3000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=9, extra=2)
