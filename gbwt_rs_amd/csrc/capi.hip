@@ -108,8 +108,14 @@ void upload(gbwt_hip_index &ix) {
             HIP_CHECK(hipMemsetAsync(ix.cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.desc2 = ix.desc2.as<uint4>();
             d.cblocks = ix.cblocks.as<uint4>();
-            launch_link_desc2(d, ix.desc2.as<uint4>(), nullptr);
+            uint32_t gather_limit = 1u << 21;     // the counts of the gather loop's packed blocks (tests lower it)
+            if (const char *v = std::getenv("GBWT_HIP_GATHER_LIMIT")) gather_limit = static_cast<uint32_t>(std::min<long>(1l << 21, std::max<long>(0, std::atol(v))));
+            launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, nullptr);
             if (n_blocks > 1) launch_fill_cblocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), nullptr);
+            ix.gblocks.reserve(n_blocks * 2 * sizeof(uint4));
+            HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
+            d.gblocks = ix.gblocks.as<uint4>();
+            if (n_blocks > 1) launch_fill_gblocks(d, counts.as<uint32_t>(), ix.gblocks.as<uint4>(), nullptr);
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
         // LF tables for the class 0 records, while they fit the budget

@@ -73,7 +73,8 @@ constexpr uint32_t DESC_SLOW = 1u << 31;             // walk descriptor, D.x: ge
 constexpr uint32_t LOOKAHEAD_COUNT_MASK = (1u << 29) - 1;
 constexpr uint32_t REC_MASK = (1u << 30) - 1;       // record indices are < 2^30; bits 30-31 of a record word carry flags
 constexpr uint32_t LEAF_EMIT2 = 1u << 31;            // two-step descriptor: this step is fused with a unary successor
-constexpr uint32_t DESC2_SLOW = 1u << 30;            // two-step descriptor, word F1.x: generic decode
+constexpr uint32_t DESC2_SLOW = 1u << 30;            // two-step descriptor, word E_a.z: generic decode
+constexpr uint32_t GATHER_OK = 1u;                   // two-step descriptor, word E_a.w: the record's packed blocks (gblocks) can count it
 constexpr uint32_t WT_TABLE = 1u << 30;              // walk table entry: the landing record is a table record, word 3 = its table base
 constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANK_BLOCK_SHIFT = 6;   // 64 offsets per rank block
@@ -96,6 +97,7 @@ struct DeviceIndex {
     const uint64_t *sample_base;   // n_sequences + 1: first sample of every sequence
     uint32_t sample_interval;  // a sample about every this many nodes
     const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
+    const uint4 *gblocks;      // 2 * n_blocks entries: the same, one 16-byte entry per 32 offsets with packed counts (gather loop)
     uint64_t data_len;
     uint64_t n_records;
     uint64_t n_sequences;      // header.sequences

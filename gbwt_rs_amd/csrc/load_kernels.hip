@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) k_fill_wtables(DeviceIndex ix, uint4 *wta
 // The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
 // The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
 // memory -- takes TWO LF steps (up to four nodes with fused unary successors):
-//   desc2[8 * v + a] = E_a = {node to emit for edge a, offset base in w_a, w_a | LEAF_EMIT2 | DESC2_SLOW, 0}   (first step, a = 0, 1;
+//   desc2[8 * v + a] = E_a = {node to emit for edge a, offset base in w_a, w_a | LEAF_EMIT2 | DESC2_SLOW, GATHER_OK}   (first step, a = 0, 1;
 //                            DESC2_SLOW: whole record, set in both; one 12-byte load per edge, so that a walker that knows a needs one)
 //   desc2[8 * v + 2 + 2 * a + b] = leaf (a, b) = {node to emit, offset base, landing record | LEAF_EMIT2, block base}
 //   desc2[8 * v + 6] = look-ahead {record, first block, number of blocks, 0};  [7] unused
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256) k_fill_wtables(DeviceIndex ix, uint4 *wta
 // (bits2) and the number of value-1 positions of w_a before the landing offset of the block's first a-path (R_a), so
 // the rank inside w_a is again one popcount.  Where the second step is not real (w_a generic, sequence ending, v
 // unary and w_a branching) the leaf (a, 0) is the identity: "emit nothing, stay in w_a at the offset reached".
-__global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out) {
+__global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, uint32_t gather_limit) {
     uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (v >= ix.n_records) return;
     const uint4 *d1 = ix.desc;
@@ -355,9 +355,13 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out) 
             }
         }
     }
+    // the gather loop's packed blocks hold counts of 21 / 22 bits: positions of v and of the records behind its edges
+    bool packed = VB.w < gather_limit;
+    for (uint32_t a = 0; a < 2; a++)
+        if (wword[a] & REC_MASK) packed = packed && ix.desc_raw[4 * static_cast<uint64_t>(wword[a] & REC_MASK) + 1].w < gather_limit;
     uint4 *o = out + 8 * v;
-    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), 0u);
-    o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), 0u);
+    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), packed ? GATHER_OK : 0u);
+    o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), packed ? GATHER_OK : 0u);
     o[2] = leaf[0]; o[3] = leaf[1]; o[4] = leaf[2]; o[5] = leaf[3];
     o[6] = make_uint4(0u, 0u, 0u, 0u);
     o[7] = make_uint4(0u, 0u, 0u, 0u);
@@ -425,6 +429,71 @@ __global__ void __launch_bounds__(256) k_fill_cblocks(DeviceIndex ix, const uint
         }
         cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
         cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
+    }
+}
+
+// The same blocks for the gather loop (walk_loops.hpp), where every load instruction costs a pass of the address path over sixty-four
+// lines: ONE 16-byte load per step instead of two.  Half a block each -- 32 offsets -- with the three counts packed:
+//   gblocks[2 * k + h] = {bits1 (32 values of v), bits2, ones1 | R_0 << 21, R_0 >> 11 | R_1 << 10}      (ones1, R_0 < 2^21, R_1 < 2^22)
+// for the offsets 64 k + 32 h ...; ones1 and R_a count up to the half's first offset / first a-path.  Records that do not fit the
+// counts have GATHER_OK cleared in their descriptor (k_link_desc2) and step in C++ when they turn up in a mixed wave.
+__global__ void __launch_bounds__(256) k_fill_gblocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *gblocks) {
+    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (v >= ix.n_records) return;
+    const uint32_t count = block_counts[v];
+    if (count == 0) return;
+    const uint4 *d1 = ix.desc;
+    const uint4 D = d1[4 * v + 2];
+    const uint32_t len = ix.desc_raw[4 * v + 1].w;
+    const uint32_t bb = ix.block_base[v];
+    const uint4 *wblocks[2] = {nullptr, nullptr};
+    uint32_t wbase[2] = {0, 0};
+    if (!(D.x & DESC_SLOW)) {
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint32_t f = a ? D.w : D.y;
+            if (!(f & EDGE_CONT)) continue;
+            const uint4 E = d1[4 * v + a];
+            const uint64_t w = E.z;
+            const uint4 WB = ix.desc_raw[4 * w + 1];
+            if ((d1[4 * w + 2].x & DESC_SLOW) || WB.y == 0 || desc_class(WB.z) != 2) continue;
+            wblocks[a] = ix.blocks + ix.block_base[w];
+            wbase[a] = E.y;
+        }
+    }
+    for (uint32_t k = 0; k < count; k++) {
+        const uint4 P = ix.blocks[bb + k];
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t first = (k << RANK_BLOCK_SHIFT) + 32u * h;                  // first offset of this half
+            const uint32_t remaining = first > len ? 0u : len - first;
+            const uint32_t valid = remaining >= 32 ? ~0u : ((1u << remaining) - 1);
+            const uint32_t bits1 = h ? P.y : P.x;
+            const uint32_t ones1 = P.z + (h ? __popc(P.x) : 0u);
+            uint32_t bits2 = 0, R[2] = {0, 0};
+            for (uint32_t a = 0; a < 2; a++) {
+                if (!wblocks[a]) continue;
+                uint32_t m = (a ? bits1 : ~bits1) & valid;
+                const uint32_t cnt = __popc(m);
+                if (cnt == 0) continue;
+                const uint32_t before = a ? ones1 : first - ones1;                        // a-paths of v before this half
+                const uint32_t j = wbase[a] + before;                                     // where the first a-path lands in w_a
+                const uint32_t q = j >> RANK_BLOCK_SHIFT, sh = j & 63u;
+                const uint4 W0 = wblocks[a][q];
+                const uint64_t w0 = (static_cast<uint64_t>(W0.y) << 32) | W0.x;
+                R[a] = W0.z + __popcll(w0 & ((uint64_t(1) << sh) - 1));
+                uint64_t val = w0 >> sh;
+                if (sh != 0 && cnt > 64 - sh) {
+                    const uint4 W1 = wblocks[a][q + 1];
+                    val |= ((static_cast<uint64_t>(W1.y) << 32) | W1.x) << (64 - sh);
+                }
+                while (m) {
+                    const uint32_t low = m & (~m + 1);
+                    if (val & 1) bits2 |= low;
+                    val >>= 1;
+                    m ^= low;
+                }
+            }
+            gblocks[2 * static_cast<uint64_t>(bb + k) + h] = make_uint4(bits1, bits2, (ones1 & 0x1FFFFFu) | (R[0] << 21), ((R[0] >> 11) & 0x3FFu) | (R[1] << 10));
+        }
     }
 }
 
@@ -558,9 +627,14 @@ void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t st
     hipLaunchKernelGGL(k_fill_wtables, dim3(static_cast<unsigned>(ix.n_records)), dim3(256), 0, stream, ix, d_wtables);
 }
 
-void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, hipStream_t stream) {
+void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2);
+    hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, gather_limit);
+}
+
+void launch_fill_gblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_gblocks, hipStream_t stream) {
+    if (ix.n_records == 0) return;
+    hipLaunchKernelGGL(k_fill_gblocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_gblocks);
 }
 
 void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream) {

@@ -427,12 +427,15 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (!together) probe_mixed_entries++;
         if (slow_exit == 2 && together) probe_fell_out++;
 #endif
-        if (slow_exit == 2) slow_exit = walk2_gather_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+        const bool mixed = slow_exit == 2;
+        if (slow_exit == 2) slow_exit = walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif
         if (slow_exit) {
-            bool generic = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec)].z & DESC2_SLOW) != 0;   // lanes on a slow record
+            const uint4 here = ix.desc2[8 * static_cast<uint64_t>(rec)];
+            bool generic = rec != 0 && (here.z & DESC2_SLOW) != 0;   // lanes on a slow record
+            const bool unpacked = mixed && rec != 0 && !generic && !(here.w & GATHER_OK);   // ... on a record too long for the gather loop's packed counts
             if (ix.wtables != nullptr) {
                 // Lanes on a table record walk on the walk tables: one 16-byte entry per step says what to emit (the
                 // successor and, where a unary record follows, the node behind it), where the walk lands and -- when that
@@ -462,6 +465,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
             if (generic) {   // no table (or no walk tables at all): one step of the generic decoder with all the reference's tests
                 generic_step(ix, sink, rec, offset, bb);
+                if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+            }
+            if (unpacked) {  // one iteration on the full-width blocks
+                two_step(ix, sink, rec, offset, bb);
                 if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
             }
             lds_poke(my_mail + 3, sink.wr);

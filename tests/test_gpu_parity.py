@@ -487,11 +487,13 @@ def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
 
 
 @pytest.mark.parametrize("env", [{"GBWT_HIP_WIDE_ADDRESSES": "1"}, {"GBWT_HIP_RING_SLOTS": "32"}, {"GBWT_HIP_UNIFORM_LOOP": "0"},
-                                 {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_HELPER_LANES": "0"}])
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_HELPER_LANES": "0"},
+                                 {"GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_GATHER_LIMIT": "0", "GBWT_HIP_WIDE_ADDRESSES": "1"}])
 def test_gather_loop_variants(monkeypatch, env):
     """The loop for mixed waves with 64-bit addresses, with a ring asked for that is smaller than two row pieces (the library
-    raises it: a 32-slot ring never holds a 128-byte piece and the walk would not end), as the only loop, and with short
-    segments; sparse and dense insertions, every path against the generator's allele matrix."""
+    raises it: a 32-slot ring never holds a 128-byte piece and the walk would not end), as the only loop, with short
+    segments, and with records declared too long for the packed counts of its blocks (some / all of them: those lanes step
+    in C++ on the full-width blocks); sparse and dense insertions, every path against the generator's allele matrix."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for every in (1, 37):
