@@ -361,7 +361,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(look_rec);
                 touch_line(d, dummy);
                 touch_line(d + 4, dummy);
-                touch_line(ix.cblocks + 2 * (static_cast<uint64_t>(look_base) + __umulhi(spread, look_count)), dummy);
+                // the two block arrays have the same geometry (32 bytes per 64 offsets); bit 31 of the count: the walker is on the full-width one
+                const uint4 *const blocks = (look_count & 0x80000000u) ? ix.cblocks : ix.gblocks;
+                touch_line(blocks + 2 * (static_cast<uint64_t>(look_base) + __umulhi(spread, look_count & 0x7FFFFFFFu)), dummy);
             }
             seen = stamp;
             if (piece) {
@@ -409,6 +411,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE   // measurement only: nodes staged by each of the two loops, for a few workgroups (profiles/r02_walk_bounds.txt #16)
     uint32_t probe_uniform = 0, probe_vector = 0, probe_entries = 0, probe_mixed_entries = 0, probe_fell_out = 0;
 #endif
+    bool full_blocks = false;    // wave-uniform
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
@@ -420,7 +423,13 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t wr0 = sink.wr;
         probe_entries++;
 #endif
-        uint32_t slow_exit = a.uniform_loop && together ? walk2_uniform_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr) : 2u;
+        uint32_t slow_exit = 2;
+        if (a.uniform_loop && together) {
+            // on the packed half-blocks until the wave meets a record they cannot count (reason 3), on the full-width blocks from then on
+            if (!full_blocks) slow_exit = walk2_uniform_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+            if (slow_exit == 3) full_blocks = true;
+            if (full_blocks) slow_exit = walk2_uniform_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+        }
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         const uint32_t wr1 = sink.wr;
         probe_uniform += wr1 - wr0;

@@ -783,30 +783,21 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
 // and only the two-step rank block -- the one thing that differs between lanes -- goes through the vector path
 // (28 bytes per lane instead of 132).  gfx9 VALU instructions read at most one SGPR, so instead of v_cndmask the
 // per-lane choices are made by running the same `v_mov / v_add  vgpr, sgpr` under the exec mask of each choice.
-// Same registers and conventions as walk2_hot_loop.  Leaves with reason 2 -- nothing in flight, state intact -- as
-// soon as the lanes are not all on one record (or some are parked); the caller then continues with walk2_hot_loop.
+// Conventions of walk2_hot_loop, registers v40-v81.  Leaves with reason 2 -- nothing in flight, state intact -- as
+// soon as the lanes are not all on one record (or some are parked); the caller then continues with the loop for mixed waves.
 // SGPRs: s[48:63] E_0 E_1 L00 L01, s[64:71] L10 L11, s[72:75] look-ahead target, s[76:85] masks, s[88:89] descriptor
 // address, s78 the record.
-__device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
-                                                       uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
-                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
-#ifdef GBWT_HIP_CXX_LOOP
-    return 2;
-#else
-    uint32_t reason;
-    const uint32_t slack = ring_mask + 1 - 8;   // leave with more than slots - 8 nodes waiting in a ring
-    const uint32_t dlo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2)), dhi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2) >> 32);
+#ifndef GBWT_HIP_CXX_LOOP
 #define GBWT_WALK2U_ISSUE(KLOAD, REFRESH)                                                                             \
     "v_readfirstlane_b32 s78, v40\n\t"                    /* the record of lane 0 */                       \
     "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                   /* bb != BLOCK_NONE */                          \
-    "v_lshrrev_b32_e32 v46, 6, v42\n\t"                                                                   \
-    "v_add_u32_e32 v46, v46, v43\n\t"                                                                     \
+    GBWT_WALK2U_INDEX                                                                                     \
     "s_lshl_b32 s76, s78, 7\n\t"                          /* two-step descriptors are 128 bytes */        \
     "s_lshr_b32 s77, s78, 25\n\t"                                                                         \
     "v_cndmask_b32_e32 v46, 0, v46, vcc\n\t"              /* block bb + offset / 64, or the zero block */ \
     "s_add_u32 s76, s76, %[dlo]\n\t"                                                                      \
     "s_addc_u32 s77, s77, %[dhi]\n\t"                                                                     \
-    "v_lshlrev_b32_e32 v60, 5, v46\n\t"                   /* two-step blocks are 32 bytes */              \
+    GBWT_WALK2U_BYTES                                                                                     \
     "v_cmp_ne_u32_e32 vcc, s78, v40\n\t"                  /* lanes on another record */                   \
     "s_load_dwordx16 s[48:63], s[76:77], 0x0\n\t"         /* E_0, E_1, leaf (0, 0), leaf (0, 1) */         \
     "s_load_dwordx8 s[64:71], s[76:77], 0x40\n\t"         /* leaf (1, 0), leaf (1, 1) */                  \
@@ -815,14 +806,6 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
     REFRESH
 // K0 = {bits1, bits2}, K1 = {ones1, R0, R1} of the lane's two-step block: SGPR base + 32-bit byte offset while the block
 // array is below 4 GiB, a 64-bit address per lane above
-#define GBWT_WALK2U_KLOAD_NARROW                                                                          \
-    "global_load_dwordx4 v[52:55], v60, %[cblocks]\n\t"                                                   \
-    "global_load_dwordx3 v[56:58], v60, %[cblocks] offset:16\n\t"
-#define GBWT_WALK2U_KLOAD_WIDE                                                                            \
-    "v_lshrrev_b32_e32 v61, 27, v46\n\t"                                                                  \
-    "v_lshl_add_u64 v[60:61], v[60:61], 0, %[cblocks]\n\t"                                                \
-    "global_load_dwordx4 v[52:55], v[60:61], off\n\t"                                                     \
-    "global_load_dwordx3 v[56:58], v[60:61], off offset:16\n\t"
 #define GBWT_WALK2U_LEAF(MASK, X, Y, Z, W)                                                                 \
     MASK "\n\t"                                                                                           \
     "v_mov_b32_e32 v80, " X "\n\t"                       /* node to emit */                              \
@@ -845,24 +828,8 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
         "s_bitcmp1_b32 s50, 30\n\t"                         /* DESC2_SLOW */ \
         "s_cbranch_scc1 .Lgbwt_walk2u_slow_%=\n\t" \
-        "v_lshrrev_b64 v[62:63], v42, v[52:53]\n\t"         /* bits1 >> bit */ \
-        "v_lshlrev_b64 v[64:65], v42, -1\n\t"               /* bits at and above `bit` */ \
-        "v_and_b32_e32 v62, 1, v62\n\t"                     /* a */ \
-        "v_and_b32_e32 v67, 0xffffffc0, v42\n\t"            /* offset - bit */ \
-        "v_add_u32_e32 v66, -1, v62\n\t"                    /* a ? 0 : ~0 */ \
-        "v_cmp_eq_u32_e32 vcc, 1, v62\n\t"                  /* vcc = a */ \
-        "v_xor_b32_e32 v68, v52, v66\n\t"                  /* m = a ? bits1 : ~bits1 */ \
-        "v_xor_b32_e32 v69, v53, v66\n\t" \
-        "v_bfi_b32 v68, v64, 0, v68\n\t"                  /* m below `bit` */ \
-        "v_bfi_b32 v69, v65, 0, v69\n\t" \
-        "v_sub_u32_e32 v67, v67, v56\n\t"                   /* (offset - bit) - ones1 */ \
-        "v_bcnt_u32_b32 v70, v68, 0\n\t" \
-        "v_cndmask_b32_e32 v67, v67, v56, vcc\n\t"          /* a ? ones1 : that */ \
-        "v_bcnt_u32_b32 v70, v69, v70\n\t"               /* p */ \
-        "v_cndmask_b32_e32 v74, v57, v58, vcc\n\t"         /* R_a */ \
-        "s_mov_b64 s[44:45], vcc\n\t"                       /* a */ \
-        "v_add_u32_e32 v67, v67, v70\n\t"                  /* rank_a */ \
-        "v_lshrrev_b64 v[76:77], v42, v[54:55]\n\t"       /* bits2 >> bit */ \
+        GBWT_WALK2U_FLAG_CHECK \
+        GBWT_WALK2U_RANK_A \
         "v_mov_b32_e32 v72, s48\n\t"                       /* edge 0: node */ \
         "v_mov_b32_e32 v73, s50\n\t"                       /*         w_0 | flags */ \
         "v_add_u32_e32 v71, s49, v67\n\t"                  /*         j = offset base + rank_a: offset in w_a */ \
@@ -871,12 +838,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "v_mov_b32_e32 v73, s54\n\t" \
         "v_add_u32_e32 v71, s53, v67\n\t" \
         "s_mov_b64 exec, -1\n\t" \
-        "v_and_b32_e32 v68, v68, v54\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
-        "v_and_b32_e32 v69, v69, v55\n\t" \
-        "v_and_b32_e32 v76, 1, v76\n\t"                   /* b */ \
-        "v_bcnt_u32_b32 v74, v68, v74\n\t" \
-        "v_cmp_eq_u32_e64 s[46:47], 1, v76\n\t"            /* s[46:47] = b */ \
-        "v_bcnt_u32_b32 v74, v69, v74\n\t"               /* ones of w_a before j */ \
+        GBWT_WALK2U_RANK_B \
         "v_sub_u32_e32 v75, v71, v74\n\t"                /* j - ones */ \
         "v_and_b32_e32 v78, 0x3fffffff, v73\n\t"          /* w_a */ \
         "v_cndmask_b32_e64 v75, v75, v74, s[46:47]\n\t"  /* rank_b */ \
@@ -889,6 +851,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         "v_mov_b32_e32 v48, s72\n\t"                        /* mailbox: look-ahead target of the record just left (before its SGPRs are reloaded) ... */ \
         "v_mov_b32_e32 v49, s73\n\t" \
         "v_mov_b32_e32 v50, s74\n\t" \
+        GBWT_WALK2U_MAIL_FLAG \
         GBWT_WALK2U_ISSUE(KLOAD, "")                        /* the loads of the next position go out now; staging the nodes runs underneath them */ \
         "s_nop 1\n\t" \
         "s_mov_b64 s[44:45], vcc\n\t"                       /* lanes that are not on the record of lane 0 */ \
@@ -934,6 +897,9 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
         ".Lgbwt_walk2u_slow_%=:\n\t" \
         "s_mov_b32 %[reason], 1\n\t" \
         "s_branch .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_unpacked_%=:\n\t" \
+        "s_mov_b32 %[reason], 3\n\t" \
+        "s_branch .Lgbwt_walk2u_out_%=\n\t" \
         ".Lgbwt_walk2u_mixed_%=:\n\t" \
         "s_mov_b32 %[reason], 2\n\t" \
         ".Lgbwt_walk2u_out_%=:\n\t" \
@@ -949,19 +915,139 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
           "v40", "v42", "v43", "v44", "v45", "v46", "v61", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v47", "v62", "v63", \
           "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81");
-    // the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered
-    // with, it had to leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted
-    // round of loads)
-    if (narrow) { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_NARROW, "ds_read_b32 v45, %[drained]\n\t") }
-    else { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_WIDE, "ds_read_b32 v45, %[drained]\n\t") }
+#define GBWT_WALK2U_BODY \
+    uint32_t reason; \
+    const uint32_t slack = ring_mask + 1 - 8;   /* leave with more than slots - 8 nodes waiting in a ring */ \
+    const uint32_t dlo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2)), dhi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2) >> 32); \
+    /* the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered with, it had to \
+       leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted round of loads) */ \
+    if (narrow) { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_NARROW, "ds_read_b32 v45, %[drained]\n\t") } \
+    else { GBWT_WALK2U_LOOP(GBWT_WALK2U_KLOAD_WIDE, "ds_read_b32 v45, %[drained]\n\t") } \
+    return reason;
+// The loop on the packed half-blocks (gblocks: one 16-byte load per lane and iteration instead of 16 + 12, 32-bit rank arithmetic; + 9 % on
+// the headline, profiles/r02_walk_bounds.txt #21).  Leaves with reason 3 on a record whose counts do not fit them (no GATHER_OK).
+#define GBWT_WALK2U_INDEX                                                                                 \
+    "v_lshrrev_b32_e32 v46, 5, v42\n\t"                                                                   \
+    "v_lshl_add_u32 v46, v43, 1, v46\n\t"
+#define GBWT_WALK2U_BYTES "v_lshlrev_b32_e32 v60, 4, v46\n\t"
+#define GBWT_WALK2U_RANK_A \
+        "v_bfe_u32 v62, v52, v42, 1\n\t"                    /* a */ \
+        "v_bfm_b32 v64, v42, 0\n\t"                         /* bits below `bit` */ \
+        "v_and_b32_e32 v67, 0xffffffe0, v42\n\t"            /* offset - bit */ \
+        "v_and_b32_e32 v56, 0x1fffff, v54\n\t"              /* ones1 */ \
+        "v_add_u32_e32 v66, -1, v62\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v62\n\t"                  /* vcc = a */ \
+        "v_xor_b32_e32 v68, v52, v66\n\t"                   /* a ? bits1 : ~bits1 */ \
+        "v_alignbit_b32 v57, v55, v54, 21\n\t" \
+        "v_and_b32_e32 v68, v68, v64\n\t"                   /* m */ \
+        "v_sub_u32_e32 v67, v67, v56\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v70, v68, 0\n\t"                    /* p */ \
+        "v_cndmask_b32_e32 v67, v67, v56, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_and_b32_e32 v57, 0x1fffff, v57\n\t"              /* R_0 */ \
+        "v_lshrrev_b32_e32 v58, 10, v55\n\t"                /* R_1 */ \
+        "s_mov_b64 s[44:45], vcc\n\t"                       /* a */ \
+        "v_add_u32_e32 v67, v67, v70\n\t"                   /* rank_a */ \
+        "v_cndmask_b32_e32 v74, v57, v58, vcc\n\t"          /* R_a */ \
+        "v_bfe_u32 v76, v53, v42, 1\n\t"                    /* b */
+#define GBWT_WALK2U_RANK_B \
+        "v_and_b32_e32 v68, v68, v53\n\t"                   /* a-paths below `bit` with value 1 in w_a */ \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v76\n\t"             /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v74, v68, v74\n\t"                  /* ones of w_a before j */
+#define GBWT_WALK2U_KLOAD_NARROW                                                                          \
+    "global_load_dwordx4 v[52:55], v60, %[cblocks]\n\t"
+#define GBWT_WALK2U_KLOAD_WIDE                                                                            \
+    "v_lshrrev_b32_e32 v61, 28, v46\n\t"                                                                  \
+    "v_lshl_add_u64 v[60:61], v[60:61], 0, %[cblocks]\n\t"                                                \
+    "global_load_dwordx4 v[52:55], v[60:61], off\n\t"
+#define GBWT_WALK2U_FLAG_CHECK \
+        "s_bitcmp0_b32 s51, 0\n\t"                          /* GATHER_OK (E_0.w) */ \
+        "s_cbranch_scc1 .Lgbwt_walk2u_unpacked_%=\n\t"
+#define GBWT_WALK2U_MAIL_FLAG
+#endif
+__device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks /* = gblocks */, uint32_t alphabet_offset, uint32_t ring_base,
+                                                       uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
+                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    return 2;
+#else
+    GBWT_WALK2U_BODY
+#endif
+}
+#ifndef GBWT_HIP_CXX_LOOP
+#undef GBWT_WALK2U_INDEX
+#undef GBWT_WALK2U_BYTES
+#undef GBWT_WALK2U_RANK_A
+#undef GBWT_WALK2U_RANK_B
+#undef GBWT_WALK2U_KLOAD_WIDE
+#undef GBWT_WALK2U_KLOAD_NARROW
+#undef GBWT_WALK2U_FLAG_CHECK
+#undef GBWT_WALK2U_MAIL_FLAG
+// The same loop on the full-width blocks (cblocks), for waves that have met such a record; bit 31 of the look-ahead count tells the
+// helper which array to touch.
+#define GBWT_WALK2U_INDEX                                                                                 \
+    "v_lshrrev_b32_e32 v46, 6, v42\n\t"                                                                   \
+    "v_add_u32_e32 v46, v46, v43\n\t"
+#define GBWT_WALK2U_BYTES "v_lshlrev_b32_e32 v60, 5, v46\n\t"                   /* two-step blocks are 32 bytes */
+#define GBWT_WALK2U_RANK_A \
+        "v_lshrrev_b64 v[62:63], v42, v[52:53]\n\t"         /* bits1 >> bit */ \
+        "v_lshlrev_b64 v[64:65], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v62, 1, v62\n\t"                     /* a */ \
+        "v_and_b32_e32 v67, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "v_add_u32_e32 v66, -1, v62\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v62\n\t"                  /* vcc = a */ \
+        "v_xor_b32_e32 v68, v52, v66\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v69, v53, v66\n\t" \
+        "v_bfi_b32 v68, v64, 0, v68\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v69, v65, 0, v69\n\t" \
+        "v_sub_u32_e32 v67, v67, v56\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v70, v68, 0\n\t" \
+        "v_cndmask_b32_e32 v67, v67, v56, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v70, v69, v70\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v74, v57, v58, vcc\n\t"         /* R_a */ \
+        "s_mov_b64 s[44:45], vcc\n\t"                       /* a */ \
+        "v_add_u32_e32 v67, v67, v70\n\t"                  /* rank_a */ \
+        "v_lshrrev_b64 v[76:77], v42, v[54:55]\n\t"       /* bits2 >> bit */
+#define GBWT_WALK2U_RANK_B \
+        "v_and_b32_e32 v68, v68, v54\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v69, v69, v55\n\t" \
+        "v_and_b32_e32 v76, 1, v76\n\t"                   /* b */ \
+        "v_bcnt_u32_b32 v74, v68, v74\n\t" \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v76\n\t"            /* s[46:47] = b */ \
+        "v_bcnt_u32_b32 v74, v69, v74\n\t"               /* ones of w_a before j */
+#define GBWT_WALK2U_KLOAD_NARROW                                                                          \
+    "global_load_dwordx4 v[52:55], v60, %[cblocks]\n\t"                                                   \
+    "global_load_dwordx3 v[56:58], v60, %[cblocks] offset:16\n\t"
+#define GBWT_WALK2U_KLOAD_WIDE                                                                            \
+    "v_lshrrev_b32_e32 v61, 27, v46\n\t"                                                                  \
+    "v_lshl_add_u64 v[60:61], v[60:61], 0, %[cblocks]\n\t"                                                \
+    "global_load_dwordx4 v[52:55], v[60:61], off\n\t"                                                     \
+    "global_load_dwordx3 v[56:58], v[60:61], off offset:16\n\t"
+#define GBWT_WALK2U_FLAG_CHECK
+#define GBWT_WALK2U_MAIL_FLAG "v_or_b32_e32 v50, 0x80000000, v50\n\t"
+#endif
+__device__ __forceinline__ uint32_t walk2_uniform_loop_full(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                       uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
+                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    return 2;
+#else
+    GBWT_WALK2U_BODY
+#endif
+}
+#ifndef GBWT_HIP_CXX_LOOP
+#undef GBWT_WALK2U_BODY
 #undef GBWT_WALK2U_LOOP
+#undef GBWT_WALK2U_INDEX
+#undef GBWT_WALK2U_BYTES
+#undef GBWT_WALK2U_RANK_A
+#undef GBWT_WALK2U_RANK_B
 #undef GBWT_WALK2U_LEAF
 #undef GBWT_WALK2U_KLOAD_WIDE
 #undef GBWT_WALK2U_KLOAD_NARROW
 #undef GBWT_WALK2U_ISSUE
-    return reason;
+#undef GBWT_WALK2U_FLAG_CHECK
+#undef GBWT_WALK2U_MAIL_FLAG
 #endif
-}
 
 // Look-ahead helper of the two-step walk: mailbox slot = {record, first block, number of blocks, sequence number} of
 // the record the walk reaches a few iterations later; touches its descriptor (128 bytes = two sectors) and one of its

@@ -489,15 +489,15 @@ def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
 @pytest.mark.parametrize("env", [{"GBWT_HIP_WIDE_ADDRESSES": "1"}, {"GBWT_HIP_RING_SLOTS": "32"}, {"GBWT_HIP_UNIFORM_LOOP": "0"},
                                  {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_HELPER_LANES": "0"},
                                  {"GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_GATHER_LIMIT": "0", "GBWT_HIP_WIDE_ADDRESSES": "1"}])
-def test_gather_loop_variants(monkeypatch, env):
-    """The loop for mixed waves with 64-bit addresses, with a ring asked for that is smaller than two row pieces (the library
+def test_walk_loop_variants(monkeypatch, env):
+    """The loops of k_walk_direct with 64-bit addresses, with a ring asked for that is smaller than two row pieces (the library
     raises it: a 32-slot ring never holds a 128-byte piece and the walk would not end), as the only loop, with short
     segments, and with records declared too long for the packed counts of its blocks (some / all of them: those lanes step
     in C++ on the full-width blocks); sparse and dense insertions, every path against the generator's allele matrix."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    for every in (1, 37):
-        s = S.Synth.chain(sites=6000, haplotypes=700, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=77, extra=1, indel_every=every)
+    for extra, every in ((1, 1), (1, 37), (0, 1)):    # (0, 1): the plain chain -- the uniform loop, on packed or (GATHER_LIMIT) full-width blocks
+        s = S.Synth.chain(sites=6000, haplotypes=700, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=77, extra=extra, indel_every=every)
         dev = open_synth(s)
         ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
         out = dev.extract_device(ids)
