@@ -102,11 +102,16 @@ __global__ void __launch_bounds__(256) k_path_totals(const uint64_t *chunk_first
 }
 
 // One workgroup per chunk: the header (first chunk of a line), the node tokens of the chunk, the trailer (last chunk).
+// The tokens of 256 positions are put together in LDS (a block scan of their widths places them) and leave as aligned 16-byte
+// stores; only the first and the last bytes of such a batch, where the text does not fill a 16-byte unit, go out one by one.
+// (With every lane storing its own six bytes one at a time the formatter wrote 330 GB/s of text.)
+constexpr uint32_t TOKEN_MAX = 12;   // ',' + ten digits + '+' (P-lines); '>' + ten digits (W-lines)
 __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
                                                                    const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint8_t *headers,
                                                                    const uint64_t *header_off, uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[FORMAT_THREADS * TOKEN_MAX + 32];
     const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
     const uint32_t t = threadIdx.x;
     uint8_t *line = out + line_start[r.path];
@@ -115,21 +120,35 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t
     uint64_t cursor = (h1 - h0) + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
     for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS) {
         const uint64_t k = base + t;
-        char tok[13];
-        uint32_t len = 0;
+        uint32_t len = 0, node = 0, id = 0, digits = 0, lead = 0;
         if (k < r.hi) {
-            const uint32_t node = nodes[k], id = node >> 1, digits = decimal_digits(id);
-            if (p_lines) {
-                if (k > r.begin) tok[len++] = ',';
-            } else tok[len++] = (node & 1u) ? '<' : '>';
-            uint32_t v = id;
-            for (uint32_t d = 0; d < digits; d++) { tok[len + digits - 1 - d] = static_cast<char>('0' + v % 10u); v /= 10u; }
-            len += digits;
-            if (p_lines) tok[len++] = (node & 1u) ? '-' : '+';
+            node = nodes[k]; id = node >> 1; digits = decimal_digits(id);
+            lead = p_lines ? (k > r.begin ? 1u : 0u) : 1u;               // ',' between the tokens of a P-line, '>' / '<' in front of a W-line's
+            len = lead + digits + (p_lines ? 1u : 0u);
         }
         uint32_t pos, total;
         BlockScan(scan_storage).ExclusiveSum(len, pos, total);
-        for (uint32_t j = 0; j < len; j++) line[cursor + pos + j] = static_cast<uint8_t>(tok[j]);
+        uint8_t *const to = line + cursor;
+        const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(to) & 15u);   // the batch's text lies at stage[mis ...]: LDS and memory are aligned alike
+        if (len) {
+            uint8_t *w = stage + mis + pos;
+            if (lead) *w++ = p_lines ? ',' : ((node & 1u) ? '<' : '>');
+            uint32_t v = id;
+            for (uint32_t d = 0; d < digits; d++) { w[digits - 1 - d] = static_cast<uint8_t>('0' + v % 10u); v /= 10u; }
+            if (p_lines) w[digits] = (node & 1u) ? '-' : '+';
+        }
+        __syncthreads();
+        const uint32_t end = mis + total;
+        uint8_t *const aligned = to - mis;
+        for (uint32_t lo = 16 * t; lo < end; lo += 16 * FORMAT_THREADS) {
+            if (lo >= mis && lo + 16 <= end) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(stage + lo), reinterpret_cast<u32x4 *>(aligned + lo));
+            } else {
+                const uint32_t from = lo < mis ? mis : lo, upto = lo + 16 < end ? lo + 16 : end;
+                for (uint32_t q = from; q < upto; q++) aligned[q] = stage[q];
+            }
+        }
         cursor += total;
         __syncthreads();
     }
