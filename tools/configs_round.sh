@@ -1,5 +1,6 @@
 #!/bin/bash
-# The other BASELINE configurations on one GPU (C2, i.i.d. stress, C5 high degree, multi-allelic, ragged rows, C3 search):
+# The other BASELINE configurations on one GPU (C2, i.i.d. stress, C5 high degree, multi-allelic, ragged rows, C3 search, GFA lines,
+# insertion chains):
 # walk / search kernel times, and for C5 the rocprofv3 kernel stats + HBM traffic (FETCH_SIZE, WRITE_SIZE in separate --pmc
 # passes, FETCH doubled per the gfx950 correction).   usage: tools/configs_round.sh OUTDIR
 set -u
@@ -20,6 +21,7 @@ run tools/sweep.py --sites 3000 --alleles 400 --model iid --configs 0:64:16 --re
 run tools/ragged_bench.py
 run tools/search_bench.py --sites 1100000 --haplotypes 5008
 run tools/gfa_bench.py --sites 20000
+run tools/indel_bench.py --extra 0,1 --indel-every 1,64 --repeats 3
 } > "$out/other_configs.txt"
 # C5 under rocprofv3: kernel stats, then the two traffic passes
 cd /tmp && export TMPDIR=/tmp
