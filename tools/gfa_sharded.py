@@ -70,6 +70,9 @@ ids = np.arange(n_paths, dtype=np.uint64)
 mine = D.shard_ids(ids, rank, world, interleaved=True)
 rounds = (len(D.shard_ids(ids, 0, world, interleaved=True)) + args.batch - 1) // args.batch   # rank 0 holds the most
 
+if len(mine):    # untimed: the first call sizes the workspace (hundreds of megabytes of text and node buffers)
+    gbz.path_lines_device(mine[:args.batch], 1)
+    gbz.path_lines_device(mine[:1], 1)              # ... and leaves another request in the cache
 sha, total, out = hashlib.sha256(), 0, open(args.out, "wb") if (args.out and rank == 0) else None
 walk_ms = gather_ms = 0.0
 torch.cuda.synchronize()
