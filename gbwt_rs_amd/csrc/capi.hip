@@ -486,6 +486,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             if (const char *v = std::getenv("GBWT_HIP_XCD_MAP")) a.xcd_map = std::atoi(v) ? 1u : 0u;
             a.uniform_loop = 1;
             if (const char *v = std::getenv("GBWT_HIP_UNIFORM_LOOP")) a.uniform_loop = std::atoi(v) ? 1u : 0u;
+            a.packed_blocks = 1;
+            if (const char *v = std::getenv("GBWT_HIP_PACKED_BLOCKS")) a.packed_blocks = std::atoi(v) ? 1u : 0u;
             a.row_piece = 32;
             if (const char *v = std::getenv("GBWT_HIP_ROW_PIECE")) { const int r = std::atoi(v); if (r == 0 || r == 16 || r == 32) a.row_piece = static_cast<uint32_t>(r); }
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one

@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE   // measurement only: nodes staged by each of the two loops, for a few workgroups (profiles/r02_walk_bounds.txt #16)
     uint32_t probe_uniform = 0, probe_vector = 0, probe_entries = 0, probe_mixed_entries = 0, probe_fell_out = 0;
 #endif
-    bool full_blocks = false;    // wave-uniform
+    bool full_blocks = a.packed_blocks == 0;    // wave-uniform
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
@@ -437,14 +437,16 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (slow_exit == 2 && together) probe_fell_out++;
 #endif
         const bool mixed = slow_exit == 2;
-        if (slow_exit == 2) slow_exit = walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr)
+                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif
         if (slow_exit) {
             const uint4 here = ix.desc2[8 * static_cast<uint64_t>(rec)];
             bool generic = rec != 0 && (here.z & DESC2_SLOW) != 0;   // lanes on a slow record
-            const bool unpacked = mixed && rec != 0 && !generic && !(here.w & GATHER_OK);   // ... on a record too long for the gather loop's packed counts
+            // a lane on a record too long for the packed counts: the wave continues on the full-width blocks (both loops), for good
+            if (mixed && !full_blocks && __ballot(rec != 0 && !generic && !(here.w & GATHER_OK)) != 0) full_blocks = true;
             if (ix.wtables != nullptr) {
                 // Lanes on a table record walk on the walk tables: one 16-byte entry per step says what to emit (the
                 // successor and, where a unary record follows, the node behind it), where the walk lands and -- when that
@@ -474,10 +476,6 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
             if (generic) {   // no table (or no walk tables at all): one step of the generic decoder with all the reference's tests
                 generic_step(ix, sink, rec, offset, bb);
-                if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
-            }
-            if (unpacked) {  // one iteration on the full-width blocks
-                two_step(ix, sink, rec, offset, bb);
                 if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
             }
             lds_poke(my_mail + 3, sink.wr);

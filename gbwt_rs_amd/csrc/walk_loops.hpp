@@ -581,7 +581,8 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
 // touches in walk2_hot_loop).  So this loop fetches only what the step needs, in three instructions: the lane's packed
 // half-block (gblocks: 32 offsets, 16 bytes), then -- once a and b are known -- E_a and leaf (a, b); it posts no
 // look-ahead target.  The price is a second round trip per iteration; the other waves of the CU cover it.
-// Same contract as walk2_hot_loop; reason 1 also when a lane sits on a record without GATHER_OK (the caller steps it).
+// Same contract as walk2_hot_loop; reason 1 also when a lane sits on a record without GATHER_OK (the caller then moves the wave
+// to walk2_gather_loop_full).
 __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const uint4 *gblocks, uint32_t alphabet_offset, uint32_t ring_base,
                                                       uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
                                                       uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
@@ -774,6 +775,207 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
     return reason;
 #endif
 }
+
+// The same loop on the full-width blocks (cblocks: 16 + 12 bytes per lane, four loads per iteration), for waves that have met a
+// record whose counts do not fit the packed half-blocks (2^21 positions or more).  Registers v40-v87.
+__device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
+                                                      uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
+                                                      uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr) {
+#ifdef GBWT_HIP_CXX_LOOP
+    __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
+    __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
+    mail[0] = 0;                                             // no look-ahead target: the helper's touches would cost what they save
+    for (;;) {
+        bool slow = false;
+        if (rec != 0) {
+            const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+            const uint4 K0 = cblocks[2 * idx];
+            const uint32_t *k1 = reinterpret_cast<const uint32_t *>(cblocks + 2 * idx + 1);
+            const uint32_t ones1 = k1[0], R0 = k1[1], R1 = k1[2];
+            const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+            const uint32_t bit = offset & 63u;
+            const uint64_t below = (uint64_t(1) << bit) - 1;
+            const uint32_t a = static_cast<uint32_t>(bits1 >> bit) & 1u, b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+            const uint4 *d = desc2 + 8 * static_cast<uint64_t>(rec);
+            const uint32_t *e = reinterpret_cast<const uint32_t *>(d + a);
+            const uint32_t n1 = e[0], base_a = e[1], wword = e[2];
+            const uint4 leaf = d[2 + 2 * a + b];
+            slow = (wword & DESC2_SLOW) != 0;
+            if (!slow) {
+                const uint64_t m = a ? bits1 : ~bits1;
+                const uint32_t p = __popcll(m & below);
+                const uint32_t rank_a = a ? ones1 + p : (offset - bit) - ones1 + p;
+                const uint32_t j = base_a + rank_a;
+                const uint32_t ones_w = (a ? R1 : R0) + __popcll(m & bits2 & below);
+                rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
+                ring[(wr & ring_mask) * ring_stride] = n1;
+                wr += n1 != 0 ? 1u : 0u;
+                ring[(wr & ring_mask) * ring_stride] = (wword & REC_MASK) + alphabet_offset;
+                wr += (wword & LEAF_EMIT2) ? 1u : 0u;
+                ring[(wr & ring_mask) * ring_stride] = leaf.x;
+                wr += leaf.x != 0 ? 1u : 0u;
+                ring[(wr & ring_mask) * ring_stride] = rec + alphabet_offset;
+                wr += (leaf.z & LEAF_EMIT2) ? 1u : 0u;
+                mail[3] = wr;
+                if (wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+            }
+        }
+        if (__ballot(slow) != 0) return 1;
+        if (__ballot(rec != 0) == 0 || __ballot(wr - flushed > ring_mask + 1 - 8) != 0) return 0;
+    }
+#else
+    // gfx950 assembly: four vector loads per iteration in two rounds (hipcc turns the C++ above into seven in three).  Conventions of walk2_hot_loop; s[44:45] = the lanes that load (those walking at the start of the PREVIOUS
+    // iteration, so that a lane that parks fetches record 0 once and keeps emitting nothing), s[42:43] = the lanes walking now.
+    uint32_t reason;
+    const uint32_t limit = flushed + (ring_mask + 1 - 8);   // leave with more than slots - 8 nodes waiting
+#define GBWT_GATHERF_K_NARROW                                                                              \
+    "v_lshlrev_b32_e32 v70, 5, v58\n\t"                   /* two-step blocks are 32 bytes */              \
+    "v_lshlrev_b32_e32 v68, 7, v40\n\t"                   /* two-step descriptors are 128 bytes */        \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx4 v[60:63], v70, %[cblocks]\n\t"             /* K0: bits1, bits2 */                \
+    "global_load_dwordx3 v[64:66], v70, %[cblocks] offset:16\n\t"   /* K1: ones1, R0, R1 */               \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_GATHERF_K_WIDE                                                                                \
+    "v_lshlrev_b64 v[70:71], 5, v[58:59]\n\t"                                                             \
+    "v_lshlrev_b64 v[68:69], 7, v[40:41]\n\t"                                                             \
+    "v_lshl_add_u64 v[70:71], v[70:71], 0, %[cblocks]\n\t"                                                \
+    "v_lshl_add_u64 v[68:69], v[68:69], 0, %[desc2]\n\t"                                                  \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx4 v[60:63], v[70:71], off\n\t"                                                     \
+    "global_load_dwordx3 v[64:66], v[70:71], off offset:16\n\t"                                           \
+    "s_mov_b64 exec, -1\n\t"
+// E_a at 16 a, leaf (a, b) at 32 + 16 (2 a + b) of the descriptor; v72 = a, v84 = b
+#define GBWT_GATHERF_D_NARROW                                                                              \
+    "v_lshl_add_u32 v46, v72, 4, v68\n\t"                                                                 \
+    "v_lshl_add_u32 v47, v72, 1, v84\n\t"                                                                \
+    "v_lshl_add_u32 v47, v47, 4, v68\n\t"                                                                 \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx3 v[48:50], v46, %[desc2]\n\t"               /* E_a: node, offset base, w_a | flags */ \
+    "global_load_dwordx4 v[52:55], v47, %[desc2] offset:32\n\t"     /* leaf (a, b) */                     \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_GATHERF_D_WIDE                                                                                \
+    "v_lshl_add_u32 v56, v72, 1, v84\n\t"                                                                \
+    "v_mov_b32_e32 v73, 0\n\t"                                                                            \
+    "v_mov_b32_e32 v57, 0\n\t"                                                                            \
+    "v_lshl_add_u64 v[46:47], v[72:73], 4, v[68:69]\n\t"                                                  \
+    "v_lshl_add_u64 v[56:57], v[56:57], 4, v[68:69]\n\t"                                                  \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                        \
+    "global_load_dwordx3 v[48:50], v[46:47], off\n\t"                                                     \
+    "global_load_dwordx4 v[52:55], v[56:57], off offset:32\n\t"                                           \
+    "s_mov_b64 exec, -1\n\t"
+#define GBWT_GATHERF_LOOP(KLOAD, DLOAD) \
+    asm volatile( \
+        "v_mov_b32_e32 v40, %[rec]\n\t" \
+        "v_mov_b32_e32 v41, 0\n\t" \
+        "v_mov_b32_e32 v42, %[offset]\n\t" \
+        "v_mov_b32_e32 v43, %[bb]\n\t" \
+        "v_mov_b32_e32 v44, %[wr]\n\t" \
+        "v_mov_b32_e32 v59, 0\n\t" \
+        "s_mov_b32 %[reason], 0\n\t" \
+        "s_mov_b64 s[44:45], -1\n\t"                        /* everybody loads in the first round (parked lanes: record 0) */ \
+        "v_cmp_ne_u32_e64 s[42:43], 0, v40\n\t" \
+        "ds_write_b32 %[mail], v41\n\t"                     /* no look-ahead target */ \
+        ".Lgbwt_gatherf_loop_%=:\n\t" \
+        "v_cmp_ne_u32_e32 vcc, -1, v43\n\t"                 /* bb != BLOCK_NONE */ \
+        "v_lshrrev_b32_e32 v58, 6, v42\n\t" \
+        "v_add_u32_e32 v58, v58, v43\n\t" \
+        "v_cndmask_b32_e32 v58, 0, v58, vcc\n\t"            /* block bb + offset / 64, or the zero block */ \
+        KLOAD \
+        "v_lshlrev_b64 v[74:75], v42, -1\n\t"               /* bits at and above `bit` */ \
+        "v_and_b32_e32 v77, 0xffffffc0, v42\n\t"            /* offset - bit */ \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_lshrrev_b64 v[72:73], v42, v[60:61]\n\t"         /* bits1 >> bit */ \
+        "v_lshrrev_b64 v[84:85], v42, v[62:63]\n\t"       /* bits2 >> bit */ \
+        "v_and_b32_e32 v72, 1, v72\n\t"                     /* a */ \
+        "v_and_b32_e32 v84, 1, v84\n\t"                   /* b */ \
+        DLOAD \
+        "v_add_u32_e32 v76, -1, v72\n\t"                    /* a ? 0 : ~0 */ \
+        "v_cmp_eq_u32_e32 vcc, 1, v72\n\t"                  /* vcc = a */ \
+        "v_cmp_eq_u32_e64 s[46:47], 1, v84\n\t"            /* s[46:47] = b */ \
+        "v_xor_b32_e32 v78, v60, v76\n\t"                  /* m = a ? bits1 : ~bits1 */ \
+        "v_xor_b32_e32 v79, v61, v76\n\t" \
+        "v_bfi_b32 v78, v74, 0, v78\n\t"                  /* m below `bit` */ \
+        "v_bfi_b32 v79, v75, 0, v79\n\t" \
+        "v_sub_u32_e32 v77, v77, v64\n\t"                   /* (offset - bit) - ones1 */ \
+        "v_bcnt_u32_b32 v80, v78, 0\n\t" \
+        "v_cndmask_b32_e32 v77, v77, v64, vcc\n\t"          /* a ? ones1 : that */ \
+        "v_bcnt_u32_b32 v80, v79, v80\n\t"               /* p */ \
+        "v_cndmask_b32_e32 v82, v65, v66, vcc\n\t"         /* R_a */ \
+        "v_add_u32_e32 v77, v77, v80\n\t"                  /* rank_a */ \
+        "v_and_b32_e32 v78, v78, v62\n\t"                 /* a-paths below `bit` with value 1 in w_a */ \
+        "v_and_b32_e32 v79, v79, v63\n\t" \
+        "v_bcnt_u32_b32 v82, v78, v82\n\t" \
+        "v_bcnt_u32_b32 v82, v79, v82\n\t"               /* ones of w_a before j */ \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_lshlrev_b32_e32 v67, 1, v50\n\t"                 /* DESC2_SLOW (bit 30 of E_a.z) -> sign */ \
+        "v_add_u32_e32 v81, v49, v77\n\t"                  /* j: offset in w_a */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v67\n\t" \
+        "v_sub_u32_e32 v83, v81, v82\n\t"                /* j - ones */ \
+        "v_and_b32_e32 v86, 0x3fffffff, v50\n\t"           /* w_a */ \
+        "s_cbranch_vccnz .Lgbwt_gatherf_slow_%=\n\t" \
+        "v_cndmask_b32_e64 v83, v83, v82, s[46:47]\n\t"  /* rank_b */ \
+        "v_mov_b32_e32 v43, v55\n\t"                        /* block base of the landing record */ \
+        "v_add_u32_e32 v42, v53, v83\n\t"                  /* the new offset */ \
+        "v_and_b32_e32 v40, 0x3fffffff, v54\n\t"            /* the new record */ \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t"           /* ring slot of the next node */ \
+        "v_cmp_ne_u32_e32 vcc, 0, v48\n\t" \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v48\n\t"                         /* node of edge a */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t"       /* counts if it is not the ENDMARKER */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v50\n\t"                  /* first step fused? */ \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v86, s41, v86\n\t"                 /* node of w_a */ \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v86\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_ne_u32_e32 vcc, 0, v52\n\t" \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t" \
+        "v_add_u32_e32 v87, s41, v40\n\t"                  /* node of the landing record */ \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v52\n\t"                         /* node of the leaf */ \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_gt_i32_e32 vcc, 0, v54\n\t"                  /* second step fused? */ \
+        "v_and_b32_e32 v67, %[ringmask], v44\n\t" \
+        "v_mad_u32_u24 v67, v67, %[stride], %[ring]\n\t" \
+        "ds_write_b32 v67, v87\n\t" \
+        "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"            /* a walker that has emitted its share parks */ \
+        "s_mov_b64 s[44:45], s[42:43]\n\t"                  /* the next round of loads: everybody who walked in this one */ \
+        "ds_write_b32 %[mail], v44 offset:12\n\t"           /* mailbox: nodes staged so far */ \
+        "v_cndmask_b32_e32 v40, 0, v40, vcc\n\t" \
+        "v_cndmask_b32_e32 v43, -1, v43, vcc\n\t" \
+        "v_cmp_lt_u32_e32 vcc, %[limit], v44\n\t"           /* more than slots - 8 nodes waiting in a ring */ \
+        "v_cmp_ne_u32_e64 s[42:43], 0, v40\n\t"             /* lanes still walking */ \
+        "s_nop 1\n\t" \
+        "s_cmp_eq_u64 s[42:43], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_gatherf_out_%=\n\t" \
+        "s_cbranch_vccz .Lgbwt_gatherf_loop_%=\n\t" \
+        "s_branch .Lgbwt_gatherf_out_%=\n\t" \
+        ".Lgbwt_gatherf_slow_%=:\n\t" \
+        "s_mov_b32 %[reason], 1\n\t" \
+        ".Lgbwt_gatherf_out_%=:\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        "v_mov_b32_e32 %[rec], v40\n\t" \
+        "v_mov_b32_e32 %[offset], v42\n\t" \
+        "v_mov_b32_e32 %[bb], v43\n\t" \
+        "v_mov_b32_e32 %[wr], v44\n\t" \
+        : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
+        : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
+          "{s41}"(alphabet_offset) \
+        : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", \
+          "v40", "v41", "v42", "v43", "v44", "v46", "v47", "v48", "v49", "v50", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", \
+          "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v68", "v69", "v70", "v71", "v67", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", \
+          "v82", "v83", "v84", "v85", "v86", "v87");
+    if (narrow) { GBWT_GATHERF_LOOP(GBWT_GATHERF_K_NARROW, GBWT_GATHERF_D_NARROW) } else { GBWT_GATHERF_LOOP(GBWT_GATHERF_K_WIDE, GBWT_GATHERF_D_WIDE) }
+#undef GBWT_GATHERF_LOOP
+#undef GBWT_GATHERF_K_NARROW
+#undef GBWT_GATHERF_K_WIDE
+#undef GBWT_GATHERF_D_NARROW
+#undef GBWT_GATHERF_D_WIDE
+    return reason;
+#endif
+}
+
 
 // ---- two-step walk, wave-uniform variant ----------------------------------------------------------------------
 // With sixty-four lanes walking, the vector-memory path is what the walk saturates (TA / TD busy 92-95 % of the kernel,

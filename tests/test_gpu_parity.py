@@ -492,8 +492,8 @@ def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
 def test_walk_loop_variants(monkeypatch, env):
     """The loops of k_walk_direct with 64-bit addresses, with a ring asked for that is smaller than two row pieces (the library
     raises it: a 32-slot ring never holds a 128-byte piece and the walk would not end), as the only loop, with short
-    segments, and with records declared too long for the packed counts of its blocks (some / all of them: those lanes step
-    in C++ on the full-width blocks); sparse and dense insertions, every path against the generator's allele matrix."""
+    segments, and with records declared too long for the packed counts of its blocks (some / all of them: such waves move
+    to the loops on the full-width blocks); sparse and dense insertions, every path against the generator's allele matrix."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for extra, every in ((1, 1), (1, 37), (0, 1)):    # (0, 1): the plain chain -- the uniform loop, on packed or (GATHER_LIMIT) full-width blocks
