@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -32,21 +34,96 @@ struct HipError { hipError_t err; const char *what; };
     } while (0)
 
 // Grow-only device buffer.
+// Where a pass's 13 GB of rows land physically is worth up to 10 % of its time: on a fresh box one hipMalloc of that size takes one
+// contiguous stretch of VRAM, and a pass over it takes 4.95 ms where the same buffer put together from 256 MB chunks that lie SPREAD
+// over the whole VRAM takes 4.50 (profiles/r02_walk_bounds.txt #25; the fast and slow "states" of a box in round 1 were this).  So
+// buffers of 4 GiB and more are built with the virtual-memory API: `spread` times as many physical chunks as needed are created,
+// every spread-th is kept and mapped into one virtual range, the others are given back.  hipMalloc whenever any of that fails.
+// GBWT_HIP_VMM="0": always hipMalloc;  "<chunk MiB>:<spread, 0 = as much as 3/4 of the free memory allows, at most 16>:<min MiB>".
+struct VmmPolicy { size_t chunk = size_t(256) << 20, min = size_t(4) << 30; unsigned spread = 0; };
+inline const VmmPolicy &vmm_policy() {
+    static const VmmPolicy policy = [] {
+        VmmPolicy p;
+        if (const char *v = std::getenv("GBWT_HIP_VMM")) {
+            unsigned long chunk = 0, spread = 0, min = 4096;
+            const int got = std::sscanf(v, "%lu:%lu:%lu", &chunk, &spread, &min);
+            if (got >= 1) { p.chunk = chunk << 20; p.spread = static_cast<unsigned>(spread); p.min = min << 20; }
+        }
+        return p;
+    }();
+    return policy;
+}
+
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
-    ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+    std::vector<hipMemGenericAllocationHandle_t> chunks;   // empty: ptr comes from hipMalloc
+    size_t mapped = 0;                                       // bytes of virtual range reserved at ptr
+    ~DeviceBuffer() { release(); }
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
     DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void release() noexcept {
+        if (mapped) {
+            (void)hipMemUnmap(ptr, mapped);
+            (void)hipMemAddressFree(ptr, mapped);
+        } else if (ptr) (void)hipFree(ptr);
+        for (auto h : chunks) (void)hipMemRelease(h);
+        chunks.clear();
+        ptr = nullptr; bytes = 0; mapped = 0;
+    }
     void reserve(size_t need) {
         if (need <= bytes) return;
-        if (ptr) { HIP_CHECK(hipFree(ptr)); ptr = nullptr; bytes = 0; }
-        size_t want = std::max<size_t>(need, 256);
+        release();
+        const size_t want = std::max<size_t>(need, 256);
+        const VmmPolicy &policy = vmm_policy();
+        if (policy.chunk != 0 && want >= policy.min && spread_chunks(want, policy)) { bytes = want; return; }
         HIP_CHECK(hipMalloc(&ptr, want));
         bytes = want;
     }
     template <class T> T *as() const { return static_cast<T *>(ptr); }
+
+private:
+    // false (and nothing held) when the virtual-memory API does not cooperate
+    bool spread_chunks(size_t want, const VmmPolicy &policy) noexcept {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) return false;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t granule = 0, free_bytes = 0, total_bytes = 0;
+        if (hipMemGetAllocationGranularity(&granule, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || granule == 0) return false;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || want > free_bytes) return false;   // sizes out of a corrupt file: let hipMalloc say no
+        const size_t chunk = (policy.chunk + granule - 1) / granule * granule, n = want / chunk + (want % chunk != 0 ? 1 : 0);
+        size_t spread = policy.spread;
+        if (spread == 0) spread = std::min<size_t>(16, std::max<size_t>(1, free_bytes / 4 * 3 / (n * chunk)));
+        // more chunks than needed, every spread-th kept: the kept ones lie `spread` chunks apart in whatever order the driver hands them out
+        std::vector<hipMemGenericAllocationHandle_t> all;
+        all.reserve(n * spread);
+        for (size_t i = 0; i < n * spread; i++) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) break;
+            all.push_back(h);
+        }
+        (void)hipGetLastError();
+        const size_t step = all.size() / n;     // >= 1 unless not even n chunks could be had
+        for (size_t i = 0; i < all.size(); i++) {
+            if (step != 0 && i % step == 0 && chunks.size() < n) chunks.push_back(all[i]);
+            else (void)hipMemRelease(all[i]);
+        }
+        bool ok = chunks.size() == n && hipMemAddressReserve(&ptr, n * chunk, 0, nullptr, 0) == hipSuccess;
+        if (ok) {
+            mapped = n * chunk;
+            for (size_t i = 0; i < n && ok; i++) ok = hipMemMap(static_cast<char *>(ptr) + i * chunk, chunk, 0, chunks[i], 0) == hipSuccess;
+            hipMemAccessDesc access{};
+            access.location = prop.location;
+            access.flags = hipMemAccessFlagsProtReadWrite;
+            ok = ok && hipMemSetAccess(ptr, mapped, &access, 1) == hipSuccess;
+        }
+        if (!ok) { (void)hipGetLastError(); release(); }
+        return ok;
+    }
 };
 
 inline gbwt_hip_status status_of(const HipError &e) {
