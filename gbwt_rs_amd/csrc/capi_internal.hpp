@@ -35,12 +35,15 @@ struct HipError { hipError_t err; const char *what; };
 
 // Grow-only device buffer.
 // Where a pass's 13 GB of rows land physically is worth up to 10 % of its time: on a fresh box one hipMalloc of that size takes one
-// contiguous stretch of VRAM, and a pass over it takes 4.95 ms where the same buffer put together from 256 MB chunks that lie SPREAD
-// over the whole VRAM takes 4.50 (profiles/r02_walk_bounds.txt #25; the fast and slow "states" of a box in round 1 were this).  So
-// buffers of 4 GiB and more are built with the virtual-memory API: `spread` times as many physical chunks as needed are created,
-// every spread-th is kept and mapped into one virtual range, the others are given back.  hipMalloc whenever any of that fails.
-// GBWT_HIP_VMM="0": always hipMalloc;  "<chunk MiB>:<spread, 0 = as much as 3/4 of the free memory allows, at most 16>:<min MiB>".
-struct VmmPolicy { size_t chunk = size_t(256) << 20, min = size_t(4) << 30; unsigned spread = 0; };
+// contiguous stretch of VRAM, and a pass over it takes 4.95 ms where the same buffer put together from chunks that lie SPREAD over the
+// VRAM takes 4.45 (profiles/r02_walk_bounds.txt #25; the fast and slow "states" of a box in round 1 were this).  So buffers of 4 GiB
+// and more are built with the virtual-memory API: `spread` times as many physical chunks as needed are created, every spread-th is
+// kept and mapped into one virtual range, the others are given back.  Chunks of 2 GiB: with 256 MB chunks the rows of ragged batches
+// (walks out of lock step) were written 5 % slower than into one hipMalloc -- smaller mappings, less TLB reach -- with 2 GiB 1 %.  The
+// price is paid when a workspace is sized: the driver clears what it hands out, about 15 ms per GB created (1.7 s for a 13 GB buffer at
+// spread 8; spread 4 keeps half of the gain, 2 nothing).  hipMalloc whenever any of that fails.
+// GBWT_HIP_VMM="0": always hipMalloc;  "<chunk MiB>:<spread, 0 = as much as 3/4 of the free memory allows, at most 8>:<min MiB>".
+struct VmmPolicy { size_t chunk = size_t(2048) << 20, min = size_t(4) << 30; unsigned spread = 0; };
 inline const VmmPolicy &vmm_policy() {
     static const VmmPolicy policy = [] {
         VmmPolicy p;
@@ -97,7 +100,7 @@ private:
         if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || want > free_bytes) return false;   // sizes out of a corrupt file: let hipMalloc say no
         const size_t chunk = (policy.chunk + granule - 1) / granule * granule, n = want / chunk + (want % chunk != 0 ? 1 : 0);
         size_t spread = policy.spread;
-        if (spread == 0) spread = std::min<size_t>(16, std::max<size_t>(1, free_bytes / 4 * 3 / (n * chunk)));
+        if (spread == 0) spread = std::min<size_t>(8, std::max<size_t>(1, free_bytes / 4 * 3 / (n * chunk)));
         // more chunks than needed, every spread-th kept: the kept ones lie `spread` chunks apart in whatever order the driver hands them out
         std::vector<hipMemGenericAllocationHandle_t> all;
         all.reserve(n * spread);
