@@ -32,8 +32,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # a pass takes 4.5 ms; the first few after the workspace has been sized run 2-4 % slower (720 G LF-steps/s with 1 + 3 passes,
+    # 737 with 3 + 5, 748 with 5 + 10 on one box), so the defaults leave them to the warm-up
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sites", type=int, default=333334)
     ap.add_argument("--haplotypes", type=int, default=5000)
     ap.add_argument("--model", choices=["mosaic", "iid"], default="mosaic")
