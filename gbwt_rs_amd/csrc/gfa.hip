@@ -79,11 +79,17 @@ __global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, co
     if (c >= chunks) return;
     const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
     uint64_t text = 0, labels = 0;
-    for (uint64_t k = r.lo + lane; k < r.hi; k += WAVE) {
-        const uint32_t node = nodes[k], id = node >> 1;
-        text += decimal_digits(id) + 1 + ((p_lines && k > r.begin) ? 1 : 0);
-        const uint64_t seq = (static_cast<uint64_t>(node & ~1u) - first_node) / 2;   // GBZ::graph_node_to_sequence, src/gbz.rs:246-255
-        if ((node & ~1u) >= first_node && seq < n_labels) labels += label_len[seq];
+    for (uint64_t k0 = r.lo + 4 * lane; k0 < r.hi; k0 += 4 * WAVE) {   // four consecutive positions per lane: the loads and the label gathers of a round overlap
+        uint32_t node[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) node[i] = k0 + i < r.hi ? nodes[k0 + i] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            if (k0 + i >= r.hi) continue;
+            text += decimal_digits(node[i] >> 1) + 1 + ((p_lines && k0 + i > r.begin) ? 1 : 0);
+            const uint64_t seq = (static_cast<uint64_t>(node[i] & ~1u) - first_node) / 2;   // GBZ::graph_node_to_sequence, src/gbz.rs:246-255
+            if ((node[i] & ~1u) >= first_node && seq < n_labels) labels += label_len[seq];
+        }
     }
     for (int d = WAVE / 2; d > 0; d >>= 1) { text += __shfl_down(text, d, WAVE); labels += __shfl_down(labels, d, WAVE); }
     if (lane == 0) { chunk_text[c] = text; chunk_seq[c] = labels; }
@@ -514,10 +520,31 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
             }
         }
         // 3. headers (path_to_p_line / path_to_w_line, src/bin/gbunzip.rs:480-524)
+        // (appended in place: five thousand headers put together from temporaries were a sixth of a call that formats a gigabyte)
         std::string headers;
+        headers.reserve(64 * n);
+        auto append_number = [&](uint64_t v) {
+            char digits[24];
+            int len = 0;
+            do { digits[len++] = static_cast<char>('0' + v % 10); v /= 10; } while (v != 0);
+            while (len > 0) headers.push_back(digits[--len]);
+        };
+        auto append_name = [&](const Strings &names, bool has_names, uint64_t id) {
+            if (has_names && id < names.size()) headers.append(reinterpret_cast<const char *>(names.bytes.data()) + names.offsets[id], names.offsets[id + 1] - names.offsets[id]);
+            else append_number(id);                          // Metadata::sample_name / contig_name fall back to the number
+        };
+        auto append_header = [&](uint64_t k, uint64_t seq_len) {
+            const PathName &pn = h.path_names[path_ids[k]];
+            if (mode == 0) { headers += "P\t"; append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t'); return; }
+            headers += "W\t"; append_name(h.sample_names, sample_names, pn.sample); headers.push_back('\t');
+            append_number(pn.phase); headers.push_back('\t');
+            append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t');
+            append_number(pn.fragment); headers.push_back('\t');
+            append_number(static_cast<uint64_t>(pn.fragment) + seq_len); headers.push_back('\t');
+        };
         std::vector<uint64_t> header_off(n + 1, 0), line_start(n + 1, 0);
         for (uint64_t k = 0; k < n; k++) {
-            if (valid[k]) headers += line_header(k, lens[n + k]);
+            if (valid[k]) append_header(k, lens[n + k]);
             header_off[k + 1] = headers.size();
             line_start[k + 1] = line_start[k] + (valid[k] ? (header_off[k + 1] - header_off[k]) + lens[k] + (mode == 0 ? 3 : 1) : host_lines[k].size());
         }
