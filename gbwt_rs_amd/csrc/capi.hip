@@ -371,6 +371,7 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
     if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = nullptr;
     std::unique_ptr<gbwt_hip_workspace> ws(new gbwt_hip_workspace);
+    ws->nodes.may_spread = true;
     ws->index = index;
     HIP_CHECK(hipSetDevice(index->device));
     HIP_CHECK(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));

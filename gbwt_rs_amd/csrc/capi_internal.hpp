@@ -36,8 +36,8 @@ struct HipError { hipError_t err; const char *what; };
 // Grow-only device buffer.
 // Where a pass's 13 GB of rows land physically is worth up to 10 % of its time: on a fresh box one hipMalloc of that size takes one
 // contiguous stretch of VRAM, and a pass over it takes 4.95 ms where the same buffer put together from chunks that lie SPREAD over the
-// VRAM takes 4.45 (profiles/r02_walk_bounds.txt #25; the fast and slow "states" of a box in round 1 were this).  So buffers of 4 GiB
-// and more are built with the virtual-memory API: `spread` times as many physical chunks as needed are created, every spread-th is
+// VRAM takes 4.45 (profiles/r02_walk_bounds.txt #25; the fast and slow "states" of a box in round 1 were this).  So the rows buffer of
+// a workspace (may_spread), from 4 GiB, is built with the virtual-memory API: `spread` times as many physical chunks as needed are created, every spread-th is
 // kept and mapped into one virtual range, the others are given back.  Chunks of 2 GiB: with 256 MB chunks the rows of ragged batches
 // (walks out of lock step) were written 5 % slower than into one hipMalloc -- smaller mappings, less TLB reach -- with 2 GiB 1 %.  The
 // price is paid when a workspace is sized: the driver clears what it hands out, about 15 ms per GB created (1.7 s for a 13 GB buffer at
@@ -62,6 +62,7 @@ struct DeviceBuffer {
     size_t bytes = 0;
     std::vector<hipMemGenericAllocationHandle_t> chunks;   // empty: ptr comes from hipMalloc
     size_t mapped = 0;                                       // bytes of virtual range reserved at ptr
+    bool may_spread = false;                                 // the extracted rows of a workspace only: spreading the index arrays gains nothing (#25)
     ~DeviceBuffer() { release(); }
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
@@ -80,7 +81,7 @@ struct DeviceBuffer {
         release();
         const size_t want = std::max<size_t>(need, 256);
         const VmmPolicy &policy = vmm_policy();
-        if (policy.chunk != 0 && want >= policy.min && spread_chunks(want, policy)) { bytes = want; return; }
+        if (may_spread && policy.chunk != 0 && want >= policy.min && spread_chunks(want, policy)) { bytes = want; return; }
         HIP_CHECK(hipMalloc(&ptr, want));
         bytes = want;
     }
