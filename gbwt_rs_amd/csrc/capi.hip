@@ -480,7 +480,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
             a.ring_slots = segmented ? 64 : 128;   // many walkers: smaller rings, more workgroups per CU (7.4 vs 8.1 ms on the headline)
             if (const char *v = std::getenv("GBWT_HIP_RING_SLOTS")) { const int r = std::atoi(v); if (r == 32 || r == 64 || r == 128) a.ring_slots = static_cast<uint32_t>(r); }
-            a.helper_naps = segmented ? 6u : 1u;   // many walkers per CU: a helper that polls less leaves more issue slots and LDS cycles to them
+            a.helper_naps = segmented ? 4u : 1u;   // many walkers per CU: a helper that polls less leaves more issue slots and LDS cycles to them (6 until the
+                                                   // packed half-blocks made the walkers faster: 3 / 4 / 6 / 8 / 10 naps = 4.30 / 4.31 / 4.35 / 4.42 / 4.51 ms)
             if (const char *v = std::getenv("GBWT_HIP_HELPER_NAPS")) a.helper_naps = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
             a.xcd_map = segmented ? 1u : 0u;

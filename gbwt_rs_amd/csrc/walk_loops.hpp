@@ -405,10 +405,11 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
     // on record 0, loads of the next position go out as early as possible, exits leave nothing in flight; a VALU write
     // of VCC / an SGPR is kept two instructions away from the VALU that reads it).  Registers v40-v125, s41, s44-s47.
     uint32_t reason;
-#ifdef GBWT_HIP_PROBE_MORE_LOADS   // measurement only: two more loads per lane and step from the descriptor's line (profiles/r02_walk_bounds.txt #16)
-#define GBWT_WALK2_PROBE_WIDE "global_load_dwordx2 v[46:47], v[88:89], off offset:112\n\t" "global_load_dwordx2 v[54:55], v[88:89], off offset:24\n\t"
-#define GBWT_WALK2_PROBE_NARROW "global_load_dwordx2 v[46:47], v88, %[desc2] offset:112\n\t" "global_load_dwordx2 v[54:55], v88, %[desc2] offset:24\n\t"
-#define GBWT_WALK2_PROBE_CLOBBERS "v46", "v47", "v54", "v55",
+#ifdef GBWT_HIP_PROBE_MORE_LOADS   // measurement only: two more loads per lane and step from the descriptor's line (profiles/r02_walk_bounds.txt #16,
+                                   // taken when k_walk_direct still ran this loop for mixed waves; today the loop serves the pool-output kernel)
+#define GBWT_WALK2_PROBE_WIDE "global_load_dwordx2 v[46:47], v[88:89], off offset:112\n\t" "global_load_dwordx2 v[68:69], v[88:89], off offset:24\n\t"
+#define GBWT_WALK2_PROBE_NARROW "global_load_dwordx2 v[46:47], v88, %[desc2] offset:112\n\t" "global_load_dwordx2 v[68:69], v88, %[desc2] offset:24\n\t"
+#define GBWT_WALK2_PROBE_CLOBBERS "v46", "v47", "v68", "v69",
 #else
 #define GBWT_WALK2_PROBE_WIDE
 #define GBWT_WALK2_PROBE_NARROW
