@@ -99,7 +99,8 @@ void upload(gbwt_hip_index &ix) {
         if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
         launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
         {
-            uint32_t hops = 7;
+            uint32_t hops = 15;   // LF steps between a walk and its look-ahead target (7 until the packed blocks and the spread rows: fresh processes,
+                                  // 7 / 11 / 15 / 23 hops = 4.40-4.44 / 4.30-4.33 / 4.27-4.28 / 4.29-4.30 ms; profiles/r02_walk_bounds.txt #26)
             if (const char *v = std::getenv("GBWT_HIP_LOOKAHEAD_HOPS")) hops = static_cast<uint32_t>(std::max(0, std::atoi(v)));
             launch_link_lookahead(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), hops, nullptr);
             // two-step walk: composed descriptors + two-step blocks
