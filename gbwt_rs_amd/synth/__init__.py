@@ -23,6 +23,8 @@ def lib():
         L.gbwt_synth_chain.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64]
         L.gbwt_synth_chain_indel.restype = p
         L.gbwt_synth_chain_indel.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32]
+        L.gbwt_synth_chain_chopped.restype = p
+        L.gbwt_synth_chain_chopped.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.gbwt_synth_from_paths.restype = p
         L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
         L.gbwt_synth_from_file.restype = p
@@ -62,10 +64,10 @@ class Synth:
         self.bidirectional = bool(bd)
 
     @classmethod
-    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0, indel_every=1):
+    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0, indel_every=1, chop=1):
         """`extra` > 0: alleles >= 1 are insertions of `extra` more nodes at every `indel_every`-th site (paths of
-        different lengths; gbwt_synth.h)."""
-        h = lib().gbwt_synth_chain_indel(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every)
+        different lengths); `chop` > 1: every node is a chain of that many nodes with consecutive ids (gbwt_synth.h)."""
+        h = lib().gbwt_synth_chain_chopped(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every, chop)
         if not h:
             raise ValueError("gbwt_synth_chain: parameters out of range")
         return cls(h)

@@ -42,6 +42,13 @@ gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t allel
 gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                                    double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every);
 
+/* ... and with every logical node (anchor, allele, inserted node) chopped into a chain of `chop` nodes with consecutive ids, as a GBZ
+ * built from a GFA chops long segments: most records are then unary (chop == 1 is gbwt_synth_chain_indel).  Node ids of site s
+ * (stride = chop + alleles + (chop - 1) + (alleles - 1) * (chop * (1 + extra) - 1)): anchor pieces s*stride+1 .., first pieces of the alleles
+ * s*stride+chop+1+a, then the remaining pieces of allele 0, of allele 1, ... */
+gbwt_synth *gbwt_synth_chain_chopped(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                                     double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every, uint32_t chop);
+
 /* Paths as CSR over GBWT-encoded nodes (2 * id + orientation, id >= 1).  bidirectional != 0 adds the
  * reverse sequence of every path (src/support.rs:310-314).  No metadata, no graph. */
 gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, int bidirectional);

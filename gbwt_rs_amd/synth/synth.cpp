@@ -81,6 +81,7 @@ struct gbwt_synth {
     uint64_t sites = 0, haplotypes = 0, alleles = 0;
     uint64_t extra = 0;             // alleles >= 1 are insertions: `extra` more nodes behind the allele node ...
     uint64_t indel_every = 1;       // ... at the sites s with s % indel_every == 0 (the tail ids of the other sites stay unused)
+    uint64_t chop = 1;              // every logical node (anchor, allele, inserted node) is a chain of `chop` nodes with consecutive ids
     std::vector<uint64_t> bits;     // alleles == 2: site-major bit rows
     uint64_t row_words = 0;
     std::vector<uint16_t> choices;  // alleles > 2: site-major
@@ -96,13 +97,18 @@ struct gbwt_synth {
         if (alleles == 2) { if (a) bits[s * row_words + (h >> 6)] |= uint64_t(1) << (h & 63); }
         else choices[s * haplotypes + h] = static_cast<uint16_t>(a);
     }
-    // node ids of site s, ascending: anchor, the A allele nodes, then the `extra` tail nodes of allele 1, of allele 2, ...
-    inline uint64_t stride() const { return alleles + 1 + (alleles - 1) * extra; }
-    inline uint64_t anchor_id(uint64_t s) const { return s * stride() + 1; }
-    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * stride() + 2 + a; }
-    inline uint64_t tail_id(uint64_t s, uint32_t a, uint64_t e) const { return s * stride() + 2 + alleles + (a - 1) * extra + e; }
+    // node ids of site s, ascending: the `chop` pieces of the anchor (the last one branches), the first pieces of the A alleles, then the
+    // tails: the remaining pieces of allele 0 (chop - 1), of allele 1 (chop * (1 + extra) - 1 where it is an insertion), of allele 2, ...
+    inline uint64_t tails_max(uint32_t a) const { return a == 0 ? chop - 1 : chop * (1 + extra) - 1; }
+    inline uint64_t tails_before(uint32_t a) const { return a == 0 ? 0 : (chop - 1) + (a - 1) * (chop * (1 + extra) - 1); }
+    inline uint64_t stride() const { return chop + alleles + tails_before(static_cast<uint32_t>(alleles)); }
+    inline uint64_t anchor_first(uint64_t s) const { return s * stride() + 1; }
+    inline uint64_t anchor_last(uint64_t s) const { return s * stride() + chop; }
+    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * stride() + chop + 1 + a; }
+    inline uint64_t tail_id(uint64_t s, uint32_t a, uint64_t e) const { return s * stride() + chop + 1 + alleles + tails_before(a) + e; }
     inline uint64_t extra_at(uint64_t s) const { return s % indel_every == 0 ? extra : 0; }
-    inline uint64_t last_id(uint64_t s, uint32_t a) const { return (a == 0 || extra_at(s) == 0) ? allele_id(s, a) : tail_id(s, a, extra - 1); }
+    inline uint64_t tails_at(uint64_t s, uint32_t a) const { return a == 0 ? chop - 1 : chop * (1 + extra_at(s)) - 1; }   // pieces behind the first one
+    inline uint64_t last_id(uint64_t s, uint32_t a) const { const uint64_t t = tails_at(s, a); return t == 0 ? allele_id(s, a) : tail_id(s, a, t - 1); }
 };
 
 namespace {
@@ -187,12 +193,17 @@ void partition(const gbwt_synth &g, uint64_t s, const SiteStats &st, const std::
 // Pool of records produced by one sweep: slot (s, k) with k = node id - anchor id (0 anchor, 1 + a = allele a, then the tails).
 struct Pool {
     std::vector<uint8_t> bytes;
-    std::vector<uint64_t> start;  // (S * stride + 1) entries, in generation order
+    std::vector<uint64_t> start;  // (S * stride + 1) entries: where the record of a slot begins ...
+    std::vector<uint32_t> len;    // ... and how long it is (slots are written in any order)
+    void begin(uint64_t slot) { start[slot] = bytes.size(); }
+    void end(uint64_t slot) { len[slot] = static_cast<uint32_t>(bytes.size() - start[slot]); }
+    void empty(uint64_t slot) { begin(slot); bytes.push_back(0); end(slot); }
 };
 
 void forward_sweep(const gbwt_synth &g, Pool &pool) {
-    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, X = g.extra, W = g.stride();
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, K = g.chop, W = g.stride();
     pool.start.assign(S * W + 1, 0);
+    pool.len.assign(S * W + 1, 0);
     pool.bytes.reserve(S * 24);
     std::vector<uint32_t> ord(n), nxt, cursor;
     for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
@@ -200,69 +211,75 @@ void forward_sweep(const gbwt_synth &g, Pool &pool) {
     std::vector<std::pair<uint64_t, uint64_t>> edges;
     std::vector<uint64_t> before(A);
     RecordWriter rw(pool.bytes);
+    auto unary = [&](uint64_t slot, uint64_t to, uint64_t offset, uint64_t visits) {   // every visit comes from the one predecessor and goes on to `to`
+        pool.begin(slot);
+        edges.clear();
+        edges.emplace_back(to, offset);
+        rw.begin(edges);
+        rw.push(0, visits);
+        rw.end();
+        pool.end(slot);
+    };
     for (uint64_t s = 0; s < S; s++) {
         st.compute(g, s);
         const uint64_t base = s * W;
-        // anchor, forward orientation: successors are the allele nodes of this site
-        pool.start[base] = pool.bytes.size();
+        // anchor, forward orientation: chop - 1 unary pieces, then the piece whose successors are the allele nodes of this site
+        for (uint64_t i = 0; i + 1 < K; i++) unary(base + i, 2 * (g.anchor_first(s) + i + 1), 0, n);
+        pool.begin(base + K - 1);
         edges.clear();
         for (uint64_t a = 0; a < A; a++) if (st.cnt[a]) edges.emplace_back(2 * g.allele_id(s, static_cast<uint32_t>(a)), 0);
         rw.begin(edges);
         for (uint32_t h : ord) rw.push(st.rank[g.allele(s, h)]);
         rw.end();
+        pool.end(base + K - 1);
         partition(g, s, st, ord, nxt, cursor);
         ord.swap(nxt);
         uint64_t acc = 0;
         for (uint64_t a = 0; a < A; a++) { before[a] = acc; acc += st.cnt[a]; }
-        // the last node of an allele has one edge to the next anchor (or the ENDMARKER at the last site); the next
-        // anchor's visits are ordered by predecessor = last node of the allele, ascending with the allele
-        auto leave = [&](uint64_t a) {
-            edges.clear();
-            if (s + 1 < S) edges.emplace_back(2 * g.anchor_id(s + 1), before[a]); else edges.emplace_back(0, 0);
-        };
-        for (uint64_t a = 0; a < A; a++) {
-            pool.start[base + 1 + a] = pool.bytes.size();
-            if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
-            if (a == 0 || g.extra_at(s) == 0) leave(a);
-            else { edges.clear(); edges.emplace_back(2 * g.tail_id(s, static_cast<uint32_t>(a), 0), 0); }
-            rw.begin(edges);
-            rw.push(0, st.cnt[a]);
-            rw.end();
-        }
-        // tails of the insertion alleles: unary records, every visit comes from the one predecessor
-        for (uint64_t a = 1; a < A; a++) {
-            for (uint64_t e = 0; e < X; e++) {
-                pool.start[base + 1 + A + (a - 1) * X + e] = pool.bytes.size();
-                if (!st.cnt[a] || g.extra_at(s) == 0) { pool.bytes.push_back(0); continue; }
-                if (e + 1 == X) leave(a);
-                else { edges.clear(); edges.emplace_back(2 * g.tail_id(s, static_cast<uint32_t>(a), e + 1), 0); }
-                rw.begin(edges);
-                rw.push(0, st.cnt[a]);
-                rw.end();
+        // allele a: first piece, then its tails; the last piece has one edge to the next anchor (or the ENDMARKER at the last site) --
+        // the next anchor's visits are ordered by predecessor = last piece of the allele, ascending with the allele
+        for (uint32_t a = 0; a < A; a++) {
+            const uint64_t tails = st.cnt[a] ? g.tails_at(s, a) : 0, first_slot = base + K + a, tail_slot = base + K + A + g.tails_before(a);
+            for (uint64_t e = tails; e < g.tails_max(a); e++) pool.empty(tail_slot + e);          // tails this site does not use
+            if (!st.cnt[a]) { pool.empty(first_slot); continue; }
+            const uint64_t out = s + 1 < S ? 2 * g.anchor_first(s + 1) : 0, out_offset = s + 1 < S ? before[a] : 0;
+            for (uint64_t piece = 0; piece <= tails; piece++) {          // piece 0 = the first piece
+                const uint64_t slot = piece == 0 ? first_slot : tail_slot + piece - 1;
+                if (piece == tails) unary(slot, out, out_offset, st.cnt[a]);
+                else unary(slot, 2 * g.tail_id(s, a, piece), 0, st.cnt[a]);
             }
         }
     }
-    pool.start[S * W] = pool.bytes.size();
 }
 
-// Reverse orientation, generated from the last site down; slots are stored in generation order:
-// slot index for site s = (S - 1 - s) * stride + k.
+// Reverse orientation, generated from the last site down; slot index for site s = (S - 1 - s) * stride + k.
 void reverse_sweep(const gbwt_synth &g, Pool &pool) {
-    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, X = g.extra, W = g.stride();
+    const uint64_t S = g.sites, n = g.haplotypes, A = g.alleles, K = g.chop, W = g.stride();
     pool.start.assign(S * W + 1, 0);
+    pool.len.assign(S * W + 1, 0);
     pool.bytes.reserve(S * 24);
     std::vector<uint32_t> ord(n), nxt, cursor;
     for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
     SiteStats st, prev;
     std::vector<std::pair<uint64_t, uint64_t>> edges;
     RecordWriter rw(pool.bytes);
+    auto unary = [&](uint64_t slot, uint64_t to, uint64_t offset, uint64_t visits) {
+        pool.begin(slot);
+        edges.clear();
+        edges.emplace_back(to, offset);
+        rw.begin(edges);
+        rw.push(0, visits);
+        rw.end();
+        pool.end(slot);
+    };
     for (uint64_t s = S; s-- > 0;) {
         st.compute(g, s);
         const uint64_t base = (S - 1 - s) * W;
         partition(g, s, st, ord, nxt, cursor);
-        ord.swap(nxt);  // order of the visits in the reverse anchor record
-        // anchor, reverse orientation: successors are the reverse last nodes of the alleles of site s - 1
-        pool.start[base] = pool.bytes.size();
+        ord.swap(nxt);  // order of the visits in the records of the reverse anchor chain
+        // anchor, reverse orientation: entered at its last piece, left at its first, whose successors are the reverse last pieces of
+        // the alleles of site s - 1
+        pool.begin(base);
         edges.clear();
         if (s > 0) {
             prev.compute(g, s - 1);
@@ -276,32 +293,19 @@ void reverse_sweep(const gbwt_synth &g, Pool &pool) {
             rw.push(0, n);
             rw.end();
         }
-        // allele nodes, reverse: one edge to the reverse anchor of this site
+        pool.end(base);
+        for (uint64_t i = 1; i < K; i++) unary(base + i, 2 * (g.anchor_first(s) + i - 1) + 1, 0, n);
+        // alleles, reverse: the first piece has one edge to the reverse last piece of this site's anchor, every tail one back towards it
         uint64_t before = 0;
-        for (uint64_t a = 0; a < A; a++) {
-            pool.start[base + 1 + a] = pool.bytes.size();
-            if (!st.cnt[a]) { pool.bytes.push_back(0); continue; }
-            edges.clear();
-            edges.emplace_back(2 * g.anchor_id(s) + 1, before);
-            rw.begin(edges);
-            rw.push(0, st.cnt[a]);
-            rw.end();
+        for (uint32_t a = 0; a < A; a++) {
+            const uint64_t tails = st.cnt[a] ? g.tails_at(s, a) : 0, first_slot = base + K + a, tail_slot = base + K + A + g.tails_before(a);
+            for (uint64_t e = tails; e < g.tails_max(a); e++) pool.empty(tail_slot + e);
+            if (!st.cnt[a]) { pool.empty(first_slot); continue; }
+            unary(first_slot, 2 * g.anchor_last(s) + 1, before, st.cnt[a]);
+            for (uint64_t e = 0; e < tails; e++) unary(tail_slot + e, 2 * (e == 0 ? g.allele_id(s, a) : g.tail_id(s, a, e - 1)) + 1, 0, st.cnt[a]);
             before += st.cnt[a];
         }
-        // tails, reverse: back towards the allele node
-        for (uint64_t a = 1; a < A; a++) {
-            for (uint64_t e = 0; e < X; e++) {
-                pool.start[base + 1 + A + (a - 1) * X + e] = pool.bytes.size();
-                if (!st.cnt[a] || g.extra_at(s) == 0) { pool.bytes.push_back(0); continue; }
-                edges.clear();
-                edges.emplace_back(2 * (e == 0 ? g.allele_id(s, static_cast<uint32_t>(a)) : g.tail_id(s, static_cast<uint32_t>(a), e - 1)) + 1, 0);
-                rw.begin(edges);
-                rw.push(0, st.cnt[a]);
-                rw.end();
-            }
-        }
     }
-    pool.start[S * W] = pool.bytes.size();
 }
 
 void add_string(gbwt_hip::Strings &s, const std::string &x) {
@@ -321,7 +325,7 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     SiteStats last;
     last.compute(g, S - 1);
     std::vector<std::pair<uint64_t, uint64_t>> edges;
-    edges.emplace_back(2 * g.anchor_id(0), 0);
+    edges.emplace_back(2 * g.anchor_first(0), 0);
     for (uint64_t a = 0; a < A; a++) if (last.cnt[a]) edges.emplace_back(2 * g.last_id(S - 1, static_cast<uint32_t>(a)) + 1, 0);
     ix.data.clear();
     ix.data.reserve(fwd.bytes.size() + rev.bytes.size() + 4 * n + 64);
@@ -339,9 +343,9 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
         for (uint64_t k = 0; k < W; k++) {
             uint64_t fs = s * W + k, rs = (S - 1 - s) * W + k;
             ix.starts.push_back(ix.data.size());
-            ix.data.insert(ix.data.end(), fwd.bytes.begin() + fwd.start[fs], fwd.bytes.begin() + fwd.start[fs + 1]);
+            ix.data.insert(ix.data.end(), fwd.bytes.begin() + fwd.start[fs], fwd.bytes.begin() + fwd.start[fs] + fwd.len[fs]);
             ix.starts.push_back(ix.data.size());
-            ix.data.insert(ix.data.end(), rev.bytes.begin() + rev.start[rs], rev.bytes.begin() + rev.start[rs + 1]);
+            ix.data.insert(ix.data.end(), rev.bytes.begin() + rev.start[rs], rev.bytes.begin() + rev.start[rs] + rev.len[rs]);
         }
     }
     // alphabet_size = largest visited GBWT node + 1: drop the records of unused trailing allele nodes
@@ -377,21 +381,29 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     ix.is_gbz = true; ix.has_translation = false;
     Rng rng(seed ^ 0xACDCACDCull);
     SiteStats st;
-    uint64_t real = 0, inserted = 0;
+    uint64_t real = 0, visits = 0;
     ix.sequences_labels.bytes.reserve(S * W);
     ix.sequences_labels.offsets.reserve(S * W + 1);
+    const uint64_t K = g.chop;
     for (uint64_t s = 0; s < S; s++) {
         st.compute(g, s);
-        if (g.extra_at(s)) inserted += n - st.cnt[0];
+        visits += n * K;                                             // the anchor's pieces
+        for (uint32_t a = 0; a < A; a++) visits += st.cnt[a] * (1 + g.tails_at(s, a));
         for (uint64_t k = 0; k < W; k++) {
             if (s * W + k + 1 > g.last_id(S - 1, top)) break;  // ids past the largest visited node
-            const uint64_t a = k == 0 ? 0 : (k <= A ? k - 1 : 1 + (k - 1 - A) / g.extra);
-            if (k == 0 || (st.cnt[a] && (k <= A || g.extra_at(s)))) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
+            bool exists = k < K;                                     // anchor pieces
+            if (!exists && k < K + A) exists = st.cnt[k - K] != 0;   // first pieces of the alleles
+            if (!exists && k >= K + A) {                             // tails: which allele, which piece
+                uint32_t a = 0;
+                while (a + 1 < A && k - K - A >= g.tails_before(a + 1)) a++;
+                exists = st.cnt[a] != 0 && k - K - A - g.tails_before(a) < g.tails_at(s, a);
+            }
+            if (exists) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
             ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
         }
     }
     ix.graph_nodes = real;
-    ix.size = 2 * (n * 2 * S + inserted * g.extra) + 2 * n;
+    ix.size = 2 * visits + 2 * n;
 }
 
 // ---- general path sets: brute-force reverse-prefix sort ------------------------------------------
@@ -480,9 +492,14 @@ gbwt_synth *gbwt_synth_chain(uint64_t sites, uint64_t haplotypes, uint32_t allel
 
 gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                                    double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every) {
-    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64 || indel_every == 0) return nullptr;
+    return gbwt_synth_chain_chopped(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every, 1);
+}
+
+gbwt_synth *gbwt_synth_chain_chopped(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                                     double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every, uint32_t chop) {
+    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64 || indel_every == 0 || chop == 0 || chop > 64) return nullptr;
     gbwt_synth *g = new gbwt_synth;
-    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra; g->indel_every = indel_every;
+    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra; g->indel_every = indel_every; g->chop = chop;
     if (alleles == 2) { g->row_words = (haplotypes + 63) / 64; g->bits.assign(sites * g->row_words, 0); }
     else g->choices.assign(sites * haplotypes, 0);
     draw_alleles(*g, model, founders, switch_rate, zipf, seed);
@@ -586,9 +603,9 @@ uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, u
         auto put = [&](uint64_t node) { if (len < cap) out[len] = static_cast<uint32_t>(2 * node); len++; };
         for (uint64_t site = 0; site < s->sites; site++) {
             const uint32_t a = s->allele(site, path_id);
-            put(s->anchor_id(site));
+            for (uint64_t i = 0; i < s->chop; i++) put(s->anchor_first(site) + i);
             put(s->allele_id(site, a));
-            if (a) for (uint64_t e = 0; e < s->extra_at(site); e++) put(s->tail_id(site, a, e));
+            for (uint64_t e = 0; e < s->tails_at(site, a); e++) put(s->tail_id(site, a, e));
         }
         return len;
     }
@@ -604,8 +621,9 @@ uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id) {
         if (path_id >= s->haplotypes) return 0;
         for (uint64_t site = 0; site < s->sites; site++) {
             const uint32_t a = s->allele(site, path_id);
-            sum += 2 * s->anchor_id(site) + 2 * s->allele_id(site, a);
-            if (a) for (uint64_t e = 0; e < s->extra_at(site); e++) sum += 2 * s->tail_id(site, a, e);
+            for (uint64_t i = 0; i < s->chop; i++) sum += 2 * (s->anchor_first(site) + i);
+            sum += 2 * s->allele_id(site, a);
+            for (uint64_t e = 0; e < s->tails_at(site, a); e++) sum += 2 * s->tail_id(site, a, e);
         }
         return sum;
     }

@@ -508,6 +508,23 @@ def test_walk_loop_variants(monkeypatch, env):
             assert np.array_equal(dev.copy_path(h), s.path(h))
 
 
+@pytest.mark.parametrize("chop,extra,every", [(3, 0, 1), (4, 1, 2), (2, 2, 1)])
+def test_chopped_chain_bit_exact(tmp_path, chop, extra, every):
+    """Every node a chain of `chop` nodes with consecutive ids -- most records unary, as in a GBZ built from a GFA with long
+    segments -- with and without insertions: forward and reverse sequences and W-lines against the oracle."""
+    s = S.Synth.chain(sites=1200, haplotypes=500, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=41, extra=extra, indel_every=every, chop=chop)
+    path = tmp_path / "chopped.gbz"
+    s.save(str(path), as_gbz=True)
+    dev = G.GBZ.load(str(path))
+    oracle = O.OracleGBZ(str(path)).gbwt()
+    for first in (0, 1):
+        ids = np.arange(first, 1000, 2, dtype=np.uint64)
+        offsets, nodes = dev.sequences_csr(ids)
+        o_off, o_nodes = oracle.extract(ids, threads=8)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    assert dev.path_lines(np.arange(1, 30, dtype=np.uint64), 1) == O.OracleGBZ(str(path)).path_lines(list(range(1, 30)), 1)
+
+
 def test_indel_chain_scale_properties():
     """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix."""
     s = S.Synth.chain(sites=60000, haplotypes=3000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=9, extra=2)

@@ -112,6 +112,22 @@ def test_indel_chain_matches_bruteforce_builder(alleles, model, extra, every):
     assert (s.sequences, s.size, s.alphabet_offset, s.alphabet_size) == (b.sequences, b.size, b.alphabet_offset, b.alphabet_size)
 
 
+@pytest.mark.parametrize("alleles,model,extra,every,chop", [(2, S.MOSAIC, 0, 1, 2), (2, S.IID, 1, 1, 3), (3, S.MOSAIC, 2, 2, 2), (5, S.IID, 0, 1, 4),
+                                                            (2, S.MOSAIC, 1, 5, 5)])
+def test_chopped_chain_matches_bruteforce_builder(alleles, model, extra, every, chop):
+    """Every node a chain of `chop` nodes with consecutive ids (most records unary, as in a GBZ built from a GFA with long segments):
+    byte for byte the brute-force builder's index."""
+    s = S.Synth.chain(sites=7, haplotypes=19, alleles=alleles, model=model, founders=4, switch_rate=0.2, seed=12, extra=extra, indel_every=every, chop=chop)
+    paths = [[int(x) for x in s.path(h)] for h in range(s.paths)]
+    for h, p in enumerate(paths):
+        assert sum(p) == s.path_checksum(h)
+        assert all(b - a == 2 for a, b in zip(p[:chop], p[1:chop]))           # the anchor's pieces: consecutive ids, forward
+    b = S.Synth.from_paths(paths, bidirectional=True)
+    assert bytes(s.data()) == bytes(b.data())
+    assert list(s.starts()) == list(b.starts())
+    assert (s.sequences, s.size, s.alphabet_offset, s.alphabet_size) == (b.sequences, b.size, b.alphabet_offset, b.alphabet_size)
+
+
 def test_indel_chain_gbz_loads_in_the_oracle(tmp_path):
     s = S.Synth.chain(sites=150, haplotypes=40, alleles=2, model=S.MOSAIC, founders=6, switch_rate=0.05, seed=3, extra=2)
     path = tmp_path / "indel.gbz"
@@ -124,6 +140,20 @@ def test_indel_chain_gbz_loads_in_the_oracle(tmp_path):
         assert g.sequence(2 * h + 1) == kat.reverse_path(truth)
     w = [l for l in z.gfa().split(b"\n") if l.startswith(b"W\t")]
     assert len(w) == 39 and int(w[0].split(b"\t")[5]) == len(s.path(1))   # 1 bp labels: walk length in bases = nodes
+
+
+def test_chopped_chain_gbz_loads_in_the_oracle(tmp_path):
+    s = S.Synth.chain(sites=60, haplotypes=30, alleles=2, model=S.MOSAIC, founders=6, switch_rate=0.05, seed=4, extra=1, indel_every=3, chop=3)
+    path = tmp_path / "chopped.gbz"
+    s.save(str(path), as_gbz=True)
+    z = O.OracleGBZ(str(path))
+    g = z.gbwt()
+    for h in (0, 11, 29):
+        truth = [int(x) for x in s.path(h)]
+        assert g.sequence(2 * h) == truth
+        assert g.sequence(2 * h + 1) == kat.reverse_path(truth)
+    w = [l for l in z.gfa().split(b"\n") if l.startswith(b"W\t")]
+    assert len(w) == 29 and int(w[0].split(b"\t")[5]) == len(s.path(1))   # 1 bp labels on every piece
 
 
 def test_chain_generator_oracle_extraction(tmp_path):
