@@ -111,12 +111,14 @@ void upload(gbwt_hip_index &ix) {
             d.cblocks = ix.cblocks.as<uint4>();
             uint32_t gather_limit = 1u << 21;     // the counts of the gather loop's packed blocks (tests lower it)
             if (const char *v = std::getenv("GBWT_HIP_GATHER_LIMIT")) gather_limit = static_cast<uint32_t>(std::min<long>(1l << 21, std::max<long>(0, std::atol(v))));
+            if (n_blocks >= (uint64_t(1) << 31)) gather_limit = 0;   // half-block indices 2 bb + offset / 32 are 32-bit in the loops: beyond that, full-width blocks only
+            ix.packed_blocks = gather_limit != 0;
             launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, nullptr);
             if (n_blocks > 1) launch_fill_cblocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), nullptr);
-            ix.gblocks.reserve(n_blocks * 2 * sizeof(uint4));
+            ix.gblocks.reserve((gather_limit ? n_blocks : 1) * 2 * sizeof(uint4));   // no record takes the packed path: only the zero block
             HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.gblocks = ix.gblocks.as<uint4>();
-            if (n_blocks > 1) launch_fill_gblocks(d, counts.as<uint32_t>(), ix.gblocks.as<uint4>(), nullptr);
+            if (n_blocks > 1 && gather_limit) launch_fill_gblocks(d, counts.as<uint32_t>(), ix.gblocks.as<uint4>(), nullptr);
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
         // LF tables for the class 0 records, while they fit the budget
@@ -489,8 +491,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             if (const char *v = std::getenv("GBWT_HIP_XCD_MAP")) a.xcd_map = std::atoi(v) ? 1u : 0u;
             a.uniform_loop = 1;
             if (const char *v = std::getenv("GBWT_HIP_UNIFORM_LOOP")) a.uniform_loop = std::atoi(v) ? 1u : 0u;
-            a.packed_blocks = 1;
-            if (const char *v = std::getenv("GBWT_HIP_PACKED_BLOCKS")) a.packed_blocks = std::atoi(v) ? 1u : 0u;
+            a.packed_blocks = ix->packed_blocks ? 1u : 0u;   // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
+            if (const char *v = std::getenv("GBWT_HIP_PACKED_BLOCKS")) a.packed_blocks = (std::atoi(v) && ix->packed_blocks) ? 1u : 0u;
             a.row_piece = 32;
             if (const char *v = std::getenv("GBWT_HIP_ROW_PIECE")) { const int r = std::atoi(v); if (r == 0 || r == 16 || r == 32) a.row_piece = static_cast<uint32_t>(r); }
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
