@@ -36,6 +36,12 @@ class Stats(C.Structure):
                 ("max_outdegree", C.c_uint64)]
 
 
+class OpenTimes(C.Structure):
+    _fields_ = [("parse_ms", C.c_double), ("upload_ms", C.c_double), ("sample_ms", C.c_double), ("total_ms", C.c_double),
+                ("samples", C.c_uint64), ("checkpoint_walkers", C.c_uint64), ("checkpoint_sampling", C.c_uint32),
+                ("checkpoint_rounds", C.c_uint32)]
+
+
 class Paths(C.Structure):
     _fields_ = [("d_offsets", C.c_void_p), ("d_nodes", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
 
@@ -54,6 +60,7 @@ SIGNATURES = {
     "gbwt_hip_open_records": (_int, [_p, _u64, _p, _u64, _u64, _u64, _u64, _u64, _int, _int, C.POINTER(_p)]),
     "gbwt_hip_close": (None, [_p]),
     "gbwt_hip_get_stats": (_int, [_p, C.POINTER(Stats)]),
+    "gbwt_hip_get_open_times": (_int, [_p, C.POINTER(OpenTimes)]),
     "gbwt_hip_workspace_create": (_int, [_p, C.POINTER(_p)]),
     "gbwt_hip_workspace_destroy": (None, [_p]),
     "gbwt_hip_workspace_stream": (_p, [_p]),

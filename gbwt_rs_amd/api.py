@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import BdState, GbwtHipError, Lines, Paths, Pos, State, Stats, check
+from ._lib import BdState, GbwtHipError, Lines, OpenTimes, Paths, Pos, State, Stats, check
 
 FORWARD, REVERSE = 0, 1  # support::Orientation, src/support.rs:30-47
 
@@ -102,6 +102,12 @@ class GBWT:
             self.close()
         except Exception:
             pass
+
+    def open_times(self):
+        """Where the time of the open went (gbwt_hip_get_open_times): a dict of milliseconds and counts."""
+        t = OpenTimes()
+        check(self._L.gbwt_hip_get_open_times(self._h, C.byref(t)))
+        return {name: getattr(t, name) for name, _ in OpenTimes._fields_}
 
     # ---- statistics (src/gbwt.rs:105-175) -----------------------------------------------------
     def len(self):

@@ -10,6 +10,7 @@
 #include <memory>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,6 +36,84 @@ void fill_stats(gbwt_hip_index &ix) {
     s.size = h.size; s.sequences = h.sequences; s.alphabet_size = h.alphabet_size; s.alphabet_offset = h.alphabet_offset;
     s.records = h.records(); s.data_bytes = h.data.size(); s.paths = h.path_names.size();
     s.bidirectional = h.bidirectional; s.has_metadata = h.has_metadata; s.is_gbz = h.is_gbz; s.has_translation = h.has_translation;
+}
+
+// max / min / common number of samples per sequence from the host copy of sample_base
+void note_sample_counts(gbwt_hip_index &ix, const std::vector<uint64_t> &base) {
+    uint64_t lo = ~uint64_t(0), hi = 0;
+    for (size_t k = 0; k + 1 < base.size(); k++) { const uint64_t c = base[k + 1] - base[k]; lo = std::min(lo, c); hi = std::max(hi, c); }
+    ix.max_samples = static_cast<uint32_t>(std::min<uint64_t>(hi, 0xFFFFFFFFull));
+    ix.uniform_samples = (base.size() > 1 && lo == hi) ? ix.max_samples : 0u;
+}
+
+// Lengths and samples of all sequences by checkpoint sampling (open_walks.hip; kernels.hpp: CheckpointWalk).  d_flags[0] collects
+// the overflow bits of the chase like the serial walks do.  false: nothing usable was built (the caller walks every sequence).
+bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags) {
+    const HostIndex &h = ix.host;
+    DeviceIndex &d = ix.dev;
+    const uint64_t S = h.sequences, nr = d.n_records;
+    if (nr == 0 || S == 0 || d.desc2 == nullptr) return false;
+    // a checkpoint per interval / 2 LF steps that end on a record that can be one (an LF step emits one node, two where it is fused with a
+    // unary successor), at most `cap` (+ 3) nodes per hop
+    const double q = std::min(0.5, 2.0 / interval);
+    CheckpointWalk w{};
+    w.threshold = static_cast<uint32_t>(q * 4294967296.0);
+    w.cap = 2 * interval;
+    w.packed = ix.packed_blocks ? 1u : 0u;
+    if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_CAP")) w.cap = static_cast<uint32_t>(std::max(1, std::atoi(v)));
+    DeviceBuffer counts, cp_first, scan_tmp, summaries, orphans, misc;
+    counts.reserve(nr * sizeof(uint64_t)); cp_first.reserve((nr + 1) * sizeof(uint64_t));
+    launch_checkpoint_counts(d, w.threshold, counts.as<uint64_t>(), nullptr);
+    const size_t tb = scan_temp_bytes(nr);
+    scan_tmp.reserve(std::max<size_t>(tb, 16));
+    launch_scan(counts.as<uint64_t>(), cp_first.as<uint64_t>(), nr, scan_tmp.ptr, tb, nullptr);
+    uint64_t positions = 0;
+    HIP_CHECK(hipMemcpy(&positions, cp_first.as<uint64_t>() + nr, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // every orphan stands for a finished walk of at least `cap` nodes, and no two walkers share a BWT position
+    const uint64_t orphan_capacity = 2 * (d.max_walk / w.cap) + S + 1024;
+    const uint64_t n_summaries = S + positions + orphan_capacity;
+    if (n_summaries >= 0xFFFFFFF0ull) return false;
+    summaries.reserve(n_summaries * sizeof(uint4)); orphans.reserve(orphan_capacity * sizeof(uint4));
+    misc.reserve(2 * sizeof(uint64_t));
+    HIP_CHECK(hipMemset(misc.ptr, 0, 2 * sizeof(uint64_t)));
+    w.cp_first = cp_first.as<uint64_t>(); w.summaries = summaries.as<uint4>(); w.orphans = orphans.as<uint4>();
+    w.orphan_count = misc.as<uint64_t>(); w.orphan_capacity = orphan_capacity; w.positions = positions;
+    w.flags = reinterpret_cast<uint32_t *>(misc.as<uint64_t>() + 1);
+    uint64_t first = 0, count = S + positions, orphans_seen = 0;
+    uint32_t rounds = 0;
+    for (;;) {
+        launch_checkpoint_walk(d, w, first, count, nullptr);
+        rounds++;
+        uint64_t state[2] = {0, 0};
+        HIP_CHECK(hipMemcpy(state, misc.ptr, sizeof(state), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipGetLastError());
+        if ((state[1] & 4u) || state[0] > orphan_capacity) return false;   // more orphans than a consistent index can have
+        if (state[0] == orphans_seen) break;
+        if (rounds > 4096) return false;                                    // walks in circles
+        first = S + positions + orphans_seen; count = state[0] - orphans_seen; orphans_seen = state[0];
+    }
+    ix.times.checkpoint_rounds = rounds; ix.times.checkpoint_walkers = S + positions + orphans_seen;
+    // the chase: count, scan, write
+    ix.seq_len.reserve(S * sizeof(uint32_t));
+    ix.sample_base.reserve((S + 1) * sizeof(uint64_t));
+    DeviceBuffer per_sequence;
+    per_sequence.reserve(S * sizeof(uint64_t));
+    launch_chase(d, summaries.as<uint4>(), n_summaries, ix.seq_len.as<uint32_t>(), per_sequence.as<uint64_t>(), nullptr, nullptr, d_flags, nullptr);
+    const size_t sb = scan_temp_bytes(S);
+    scan_tmp.reserve(std::max<size_t>(sb, 16));
+    launch_scan(per_sequence.as<uint64_t>(), ix.sample_base.as<uint64_t>(), S, scan_tmp.ptr, sb, nullptr);
+    std::vector<uint64_t> base(S + 1);
+    HIP_CHECK(hipMemcpy(base.data(), ix.sample_base.ptr, base.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint32_t overflow = 0;
+    HIP_CHECK(hipMemcpy(&overflow, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (overflow) return true;                                              // the caller reports it; no samples
+    ix.samples.reserve(std::max<uint64_t>(base[S], 1) * sizeof(uint4));
+    launch_chase(d, summaries.as<uint4>(), n_summaries, nullptr, nullptr, ix.sample_base.as<uint64_t>(), ix.samples.as<uint4>(), d_flags, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipGetLastError());
+    ix.times.samples = base[S];
+    note_sample_counts(ix, base);
+    return true;
 }
 
 // Uploads the host image and runs the load-time device passes.
@@ -185,13 +264,14 @@ void upload(gbwt_hip_index &ix) {
     }
     d.endmarker = ix.endmarker.as<uint2>();
     d.n_endmarker = end_len;
-    // Lengths of all sequences: one counting walk at open (GBWT_HIP_SEQ_LEN=0 skips it; extractions then go through the
+    // Lengths of all sequences and the sequence samples (GBWT_HIP_SEQ_LEN=0 skips both; extractions then go through the
     // pool of chained blocks and walk every sequence from one end).
     d.seq_len = nullptr;
     const char *want_len = std::getenv("GBWT_HIP_SEQ_LEN");
     if (h.sequences > 0 && !(want_len && std::atoi(want_len) == 0)) {
+        const auto t_samples = std::chrono::steady_clock::now();
         ix.seq_len.reserve(h.sequences * sizeof(uint32_t));
-        // 16 bytes per sample.  Large indexes: every 2 048 nodes (1 024 .. 4 096 measure within 3 % of each other on the
+        // 16 bytes per sample.  Large indexes: about every 2 048 nodes (1 024 .. 4 096 measure within 3 % of each other on the
         // headline); smaller ones get shorter intervals, down to 64 nodes, so that an extraction still has enough
         // walkers to fill the GPU -- about four million samples per index at most.  GBWT_HIP_SAMPLE_INTERVAL=0: none.
         const uint64_t all_nodes = h.size >= h.sequences ? h.size - h.sequences : 0;
@@ -208,12 +288,16 @@ void upload(gbwt_hip_index &ix) {
         if (want_pairs) prints.reserve(h.sequences * 2 * sizeof(uint64_t));
         HIP_CHECK(hipMemset(d_stats, 0, 2 * sizeof(uint64_t)));
         uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_stats);   // [0] = a length overflowed, [2] = a pair does not match
-        // with samples and without fingerprints, lengths and samples come out of ONE walk (pooled samples, placed afterwards)
+        // Samples by checkpoint sampling (open_walks.hip): no sequence is walked from end to end.  GBWT_HIP_SERIAL_SAMPLES=1 (and
+        // indexes it cannot number with 32 bits, or whose records send walks in circles) take the walk of every sequence instead.
+        const char *serial = std::getenv("GBWT_HIP_SERIAL_SAMPLES");
+        bool by_checkpoints = sampled && !want_pairs && !(serial && std::atoi(serial) != 0) && checkpoint_samples(ix, interval, d_flags);
+        // serial: with samples and without fingerprints, lengths and samples come out of ONE walk (pooled samples, placed afterwards)
         DeviceBuffer pool, tags;
         uint64_t pooled = 0;
         const uint64_t pool_capacity = all_nodes / std::max<uint32_t>(interval, 1) + 2 * h.sequences + 1024;
         const char *two = std::getenv("GBWT_HIP_TWO_PASS_OPEN");
-        bool one_walk = sampled && !want_pairs && h.sequences <= 0xFFFFFFFFull && !(two && std::atoi(two) != 0);
+        bool one_walk = !by_checkpoints && sampled && !want_pairs && h.sequences <= 0xFFFFFFFFull && !(two && std::atoi(two) != 0);
         if (one_walk) {
             pool.reserve(pool_capacity * sizeof(uint4)); tags.reserve(pool_capacity * sizeof(uint2));
             HIP_CHECK(hipMemset(d_stats + 2, 0, sizeof(uint64_t)));
@@ -221,7 +305,7 @@ void upload(gbwt_hip_index &ix) {
             HIP_CHECK(hipMemcpy(&pooled, d_stats + 2, sizeof(uint64_t), hipMemcpyDeviceToHost));
             if (pooled > pool_capacity) one_walk = false;            // cannot happen (one sample per interval + one per sequence): walk twice
         }
-        if (!one_walk)
+        if (!one_walk && !by_checkpoints)
         launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), want_pairs ? prints.as<uint64_t>() : nullptr, d_flags, nullptr);
         if (want_pairs)
             launch_check_orientation_pairs(ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), h.sequences / 2, d_flags + 2, nullptr);
@@ -238,9 +322,9 @@ void upload(gbwt_hip_index &ix) {
                 const auto mm = std::minmax_element(lens.begin(), lens.end());
                 ix.uniform_len = (*mm.first == *mm.second) ? *mm.first : 0u;
             }
-            // Sequence samples: where every sequence is about every `interval` nodes (second walk), so that extractions
+            // Sequence samples: where every sequence is about every `interval` nodes, so that extractions
             // can fill a row with many walkers at once.
-            if (sampled) {
+            if (sampled && !by_checkpoints) {
                 DeviceBuffer counts, scan_tmp;
                 counts.reserve(h.sequences * sizeof(uint64_t));
                 ix.sample_base.reserve((h.sequences + 1) * sizeof(uint64_t));
@@ -256,23 +340,37 @@ void upload(gbwt_hip_index &ix) {
                 else launch_record_samples(d, ix.sample_base.as<uint64_t>(), interval, ix.samples.as<uint4>(), nullptr);
                 HIP_CHECK(hipDeviceSynchronize());
                 HIP_CHECK(hipGetLastError());
+                ix.times.samples = total_samples;
+                std::vector<uint64_t> base(h.sequences + 1);
+                HIP_CHECK(hipMemcpy(base.data(), ix.sample_base.ptr, base.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                note_sample_counts(ix, base);
+            }
+            if (sampled) {
                 d.samples = ix.samples.as<uint4>();
                 d.sample_base = ix.sample_base.as<uint64_t>();
                 d.sample_interval = interval;
             }
         }
+        ix.times.checkpoint_sampling = by_checkpoints ? 1u : 0u;
+        ix.times.sample_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_samples).count();
     }
 }
 
 // Takes ownership of `ix`; anything thrown on the way (corrupt sizes, HIP failures, allocation failures) destroys it and is
 // turned into a status by the guard of the calling entry point.
-gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index **out) {
+gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index **out, std::chrono::steady_clock::time_point t_open) {
+    const auto t_parsed = std::chrono::steady_clock::now();
     fill_stats(*ix);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
     upload(*ix);
     upload_label_lengths(*ix);
+    const auto t_done = std::chrono::steady_clock::now();
+    const auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
+    ix->times.parse_ms = ms(t_parsed - t_open);
+    ix->times.total_ms = ms(t_done - t_open);
+    ix->times.upload_ms = ms(t_done - t_parsed) - ix->times.sample_ms;
     *out = ix.release();
     return GBWT_HIP_OK;
 }
@@ -338,10 +436,11 @@ gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index 
     GBWT_HIP_GUARD_BEGIN
     if (!path || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = nullptr;
+    const auto t_open = std::chrono::steady_clock::now();
     std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
     ix->host = load_index_file(path);
-    return open_common(std::move(ix), out);
+    return open_common(std::move(ix), out, t_open);
     GBWT_HIP_GUARD_END
 }
 
@@ -351,11 +450,12 @@ gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, co
     GBWT_HIP_GUARD_BEGIN
     if (!out || (data_len && !data) || (n_records && !starts)) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = nullptr;
+    const auto t_open = std::chrono::steady_clock::now();
     std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
     ix->host = index_from_records(data, data_len, starts, n_records, alphabet_offset, alphabet_size, n_sequences, size,
                                   bidirectional != 0);
-    return open_common(std::move(ix), out);
+    return open_common(std::move(ix), out, t_open);
     GBWT_HIP_GUARD_END
 }
 
@@ -365,6 +465,14 @@ gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *
     GBWT_HIP_GUARD_BEGIN
     if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = index->stats;
+    return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_get_open_times(const gbwt_hip_index *index, gbwt_hip_open_times *out) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    *out = index->times;
     return GBWT_HIP_OK;
     GBWT_HIP_GUARD_END
 }
@@ -434,8 +542,9 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
             uint64_t total = 0;
             uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
-            bool all_valid = ix->uniform_len != 0;
-            for (uint64_t k = 0; k < n && all_valid; k++) all_valid = seq_ids[k] < ix->host.sequences;
+            bool ids_valid = true;
+            for (uint64_t k = 0; k < n && ids_valid; k++) ids_valid = seq_ids[k] < ix->host.sequences;
+            const bool all_valid = ids_valid && ix->uniform_len != 0;
             if (all_valid) {
                 // every row has the same, known length: total and extremes without a round trip to the device (the offsets are
                 // still scanned there, behind which the walk is simply enqueued)
@@ -446,18 +555,20 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
                 HIP_CHECK(hipMemcpyAsync(extremes, ws->counters.ptr, sizeof(extremes), hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
             }
-            const uint32_t max_len = extremes[0], min_len = ~extremes[1];
+            const uint32_t max_len = extremes[0];
             ws->nodes.reserve(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
             WalkArgs a{};
             a.seq_ids = ws->seq_ids.as<uint64_t>(); a.n = n;
             a.mode = ws->walk_mode;
             // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
             const char *seg = std::getenv("GBWT_HIP_SEGMENTS");
-            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && !(seg && std::atoi(seg) == 0);   // (the walker order sorts 32-bit row numbers)
-            a.segments = segmented ? (max_len - 1) / ix->dev.sample_interval + 1 : 0u;
+            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && ix->max_samples > 0 && !(seg && std::atoi(seg) == 0);   // (the walker order sorts 32-bit row numbers)
+            // the samples lie where the sequences pass checkpoint records, so the number of segments of a row comes from its samples, not from its length
+            a.segments = segmented ? ix->max_samples : 0u;
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
-            const bool same_segments = segmented && min_len > 0 && (min_len - 1) / ix->dev.sample_interval + 1 == a.segments;
+            const bool same_segments = segmented && ids_valid && ix->uniform_samples != 0;
             if (same_segments) {
+                a.segments = ix->uniform_samples;
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
             } else if (segmented) {

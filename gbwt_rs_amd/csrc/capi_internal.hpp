@@ -177,6 +177,9 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceBuffer node_real;     // u8 per node id < mapping_len: GBZ::has_node
     gbwt_hip::DeviceIndex dev{};
     bool packed_blocks = true;        // gblocks was built (false: the index is too large for 32-bit half-block indices, or GBWT_HIP_GATHER_LIMIT=0)
+    uint32_t max_samples = 0;         // the largest number of samples of a sequence
+    uint32_t uniform_samples = 0;     // every sequence has this many samples (0: they differ): the walkers of an extraction are then w = segment * n + row
+    gbwt_hip_open_times times{};      // where the time of the open went (gbwt_hip_get_open_times)
     uint32_t uniform_len = 0;         // every sequence has this many nodes (0: lengths differ, or unknown): an extraction then knows its offsets without asking the device
     bool orientation_pairs = false;   // verified at open: sequence 2k + 1 is sequence 2k reversed (rows can be filled from both ends)
     gbwt_hip_stats stats{};

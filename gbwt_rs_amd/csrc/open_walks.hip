@@ -169,6 +169,198 @@ __global__ void __launch_bounds__(256) k_check_orientation_pairs(const uint32_t 
     if (!good) atomicOr(mismatch, 1u);
 }
 
+
+// ---- checkpoint sampling: the sequence samples WITHOUT a walk of every sequence from end to end --------------------------
+// The counting walk above follows each sequence with one lane: 666 668 dependent steps per lane on the headline index, 10 000 lanes
+// -- 185 ms for what an extraction does in 4 (the one-shot flow of gbunzip, src/bin/gbunzip.rs:24-59, pays it once per file).
+// Checkpoint sampling cuts the chains by RECORD instead of by sequence:
+//   * a record is a CHECKPOINT when a multiplicative hash of its index falls below a threshold (no table, three instructions);
+//   * one walker per BWT position of every checkpoint record, plus one per sequence start, walks forward -- the two-step walk of
+//     the extraction, counting instead of emitting -- until an iteration ends on a checkpoint record, the sequence ends, or `cap`
+//     nodes have been emitted.  Every BWT position is walked once by exactly one walker (LF is injective), at full occupancy;
+//   * a walker that reaches the cap leaves an ORPHAN: its position becomes a walker of the next round (a few short rounds: the
+//     number of walkers shrinks geometrically), so every gap between two hops is at most cap + 3 nodes;
+//   * what a walker leaves is a SUMMARY {record, offset, nodes walked, summary index of the position it landed on}: the
+//     positions of one sequence form a linked list, about a thousand nodes per hop;
+//   * one lane per sequence then chases its list (k_chase: one 16-byte load per hop instead of a thousand LF steps) and writes
+//     the sequence samples and the length.
+// The samples lie where sequences pass the same record, not every so many nodes of each sequence: rows that travel through the
+// same records have their samples at the same records whatever happened to them upstream (an insertion shifts node counts, not
+// checkpoints), so the walkers of a segment start together again.
+constexpr uint32_t CP_HASH = 2654435761u;
+constexpr uint32_t CP_END = 0xFFFFFFFFu;
+// Checkpoints are records that are not unary: a unary record can lie INSIDE a fused edge (k_link_desc: an edge into a unary record
+// emits it and lands behind it), where no walk ever stops; every other record a walk visits, it visits at the end of an LF step.
+__device__ __forceinline__ bool hashed_checkpoint(uint32_t rec, uint32_t threshold) { return rec != 0 && rec * CP_HASH < threshold; }
+__device__ __forceinline__ uint32_t checkpoint_len(const DeviceIndex &ix, uint64_t rec) {   // Record::len of a record that can be a checkpoint, else 0
+    const uint4 B = ix.desc_raw[4 * rec + 1], C = ix.desc_raw[4 * rec + 2];
+    return (B.y != 0 && B.y != DESC_UNARY) ? C.y : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_checkpoint_counts(DeviceIndex ix, uint32_t threshold, uint64_t *counts) {
+    const uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (rec < ix.n_records) counts[rec] = hashed_checkpoint(static_cast<uint32_t>(rec), threshold) ? checkpoint_len(ix, rec) : 0u;
+}
+
+struct NodeCounter {
+    uint32_t wr = 0;
+    __device__ __forceinline__ void push(uint32_t, bool counts) { wr += counts ? 1u : 0u; }
+};
+
+// One iteration of the two-step walk that counts its nodes and emits nothing: on the packed half-blocks (three loads: the lane's
+// half-block, then E_a and leaf (a, b) -- the gather loop of the extraction in plain C++, walk_loops.hpp), or one generic step where
+// a record asks for it.  It stops BETWEEN its two LF steps when the first one lands on a hashed record (`threshold`; the caller
+// then looks whether that record is a checkpoint): true, with (rec, offset) = that position and bb unknown.
+__device__ __forceinline__ bool counting_step(const DeviceIndex &ix, bool packed, uint32_t threshold, NodeCounter &sink, uint32_t &rec, uint32_t &offset, uint32_t &bb) {
+    const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
+    uint32_t a, b, rank_a, ones_w_base, mw;     // first-step value, second-step value, rank of the offset among the a-positions, counts of the second step
+    uint4 E;
+    if (packed) {
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : 2 * static_cast<uint64_t>(bb) + (offset >> 5);
+        const uint4 K = ix.gblocks[idx];
+        const uint32_t bit = offset & 31u, below = (1u << bit) - 1;
+        a = (K.x >> bit) & 1u; b = (K.y >> bit) & 1u;
+        E = d[a];
+        if ((E.z & DESC2_SLOW) || !(E.w & GATHER_OK)) { packed = false; }
+        else {
+            const uint32_t ones1 = K.z & 0x1FFFFFu, R0 = ((K.z >> 21) | (K.w << 11)) & 0x1FFFFFu, R1 = K.w >> 10;
+            const uint32_t m = (a ? K.x : ~K.x) & below;
+            const uint32_t p = __popc(m);
+            rank_a = a ? ones1 + p : (offset - bit) - ones1 + p;
+            ones_w_base = a ? R1 : R0; mw = __popc(m & K.y);
+        }
+    }
+    if (!packed) {
+        const uint4 E0 = d[0];
+        if (E0.z & DESC2_SLOW) { generic_step(ix, sink, rec, offset, bb); return false; }
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT);
+        const uint4 K0 = ix.cblocks[2 * idx], K1 = ix.cblocks[2 * idx + 1];
+        const uint64_t bits1 = (static_cast<uint64_t>(K0.y) << 32) | K0.x, bits2 = (static_cast<uint64_t>(K0.w) << 32) | K0.z;
+        const uint32_t bit = offset & 63u;
+        const uint64_t below = (uint64_t(1) << bit) - 1;
+        a = static_cast<uint32_t>(bits1 >> bit) & 1u; b = static_cast<uint32_t>(bits2 >> bit) & 1u;
+        const uint64_t m = (a ? bits1 : ~bits1) & below;
+        rank_a = a ? K1.x + __popcll(m) : (offset - bit) - K1.x + __popcll(m);
+        E = a ? d[1] : E0;
+        ones_w_base = a ? K1.z : K1.y; mw = __popcll(m & bits2);
+    }
+    const uint32_t j = E.y + rank_a, w = E.z & REC_MASK;
+    sink.wr += (E.x != 0 ? 1u : 0u) + ((E.z & LEAF_EMIT2) ? 1u : 0u);
+    if (hashed_checkpoint(w, threshold)) { rec = w; offset = j; bb = BLOCK_NONE; return true; }
+    const uint4 leaf = d[2 + 2 * a + b];
+    const uint32_t ones_w = ones_w_base + mw;
+    rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
+    sink.wr += (leaf.x != 0 ? 1u : 0u) + ((leaf.z & LEAF_EMIT2) ? 1u : 0u);
+    return false;
+}
+
+struct CheckpointArgs {
+    const uint64_t *cp_first;      // [n_records + 1]: first checkpoint position of every record (exclusive scan of k_checkpoint_counts)
+    uint4 *summaries;              // [sequences + positions + orphan capacity]
+    uint4 *orphans;                // [orphan capacity] {record, offset, block base, 0}
+    unsigned long long *orphan_count;
+    uint64_t orphan_capacity;
+    uint64_t positions;            // checkpoint positions = cp_first[n_records]
+    uint64_t first, count;         // the walkers of this launch: summary indices first .. first + count
+    uint32_t threshold, cap;
+    uint32_t packed;               // the index has packed half-blocks (gblocks)
+    uint32_t *flags;               // bit 2: the orphan pool is full (no samples from this pass)
+};
+
+__global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, CheckpointArgs c) {
+    const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t g = c.first + t;
+    const uint64_t S = ix.n_sequences;
+    uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
+    bool active = t < c.count;
+    if (active) {
+        if (g < S) {                                           // a sequence start: the position after the start node (GBWT::start, src/gbwt.rs:213-219)
+            if (g < ix.n_endmarker) {
+                const uint2 e = ix.endmarker[g];
+                offset = e.y;
+                if (e.x == 0 || !arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+            }
+        } else if (g < S + c.positions) {                      // position w of the checkpoint records: the last record with cp_first <= w
+            const uint64_t w = g - S;
+            uint64_t lo = 0, hi = ix.n_records;                // cp_first[lo] <= w < cp_first[hi]
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) / 2;
+                if (c.cp_first[mid] <= w) lo = mid; else hi = mid;
+            }
+            rec = static_cast<uint32_t>(lo); offset = static_cast<uint32_t>(w - c.cp_first[lo]); bb = ix.block_base[lo];
+        } else {
+            const uint4 o = c.orphans[g - S - c.positions];
+            rec = o.x; offset = o.y; bb = o.z;
+        }
+        if (rec == 0) { c.summaries[g] = make_uint4(0u, 0u, 0u, CP_END); active = false; }
+    }
+    NodeCounter sink;
+    const uint32_t lane = threadIdx.x % WAVE;
+    while (__ballot(active) != 0) {
+        bool orphan = false;
+        if (active) {
+            const bool between = counting_step(ix, c.packed != 0, c.threshold, sink, rec, offset, bb);
+            if (rec == 0) { c.summaries[g] = make_uint4(0u, 0u, sink.wr, CP_END); active = false; }
+            else if (hashed_checkpoint(rec, c.threshold) && offset < checkpoint_len(ix, rec)) {
+                c.summaries[g] = make_uint4(rec, offset, sink.wr, static_cast<uint32_t>(S + c.cp_first[rec] + offset));
+                active = false;
+            } else {
+                if (between) bb = ix.block_base[rec];          // a hashed record that is no checkpoint after all (unary): the walk goes on from it
+                if (sink.wr >= c.cap) { orphan = true; active = false; }
+            }
+        }
+        const uint64_t mask = __ballot(orphan);                // one atomic per wave: in a lock-step batch all 64 lanes reach the cap together
+        if (mask != 0) {
+            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(c.orphan_count, static_cast<unsigned long long>(__popcll(mask)));
+            base = __shfl(base, static_cast<int>(leader));
+            if (orphan) {
+                const uint64_t slot = base + __popcll(mask & ((uint64_t(1) << lane) - 1));
+                if (slot < c.orphan_capacity) {
+                    c.orphans[slot] = make_uint4(rec, offset, bb, 0u);
+                    c.summaries[g] = make_uint4(rec, offset, sink.wr, static_cast<uint32_t>(S + c.positions + slot));
+                } else {
+                    c.summaries[g] = make_uint4(0u, 0u, sink.wr, CP_END);
+                    atomicOr(c.flags, 4u);
+                }
+            }
+        }
+    }
+}
+
+// One lane per sequence: the chain of summaries from the sequence start.  samples == nullptr: count the samples and the length;
+// otherwise write them: sample 0 = the position after the start node (as the walker of segment 0 expects it), then one per hop.
+__global__ void __launch_bounds__(64) k_chase(DeviceIndex ix, const uint4 *summaries, uint64_t n_summaries, uint32_t *seq_len, uint64_t *counts,
+                                              const uint64_t *sample_base, uint4 *samples, uint32_t *overflow) {
+    const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (id >= ix.n_sequences) return;
+    uint64_t n = 0, wr = 0;
+    uint4 *out = samples ? samples + sample_base[id] : nullptr;
+    const uint64_t room = samples ? sample_base[id + 1] - sample_base[id] : 0;
+    if (id < ix.n_endmarker && ix.endmarker[id].x != 0) {
+        const uint2 e = ix.endmarker[id];
+        uint32_t rec = 0, bb = BLOCK_NONE;
+        if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+        wr = 1;
+        if (out && n < room) out[n] = make_uint4(rec, e.y, bb, 1u);
+        n++;
+        uint64_t p = id, hops = 0;
+        while (rec != 0) {
+            if (p >= n_summaries || ++hops > ix.max_walk) { if (overflow) atomicOr(overflow, 2u); break; }
+            const uint4 s = summaries[p];
+            wr += s.z;
+            if (wr > 0xFFFFFFF0ull) { if (overflow) atomicOr(overflow, 1u); break; }
+            rec = s.x;
+            if (rec == 0) break;
+            if (out && n < room) out[n] = make_uint4(rec, s.y, ix.block_base[rec], static_cast<uint32_t>(wr));
+            n++;
+            p = s.w;
+        }
+    }
+    if (!samples) { seq_len[id] = static_cast<uint32_t>(wr); counts[id] = n; }
+}
+
 }  // namespace
 
 void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_t *d_prints, uint32_t *d_overflow, hipStream_t stream) {
@@ -203,6 +395,27 @@ void launch_record_samples(const DeviceIndex &ix, const uint64_t *d_sample_base,
     if (ix.n_sequences == 0) return;
     hipLaunchKernelGGL(k_record_samples, dim3(grid_for(ix.n_sequences, 256)), dim3(256), 0, stream, ix, d_sample_base, interval, d_samples,
                        static_cast<uint32_t *>(nullptr));
+}
+
+
+void launch_checkpoint_counts(const DeviceIndex &ix, uint32_t threshold, uint64_t *d_counts, hipStream_t stream) {
+    if (ix.n_records) hipLaunchKernelGGL(k_checkpoint_counts, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, threshold, d_counts);
+}
+
+void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, uint64_t first, uint64_t count, hipStream_t stream) {
+    if (count == 0) return;
+    CheckpointArgs c{};
+    c.cp_first = w.cp_first; c.summaries = w.summaries; c.orphans = w.orphans; c.orphan_count = reinterpret_cast<unsigned long long *>(w.orphan_count);
+    c.orphan_capacity = w.orphan_capacity; c.positions = w.positions; c.first = first; c.count = count; c.threshold = w.threshold; c.cap = w.cap; c.packed = w.packed;
+    c.flags = w.flags;
+    hipLaunchKernelGGL(k_checkpoint_walk, dim3(grid_for(count, 256)), dim3(256), 0, stream, ix, c);
+}
+
+void launch_chase(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, uint32_t *d_seq_len, uint64_t *d_counts, const uint64_t *d_sample_base,
+                  uint4 *d_samples, uint32_t *d_overflow, hipStream_t stream) {
+    if (ix.n_sequences == 0) return;
+    hipLaunchKernelGGL(k_chase, dim3(grid_for(ix.n_sequences, 64)), dim3(64), 0, stream, ix, d_summaries, n_summaries, d_seq_len, d_counts, d_sample_base,
+                       d_samples, d_overflow);
 }
 
 }  // namespace gbwt_hip

@@ -95,6 +95,18 @@ gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, co
 void gbwt_hip_close(gbwt_hip_index *index);
 gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *out);
 
+/* Where the time of gbwt_hip_open_* went (host clock, milliseconds; the one-shot flow of gbunzip, src/bin/gbunzip.rs:24-59, pays all
+ * of it once per file): parse_ms = reading and validating the file (0 for gbwt_hip_open_records), upload_ms = host-to-device copies
+ * and the per-record passes (descriptors, rank blocks, tables, endmarker), sample_ms = sequence lengths + sequence samples,
+ * total_ms = the whole call.  samples = sequence samples built; checkpoint_sampling = 1 when they came from checkpoint sampling
+ * (no sequence walked from end to end), with its number of rounds and walkers. */
+typedef struct {
+    double parse_ms, upload_ms, sample_ms, total_ms;
+    uint64_t samples, checkpoint_walkers;
+    uint32_t checkpoint_sampling, checkpoint_rounds;
+} gbwt_hip_open_times;
+gbwt_hip_status gbwt_hip_get_open_times(const gbwt_hip_index *index, gbwt_hip_open_times *out);
+
 /* Workspaces own a HIP stream and reusable device scratch (path pool, CSR outputs). */
 gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_workspace **out);
 void gbwt_hip_workspace_destroy(gbwt_hip_workspace *ws);

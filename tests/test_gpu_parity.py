@@ -729,7 +729,10 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "128", "GBWT_HIP_WIDE_ADDRESSES": "1"},   # both loops with 64-bit addresses
                 {"GBWT_HIP_SAMPLE_INTERVAL": "1000", "GBWT_HIP_PATHS_PER_WAVE": "13"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_WALK_TABLES": "0"},   # outdegree > 2: plain table steps, one at a time
-                {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_TWO_PASS_OPEN": "1"},  # lengths and samples from two walks at open instead of one
+                {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_SERIAL_SAMPLES": "1", "GBWT_HIP_TWO_PASS_OPEN": "1"},  # every sequence walked at open: lengths, then samples
+                {"GBWT_HIP_SAMPLE_INTERVAL": "40", "GBWT_HIP_SERIAL_SAMPLES": "1"},   # ... both in one walk (samples every 40 nodes of each sequence)
+                {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CHECKPOINT_CAP": "5"},   # checkpoint sampling with hops of at most 5 + 3 nodes: many rounds of orphans
+                {"GBWT_HIP_SAMPLE_INTERVAL": "2048", "GBWT_HIP_CHECKPOINT_CAP": "100000"},   # ... with hardly any checkpoint: whole sequences in one hop
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
 
