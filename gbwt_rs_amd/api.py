@@ -23,6 +23,7 @@ from . import _lib
 from ._lib import BdState, GbwtHipError, Lines, OpenTimes, Paths, Pos, State, Stats, check
 
 FORWARD, REVERSE = 0, 1  # support::Orientation, src/support.rs:30-47
+PATHS_DEFAULT, PATHS_PAN_SN, PATHS_REF_ONLY = 0, 1, 2  # gbunzip's PathMode, src/bin/gbunzip.rs:63-76
 
 POS_DTYPE = np.dtype([("node", "<u8"), ("offset", "<u8")])
 STATE_DTYPE = np.dtype([("node", "<u8"), ("start", "<u8"), ("end", "<u8")])
@@ -102,6 +103,13 @@ class GBWT:
             self.close()
         except Exception:
             pass
+
+    def new_workspace(self):
+        """A fresh workspace: the GBWT_HIP_* extraction knobs are read when a workspace is created, not per call."""
+        if getattr(self, "_ws", None):
+            self._L.gbwt_hip_workspace_destroy(self._ws)
+        self._ws = C.c_void_p()
+        check(self._L.gbwt_hip_workspace_create(self._h, C.byref(self._ws)))
 
     def open_times(self):
         """Where the time of the open went (gbwt_hip_get_open_times): a dict of milliseconds and counts."""
@@ -313,7 +321,8 @@ class GBZ(GBWT):
         return None if seq is None else [decode_node(x) for x in seq]
 
     def path_lines(self, path_ids, mode):
-        """gbunzip's P-lines (mode 0) or W-lines (mode 1) for the given paths, as bytes (src/bin/gbunzip.rs:438-550)."""
+        """gbunzip's P-lines (mode 0), W-lines (mode 1) or P-lines with PanSN names (mode 2) for the given paths, as bytes
+        (src/bin/gbunzip.rs:438-550)."""
         ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
         total = C.c_uint64(0)
         check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, None, 0, C.byref(total)))
@@ -321,9 +330,9 @@ class GBZ(GBWT):
         check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, buf, total.value, C.byref(total)))
         return buf.raw[: total.value]
 
-    def write_gfa(self, path):
-        """The file `gbunzip -t 1` writes for this GBZ (src/bin/gbunzip.rs:205-226)."""
-        check(self._L.gbwt_hip_write_gfa(self._h, self._ws, os.fsencode(path)))
+    def write_gfa(self, path, path_mode=PATHS_DEFAULT):
+        """The file `gbunzip -t 1 --paths MODE` writes for this GBZ (src/bin/gbunzip.rs:205-226; PathMode 63-76)."""
+        check(self._L.gbwt_hip_write_gfa_mode(self._h, self._ws, os.fsencode(path), path_mode))
 
     def paths_csr(self, path_ids, orientation=FORWARD):
         """GBZ::path(id, orientation) for every id, as CSR of GBWT-encoded nodes (support::encode_path, src/support.rs:229-231)."""
@@ -338,5 +347,5 @@ class GBZ(GBWT):
         return out
 
 
-__all__ = ["GBWT", "GBZ", "GbwtHipError", "Lines", "Paths", "FORWARD", "REVERSE", "POS_DTYPE", "STATE_DTYPE", "BD_DTYPE", "encode_node",
+__all__ = ["GBWT", "GBZ", "GbwtHipError", "Lines", "Paths", "FORWARD", "REVERSE", "PATHS_DEFAULT", "PATHS_PAN_SN", "PATHS_REF_ONLY", "POS_DTYPE", "STATE_DTYPE", "BD_DTYPE", "encode_node",
            "decode_node", "flip_node", "encode_path", "device_count", "parse_file", "Pos", "State", "BdState"]

@@ -44,6 +44,8 @@ void note_sample_counts(gbwt_hip_index &ix, const std::vector<uint64_t> &base) {
     for (size_t k = 0; k + 1 < base.size(); k++) { const uint64_t c = base[k + 1] - base[k]; lo = std::min(lo, c); hi = std::max(hi, c); }
     ix.max_samples = static_cast<uint32_t>(std::min<uint64_t>(hi, 0xFFFFFFFFull));
     ix.uniform_samples = (base.size() > 1 && lo == hi) ? ix.max_samples : 0u;
+    ix.sample_counts.resize(base.size() - 1);
+    for (size_t k = 0; k + 1 < base.size(); k++) ix.sample_counts[k] = static_cast<uint32_t>(std::min<uint64_t>(base[k + 1] - base[k], 0xFFFFFFFFull));
 }
 
 // Lengths and samples of all sequences by checkpoint sampling (open_walks.hip; kernels.hpp: CheckpointWalk).  d_flags[0] collects
@@ -58,7 +60,7 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     const double q = std::min(0.5, 2.0 / interval);
     CheckpointWalk w{};
     w.threshold = static_cast<uint32_t>(q * 4294967296.0);
-    w.cap = 2 * interval;
+    w.cap = interval;     // A/B on the headline (profiles/r03_sampling_ab.txt): cap = interval 4.31 ms per pass, 1.5 x 4.38, 2 x 4.46; the serial samples 4.34
     w.packed = ix.packed_blocks ? 1u : 0u;
     if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_CAP")) w.cap = static_cast<uint32_t>(std::max(1, std::atoi(v)));
     DeviceBuffer counts, cp_first, scan_tmp, summaries, orphans, misc;
@@ -145,8 +147,12 @@ void upload(gbwt_hip_index &ix) {
         d.starts64 = ix.starts.as<uint64_t>();
     }
 
-    // Load-time device passes: per-record descriptors + rank blocks, record statistics, then the endmarker
+    // Load-time device passes: per-record descriptors + rank blocks + record statistics, then the endmarker
     // (src/gbwt.rs:413-414).
+    DeviceBuffer tmp;
+    tmp.reserve(8 * sizeof(uint64_t));
+    HIP_CHECK(hipMemset(tmp.ptr, 0, 8 * sizeof(uint64_t)));
+    uint64_t *d_stats = tmp.as<uint64_t>();
     {
         const uint64_t nr = std::max<uint64_t>(n_records, 1);
         ix.desc.reserve(nr * 4 * sizeof(uint4));
@@ -154,7 +160,7 @@ void upload(gbwt_hip_index &ix) {
         ix.block_base.reserve(nr * sizeof(uint32_t));
         DeviceBuffer counts, scan_tmp;
         counts.reserve(nr * sizeof(uint32_t));
-        launch_build_desc(d, ix.desc_raw.as<uint4>(), counts.as<uint32_t>(), nullptr);
+        launch_build_desc(d, ix.desc_raw.as<uint4>(), counts.as<uint32_t>(), d_stats, nullptr);
         d.desc_raw = ix.desc_raw.as<uint4>();
         d.desc = ix.desc.as<uint4>();
         uint64_t n_blocks = 1;  // block 0: all zero, read by the records that have no blocks of their own
@@ -193,11 +199,10 @@ void upload(gbwt_hip_index &ix) {
             if (n_blocks >= (uint64_t(1) << 31)) gather_limit = 0;   // half-block indices 2 bb + offset / 32 are 32-bit in the loops: beyond that, full-width blocks only
             ix.packed_blocks = gather_limit != 0;
             launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, nullptr);
-            if (n_blocks > 1) launch_fill_cblocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), nullptr);
             ix.gblocks.reserve((gather_limit ? n_blocks : 1) * 2 * sizeof(uint4));   // no record takes the packed path: only the zero block
             HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.gblocks = ix.gblocks.as<uint4>();
-            if (n_blocks > 1 && gather_limit) launch_fill_gblocks(d, counts.as<uint32_t>(), ix.gblocks.as<uint4>(), nullptr);
+            if (n_blocks > 1) launch_fill_two_step_blocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), gather_limit ? ix.gblocks.as<uint4>() : nullptr, nullptr);
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
         // LF tables for the class 0 records, while they fit the budget
@@ -239,12 +244,6 @@ void upload(gbwt_hip_index &ix) {
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
     }
-    DeviceBuffer tmp;
-    tmp.reserve(8 * sizeof(uint64_t));
-    HIP_CHECK(hipMemset(tmp.ptr, 0, 8 * sizeof(uint64_t)));
-    uint64_t *d_stats = tmp.as<uint64_t>();
-    launch_record_stats(d, d_stats, nullptr);
-    launch_endmarker_sigma(d, d_stats + 4, nullptr);
     uint64_t hs[8];
     HIP_CHECK(hipMemcpy(hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
@@ -253,15 +252,13 @@ void upload(gbwt_hip_index &ix) {
     if (hs[2] != 0) throw InvalidData("BWT: record without a readable outdegree");
     if (hs[0] >= (uint64_t(1) << 32)) throw InvalidData("record longer than 2^32 positions is not supported");
     d.max_walk = hs[3];
-    const uint64_t end_len = hs[4], end_sigma = hs[5];
+    // the endmarker: record 0 decompressed by the loader (host_index.cpp; the reference's GBWT::load does it on the CPU as well,
+    // src/gbwt.rs:413-414) -- a single lane of the GPU took 6 ms for the 10 000 runs of the headline index, the host 0.1
+    const std::vector<std::pair<uint32_t, uint32_t>> endmarker = decompress_endmarker(h, std::max<uint64_t>(hs[0], 1));
+    const uint64_t end_len = endmarker.size();
     ix.endmarker.reserve(std::max<uint64_t>(end_len, 1) * sizeof(uint2));
-    if (end_len > 0) {
-        DeviceBuffer scratch;
-        scratch.reserve(2 * end_sigma * sizeof(uint64_t));
-        launch_endmarker_decompress(d, ix.endmarker.as<uint2>(), end_len, scratch.as<uint64_t>(), d_stats + 6, nullptr);
-        HIP_CHECK(hipDeviceSynchronize());
-        HIP_CHECK(hipGetLastError());
-    }
+    static_assert(sizeof(std::pair<uint32_t, uint32_t>) == sizeof(uint2), "pairs are uploaded as uint2");
+    if (end_len > 0) HIP_CHECK(hipMemcpy(ix.endmarker.ptr, endmarker.data(), end_len * sizeof(uint2), hipMemcpyHostToDevice));
     d.endmarker = ix.endmarker.as<uint2>();
     d.n_endmarker = end_len;
     // Lengths of all sequences and the sequence samples (GBWT_HIP_SEQ_LEN=0 skips both; extractions then go through the
@@ -483,6 +480,8 @@ gbwt_hip_status gbwt_hip_workspace_create(const gbwt_hip_index *index, gbwt_hip_
     *out = nullptr;
     std::unique_ptr<gbwt_hip_workspace> ws(new gbwt_hip_workspace);
     ws->nodes.may_spread = true;
+    ws->nodes.policy = vmm_policy_from_env();
+    ws->knobs = ExtractKnobs::from_env();
     ws->index = index;
     HIP_CHECK(hipSetDevice(index->device));
     HIP_CHECK(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
@@ -518,6 +517,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
     // gets an empty row (the kernels test the id), the rest of the batch is extracted; callers tell None from an empty
     // sequence by id < sequences.
     ws->extract_cached = false;
+    ws->timed = false; ws->last_n = 0; ws->last_total = 0;   // what copy_result / path_sums / copy_path trust: set again only when this call succeeds
     try {
         HIP_CHECK(hipSetDevice(ix->device));
         hipStream_t s = ws->stream;
@@ -533,8 +533,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         uint64_t pool_blocks = all_nodes / POOL_BLOCK_NODES + n + 1;
         HIP_CHECK(hipEventRecord(ws->ev[3], s));   // everything the extraction puts on the stream lies between ev[3] and ev[2]
         if (n) HIP_CHECK(hipMemcpyAsync(ws->seq_ids.ptr, seq_ids, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        const char *no_direct = std::getenv("GBWT_HIP_DIRECT");
-        if (n && ix->dev.seq_len && ws->walk_mode == WALK_TWO_STEP && !(no_direct && std::atoi(no_direct) == 0)) {
+        const ExtractKnobs &knobs = ws->knobs;
+        if (n && ix->dev.seq_len && ws->walk_mode == WALK_TWO_STEP && knobs.direct != 0) {
             // Lengths known: offsets first, then every lane writes into its row; in a bidirectional index two walkers per
             // sequence, one from each end.
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
@@ -561,14 +561,20 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.seq_ids = ws->seq_ids.as<uint64_t>(); a.n = n;
             a.mode = ws->walk_mode;
             // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
-            const char *seg = std::getenv("GBWT_HIP_SEGMENTS");
-            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && ix->max_samples > 0 && !(seg && std::atoi(seg) == 0);   // (the walker order sorts 32-bit row numbers)
+            const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && ix->max_samples > 0 && knobs.segments != 0;   // (the walker order sorts 32-bit row numbers)
             // the samples lie where the sequences pass checkpoint records, so the number of segments of a row comes from its samples, not from its length
             a.segments = segmented ? ix->max_samples : 0u;
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
-            const bool same_segments = segmented && ids_valid && ix->uniform_samples != 0;
+            // every row of the batch with the same number of samples (the forward sequences of haplotypes over one reference frame: the
+            // headline's shape): walker w = segment * n + row, no order to compute
+            uint32_t common = ix->uniform_samples;
+            if (segmented && ids_valid && common == 0 && n != 0) {
+                common = ix->sample_counts[seq_ids[0]];
+                for (uint64_t k = 1; k < n && common != 0; k++) if (ix->sample_counts[seq_ids[k]] != common) common = 0;
+            }
+            const bool same_segments = segmented && ids_valid && common != 0;
             if (same_segments) {
-                a.segments = ix->uniform_samples;
+                a.segments = common;
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
             } else if (segmented) {
@@ -589,27 +595,21 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             // about one workgroup per four SIMDs keeps every workgroup resident (32 KB of LDS each)
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                : segmented ? 64u : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (walkers + 1023) / 1024)));
-            a.helper_lanes = 64;
-            if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
-            a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
-            a.ring_slots = segmented ? 64 : 128;   // many walkers: smaller rings, more workgroups per CU (7.4 vs 8.1 ms on the headline)
-            if (const char *v = std::getenv("GBWT_HIP_RING_SLOTS")) { const int r = std::atoi(v); if (r == 32 || r == 64 || r == 128) a.ring_slots = static_cast<uint32_t>(r); }
-            a.helper_naps = segmented ? 4u : 1u;   // many walkers per CU: a helper that polls less leaves more issue slots and LDS cycles to them (6 until the
-                                                   // packed half-blocks made the walkers faster: 3 / 4 / 6 / 8 / 10 naps = 4.30 / 4.31 / 4.35 / 4.42 / 4.51 ms)
-            if (const char *v = std::getenv("GBWT_HIP_HELPER_NAPS")) a.helper_naps = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+            a.helper_lanes = knobs.helper_lanes >= 0 ? static_cast<uint32_t>(knobs.helper_lanes) : 64u;
+            a.wide_addresses = knobs.wide_addresses ? 1u : 0u;
+            a.ring_slots = knobs.ring_slots > 0 ? static_cast<uint32_t>(knobs.ring_slots) : (segmented ? 64u : 128u);   // many walkers: smaller rings, more workgroups per CU (7.4 vs 8.1 ms on the headline)
+            // many walkers per CU: a helper that polls less leaves more issue slots and LDS cycles to them (6 until the packed half-blocks
+            // made the walkers faster: 3 / 4 / 6 / 8 / 10 naps = 4.30 / 4.31 / 4.35 / 4.42 / 4.51 ms)
+            a.helper_naps = knobs.helper_naps >= 0 ? static_cast<uint32_t>(knobs.helper_naps) : (segmented ? 4u : 1u);
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
-            a.xcd_map = segmented ? 1u : 0u;
-            if (const char *v = std::getenv("GBWT_HIP_XCD_MAP")) a.xcd_map = std::atoi(v) ? 1u : 0u;
-            a.uniform_loop = 1;
-            if (const char *v = std::getenv("GBWT_HIP_UNIFORM_LOOP")) a.uniform_loop = std::atoi(v) ? 1u : 0u;
-            a.packed_blocks = ix->packed_blocks ? 1u : 0u;   // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
-            if (const char *v = std::getenv("GBWT_HIP_PACKED_BLOCKS")) a.packed_blocks = (std::atoi(v) && ix->packed_blocks) ? 1u : 0u;
-            a.row_piece = 32;
-            if (const char *v = std::getenv("GBWT_HIP_ROW_PIECE")) { const int r = std::atoi(v); if (r == 0 || r == 16 || r == 32) a.row_piece = static_cast<uint32_t>(r); }
+            a.xcd_map = knobs.xcd_map >= 0 ? (knobs.xcd_map ? 1u : 0u) : (segmented ? 1u : 0u);
+            a.uniform_loop = knobs.uniform_loop >= 0 ? (knobs.uniform_loop ? 1u : 0u) : 1u;
+            // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
+            a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;
+            a.row_piece = knobs.row_piece >= 0 ? static_cast<uint32_t>(knobs.row_piece) : 32u;
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
-            if (const char *v = std::getenv("GBWT_HIP_DEBUG_DRY_ROWS")) a.debug = static_cast<uint32_t>(std::atoi(v));   // timing experiments only, see WalkArgs::debug   // timing experiments only: rows stay unwritten
-            const char *both = std::getenv("GBWT_HIP_BOTH_ENDS");
-            a.both_ends = ix->orientation_pairs && !(both && std::atoi(both) == 0) ? 1u : 0u;
+            a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
+            a.both_ends = (ix->orientation_pairs && knobs.both_ends != 0) ? 1u : 0u;
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);
             HIP_CHECK(hipEventRecord(ws->ev[1], s));
@@ -638,9 +638,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                                    : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(32, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
-            a.helper_lanes = 64;
-            if (const char *v = std::getenv("GBWT_HIP_HELPER_LANES")) a.helper_lanes = static_cast<uint32_t>(std::max(0, std::atoi(v)));
-            a.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") ? 1u : 0u;
+            a.helper_lanes = knobs.helper_lanes >= 0 ? static_cast<uint32_t>(knobs.helper_lanes) : 64u;
+            a.wide_addresses = knobs.wide_addresses ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             launch_walk(ix->dev, a, s);
@@ -681,10 +680,8 @@ namespace {
 // stages through one pinned buffer on one thread and also pays the first-touch page faults of a fresh destination on
 // that thread (0.5 - 1.1 s for 13.3 GB).  Here a few threads take alternate chunks, each with a pinned buffer and a
 // stream of its own: the copies over PCIe, the copies out of the pinned buffers and the page faults run side by side.
-void copy_to_host(int device, void *dst, const void *src, size_t bytes) {
+void copy_to_host(int device, void *dst, const void *src, size_t bytes, unsigned threads) {
     constexpr size_t CHUNK = size_t(32) << 20;
-    const char *knob = std::getenv("GBWT_HIP_COPY_THREADS");
-    const unsigned threads = knob ? static_cast<unsigned>(std::max(1, std::atoi(knob))) : 4u;
     if (bytes < 4 * CHUNK || threads < 2) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return; }
     const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
     std::atomic<size_t> next{0};
@@ -733,7 +730,7 @@ gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *w
         *total = p.total;
         if (!out_nodes) return GBWT_HIP_OK;
         if (capacity < p.total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(p.total));
-        if (p.total) copy_to_host(ix->device, out_nodes, p.d_nodes, p.total * sizeof(uint32_t));
+        if (p.total) copy_to_host(ix->device, out_nodes, p.d_nodes, p.total * sizeof(uint32_t), ws->knobs.copy_threads);
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
@@ -760,7 +757,7 @@ gbwt_hip_status gbwt_hip_copy_result(const gbwt_hip_index *ix, gbwt_hip_workspac
     if (out_offsets) HIP_CHECK(hipMemcpy(out_offsets, ws->offsets.ptr, (ws->last_n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (out_nodes) {
         if (capacity < ws->last_total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ws->last_total));
-        if (ws->last_total) copy_to_host(ix->device, out_nodes, ws->nodes.ptr, ws->last_total * sizeof(uint32_t));
+        if (ws->last_total) copy_to_host(ix->device, out_nodes, ws->nodes.ptr, ws->last_total * sizeof(uint32_t), ws->knobs.copy_threads);
     }
     return GBWT_HIP_OK;
     GBWT_HIP_GUARD_END

@@ -42,46 +42,68 @@ struct HipError { hipError_t err; const char *what; };
 // (walks out of lock step) were written 5 % slower than into one hipMalloc -- smaller mappings, less TLB reach -- with 2 GiB 1 %.  The
 // price is paid when a workspace is sized: the driver clears what it hands out, about 15 ms per GB created (1.7 s for a 13 GB buffer at
 // spread 8; spread 4 keeps half of the gain, 2 nothing).  hipMalloc whenever any of that fails.
-// GBWT_HIP_VMM="0": always hipMalloc;  "<chunk MiB>:<spread, 0 = as much as 3/4 of the free memory allows, at most 8>:<min MiB>".
-struct VmmPolicy { size_t chunk = size_t(2048) << 20, min = size_t(4) << 30; unsigned spread = 0; };
-inline const VmmPolicy &vmm_policy() {
-    static const VmmPolicy policy = [] {
-        VmmPolicy p;
-        if (const char *v = std::getenv("GBWT_HIP_VMM")) {
-            unsigned long chunk = 0, spread = 0, min = 4096;
-            const int got = std::sscanf(v, "%lu:%lu:%lu", &chunk, &spread, &min);
-            if (got >= 1) { p.chunk = chunk << 20; p.spread = static_cast<unsigned>(spread); p.min = min << 20; }
-        }
-        return p;
-    }();
-    return policy;
+// GBWT_HIP_VMM="0": always hipMalloc;  "<chunk MiB>:<spread, 0 = as much as half of the free memory allows, at most 8>:<min MiB>:<after>"
+// (after = requests served as one hipMalloc before the buffer is rebuilt from spread chunks; 0 = spread at once).
+struct VmmPolicy { size_t chunk = size_t(2048) << 20, min = size_t(4) << 30; unsigned spread = 0, after = 2; };
+// GBWT_HIP_VMM, read when a workspace is created (the policy travels with its rows buffer)
+inline VmmPolicy vmm_policy_from_env() {
+    VmmPolicy p;
+    if (const char *v = std::getenv("GBWT_HIP_VMM")) {
+        unsigned long chunk = 0, spread = 0, min = 4096;
+        const int got = std::sscanf(v, "%lu:%lu:%lu", &chunk, &spread, &min);
+        if (got >= 1) { p.chunk = chunk << 20; p.spread = static_cast<unsigned>(spread); p.min = min << 20; }
+    }
+    return p;
 }
 
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
     std::vector<hipMemGenericAllocationHandle_t> chunks;   // empty: ptr comes from hipMalloc
-    size_t mapped = 0;                                       // bytes of virtual range reserved at ptr
+    size_t reserved = 0;                                     // bytes of virtual range reserved at ptr (0: hipMalloc)
+    size_t chunk_bytes = 0, mapped_chunks = 0;               // the first mapped_chunks chunks are mapped at ptr + i * chunk_bytes
     bool may_spread = false;                                 // the extracted rows of a workspace only: spreading the index arrays gains nothing (#25)
+    VmmPolicy policy;                                        // how (set by the workspace from GBWT_HIP_VMM)
+    unsigned uses = 0;                                       // requests the buffer has served at its present size
     ~DeviceBuffer() { release(); }
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
     DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    // hipFree waits for the work that may still use the memory; unmapping does not.  The rows of a workspace are handed out as raw
+    // device pointers (gbwt_hip_paths, dist.device_view) that a consumer may still be reading on ANOTHER stream -- a torch kernel,
+    // an RCCL send -- so a mapped buffer waits for the whole device before it goes.
     void release() noexcept {
-        if (mapped) {
-            (void)hipMemUnmap(ptr, mapped);
-            (void)hipMemAddressFree(ptr, mapped);
+        if (reserved) {
+            (void)hipDeviceSynchronize();
+            // one hipMemUnmap per hipMemMap: a single call over the whole range is not documented to undo several mappings, and
+            // a chunk that stays mapped keeps its 2 GiB of VRAM for good
+            for (size_t i = 0; i < mapped_chunks; i++) (void)hipMemUnmap(static_cast<char *>(ptr) + i * chunk_bytes, chunk_bytes);
+            (void)hipMemAddressFree(ptr, reserved);
         } else if (ptr) (void)hipFree(ptr);
         for (auto h : chunks) (void)hipMemRelease(h);
+        (void)hipGetLastError();
         chunks.clear();
-        ptr = nullptr; bytes = 0; mapped = 0;
+        ptr = nullptr; bytes = 0; reserved = 0; chunk_bytes = 0; mapped_chunks = 0;
     }
+    // Spreading costs seconds (the driver clears every chunk it hands out, and gives the unused ones back lazily: the NEXT large
+    // allocation of the process waits for that), so a buffer starts as one hipMalloc -- what a one-shot extraction sees -- and is
+    // rebuilt from spread chunks once it has served `policy.after` requests: a workspace that is used again and again (a server, the
+    // timed passes of bench.py) pays once and gains on every pass after that.  The contents do not survive; callers reserve before
+    // they write.
     void reserve(size_t need) {
-        if (need <= bytes) return;
+        if (need <= bytes) {
+            if (may_spread && reserved == 0 && policy.chunk != 0 && bytes >= policy.min && ++uses == policy.after) {
+                const size_t want = bytes;
+                release();
+                if (!spread_chunks(want)) HIP_CHECK(hipMalloc(&ptr, want));
+                bytes = want;
+            }
+            return;
+        }
         release();
+        uses = 0;
         const size_t want = std::max<size_t>(need, 256);
-        const VmmPolicy &policy = vmm_policy();
-        if (may_spread && policy.chunk != 0 && want >= policy.min && spread_chunks(want, policy)) { bytes = want; return; }
+        if (may_spread && policy.chunk != 0 && want >= policy.min && policy.after == 0 && spread_chunks(want)) { bytes = want; return; }
         HIP_CHECK(hipMalloc(&ptr, want));
         bytes = want;
     }
@@ -89,7 +111,7 @@ struct DeviceBuffer {
 
 private:
     // false (and nothing held) when the virtual-memory API does not cooperate
-    bool spread_chunks(size_t want, const VmmPolicy &policy) noexcept {
+    bool spread_chunks(size_t want) noexcept {
         int device = 0;
         if (hipGetDevice(&device) != hipSuccess) return false;
         hipMemAllocationProp prop{};
@@ -100,8 +122,10 @@ private:
         if (hipMemGetAllocationGranularity(&granule, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || granule == 0) return false;
         if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || want > free_bytes) return false;   // sizes out of a corrupt file: let hipMalloc say no
         const size_t chunk = (policy.chunk + granule - 1) / granule * granule, n = want / chunk + (want % chunk != 0 ? 1 : 0);
+        // spread 0 = automatic: at most 8, and never more than HALF of the free memory in flight while the chunks are chosen -- other
+        // contexts on the device (a second rank sharing the GPU, a torch allocator) must not see a spurious out-of-memory
         size_t spread = policy.spread;
-        if (spread == 0) spread = std::min<size_t>(8, std::max<size_t>(1, free_bytes / 4 * 3 / (n * chunk)));
+        if (spread == 0) spread = std::min<size_t>(8, std::max<size_t>(1, free_bytes / 2 / (n * chunk)));
         // more chunks than needed, every spread-th kept: the kept ones lie `spread` chunks apart in whatever order the driver hands them out
         std::vector<hipMemGenericAllocationHandle_t> all;
         all.reserve(n * spread);
@@ -118,12 +142,15 @@ private:
         }
         bool ok = chunks.size() == n && hipMemAddressReserve(&ptr, n * chunk, 0, nullptr, 0) == hipSuccess;
         if (ok) {
-            mapped = n * chunk;
-            for (size_t i = 0; i < n && ok; i++) ok = hipMemMap(static_cast<char *>(ptr) + i * chunk, chunk, 0, chunks[i], 0) == hipSuccess;
+            reserved = n * chunk; chunk_bytes = chunk;
+            for (size_t i = 0; i < n && ok; i++) {
+                ok = hipMemMap(static_cast<char *>(ptr) + i * chunk, chunk, 0, chunks[i], 0) == hipSuccess;
+                if (ok) mapped_chunks = i + 1;                 // a failure half-way unwinds exactly what was mapped
+            }
             hipMemAccessDesc access{};
             access.location = prop.location;
             access.flags = hipMemAccessFlagsProtReadWrite;
-            ok = ok && hipMemSetAccess(ptr, mapped, &access, 1) == hipSuccess;
+            ok = ok && hipMemSetAccess(ptr, reserved, &access, 1) == hipSuccess;
         }
         if (!ok) { (void)hipGetLastError(); release(); }
         return ok;
@@ -178,6 +205,7 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceIndex dev{};
     bool packed_blocks = true;        // gblocks was built (false: the index is too large for 32-bit half-block indices, or GBWT_HIP_GATHER_LIMIT=0)
     uint32_t max_samples = 0;         // the largest number of samples of a sequence
+    std::vector<uint32_t> sample_counts;   // samples of every sequence (host copy: an extraction looks whether its rows all have the same number)
     uint32_t uniform_samples = 0;     // every sequence has this many samples (0: they differ): the walkers of an extraction are then w = segment * n + row
     gbwt_hip_open_times times{};      // where the time of the open went (gbwt_hip_get_open_times)
     uint32_t uniform_len = 0;         // every sequence has this many nodes (0: lengths differ, or unknown): an extraction then knows its offsets without asking the device
@@ -185,8 +213,34 @@ struct gbwt_hip_index {
     gbwt_hip_stats stats{};
 };
 
+// The GBWT_HIP_* tuning / measurement switches of an extraction, read ONCE when the workspace is created: gbwt_hip_extract_device
+// itself never looks at the environment (getenv is not safe against a concurrent setenv, and several host threads extract from one
+// index at the same time, each with its own workspace -- include/gbwt_hip.h).  -1 = not set: the library's default for the batch.
+struct ExtractKnobs {
+    int direct = 1, segments = 1, both_ends = 1;             // GBWT_HIP_DIRECT / _SEGMENTS / _BOTH_ENDS (0 switches the feature off)
+    int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1;
+    bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
+    uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
+    unsigned copy_threads = 4;                                // GBWT_HIP_COPY_THREADS
+    static ExtractKnobs from_env() {
+        ExtractKnobs k;
+        const auto num = [](const char *name, int unset) { const char *v = std::getenv(name); return v ? std::atoi(v) : unset; };
+        k.direct = num("GBWT_HIP_DIRECT", 1); k.segments = num("GBWT_HIP_SEGMENTS", 1); k.both_ends = num("GBWT_HIP_BOTH_ENDS", 1);
+        k.helper_lanes = std::max(-1, num("GBWT_HIP_HELPER_LANES", -1));
+        k.ring_slots = num("GBWT_HIP_RING_SLOTS", -1); if (k.ring_slots != 32 && k.ring_slots != 64 && k.ring_slots != 128) k.ring_slots = -1;
+        k.helper_naps = std::max(-1, num("GBWT_HIP_HELPER_NAPS", -1));
+        k.xcd_map = num("GBWT_HIP_XCD_MAP", -1); k.uniform_loop = num("GBWT_HIP_UNIFORM_LOOP", -1); k.packed_blocks = num("GBWT_HIP_PACKED_BLOCKS", -1);
+        k.row_piece = num("GBWT_HIP_ROW_PIECE", -1); if (k.row_piece != 0 && k.row_piece != 16 && k.row_piece != 32) k.row_piece = -1;
+        k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;
+        k.debug = static_cast<uint32_t>(num("GBWT_HIP_DEBUG_DRY_ROWS", 0));
+        k.copy_threads = static_cast<unsigned>(std::max(1, num("GBWT_HIP_COPY_THREADS", 4)));
+        return k;
+    }
+};
+
 struct gbwt_hip_workspace {
     const gbwt_hip_index *index = nullptr;
+    ExtractKnobs knobs;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t qev[2] = {nullptr, nullptr};   // around the kernel(s) of the last navigation / search call

@@ -425,7 +425,8 @@ void upload_label_lengths(gbwt_hip_index &ix) {
 static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode) {
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !path_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null path_ids");
-    if (mode != 0 && mode != 1) return fail(GBWT_HIP_BAD_ARGUMENT, "mode must be 0 (P-lines) or 1 (W-lines)");
+    if (mode < 0 || mode > 2) return fail(GBWT_HIP_BAD_ARGUMENT, "mode must be 0 (P-lines), 1 (W-lines) or 2 (P-lines with PanSN names)");
+    const int p_lines = mode != 1 ? 1 : 0;
     if (ws->lines_cached && ws->lines_mode == mode && ws->lines_key.size() == n && (n == 0 || std::memcmp(ws->lines_key.data(), path_ids, n * sizeof(uint64_t)) == 0))
         return GBWT_HIP_OK;
     ws->lines_cached = false;
@@ -471,12 +472,12 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         if (translated) {
             ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
             hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks,
-                               segment_tables(ix), mode == 0 ? 1 : 0, d_chunk_text, d_chunk_seq, d_chunk_bad);
+                               segment_tables(ix), p_lines, d_chunk_text, d_chunk_seq, d_chunk_bad);
             launch_scan(d_chunk_bad, d_bad_before, chunks, ws->scan_temp.ptr, tb_c, s);
         } else {
             hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks,
                                ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
-                               static_cast<uint32_t>(h.alphabet_offset + 1), mode == 0 ? 1 : 0, d_chunk_text, d_chunk_seq);
+                               static_cast<uint32_t>(h.alphabet_offset + 1), p_lines, d_chunk_text, d_chunk_seq);
         }
         launch_scan(d_chunk_text, d_text_before, chunks, ws->scan_temp.ptr, tb_c, s);
         launch_scan(d_chunk_seq, d_seq_before, chunks, ws->scan_temp.ptr, tb_c, s);
@@ -491,6 +492,8 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         auto line_header = [&](uint64_t k, uint64_t seq_len) {
             const PathName &pn = h.path_names[path_ids[k]];
             if (mode == 0) return "P\t" + name_or_id(h.contig_names, contig_names, pn.contig) + "\t";
+            if (mode == 2) return "P\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "#" + std::to_string(pn.phase) + "#" +
+                                  name_or_id(h.contig_names, contig_names, pn.contig) + "\t";   // Metadata::pan_sn_path, src/gbwt.rs:709-713
             return "W\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "\t" + std::to_string(pn.phase) + "\t" +
                    name_or_id(h.contig_names, contig_names, pn.contig) + "\t" + std::to_string(pn.fragment) + "\t" +
                    std::to_string(static_cast<uint64_t>(pn.fragment) + seq_len) + "\t";
@@ -513,13 +516,13 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
                 line = line_header(k, seq_len);
                 for (size_t j = 0; j < tokens.size(); j++) {
                     const std::string name = h.segment_names.str(tokens[j].first);
-                    if (mode == 0) line += (j ? "," : "") + name + (tokens[j].second ? "-" : "+");
+                    if (p_lines) line += (j ? "," : "") + name + (tokens[j].second ? "-" : "+");
                     else line += (tokens[j].second ? "<" : ">") + name;
                 }
-                line += mode == 0 ? "\t*\n" : "\n";
+                line += p_lines ? "\t*\n" : "\n";
             }
         }
-        // 3. headers (path_to_p_line / path_to_w_line, src/bin/gbunzip.rs:480-524)
+        // 3. headers (path_to_p_line / path_to_pan_sn / path_to_w_line, src/bin/gbunzip.rs:480-524)
         // (appended in place: five thousand headers put together from temporaries were a sixth of a call that formats a gigabyte)
         std::string headers;
         headers.reserve(64 * n);
@@ -536,6 +539,12 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         auto append_header = [&](uint64_t k, uint64_t seq_len) {
             const PathName &pn = h.path_names[path_ids[k]];
             if (mode == 0) { headers += "P\t"; append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t'); return; }
+            if (mode == 2) {                                 // sample#phase#contig (Metadata::pan_sn_path, src/gbwt.rs:709-713)
+                headers += "P\t"; append_name(h.sample_names, sample_names, pn.sample); headers.push_back('#');
+                append_number(pn.phase); headers.push_back('#');
+                append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t');
+                return;
+            }
             headers += "W\t"; append_name(h.sample_names, sample_names, pn.sample); headers.push_back('\t');
             append_number(pn.phase); headers.push_back('\t');
             append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t');
@@ -546,7 +555,7 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         for (uint64_t k = 0; k < n; k++) {
             if (valid[k]) append_header(k, lens[n + k]);
             header_off[k + 1] = headers.size();
-            line_start[k + 1] = line_start[k] + (valid[k] ? (header_off[k + 1] - header_off[k]) + lens[k] + (mode == 0 ? 3 : 1) : host_lines[k].size());
+            line_start[k + 1] = line_start[k] + (valid[k] ? (header_off[k + 1] - header_off[k]) + lens[k] + (p_lines ? 3 : 1) : host_lines[k].size());
         }
         const uint64_t total = line_start[n];
         // 4. format on the device; the lines the host had to replay are copied into their places
@@ -559,11 +568,11 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         HIP_CHECK(hipMemcpyAsync(ws->gfa_c.ptr, headers.data(), headers.size(), hipMemcpyHostToDevice, s));
         if (translated)
             hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_text_before, segment_tables(ix), mode == 0 ? 1 : 0, ws->gfa_valid.as<uint8_t>(), d_line_start,
+                               d_chunk_first, d_text_before, segment_tables(ix), p_lines, ws->gfa_valid.as<uint8_t>(), d_line_start,
                                ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
         else
             hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_text_before, mode == 0 ? 1 : 0, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off,
+                               d_chunk_first, d_text_before, p_lines, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off,
                                ws->gfa_text.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
         for (uint64_t k = 0; k < n; k++)
@@ -628,8 +637,13 @@ gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *ix, gbwt_hip_wo
 }
 
 gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path) {
+    return gbwt_hip_write_gfa_mode(ix, ws, path, GBWT_HIP_PATHS_DEFAULT);
+}
+
+gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path, int path_mode) {
     GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !path) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (path_mode < GBWT_HIP_PATHS_DEFAULT || path_mode > GBWT_HIP_PATHS_REF_ONLY) return fail(GBWT_HIP_BAD_ARGUMENT, "unknown path mode");
     try {
         require_gfa_capable(ix);
         const HostIndex &h = ix->host;
@@ -704,21 +718,30 @@ gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace 
             if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
         }
         std::fwrite(text.data(), 1, text.size(), f.get());
-        // paths, then walks, ascending path id (-t 1 order; write_paths / write_walks, src/bin/gbunzip.rs:343-417)
+        // write_gfa_impl's match on the path mode (src/bin/gbunzip.rs:212-222), ascending path id (-t 1 order):
+        //   default: paths of the generic sample as P-lines, then the others as W-lines (write_paths / write_walks, 343-417)
+        //   pan-sn : every path as a P-line with its PanSN name (write_pan_sn, 371-393)
+        //   ref-only: the P-lines of the default mode only
         uint64_t ref_sample = 0;
         const bool have_ref = (h.metadata_flags & 2) && h.sample_names.find(GENERIC_SAMPLE, ref_sample);
         if (!have_ref) ref_sample = h.sample_count;
-        for (int mode = 0; mode < 2; mode++) {
-            if (mode == 0 && !have_ref) continue;
+        struct Pass { int line_mode; int which; };           // which: 0 = paths of the generic sample, 1 = the others, 2 = all
+        std::vector<Pass> passes;
+        if (path_mode == GBWT_HIP_PATHS_PAN_SN) passes.push_back(Pass{2, 2});
+        else {
+            if (have_ref) passes.push_back(Pass{0, 0});
+            if (path_mode == GBWT_HIP_PATHS_DEFAULT) passes.push_back(Pass{1, 1});
+        }
+        for (const Pass &pass : passes) {
             std::vector<uint64_t> ids;
             for (uint64_t p = 0; p < h.path_names.size(); p++)
-                if ((h.path_names[p].sample == ref_sample) == (mode == 0)) ids.push_back(p);
+                if (pass.which == 2 || (h.path_names[p].sample == ref_sample) == (pass.which == 0)) ids.push_back(p);
             const uint64_t batch = 4096;
             std::vector<char> buf;
             for (uint64_t b0 = 0; b0 < ids.size(); b0 += batch) {
                 const uint64_t nb = std::min<uint64_t>(batch, ids.size() - b0);
                 uint64_t total = 0;
-                gbwt_hip_status st = path_lines_impl(ix, ws, ids.data() + b0, nb, mode, nullptr, 0, &total, &buf);
+                gbwt_hip_status st = path_lines_impl(ix, ws, ids.data() + b0, nb, pass.line_mode, nullptr, 0, &total, &buf);
                 if (st != GBWT_HIP_OK) return st;
                 if (std::fwrite(buf.data(), 1, total, f.get()) != total) return fail(GBWT_HIP_IO_ERROR, "short write");
             }

@@ -377,6 +377,55 @@ HostIndex load_index_file(const std::string &path) {
     return h;
 }
 
+std::vector<std::pair<uint32_t, uint32_t>> decompress_endmarker(const HostIndex &h, uint64_t limit) {
+    std::vector<std::pair<uint32_t, uint32_t>> out;
+    if (h.records() == 0 || h.starts[1] <= h.starts[0]) return out;
+    const uint8_t *p = h.data.data() + h.starts[0], *end = h.data.data() + h.starts[1];
+    auto varint = [&](uint64_t &v) -> bool {                  // ByteCodeIter::next, src/support.rs:1151-1164
+        v = 0;
+        unsigned shift = 0;
+        while (p < end) {
+            const uint8_t b = *p++;
+            if (shift < 64) v += static_cast<uint64_t>(b & 0x7F) << shift;
+            shift += 7;
+            if (!(b & 0x80)) return true;
+        }
+        return false;
+    };
+    uint64_t sigma = 0, node = 0;
+    if (!varint(sigma) || sigma == 0 || sigma > static_cast<uint64_t>(end - p)) return out;   // every edge takes at least two bytes
+    std::vector<uint64_t> nodes(sigma), offsets(sigma);
+    for (uint64_t e = 0; e < sigma; e++) {                       // Record::decompress_edges, src/bwt.rs:378-395
+        uint64_t delta = 0, off = 0;
+        if (!varint(delta) || !varint(off)) return out;
+        node += delta;
+        nodes[e] = node; offsets[e] = off;
+    }
+    // RLE::sanitize, src/support.rs:1292-1296: sigma >= 255 -> two varints per run; else value + sigma * (len - 1) in one byte,
+    // and a varint with the rest of the length behind a byte that holds threshold - 1
+    const uint64_t threshold = sigma >= 255 ? 0 : 256 / sigma;
+    out.reserve(std::min<uint64_t>(limit, h.sequences));
+    while (p < end && out.size() < limit) {
+        uint64_t value = 0, len = 0;
+        if (sigma >= 255) {
+            if (!varint(value) || !varint(len)) break;
+            len++;
+        } else {
+            const uint64_t b = *p++;
+            value = b % sigma; len = b / sigma + 1;
+            if (len == threshold) {
+                uint64_t extra = 0;
+                if (!varint(extra)) break;
+                len += extra;
+            }
+        }
+        if (value >= sigma) break;                               // malformed
+        for (uint64_t k = 0; k < len && out.size() < limit; k++)
+            out.emplace_back(static_cast<uint32_t>(nodes[value]), static_cast<uint32_t>(offsets[value]++));
+    }
+    return out;
+}
+
 HostIndex index_from_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
                              uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,
                              bool bidirectional) {

@@ -74,6 +74,12 @@ HostIndex load_index_file(const std::string &path);
 // src/graph.rs:284-294.  Used by the synthetic generator and by the writer round-trip tests.
 void save_index_file(const HostIndex &index, const std::string &path, bool as_gbz);
 
+// Record::decompress of record 0, the endmarker (GBWT::load does the same at load time, src/gbwt.rs:413-414: `endmarker =
+// record.decompress()`): one (node, offset) per sequence = GBWT::start(id) without the guards.  Part of reading the file, like the
+// Elias-Fano index: the run stream is parsed byte by byte (RLEIter::next, src/support.rs:1413-1430; Record::decompress
+// src/bwt.rs:466-478).  A malformed record ends the list where the reference's iterator would end it; at most `limit` entries.
+std::vector<std::pair<uint32_t, uint32_t>> decompress_endmarker(const HostIndex &index, uint64_t limit);
+
 // Builds the host image from raw parts (gbwt_hip_open_records).
 HostIndex index_from_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
                              uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,

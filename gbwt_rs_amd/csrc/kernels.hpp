@@ -16,15 +16,12 @@ constexpr uint32_t POOL_NONE = 0xFFFFFFFFu;
 constexpr uint32_t FLAG_POOL_OVERFLOW = 1u;
 
 // ---- load-time passes -------------------------------------------------------------------------
-// stats[0] = max Record::len, stats[1] = max outdegree, stats[2] = number of malformed records
-void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream);
-// Record::decompress of record 0 into d_out[n_out] (src/gbwt.rs:413-414); d_scratch: 2 * sigma u64.
-// d_result[0] = number of positions produced, d_result[1] = outdegree of record 0 (first call sizes scratch)
 // per-record descriptors + rank blocks (device_index.hpp): d_desc has 4 * n_records entries; build_desc also
-// writes the number of rank blocks of every record, block_scan + finish_block_base turn the counts into
-// first-block indices (BLOCK_NONE where there are none; block 0 is the shared zero block), fill_blocks decodes
+// writes the number of rank blocks of every record and the statistics of the index (d_stats, zeroed by the caller: [0] = max
+// Record::len, [1] = max outdegree, [2] = number of malformed records, [3] = all BWT positions); block_scan + finish_block_base turn
+// the counts into first-block indices (BLOCK_NONE where there are none; block 0 is the shared zero block), fill_blocks decodes
 // the outdegree-2 records into their blocks, link_desc stores the successors' block bases into the descriptors.
-void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, hipStream_t stream);
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, uint64_t *d_stats, hipStream_t stream);
 size_t block_scan_temp_bytes(uint64_t n);
 void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream);
 void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream);
@@ -38,13 +35,9 @@ void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t
 void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t stream);
 // two-step walk (device_index.hpp): composed descriptors, two-step rank blocks, look-ahead targets
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, hipStream_t stream);   // gather_limit: Record::len below which the packed blocks can count
-void launch_fill_gblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_gblocks, hipStream_t stream);
-void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream);
+void launch_fill_two_step_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, uint4 *d_gblocks /* or null */, hipStream_t stream);
 void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
 void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream);
-void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream);
-void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
-                                 uint64_t *d_result, hipStream_t stream);
 
 // ---- extraction -------------------------------------------------------------------------------
 struct WalkArgs {

@@ -14,34 +14,6 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // Load-time passes
 
-// One lane per record: Record::len and outdegree maxima (sizes u32 offsets on device, feeds stats), and the sum of the lengths.
-// Reduced over the wave first: two million lanes on four addresses took 25 ms of atomics on the headline index.
-__global__ void __launch_bounds__(256) k_record_stats(DeviceIndex ix, uint64_t *stats) {
-    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    uint64_t len = 0, sigma = 0, bad = 0;
-    if (rec < ix.n_records) {
-        uint64_t start, limit;
-        record_bounds(ix, rec, start, limit);
-        if (start < limit) {
-            ByteCursor c(ix.data, start, limit);
-            if (!c.varint(sigma)) { bad = 1; sigma = 0; }
-            else if (sigma != 0) len = record_len(c, sigma);
-        }
-    }
-    uint64_t max_len = len, max_sigma = sigma, sum = len;
-    for (int d = WAVE / 2; d > 0; d >>= 1) {
-        max_len = max(max_len, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_len), d)));
-        max_sigma = max(max_sigma, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_sigma), d)));
-        sum += __shfl_down(static_cast<unsigned long long>(sum), d);
-        bad += __shfl_down(static_cast<unsigned long long>(bad), d);
-    }
-    if (threadIdx.x % WAVE != 0) return;
-    if (max_len) atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(max_len));
-    if (max_sigma) atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(max_sigma));
-    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), static_cast<unsigned long long>(bad));
-    if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(sum));   // all BWT positions = GBWT::len of a consistent index
-}
-
 // 16 bytes of the stream at data[pos..], zero-filled past `limit`.
 __device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t pos, uint64_t limit) {
     uint32_t w[4] = {0, 0, 0, 0};
@@ -49,10 +21,14 @@ __device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t po
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// One lane per record: the RAW descriptor (device_index.hpp) and the number of rank blocks the record gets.
-__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *block_counts) {
-    uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (rec >= ix.n_records) return;
+// One lane per record: the RAW descriptor (device_index.hpp), the number of rank blocks the record gets, and the statistics of the
+// index: stats[0] = max Record::len, [1] = max outdegree, [2] = records without a readable outdegree, [3] = all BWT positions
+// (= GBWT::len of a consistent index; bounds the walks at open).  Reduced over the wave first: two million lanes on four addresses
+// took 25 ms of atomics on the headline index.
+__global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *block_counts, uint64_t *stats) {
+    const uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    uint64_t stat_len = 0, stat_sigma = 0, stat_bad = 0;
+    if (rec < ix.n_records) {
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
     uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0), C = make_uint4(0, 0, 0, 0), D = make_uint4(0, 0, 0, 0);
@@ -60,7 +36,10 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
     if (limit > start) {
         ByteCursor c(ix.data, start, limit);
         uint64_t sigma = 0;
-        if (c.varint(sigma) && sigma != 0) {
+        const bool readable = c.varint(sigma);
+        if (!readable) stat_bad = 1;
+        if (readable && sigma != 0) {
+            stat_sigma = sigma;
             B.x = static_cast<uint32_t>(start); B.y = static_cast<uint32_t>(limit - start);
             B.z = static_cast<uint32_t>((start >> 32) & 0xFF) << 24;
             bool classed = false;
@@ -85,6 +64,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                     if (!c.at_end() || runs == 0) lean = false;
                     if (lean && total < 0xFFFFFFFFull) {
                         classed = true;
+                        stat_len = total;
                         A.x = static_cast<uint32_t>(n0); A.y = static_cast<uint32_t>(o0);
                         A.z = static_cast<uint32_t>(n0 + d1); A.w = static_cast<uint32_t>(o1);
                         B.z |= static_cast<uint32_t>(body) | (static_cast<uint32_t>(sigma) << 16);
@@ -103,6 +83,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                 uint64_t s2 = 0;
                 c2.varint(s2);
                 const uint64_t total = record_len(c2, s2);
+                stat_len = total;
                 C.y = total < 0xFFFFFFFFull ? static_cast<uint32_t>(total) : 0xFFFFFFFFu;
             }
         }
@@ -112,6 +93,19 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
     desc[4 * rec + 2] = C;
     desc[4 * rec + 3] = D;
     block_counts[rec] = n_blocks;
+    }
+    uint64_t max_len = stat_len, max_sigma = stat_sigma, sum = stat_len, bad = stat_bad;
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        max_len = max(max_len, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_len), d)));
+        max_sigma = max(max_sigma, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_sigma), d)));
+        sum += __shfl_down(static_cast<unsigned long long>(sum), d);
+        bad += __shfl_down(static_cast<unsigned long long>(bad), d);
+    }
+    if (threadIdx.x % WAVE != 0) return;
+    if (max_len) atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(max_len));
+    if (max_sigma) atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(max_sigma));
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), static_cast<unsigned long long>(bad));
+    if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(sum));
 }
 
 // One lane per record: raw descriptor -> walk descriptor (device_index.hpp).  Everything the walk would otherwise
@@ -367,14 +361,48 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
     o[7] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// One lane per record with rank blocks: the two-step blocks (32 bytes per 64 offsets):
+// The two-step blocks of every record with rank blocks, in both layouts.  Full width (32 bytes per 64 offsets):
 //   cblocks[2 * k]     = {bits1 (values of v), bits2 (value in w_a of the sequence at each offset; 0 where the second
 //                         step is not a real step through a record with blocks)}
 //   cblocks[2 * k + 1] = {value-1 positions of v before the block, R_0, R_1, 0}
 // The a-paths of a block land on consecutive offsets of w_a (LF keeps their order), so their values there are a
 // contiguous bit range of w_a's blocks, spread back onto the positions of the a-paths.
-__global__ void __launch_bounds__(256) k_fill_cblocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *cblocks) {
-    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+// Packed (gblocks, may be null), for the loops where every load instruction costs a pass of the address path over sixty-four lines:
+// ONE 16-byte load per step instead of two.  Half a block each -- 32 offsets -- with the three counts packed:
+//   gblocks[2 * k + h] = {bits1 (32 values of v), bits2, ones1 | R_0 << 21, R_0 >> 11 | R_1 << 10}      (ones1, R_0 < 2^21, R_1 < 2^22)
+// for the offsets 64 k + 32 h ...; ones1 and R_a count up to the half's first offset / first a-path.  Records that do not fit the
+// counts have GATHER_OK cleared in their descriptor (k_link_desc2).
+// A WAVE per record, a lane per block: the blocks of a record are independent of each other once its plain rank blocks exist, and a
+// lane per record (79 blocks one after the other for a record of 5 000 positions, every one behind two dependent loads) made these two
+// arrays 12 of the 33 ms of kernel time of an open of the headline index.
+struct SecondStep { const uint4 *wblocks[2]; uint32_t wbase[2]; };
+
+// the values in w_a of the a-paths selected by m (an ascending subset of 64 / 32 positions), and the count R_a before the first of them
+template <class Mask>
+__device__ __forceinline__ Mask second_step_bits(const uint4 *wblocks, uint32_t j, Mask m, uint32_t &R) {
+    const uint32_t q = j >> RANK_BLOCK_SHIFT, sh = j & 63u;
+    const uint32_t cnt = sizeof(Mask) == 8 ? __popcll(m) : __popc(static_cast<uint32_t>(m));
+    const uint4 W0 = wblocks[q];
+    const uint64_t w0 = (static_cast<uint64_t>(W0.y) << 32) | W0.x;
+    R = W0.z + __popcll(w0 & ((uint64_t(1) << sh) - 1));
+    uint64_t val = w0 >> sh;
+    if (sh != 0 && cnt > 64 - sh) {
+        const uint4 W1 = wblocks[q + 1];
+        val |= ((static_cast<uint64_t>(W1.y) << 32) | W1.x) << (64 - sh);
+    }
+    Mask bits2 = 0;
+    while (m) {                                                                     // spread the low cnt bits of val over the set bits of m
+        const Mask low = m & (~m + 1);
+        if (val & 1) bits2 |= low;
+        val >>= 1;
+        m ^= low;
+    }
+    return bits2;
+}
+
+__global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *cblocks, uint4 *gblocks) {
+    const uint64_t v = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
     if (v >= ix.n_records) return;
     const uint32_t count = block_counts[v];
     if (count == 0) return;
@@ -383,8 +411,7 @@ __global__ void __launch_bounds__(256) k_fill_cblocks(DeviceIndex ix, const uint
     const uint32_t len = ix.desc_raw[4 * v + 1].w;
     const uint32_t bb = ix.block_base[v];
     // per edge: landing record with blocks of its own, or none
-    const uint4 *wblocks[2] = {nullptr, nullptr};
-    uint32_t wbase[2] = {0, 0};
+    SecondStep s2{{nullptr, nullptr}, {0, 0}};
     if (!(D.x & DESC_SLOW)) {
         for (uint32_t a = 0; a < 2; a++) {
             const uint32_t f = a ? D.w : D.y;
@@ -393,104 +420,40 @@ __global__ void __launch_bounds__(256) k_fill_cblocks(DeviceIndex ix, const uint
             const uint64_t w = E.z;
             const uint4 WB = ix.desc_raw[4 * w + 1];
             if ((d1[4 * w + 2].x & DESC_SLOW) || WB.y == 0 || desc_class(WB.z) != 2) continue;
-            wblocks[a] = ix.blocks + ix.block_base[w];
-            wbase[a] = E.y;
+            s2.wblocks[a] = ix.blocks + ix.block_base[w];
+            s2.wbase[a] = E.y;
         }
     }
-    for (uint32_t k = 0; k < count; k++) {
+    for (uint32_t k = lane; k < count; k += WAVE) {
         const uint4 P = ix.blocks[bb + k];
-        const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
-        const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
-        const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
-        uint64_t bits2 = 0;
-        uint32_t R[2] = {0, 0};
-        for (uint32_t a = 0; a < 2; a++) {
-            if (!wblocks[a]) continue;
-            uint64_t m = (a ? bits1 : ~bits1) & valid;
-            const uint32_t cnt = __popcll(m);
-            if (cnt == 0) continue;
-            const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
-            const uint32_t j = wbase[a] + before;                                      // where the first a-path lands in w_a
-            const uint32_t q = j >> RANK_BLOCK_SHIFT, sh = j & 63u;
-            const uint4 W0 = wblocks[a][q];
-            const uint64_t w0 = (static_cast<uint64_t>(W0.y) << 32) | W0.x;
-            R[a] = W0.z + __popcll(w0 & ((uint64_t(1) << sh) - 1));
-            uint64_t val = w0 >> sh;
-            if (sh != 0 && cnt > 64 - sh) {
-                const uint4 W1 = wblocks[a][q + 1];
-                val |= ((static_cast<uint64_t>(W1.y) << 32) | W1.x) << (64 - sh);
+        {   // full width
+            const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
+            const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
+            const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
+            uint64_t bits2 = 0;
+            uint32_t R[2] = {0, 0};
+            for (uint32_t a = 0; a < 2; a++) {
+                const uint64_t m = (a ? bits1 : ~bits1) & valid;
+                if (!s2.wblocks[a] || m == 0) continue;
+                const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
+                bits2 |= second_step_bits<uint64_t>(s2.wblocks[a], s2.wbase[a] + before, m, R[a]);
             }
-            while (m) {                                                                 // spread the low cnt bits of val over the set bits of m
-                const uint64_t low = m & (~m + 1);
-                if (val & 1) bits2 |= low;
-                val >>= 1;
-                m ^= low;
-            }
+            cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
+            cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
         }
-        cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
-        cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
-    }
-}
-
-// The same blocks for the gather loop (walk_loops.hpp), where every load instruction costs a pass of the address path over sixty-four
-// lines: ONE 16-byte load per step instead of two.  Half a block each -- 32 offsets -- with the three counts packed:
-//   gblocks[2 * k + h] = {bits1 (32 values of v), bits2, ones1 | R_0 << 21, R_0 >> 11 | R_1 << 10}      (ones1, R_0 < 2^21, R_1 < 2^22)
-// for the offsets 64 k + 32 h ...; ones1 and R_a count up to the half's first offset / first a-path.  Records that do not fit the
-// counts have GATHER_OK cleared in their descriptor (k_link_desc2) and step in C++ when they turn up in a mixed wave.
-__global__ void __launch_bounds__(256) k_fill_gblocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *gblocks) {
-    uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (v >= ix.n_records) return;
-    const uint32_t count = block_counts[v];
-    if (count == 0) return;
-    const uint4 *d1 = ix.desc;
-    const uint4 D = d1[4 * v + 2];
-    const uint32_t len = ix.desc_raw[4 * v + 1].w;
-    const uint32_t bb = ix.block_base[v];
-    const uint4 *wblocks[2] = {nullptr, nullptr};
-    uint32_t wbase[2] = {0, 0};
-    if (!(D.x & DESC_SLOW)) {
-        for (uint32_t a = 0; a < 2; a++) {
-            const uint32_t f = a ? D.w : D.y;
-            if (!(f & EDGE_CONT)) continue;
-            const uint4 E = d1[4 * v + a];
-            const uint64_t w = E.z;
-            const uint4 WB = ix.desc_raw[4 * w + 1];
-            if ((d1[4 * w + 2].x & DESC_SLOW) || WB.y == 0 || desc_class(WB.z) != 2) continue;
-            wblocks[a] = ix.blocks + ix.block_base[w];
-            wbase[a] = E.y;
-        }
-    }
-    for (uint32_t k = 0; k < count; k++) {
-        const uint4 P = ix.blocks[bb + k];
+        if (gblocks == nullptr) continue;
         for (uint32_t h = 0; h < 2; h++) {
-            const uint32_t first = (k << RANK_BLOCK_SHIFT) + 32u * h;                  // first offset of this half
+            const uint32_t first = (k << RANK_BLOCK_SHIFT) + 32u * h;                      // first offset of this half
             const uint32_t remaining = first > len ? 0u : len - first;
             const uint32_t valid = remaining >= 32 ? ~0u : ((1u << remaining) - 1);
             const uint32_t bits1 = h ? P.y : P.x;
             const uint32_t ones1 = P.z + (h ? __popc(P.x) : 0u);
             uint32_t bits2 = 0, R[2] = {0, 0};
             for (uint32_t a = 0; a < 2; a++) {
-                if (!wblocks[a]) continue;
-                uint32_t m = (a ? bits1 : ~bits1) & valid;
-                const uint32_t cnt = __popc(m);
-                if (cnt == 0) continue;
-                const uint32_t before = a ? ones1 : first - ones1;                        // a-paths of v before this half
-                const uint32_t j = wbase[a] + before;                                     // where the first a-path lands in w_a
-                const uint32_t q = j >> RANK_BLOCK_SHIFT, sh = j & 63u;
-                const uint4 W0 = wblocks[a][q];
-                const uint64_t w0 = (static_cast<uint64_t>(W0.y) << 32) | W0.x;
-                R[a] = W0.z + __popcll(w0 & ((uint64_t(1) << sh) - 1));
-                uint64_t val = w0 >> sh;
-                if (sh != 0 && cnt > 64 - sh) {
-                    const uint4 W1 = wblocks[a][q + 1];
-                    val |= ((static_cast<uint64_t>(W1.y) << 32) | W1.x) << (64 - sh);
-                }
-                while (m) {
-                    const uint32_t low = m & (~m + 1);
-                    if (val & 1) bits2 |= low;
-                    val >>= 1;
-                    m ^= low;
-                }
+                const uint32_t m = (a ? bits1 : ~bits1) & valid;
+                if (!s2.wblocks[a] || m == 0) continue;
+                const uint32_t before = a ? ones1 : first - ones1;                            // a-paths of v before this half
+                bits2 |= second_step_bits<uint32_t>(s2.wblocks[a], s2.wbase[a] + before, m, R[a]);
             }
             gblocks[2 * static_cast<uint64_t>(bb + k) + h] = make_uint4(bits1, bits2, (ones1 & 0x1FFFFFu) | (R[0] << 21), ((R[0] >> 11) & 0x3FFu) | (R[1] << 10));
         }
@@ -547,58 +510,11 @@ __global__ void __launch_bounds__(256) k_fill_blocks(DeviceIndex ix, const uint3
     if (k < count) out[k] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
 }
 
-// Outdegree + length of the endmarker record (record 0), to size the decompression scratch.
-__global__ void k_endmarker_sigma(DeviceIndex ix, uint64_t *result) {
-    result[0] = 0; result[1] = 0;
-    if (ix.n_records == 0) return;
-    uint64_t start, limit;
-    record_bounds(ix, 0, start, limit);
-    if (start >= limit) return;
-    ByteCursor c(ix.data, start, limit);
-    uint64_t sigma;
-    if (!c.varint(sigma) || sigma == 0) return;
-    result[1] = sigma;
-    result[0] = record_len(c, sigma);
-}
-
-// Record::decompress (src/bwt.rs:465-475) of the endmarker record, done once at open.  Single
-// lane: the record has one run per sequence in the worst case and this is load-time work.
-__global__ void k_endmarker_decompress(DeviceIndex ix, uint2 *out, uint64_t n_out, uint64_t *scratch, uint64_t *result) {
-    uint64_t start, limit;
-    record_bounds(ix, 0, start, limit);
-    ByteCursor c(ix.data, start, limit);
-    uint64_t sigma = 0;
-    c.varint(sigma);
-    uint64_t *nodes = scratch, *offsets = scratch + sigma;
-    uint64_t node = 0;
-    for (uint64_t e = 0; e < sigma; e++) {
-        uint64_t delta = 0, off = 0;
-        c.varint(delta); c.varint(off);
-        node += delta;
-        nodes[e] = node; offsets[e] = off;
-    }
-    RunDecoder rd(sigma);
-    uint64_t produced = 0, value, len;
-    while (rd.next(c, value, len)) {
-        if (value >= sigma) break;  // malformed
-        for (uint64_t k = 0; k < len && produced < n_out; k++) {
-            out[produced++] = make_uint2(static_cast<uint32_t>(nodes[value]), static_cast<uint32_t>(offsets[value]));
-            offsets[value]++;
-        }
-    }
-    result[0] = produced;
-}
-
 }  // namespace
 
-void launch_record_stats(const DeviceIndex &ix, uint64_t *d_stats, hipStream_t stream) {
+void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, uint64_t *d_stats, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_record_stats, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_stats);
-}
-
-void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, hipStream_t stream) {
-    if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts);
+    hipLaunchKernelGGL(k_build_desc, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc, d_block_counts, d_stats);
 }
 
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream) {
@@ -632,14 +548,9 @@ void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_li
     hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, gather_limit);
 }
 
-void launch_fill_gblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_gblocks, hipStream_t stream) {
+void launch_fill_two_step_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, uint4 *d_gblocks, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_fill_gblocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_gblocks);
-}
-
-void launch_fill_cblocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, hipStream_t stream) {
-    if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_fill_cblocks, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_block_counts, d_cblocks);
+    hipLaunchKernelGGL(k_fill_two_step_blocks, dim3(grid_for(ix.n_records * WAVE, 256)), dim3(256), 0, stream, ix, d_block_counts, d_cblocks, d_gblocks);
 }
 
 void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
@@ -672,15 +583,6 @@ void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_
 
 void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_finish_block_base, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_block_base, n);
-}
-
-void launch_endmarker_sigma(const DeviceIndex &ix, uint64_t *d_result, hipStream_t stream) {
-    hipLaunchKernelGGL(k_endmarker_sigma, dim3(1), dim3(1), 0, stream, ix, d_result);
-}
-
-void launch_endmarker_decompress(const DeviceIndex &ix, uint2 *d_out, uint64_t n_out, uint64_t *d_scratch,
-                                 uint64_t *d_result, hipStream_t stream) {
-    hipLaunchKernelGGL(k_endmarker_decompress, dim3(1), dim3(1), 0, stream, ix, d_out, n_out, d_scratch, d_result);
 }
 
 size_t scan_temp_bytes(uint64_t n) {

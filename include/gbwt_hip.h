@@ -206,8 +206,9 @@ gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspa
 
 /* ---- GFA text (GBZ handles with metadata) ------------------------------------------------------------
  * gbwt_hip_path_lines: the lines gbunzip writes for the given paths, in the order given, byte for byte:
- * mode 0 = P-lines (write_p_line / path_to_p_line, src/bin/gbunzip.rs:438-485), mode 1 = W-lines
- * (path_to_w_line, src/bin/gbunzip.rs:495-550).  The forward sequences are walked and the node tokens
+ * mode 0 = P-lines named by the contig (write_p_line / path_to_p_line, src/bin/gbunzip.rs:438-485), mode 1 = W-lines
+ * (path_to_w_line, src/bin/gbunzip.rs:495-550), mode 2 = P-lines with PanSN names sample#phase#contig (path_to_pan_sn,
+ * src/bin/gbunzip.rs:487-491; Metadata::pan_sn_path, src/gbwt.rs:709-713).  The forward sequences are walked and the node tokens
  * formatted on the device; the host only contributes the name fields.  `*total` receives the number of bytes;
  * out == NULL is a size query; capacity < total -> GBWT_HIP_CAPACITY.  Graphs with a node-to-segment
  * translation print segment names (GBZ::segment_path / SegmentPathIter, src/gbz.rs:477-486, 1098-1169). */
@@ -222,6 +223,11 @@ gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *index, gbwt_hip
 /* gbwt_hip_write_gfa: the whole file `gbunzip -t 1` writes (write_gfa_impl, src/bin/gbunzip.rs:205-226, default
  * path mode): H, S and L lines from the host copy of the graph, then P-lines and W-lines in ascending path id. */
 gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const char *path);
+/* The same with gbunzip's `--paths MODE` (PathMode, src/bin/gbunzip.rs:63-76; dispatch 212-222): default = P-lines of the paths of
+ * the generic sample `_gbwt_ref`, then W-lines of all others; pan-sn = every path as a P-line with its PanSN name (write_pan_sn,
+ * 371-393); ref-only = the P-lines of the default mode and nothing else. */
+enum { GBWT_HIP_PATHS_DEFAULT = 0, GBWT_HIP_PATHS_PAN_SN = 1, GBWT_HIP_PATHS_REF_ONLY = 2 };
+gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const char *path, int path_mode);
 
 /* ---- checking hooks for device-resident results -------------------------------------------------
  * Per-path sums of the node ids of the last gbwt_hip_extract_device call on `ws` (a wave-per-path

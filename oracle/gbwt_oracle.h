@@ -150,7 +150,9 @@ const go_gbwt *go_gbz_gbwt(const go_gbz *z);
 /* gbunzip GFA text (src/bin/gbunzip.rs:193-550, default path mode, single-thread order).
  * Returns malloc'd buffer, *len bytes. */
 char *go_gbz_write_gfa(const go_gbz *z, size_t *len);
-/* only the P/W lines for the given path ids (path_to_p_line / path_to_w_line), mode 0 = P, 1 = W */
+char *go_gbz_write_gfa_mode(const go_gbz *z, int path_mode, size_t *len);   /* 0 default, 1 pan-sn, 2 ref-only */
+char *go_metadata_pan_sn_path(const go_gbwt *g, uint64_t path_id, size_t *len);   /* Metadata::pan_sn_path; NULL = None */
+/* only the lines for the given path ids: mode 0 = P (path_to_p_line), 1 = W (path_to_w_line), 2 = P with PanSN names (path_to_pan_sn) */
 char *go_gbz_path_lines(const go_gbz *z, const uint64_t *path_ids, uint64_t n, int mode, size_t *len);
 void go_free(void *p);
 /* metadata peek for tests */

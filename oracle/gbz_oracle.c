@@ -618,12 +618,10 @@ static void sb_name(sbuf *b, const go_strings *names, uint64_t id, int has_names
     else sb_u64(b, id);
 }
 
-/* write_p_line / path_to_p_line, src/bin/gbunzip.rs:438-485 */
-static void p_line(const go_gbz *z, uint64_t path_id, sbuf *b) {
-    const go_metadata *m = z->index->metadata;
-    go_path_name pn = m->path_names[path_id];
+/* write_p_line, src/bin/gbunzip.rs:438-478: "P", name, the path as name+/- tokens, overlaps "*" */
+static void write_p_line(const go_gbz *z, uint64_t path_id, const char *name, size_t name_len, sbuf *b) {
     sb_str(b, "P\t");
-    sb_name(b, &m->contig_names, pn.contig, (m->flags & 4) != 0);
+    sb_write(b, name, name_len);
     sb_str(b, "\t");
     uint64_t n, seq_len;
     path_item *items = collect_path(z, path_id, &n, &seq_len);
@@ -634,6 +632,39 @@ static void p_line(const go_gbz *z, uint64_t path_id, sbuf *b) {
     }
     free(items);
     sb_str(b, "\t*\n");
+}
+
+/* path_to_p_line, src/bin/gbunzip.rs:480-485: named by the contig */
+static void p_line(const go_gbz *z, uint64_t path_id, sbuf *b) {
+    const go_metadata *m = z->index->metadata;
+    go_path_name pn = m->path_names[path_id];
+    sbuf name = { NULL, 0, 0 };
+    sb_name(&name, &m->contig_names, pn.contig, (m->flags & 4) != 0);
+    write_p_line(z, path_id, name.p, name.len, b);
+    free(name.p);
+}
+
+/* Metadata::pan_sn_path, src/gbwt.rs:709-713: sample_name # phase # contig_name (sample_name / contig_name fall back to the
+   number, src/gbwt.rs:752-758, 800-806) */
+char *go_metadata_pan_sn_path(const go_gbwt *g, uint64_t path_id, size_t *len) {
+    const go_metadata *m = g->metadata;
+    *len = 0;
+    if (!m || path_id >= m->n_paths) return NULL;
+    go_path_name pn = m->path_names[path_id];
+    sbuf name = { NULL, 0, 0 };
+    sb_name(&name, &m->sample_names, pn.sample, (m->flags & 2) != 0);
+    sb_str(&name, "#"); sb_u64(&name, pn.phase); sb_str(&name, "#");
+    sb_name(&name, &m->contig_names, pn.contig, (m->flags & 4) != 0);
+    *len = name.len;
+    return name.p;
+}
+
+/* path_to_pan_sn, src/bin/gbunzip.rs:487-491 */
+static void pan_sn_line(const go_gbz *z, uint64_t path_id, sbuf *b) {
+    size_t len = 0;
+    char *name = go_metadata_pan_sn_path(z->index, path_id, &len);
+    write_p_line(z, path_id, name, len, b);
+    free(name);
 }
 
 /* path_to_w_line, src/bin/gbunzip.rs:495-550 */
@@ -663,29 +694,36 @@ char *go_gbz_path_lines(const go_gbz *z, const uint64_t *path_ids, uint64_t n, i
     if (!z->index->metadata) { *len = 0; return b.p; }
     for (uint64_t k = 0; k < n; k++) {
         if (path_ids[k] >= z->index->metadata->n_paths) continue;
-        if (mode == 0) p_line(z, path_ids[k], &b); else w_line(z, path_ids[k], &b);
+        if (mode == 0) p_line(z, path_ids[k], &b); else if (mode == 2) pan_sn_line(z, path_ids[k], &b); else w_line(z, path_ids[k], &b);
     }
     *len = b.len;
     if (!b.p) b.p = (char *)calloc(1, 1);
     return b.p;
 }
 
-/* write_gfa_impl, default path mode, single-thread order (src/bin/gbunzip.rs:193-226, 343-417) */
-char *go_gbz_write_gfa(const go_gbz *z, size_t *len) {
+/* write_gfa_impl, single-thread order (src/bin/gbunzip.rs:193-226, 343-417); path_mode 0 = default (P-lines of the generic sample,
+   W-lines of the others), 1 = pan-sn (every path a P-line with its PanSN name), 2 = ref-only (the P-lines only): PathMode,
+   src/bin/gbunzip.rs:63-76, 212-222 */
+char *go_gbz_write_gfa_mode(const go_gbz *z, int path_mode, size_t *len) {
     sbuf b = { NULL, 0, 0 };
     const char *rs = go_tags_get(&z->index->tags, "reference_samples");
     if (rs) { sb_str(&b, "H\tVN:Z:1.1\tRS:Z:"); sb_str(&b, rs); sb_str(&b, "\n"); }
     else sb_str(&b, "H\tVN:Z:1.1\n");
     write_segments_links(z, &b);
     const go_metadata *m = z->index->metadata;
-    if (m) {
+    if (m && path_mode == 1) {
+        for (uint64_t p = 0; p < m->n_paths; p++) pan_sn_line(z, p, &b);
+    } else if (m) {
         uint64_t ref_sample = 0;
         int have_ref = (m->flags & 2) && strings_find(&m->sample_names, GENERIC_SAMPLE, &ref_sample);
         if (have_ref) {
             for (uint64_t p = 0; p < m->n_paths; p++) if (m->path_names[p].sample == ref_sample) p_line(z, p, &b);
         } else ref_sample = m->sample_count;
-        for (uint64_t p = 0; p < m->n_paths; p++) if (m->path_names[p].sample != ref_sample) w_line(z, p, &b);
+        if (path_mode == 0)
+            for (uint64_t p = 0; p < m->n_paths; p++) if (m->path_names[p].sample != ref_sample) w_line(z, p, &b);
     }
     *len = b.len;
     return b.p;
 }
+
+char *go_gbz_write_gfa(const go_gbz *z, size_t *len) { return go_gbz_write_gfa_mode(z, 0, len); }

@@ -139,6 +139,8 @@ def lib():
         "go_gbz_free": (None, [p]),
         "go_gbz_gbwt": (p, [p]),
         "go_gbz_write_gfa": (p, [p, C.POINTER(C.c_size_t)]),
+        "go_gbz_write_gfa_mode": (p, [p, C.c_int, C.POINTER(C.c_size_t)]),
+        "go_metadata_pan_sn_path": (p, [p, u64, C.POINTER(C.c_size_t)]),
         "go_gbz_path_lines": (p, [p, p, u64, C.c_int, C.POINTER(C.c_size_t)]),
         "go_free": (None, [p]),
         "go_gbz_paths": (u64, [p]),
@@ -513,10 +515,21 @@ class OracleGBZ:
         seq = self.gbwt().sequence(2 * path_id + int(reverse))
         return None if seq is None else [(x // 2, x & 1) for x in seq]
 
-    def gfa(self):
+    def gfa(self, path_mode=0):
+        """gbunzip's output; path_mode 0 = default, 1 = pan-sn, 2 = ref-only (PathMode, src/bin/gbunzip.rs:63-76)."""
         n = C.c_size_t(0)
-        p = self.L.go_gbz_write_gfa(self.h, C.byref(n))
+        p = self.L.go_gbz_write_gfa_mode(self.h, path_mode, C.byref(n))
         out = C.string_at(p, n.value)
+        self.L.go_free(p)
+        return out
+
+    def pan_sn_path(self, path_id):
+        """Metadata::pan_sn_path (src/gbwt.rs:709-713); None for an id without a name."""
+        n = C.c_size_t(0)
+        p = self.L.go_metadata_pan_sn_path(self.L.go_gbz_gbwt(self.h), path_id, C.byref(n))
+        if not p:
+            return None
+        out = C.string_at(p, n.value).decode()
         self.L.go_free(p)
         return out
 

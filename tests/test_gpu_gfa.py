@@ -100,6 +100,51 @@ def test_synthetic_translation_broken_paths(tmp_path):
     assert out.read_bytes() == oracle.gfa()
 
 
+@pytest.mark.parametrize("name", ["example.gbz", "example-v1.gbz", "translation.gbz"])
+def test_path_modes_on_fixtures(tmp_path, name):
+    """gbunzip --paths default / pan-sn / ref-only (PathMode, src/bin/gbunzip.rs:63-76, 212-222) through gbwt_hip_write_gfa_mode, and
+    the PanSN P-lines (mode 2 of gbwt_hip_path_lines; path_to_pan_sn 487-491, Metadata::pan_sn_path src/gbwt.rs:709-713)."""
+    path = os.path.join(O.GOLDEN, name)
+    dev, oracle = G.GBZ.load(path), O.OracleGBZ(path)
+    for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+        out = tmp_path / f"mode{mode}.gfa"
+        dev.write_gfa(str(out), mode)
+        assert out.read_bytes() == oracle.gfa(mode), mode
+    ids = list(range(dev.paths()))
+    assert dev.path_lines(ids, 2) == oracle.path_lines(ids, 2)
+    assert dev.path_lines(ids[::-1], 2) == oracle.path_lines(ids[::-1], 2)
+    if name.startswith("example"):
+        assert dev.path_lines([3], 2) == b"P\tsample#2#A\t11+,13+,14+,16+,17+\t*\n"      # pan_sn_path(3) == "sample#2#A", src/gbwt.rs:598
+    with pytest.raises(G.GbwtHipError):
+        dev.path_lines(ids, 3)
+    with pytest.raises(G.GbwtHipError):
+        dev.write_gfa(str(tmp_path / "bad.gfa"), 3)
+
+
+def test_path_modes_on_synthetic(tmp_path):
+    """The three path modes on a generated GBZ with hundreds of haplotypes and on a translated graph with broken segment paths."""
+    s = S.Synth.chain(sites=500, haplotypes=260, alleles=3, model=S.MOSAIC, founders=8, switch_rate=0.02, seed=19)
+    path = tmp_path / "synth.gbz"
+    s.save(str(path), as_gbz=True)
+    dev, oracle = G.GBZ.load(str(path)), O.OracleGBZ(str(path))
+    for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+        out = tmp_path / f"synth{mode}.gfa"
+        dev.write_gfa(str(out), mode)
+        got, exp = out.read_bytes(), oracle.gfa(mode)
+        assert hashlib.sha256(got).hexdigest() == hashlib.sha256(exp).hexdigest() and got == exp, mode
+    starts = [1, 4, 5, 7, 8, 12]
+    fwd = lambda a, b: [2 * v for v in range(a, b + 1)]
+    rev = lambda a, b: [2 * v + 1 for v in range(b, a - 1, -1)]
+    paths = [fwd(1, 3) + fwd(4, 4), fwd(2, 3) + fwd(4, 4), fwd(1, 3) + rev(5, 6) + fwd(7, 7), fwd(8, 9) + rev(9, 9), (fwd(1, 3) + rev(5, 6)) * 2000, fwd(12, 12)]
+    dev, oracle = translated_graph(tmp_path, paths, starts, "modes.gbz")
+    for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+        out = tmp_path / f"modes{mode}.gfa"
+        dev.write_gfa(str(out), mode)
+        assert out.read_bytes() == oracle.gfa(mode), mode
+    ids = list(range(len(paths)))
+    assert dev.path_lines(ids, 2) == oracle.path_lines(ids, 2)
+
+
 def test_bare_gbwt_has_no_gfa():
     dev = G.GBZ.load(os.path.join(O.GOLDEN, "example.gbwt"))
     with pytest.raises(G.GbwtHipError):

@@ -384,6 +384,90 @@ def test_random_path_sets(seed, cyclic):
     check_follow(dev, oracle)
 
 
+
+def _check_positions_sampled(dev, oracle, rng, per_record=24):
+    """forward / backward at the first, the last, one past the last and random offsets of every record; find + extend + bd over
+    whole records and random sub-ranges."""
+    queries, q_states, q_nodes = [], [], []
+    first = oracle.alphabet_offset() + 1
+    for node in range(first, oracle.alphabet_size()):
+        st = oracle.find(node)
+        ln = st[2] if st else 0
+        offs = {0, ln, ln + 1, max(0, ln - 1)} | {rng.randrange(0, ln + 1) for _ in range(per_record)}
+        queries += [(node, o) for o in sorted(offs)]
+        if st:
+            a = rng.randrange(0, ln); b = rng.randrange(a, ln + 1)
+            for rng_ in ((0, ln), (a, b)):
+                for _ in range(3):
+                    fw = oracle.forward((node, rng.randrange(rng_[0], max(rng_[0] + 1, rng_[1]))))
+                    q_states.append((node, rng_[0], rng_[1])); q_nodes.append(fw[0] if fw else first)
+    out, ok = dev.forward(np.array(queries, dtype=G.POS_DTYPE))
+    bout, bok = dev.backward(np.array(queries, dtype=G.POS_DTYPE))
+    for q, r, v, br, bv in zip(queries, out, ok, bout, bok):
+        exp, bexp = oracle.forward(q), oracle.backward(q)
+        assert bool(v) == (exp is not None) and (exp is None or tuple(int(x) for x in r) == exp), q
+        assert bool(bv) == (bexp is not None) and (bexp is None or tuple(int(x) for x in br) == bexp), q
+    out, ok = dev.extend(states(q_states), q_nodes)
+    for st, d, r, v in zip(q_states, q_nodes, out, ok):
+        exp = oracle.extend(st, d)
+        assert bool(v) == (exp is not None) and (exp is None or tuple(int(x) for x in r) == exp), (st, d)
+    q_bd = [((n, a, b), (n ^ 1, 0, b - a)) for (n, a, b) in q_states]
+    for fn, ofn in ((dev.extend_forward, oracle.extend_forward), (dev.extend_backward, oracle.extend_backward)):
+        out, ok = fn(bd_states(q_bd), q_nodes)
+        for st, d, r, v in zip(q_bd, q_nodes, out, ok):
+            exp = ofn(st, d)
+            assert bool(v) == (exp is not None) and (exp is None or bd_tuple(r) == exp), (st, d)
+
+
+@pytest.mark.parametrize("alleles,haplotypes", [(150, 2500), (253, 4000), (128, 2500)])
+def test_rle_one_byte_plus_varint_regime(alleles, haplotypes):
+    """129 <= sigma <= 254: the run-length threshold is 1, so EVERY run is one byte (the value) + a varint (length - 1)
+    (src/support.rs:1292-1296, 1413-1430; src/support/tests.rs:461-469) -- the regime between the byte-packed runs of small
+    alphabets and the two-varint runs of sigma >= 255, and the one that stresses RunDecoder's reciprocal division."""
+    s = S.Synth.chain(sites=10, haplotypes=haplotypes, alleles=alleles, model=S.IID, zipf=0.0, seed=alleles)
+    dev, oracle = open_synth(s), oracle_of(s)
+    assert 128 < dev.stats.max_outdegree < 255, dev.stats.max_outdegree
+    ids = np.arange(s.sequences, dtype=np.uint64)
+    offsets, nodes = dev.sequences_csr(ids)
+    o_off, o_nodes = oracle.extract(ids, threads=8)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    # every offset of the widest records (the anchors), sampled offsets elsewhere
+    rng = random.Random(alleles)
+    first = s.alphabet_offset + 1
+    wide = sorted(range(first, s.alphabet_size), key=lambda n: -((oracle.find(n) or (0, 0, 0))[2]))[:3]
+    queries = [(n, o) for n in wide for o in range(oracle.find(n)[2] + 2)]
+    out, ok = dev.forward(np.array(queries, dtype=G.POS_DTYPE))
+    for q, r, v in zip(queries, out, ok):
+        exp = oracle.forward(q)
+        assert bool(v) == (exp is not None) and (exp is None or tuple(int(x) for x in r) == exp), q
+    _check_positions_sampled(dev, oracle, rng, per_record=4)
+    for mode in (1, 2):                                      # the lane-serial and the wave-cooperative decoder read the same streams
+        dev.tune(walk_mode=mode)
+        offsets, nodes = dev.sequences_csr(ids[:400])
+        assert np.array_equal(nodes, o_nodes[:o_off[400]])
+
+
+def test_long_runs_in_small_alphabets():
+    """sigma = 1: threshold 256, a run of 256 or more is the byte 255 + varint(length - 256) -- here with three-byte varints
+    (runs of more than 2^14 + 256); sigma = 2: threshold 128 (src/support.rs:1292-1296; src/support/tests.rs:439-459)."""
+    trunk = [2 * v for v in range(1, 7)]
+    paths = [trunk] * 21000 + [trunk[:3] + [2 * 9] + trunk[4:]] * 400 + [trunk] * 18000 + [[2 * 9, 2 * 3 + 1]] * 3
+    s = S.Synth.from_paths(paths, bidirectional=True)
+    dev, oracle = open_synth(s), oracle_of(s)
+    assert dev.stats.max_record_len >= (1 << 14) + 256
+    run = 21000 + 400 + 18000 - 256                          # node 1's record: one run of 39 400 -> 255, then varint(39 144) in three bytes
+    assert bytes([255, 0x80 | (run & 0x7F), 0x80 | ((run >> 7) & 0x7F), run >> 14]) in bytes(s.data())
+    ids = np.arange(s.sequences, dtype=np.uint64)
+    offsets, nodes = dev.sequences_csr(ids)
+    o_off, o_nodes = oracle.extract(ids, threads=8)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    _check_positions_sampled(dev, oracle, random.Random(5), per_record=64)
+    for mode in (1, 2, 3):
+        dev.tune(walk_mode=mode)
+        offsets, nodes = dev.sequences_csr(ids[::97])
+        e_off, e_nodes = oracle.extract(ids[::97], threads=8)
+        assert np.array_equal(offsets, e_off) and np.array_equal(nodes, e_nodes)
+
 @pytest.mark.parametrize("alleles,model,zipf", [(2, S.MOSAIC, 1.2), (2, S.IID, 1.2), (7, S.IID, 1.0), (300, S.IID, 0.2), (400, S.IID, 0.0)])
 def test_chain_indexes(alleles, model, zipf):
     """Bubble / star chains incl. the sigma >= 255 two-varint regime and runs longer than one byte can hold."""

@@ -63,3 +63,35 @@ def test_translation_gfa(name):
 def test_path_lines_subset():
     z = gbz("example.gbz")
     assert z.path_lines([0, 1], 0) + z.path_lines([2, 3, 4, 5], 1) == kat.EXAMPLE_PW_LINES
+
+
+def test_pan_sn_names():
+    """Metadata::pan_sn_path, doc-test src/gbwt.rs:596-598: path 3 of the example is "sample#2#A"; generic paths carry phase 0
+    in memory (src/gbwt.rs:879-886)."""
+    z = gbz("example.gbz")
+    assert z.pan_sn_path(3) == "sample#2#A"
+    assert [z.pan_sn_path(i) for i in range(6)] == ["_gbwt_ref#0#A", "_gbwt_ref#0#B", "sample#1#A", "sample#2#A", "sample#1#B", "sample#2#B"]
+    assert z.pan_sn_path(6) is None
+
+
+@pytest.mark.parametrize("name", ["example.gbz", "translation.gbz"])
+def test_path_modes(name):
+    """gbunzip --paths default / pan-sn / ref-only (src/bin/gbunzip.rs:63-76, 212-222): the three files share H, S and L lines;
+    pan-sn writes every path as a P-line named sample#phase#contig (write_pan_sn 371-393), ref-only stops after the P-lines
+    of the generic sample."""
+    z = gbz(name)
+    default, pan_sn, ref_only = z.gfa(0), z.gfa(1), z.gfa(2)
+    assert default == z.gfa()
+    split = default.index(b"P\t")
+    assert pan_sn[:split] == default[:split] and ref_only[:split] == default[:split]
+    n = z.paths()
+    assert pan_sn[split:] == z.path_lines(list(range(n)), 2)
+    generic = [i for i in range(n) if z.pan_sn_path(i).startswith("_gbwt_ref#")]
+    assert ref_only[split:] == z.path_lines(generic, 0)
+    assert default == ref_only + z.path_lines([i for i in range(n) if i not in generic], 1)
+    # a PanSN line is the P-line of the path under another name
+    for i in range(n):
+        p, q = z.path_lines([i], 0).split(b"\t"), z.path_lines([i], 2).split(b"\t")
+        assert q[1] == z.pan_sn_path(i).encode() and p[0] == q[0] == b"P" and p[2:] == q[2:]
+    if name == "example.gbz":
+        assert z.path_lines([3], 2) == b"P\tsample#2#A\t11+,13+,14+,16+,17+\t*\n"

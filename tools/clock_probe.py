@@ -32,6 +32,7 @@ def sampler():
 
 for dry in ("0", "1", "64"):
     os.environ["GBWT_HIP_DEBUG_DRY_ROWS"] = dry
+    dev.new_workspace()   # the knobs are read when a workspace is created
     samples.clear()
     stop = False
     t = threading.Thread(target=sampler)

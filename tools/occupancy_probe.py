@@ -18,6 +18,7 @@ dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_si
 for dry in (0, 1):
     for half in (0, 16384):
         os.environ["GBWT_HIP_DEBUG_DRY_ROWS"] = str(dry + half)
+        dev.new_workspace()   # the knobs are read when a workspace is created
         for n in (64, 128, 192, 256, 384, 768):
             ids = np.arange(0, 2 * n, 2, dtype=np.uint64)
             best = 1e9

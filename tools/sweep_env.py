@@ -54,6 +54,8 @@ for cfg in [c for c in args.configs.split(";")] or [""]:
         dev = None
         dev, open_s = open_index()
         last_open = open_key
+    else:
+        dev.new_workspace()   # the extraction knobs are read when a workspace is created
     times, totals = [], []
     for _ in range(args.reps + 1):
         dev.extract_device(ids)
