@@ -27,6 +27,8 @@ def lib():
         L.gbwt_synth_chain_chopped.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.gbwt_synth_from_paths.restype = p
         L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
+        L.gbwt_synth_merge.restype = p
+        L.gbwt_synth_merge.argtypes = [p, u64, p, p, u64, p, u64, u64]
         L.gbwt_synth_from_file.restype = p
         L.gbwt_synth_from_file.argtypes = [C.c_char_p, C.c_char_p, u64]
         L.gbwt_synth_attach_gbz.restype = C.c_int
@@ -81,12 +83,59 @@ class Synth:
         return cls(lib().gbwt_synth_from_paths(offsets.ctypes.data, flat.ctypes.data, len(paths), int(bidirectional)))
 
     @classmethod
+    def merge(cls, parts, path_names, sample_names, contig_names, haplotypes):
+        """One index out of several chains (gbwt_synth.h): `parts` = Synth.chain objects (the graph components), `path_names` = one
+        (sample, contig, phase, fragment) per path of the merged index (the paths of part 0, then of part 1, ...)."""
+        handles = (C.c_void_p * len(parts))(*[q._h for q in parts])
+        names = np.ascontiguousarray(path_names, dtype=np.uint32).reshape(-1, 4)
+        assert len(names) == sum(q.paths for q in parts)
+        samples = (C.c_char_p * len(sample_names))(*[x.encode() for x in sample_names])
+        contigs = (C.c_char_p * len(contig_names))(*[x.encode() for x in contig_names])
+        merged = cls(lib().gbwt_synth_merge(handles, len(parts), names.ctypes.data, samples, len(sample_names), contigs, len(contig_names), haplotypes))
+        merged.path_names = names                              # (sample, contig, phase, fragment) per path
+        merged.generic_sample = list(sample_names).index("_gbwt_ref") if "_gbwt_ref" in sample_names else len(sample_names)
+        return merged
+
+    @classmethod
+    def genome(cls, contigs=24, fragments=3, haplotypes=12, sites=60, seed=1, extra=1, generic_per_contig=1):
+        """Config C4's shape at any scale: `contigs` contigs, each cut into `fragments` graph components that a random
+        subset of the `haplotypes` haplotypes (sample s<h/2>, phase h%2+1) walks -- one ragged walk per (haplotype, component),
+        with the fragment field = where the walk starts on its haplotype (the running sum of the earlier fragments plus gaps) -- and
+        `generic_per_contig` reference paths (sample _gbwt_ref) in the first component of every contig."""
+        import random
+        rng = random.Random(seed)
+        parts, names = [], []
+        n_samples = (haplotypes + 1) // 2
+        for c in range(contigs):
+            at = [rng.randrange(0, 1000) for _ in range(haplotypes)]         # where every haplotype is on this contig
+            for f in range(fragments):
+                generic = generic_per_contig if f == 0 else 0
+                walkers = sorted(rng.sample(range(haplotypes), rng.randint(max(1, haplotypes // 2), haplotypes)))
+                n_sites = max(2, int(sites * rng.uniform(0.5, 2.0)))
+                part = cls.chain(sites=n_sites, haplotypes=generic + len(walkers), alleles=2, model=MOSAIC, founders=max(2, min(8, len(walkers))),
+                                 switch_rate=0.02, seed=rng.randrange(1 << 30), extra=extra if (c + f) % 2 else 0, indel_every=3)
+                parts.append(part)
+                names += [(n_samples, c, 0, 0)] * generic
+                for h in walkers:
+                    names.append((h // 2, c, h % 2 + 1, at[h]))
+                    at[h] += 3 * n_sites + rng.randrange(0, 500)
+        samples = [f"s{k}" for k in range(n_samples)] + ["_gbwt_ref"]
+        return cls.merge(parts, names, samples, [f"chr{c + 1}" for c in range(contigs)], haplotypes)
+
+    @classmethod
     def from_file(cls, path):
         err = C.create_string_buffer(256)
         h = lib().gbwt_synth_from_file(os.fsencode(path), err, 256)
         if not h:
             raise ValueError(err.value.decode())
         return cls(h)
+
+    def generic_paths(self):
+        """Ids of the paths gbunzip writes as P-lines (sample _gbwt_ref); all others are walks (src/bin/gbunzip.rs:343-417)."""
+        names = getattr(self, "path_names", None)
+        if names is None:
+            return [0] if self.paths else []                   # the chain generators: path 0
+        return [p for p in range(len(names)) if names[p][0] == self.generic_sample]
 
     def attach_gbz(self, segment_starts=(), seed=1):
         """Adds path metadata + node labels (+ a node-to-segment translation) so that the index can be saved as a GBZ."""

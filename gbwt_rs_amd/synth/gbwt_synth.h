@@ -59,6 +59,14 @@ gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes
  * next start and is named "seg<start>" (src/graph.rs:84-89, 186-218).  Returns 0 on success. */
 int gbwt_synth_attach_gbz(gbwt_synth *s, const uint64_t *segment_starts, uint64_t n_segments, uint64_t seed);
 
+/* One index out of several chains (gbwt_synth_chain*): the graph components of a whole-genome GBZ.  The node ids of part k follow those
+ * of part k - 1 (its ids are shifted, its records re-encoded with the shifted edge lists), its paths follow the paths of part k - 1, and
+ * the endmarker records are merged.  `path_names` = 4 numbers per path of the merged index (sample, contig, phase, fragment: PathName,
+ * src/gbwt.rs:912-926) -- any assignment: several samples and phases, contigs, non-zero fragment offsets, several generic paths (sample =
+ * the id of "_gbwt_ref").  The parts are only read.  Config C4's shape: contigs x fragments = parts, haplotypes = paths per part. */
+gbwt_synth *gbwt_synth_merge(const gbwt_synth *const *parts, uint64_t n_parts, const uint32_t *path_names, const char *const *sample_names,
+                             uint64_t n_samples, const char *const *contig_names, uint64_t n_contigs, uint64_t haplotype_count);
+
 /* Loads a .gbwt / .gbz with the product loader (for writer round-trip tests). */
 gbwt_synth *gbwt_synth_from_file(const char *path, char *err, uint64_t errlen);
 

@@ -88,6 +88,10 @@ struct gbwt_synth {
     // explicit truth (from_paths)
     std::vector<uint64_t> path_offsets;
     std::vector<uint32_t> path_nodes;
+    // merged truth (gbwt_synth_merge): the chains this index was put together from (without their record streams), the first path of
+    // each in the merged numbering and the shift of its node ids
+    std::vector<gbwt_synth> parts;
+    std::vector<uint64_t> part_first_path, part_shift;
 
     inline uint32_t allele(uint64_t s, uint64_t h) const {
         if (alleles == 2) return static_cast<uint32_t>((bits[s * row_words + (h >> 6)] >> (h & 63)) & 1);
@@ -562,6 +566,121 @@ int gbwt_synth_attach_gbz(gbwt_synth *g, const uint64_t *segment_starts, uint64_
     return 0;
 }
 
+gbwt_synth *gbwt_synth_merge(const gbwt_synth *const *parts, uint64_t n_parts, const uint32_t *path_names, const char *const *sample_names, uint64_t n_samples,
+                             const char *const *contig_names, uint64_t n_contigs, uint64_t haplotype_count) {
+    if (n_parts == 0) return nullptr;
+    uint64_t total_paths = 0;
+    for (uint64_t k = 0; k < n_parts; k++) {
+        const gbwt_synth *p = parts[k];
+        if (!p || p->sites == 0 || !p->index.bidirectional || p->index.alphabet_offset != 1 || p->index.alphabet_size % 2 != 0 || !p->index.is_gbz) return nullptr;
+        total_paths += p->haplotypes;
+    }
+    gbwt_synth *g = new gbwt_synth;
+    HostIndex &ix = g->index;
+    ix.alphabet_offset = 1; ix.bidirectional = true;
+    ix.sequences = 2 * total_paths;
+    ix.tags.emplace_back("source", "gbwt_rs_amd/synth");
+    ix.gbz_tags.emplace_back("source", "gbwt_rs_amd/synth");
+    // node ids of part k are shifted by the node ids of the parts before it; GBWT nodes by twice that
+    uint64_t id_shift = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> edges, end_edges;
+    std::vector<uint8_t> end_runs;          // (edge rank, run length) pairs of the merged endmarker record, re-encoded below
+    std::vector<std::pair<uint64_t, uint64_t>> end_run_list;
+    auto get_varint = [](const uint8_t *&p, const uint8_t *end, uint64_t &v) {
+        v = 0;
+        unsigned shift = 0;
+        while (p < end) { const uint8_t b = *p++; v += static_cast<uint64_t>(b & 0x7F) << shift; shift += 7; if (!(b & 0x80)) return true; }
+        return false;
+    };
+    std::vector<uint8_t> body;              // records 1 .. of the merged index
+    std::vector<uint64_t> body_starts;
+    for (uint64_t k = 0; k < n_parts; k++) {
+        const gbwt_synth &p = *parts[k];
+        const HostIndex &px = p.index;
+        const uint64_t node_shift = 2 * id_shift;
+        g->part_first_path.push_back(ix.path_names.size());
+        g->part_shift.push_back(id_shift);
+        // its endmarker record: edges shifted, runs decoded (they are re-encoded against the merged edge list)
+        {
+            const uint8_t *q = px.data.data() + px.starts[0], *end = px.data.data() + px.starts[1];
+            uint64_t sigma = 0, node = 0;
+            get_varint(q, end, sigma);
+            const uint64_t rank_base = end_edges.size();
+            for (uint64_t e = 0; e < sigma; e++) {
+                uint64_t delta = 0, off = 0;
+                get_varint(q, end, delta); get_varint(q, end, off);
+                node += delta;
+                end_edges.emplace_back(node == 0 ? 0 : node + node_shift, 0);
+            }
+            const uint64_t threshold = sigma >= 255 ? 0 : 256 / sigma;
+            while (q < end) {
+                uint64_t value = 0, len = 0;
+                if (sigma >= 255) { get_varint(q, end, value); get_varint(q, end, len); len++; }
+                else { const uint64_t b = *q++; value = b % sigma; len = b / sigma + 1; if (len == threshold) { uint64_t x = 0; get_varint(q, end, x); len += x; } }
+                end_run_list.emplace_back(rank_base + value, len);
+            }
+        }
+        // its other records: the nodes of the edge list shifted, the run stream as it is
+        for (uint64_t r = 1; r < px.records(); r++) {
+            body_starts.push_back(body.size());
+            const uint8_t *q = px.data.data() + px.starts[r], *end = px.data.data() + px.starts[r + 1];
+            uint64_t sigma = 0, node = 0;
+            if (!get_varint(q, end, sigma) || sigma == 0) { body.push_back(0); continue; }
+            edges.clear();
+            for (uint64_t e = 0; e < sigma; e++) {
+                uint64_t delta = 0, off = 0;
+                get_varint(q, end, delta); get_varint(q, end, off);
+                node += delta;
+                edges.emplace_back(node == 0 ? 0 : node + node_shift, off);
+            }
+            put_varint(body, sigma);
+            uint64_t prev = 0;
+            for (auto &e : edges) { put_varint(body, e.first - prev); put_varint(body, e.second); prev = e.first; }
+            body.insert(body.end(), q, end);
+        }
+        // labels, truth
+        for (uint64_t q = 0; q < px.sequences_labels.size(); q++) {
+            ix.sequences_labels.bytes.insert(ix.sequences_labels.bytes.end(), px.sequences_labels.bytes.begin() + px.sequences_labels.offsets[q],
+                                             px.sequences_labels.bytes.begin() + px.sequences_labels.offsets[q + 1]);
+            ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
+        }
+        const uint64_t ids = (px.alphabet_size - 2) / 2;           // node ids 1 .. ids
+        for (uint64_t q = px.sequences_labels.size(); q < ids; q++) ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
+        ix.graph_nodes += px.graph_nodes;
+        ix.size += px.size;
+        for (uint64_t h = 0; h < p.haplotypes; h++) {
+            const uint32_t *f = path_names + 4 * ix.path_names.size();
+            ix.path_names.push_back(PathName{f[0], f[1], f[2], f[3]});
+        }
+        gbwt_synth truth;                                          // the allele matrix only
+        truth.sites = p.sites; truth.haplotypes = p.haplotypes; truth.alleles = p.alleles; truth.extra = p.extra; truth.indel_every = p.indel_every;
+        truth.chop = p.chop; truth.bits = p.bits; truth.row_words = p.row_words; truth.choices = p.choices;
+        g->parts.push_back(std::move(truth));
+        id_shift += ids;
+    }
+    // the merged endmarker record: a consistent GBWT lists an edge once, and the parts' nodes are disjoint and ascending
+    ix.data.clear();
+    ix.starts.assign(1, 0);
+    {
+        RecordWriter rw(ix.data);
+        rw.begin(end_edges);
+        for (auto &r : end_run_list) rw.push(r.first, r.second);
+        rw.end();
+    }
+    const uint64_t base = ix.data.size();
+    for (uint64_t b : body_starts) ix.starts.push_back(base + b);
+    ix.data.insert(ix.data.end(), body.begin(), body.end());
+    ix.starts.push_back(ix.data.size());
+    ix.alphabet_size = 2 * id_shift + 2;
+    ix.is_gbz = true; ix.has_translation = false;
+    ix.has_metadata = true; ix.metadata_flags = 7;
+    for (uint64_t k = 0; k < n_samples; k++) add_string(ix.sample_names, sample_names[k]);
+    for (uint64_t k = 0; k < n_contigs; k++) add_string(ix.contig_names, contig_names[k]);
+    ix.sample_count = n_samples; ix.contig_count = n_contigs; ix.haplotype_count = haplotype_count;
+    g->haplotypes = total_paths;
+    return g;
+}
+
 gbwt_synth *gbwt_synth_from_file(const char *path, char *err, uint64_t errlen) {
     gbwt_synth *g = new gbwt_synth;
     try {
@@ -596,7 +715,20 @@ int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz) {
     }
 }
 
+static bool merged_part(const gbwt_synth *s, uint64_t path_id, uint64_t &part, uint64_t &local) {
+    if (s->parts.empty() || path_id >= s->haplotypes) return false;
+    part = std::upper_bound(s->part_first_path.begin(), s->part_first_path.end(), path_id) - s->part_first_path.begin() - 1;
+    local = path_id - s->part_first_path[part];
+    return true;
+}
+
 uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, uint64_t cap) {
+    uint64_t part = 0, local = 0;
+    if (merged_part(s, path_id, part, local)) {
+        const uint64_t len = gbwt_synth_path(&s->parts[part], local, out, cap);
+        for (uint64_t k = 0; k < len && k < cap; k++) out[k] += static_cast<uint32_t>(2 * s->part_shift[part]);
+        return len;
+    }
     if (s->sites) {
         if (path_id >= s->haplotypes) return 0;
         uint64_t len = 0;
@@ -616,7 +748,9 @@ uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, u
 }
 
 uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id) {
-    uint64_t sum = 0;
+    uint64_t sum = 0, part = 0, local = 0;
+    if (merged_part(s, path_id, part, local))
+        return gbwt_synth_path_checksum(&s->parts[part], local) + 2 * s->part_shift[part] * gbwt_synth_path(&s->parts[part], local, nullptr, 0);
     if (s->sites) {
         if (path_id >= s->haplotypes) return 0;
         for (uint64_t site = 0; site < s->sites; site++) {

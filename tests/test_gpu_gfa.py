@@ -145,6 +145,36 @@ def test_path_modes_on_synthetic(tmp_path):
     assert dev.path_lines(ids, 2) == oracle.path_lines(ids, 2)
 
 
+def test_config_c4_shape_whole_file(tmp_path):
+    """Config 4's shape: 24 contigs x 3 graph components each, ~2 300 ragged walks of 20 samples x 2 phases with non-zero
+    fragment offsets, 24 generic paths -- the whole file in the three path modes and the W-lines in any order against the oracle
+    (write_walks selects by sample, src/bin/gbunzip.rs:396-417; fragment and fragment + length, 508-519; PathName, src/gbwt.rs:912-970),
+    and every sequence of the index, forward and reverse."""
+    g = S.Synth.genome(contigs=24, fragments=3, haplotypes=40, sites=60, seed=11)
+    assert g.paths > 2000
+    path = tmp_path / "c4.gbz"
+    g.save(str(path), as_gbz=True)
+    dev, oracle = G.GBZ.load(str(path)), O.OracleGBZ(str(path))
+    for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+        out = tmp_path / f"c4_{mode}.gfa"
+        dev.write_gfa(str(out), mode)
+        got, exp = out.read_bytes(), oracle.gfa(mode)
+        assert hashlib.sha256(got).hexdigest() == hashlib.sha256(exp).hexdigest() and got == exp, mode
+    text = oracle.gfa()
+    walks = [l.split(b"\t") for l in text.split(b"\n") if l.startswith(b"W\t")]
+    assert len({f[3] for f in walks}) == 24 and sum(int(f[4]) != 0 for f in walks) > 1000
+    rng = np.random.default_rng(4)
+    ids = rng.permutation(g.paths)[:700]
+    for mode in (1, 2):
+        assert dev.path_lines(ids, mode) == oracle.path_lines(ids, mode)
+    seqs = np.arange(g.sequences, dtype=np.uint64)
+    offsets, nodes = dev.sequences_csr(seqs)
+    o_off, o_nodes = oracle.gbwt().extract(seqs, threads=8)
+    assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes)
+    for p in (0, 1, g.paths // 2, g.paths - 1):
+        assert np.array_equal(nodes[offsets[2 * p]:offsets[2 * p + 1]], g.path(p))
+
+
 def test_bare_gbwt_has_no_gfa():
     dev = G.GBZ.load(os.path.join(O.GOLDEN, "example.gbwt"))
     with pytest.raises(G.GbwtHipError):
