@@ -34,7 +34,7 @@ void fill_stats(gbwt_hip_index &ix) {
     const HostIndex &h = ix.host;
     gbwt_hip_stats &s = ix.stats;
     s.size = h.size; s.sequences = h.sequences; s.alphabet_size = h.alphabet_size; s.alphabet_offset = h.alphabet_offset;
-    s.records = h.records(); s.data_bytes = h.data.size(); s.paths = h.path_names.size();
+    s.records = h.records(); s.data_bytes = h.record_bytes_len(); s.paths = h.path_names.size();
     s.bidirectional = h.bidirectional; s.has_metadata = h.has_metadata; s.is_gbz = h.is_gbz; s.has_translation = h.has_translation;
 }
 
@@ -118,34 +118,56 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     return true;
 }
 
+// GBWT_HIP_TRACE_OPEN=1: where the wall time of an open goes, phase by phase, on stderr (each mark waits for the device first)
+struct OpenTrace {
+    bool on = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[open] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = std::chrono::steady_clock::now();
+    }
+};
+
 // Uploads the host image and runs the load-time device passes.
 void upload(gbwt_hip_index &ix) {
+    OpenTrace trace;
     HostIndex &h = ix.host;
     if (h.alphabet_size > (uint64_t(1) << 32)) throw InvalidData("alphabet_size > 2^32 is not supported (u32 node ids on device)");
     HIP_CHECK(hipSetDevice(ix.device));
     const uint64_t n_records = h.records();
-    ix.data.reserve(h.data.size() + DATA_PAD);
-    HIP_CHECK(hipMemset(ix.data.ptr, 0, h.data.size() + DATA_PAD));
-    if (!h.data.empty()) HIP_CHECK(hipMemcpy(ix.data.ptr, h.data.data(), h.data.size(), hipMemcpyHostToDevice));
+    const uint64_t data_bytes = h.record_bytes_len();      // read from the mapped file while the loader's background copy is still running
+    ix.data.reserve(data_bytes + DATA_PAD);
+    HIP_CHECK(hipMemset(ix.data.ptr, 0, data_bytes + DATA_PAD));
     DeviceIndex &d = ix.dev;
     d = DeviceIndex{};
     d.data = ix.data.as<uint8_t>();
-    d.data_len = h.data.size();
+    d.data_len = data_bytes;
     d.n_records = n_records;
     d.n_sequences = h.sequences;
     d.alphabet_offset = static_cast<uint32_t>(h.alphabet_offset);
     d.first_node = static_cast<uint32_t>(h.alphabet_offset + 1);
-    if (h.data.size() < (uint64_t(1) << 32)) {
-        std::vector<uint32_t> s32(h.starts.begin(), h.starts.end());
-        if (s32.empty()) s32.push_back(0);
-        ix.starts.reserve(s32.size() * sizeof(uint32_t));
-        HIP_CHECK(hipMemcpy(ix.starts.ptr, s32.data(), s32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        d.starts32 = ix.starts.as<uint32_t>();
-    } else {
-        ix.starts.reserve(h.starts.size() * sizeof(uint64_t));
-        HIP_CHECK(hipMemcpy(ix.starts.ptr, h.starts.data(), h.starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        d.starts64 = ix.starts.as<uint64_t>();
-    }
+    // the record starts travel next to the record bytes (a thread of their own: narrowing two million offsets and staging them is 3 ms)
+    const bool narrow_starts = data_bytes < (uint64_t(1) << 32);
+    ix.starts.reserve(std::max<size_t>(h.starts.size(), 1) * (narrow_starts ? sizeof(uint32_t) : sizeof(uint64_t)));
+    std::atomic<int> starts_failed{0};
+    std::thread starts_thread([&]() {
+        if (hipSetDevice(ix.device) != hipSuccess) { starts_failed = 1; return; }
+        if (narrow_starts) {
+            std::vector<uint32_t> s32(h.starts.begin(), h.starts.end());
+            if (s32.empty()) s32.push_back(0);
+            if (hipMemcpy(ix.starts.ptr, s32.data(), s32.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) starts_failed = 1;
+        } else if (hipMemcpy(ix.starts.ptr, h.starts.data(), h.starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) starts_failed = 1;
+    });
+    // (slices on four threads, or the mapped pages pinned with hipHostRegister for the copy, measure the same 9 ms as this one call)
+    const hipError_t copied = data_bytes ? hipMemcpy(ix.data.ptr, h.record_bytes(), data_bytes, hipMemcpyHostToDevice) : hipSuccess;
+    starts_thread.join();
+    if (copied != hipSuccess) throw HipError{copied, "hipMemcpy (record bytes)"};
+    if (starts_failed) throw HipError{hipErrorUnknown, "hipMemcpy (record starts)"};
+    if (narrow_starts) d.starts32 = ix.starts.as<uint32_t>(); else d.starts64 = ix.starts.as<uint64_t>();
+    trace.mark("record bytes + starts to the device");
 
     // Load-time device passes: per-record descriptors + rank blocks + record statistics, then the endmarker
     // (src/gbwt.rs:413-414).
@@ -160,7 +182,9 @@ void upload(gbwt_hip_index &ix) {
         ix.block_base.reserve(nr * sizeof(uint32_t));
         DeviceBuffer counts, scan_tmp;
         counts.reserve(nr * sizeof(uint32_t));
+        trace.mark("starts + allocations");
         launch_build_desc(d, ix.desc_raw.as<uint4>(), counts.as<uint32_t>(), d_stats, nullptr);
+        trace.mark("k_build_desc");
         d.desc_raw = ix.desc_raw.as<uint4>();
         d.desc = ix.desc.as<uint4>();
         uint64_t n_blocks = 1;  // block 0: all zero, read by the records that have no blocks of their own
@@ -181,7 +205,9 @@ void upload(gbwt_hip_index &ix) {
         d.block_base = ix.block_base.as<uint32_t>();
         d.blocks = ix.blocks.as<uint4>();
         d.n_blocks = n_blocks;
+        trace.mark("block scan + allocation");
         if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
+        trace.mark("k_fill_blocks");
         launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
         {
             uint32_t hops = 15;   // LF steps between a walk and its look-ahead target (7 until the packed blocks and the spread rows: fresh processes,
@@ -198,11 +224,13 @@ void upload(gbwt_hip_index &ix) {
             if (const char *v = std::getenv("GBWT_HIP_GATHER_LIMIT")) gather_limit = static_cast<uint32_t>(std::min<long>(1l << 21, std::max<long>(0, std::atol(v))));
             if (n_blocks >= (uint64_t(1) << 31)) gather_limit = 0;   // half-block indices 2 bb + offset / 32 are 32-bit in the loops: beyond that, full-width blocks only
             ix.packed_blocks = gather_limit != 0;
+            trace.mark("link + lookahead + allocations");
             launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, nullptr);
             ix.gblocks.reserve((gather_limit ? n_blocks : 1) * 2 * sizeof(uint4));   // no record takes the packed path: only the zero block
             HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.gblocks = ix.gblocks.as<uint4>();
             if (n_blocks > 1) launch_fill_two_step_blocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), gather_limit ? ix.gblocks.as<uint4>() : nullptr, nullptr);
+            trace.mark("two-step descriptors + blocks");
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
         // LF tables for the class 0 records, while they fit the budget
@@ -244,6 +272,7 @@ void upload(gbwt_hip_index &ix) {
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
     }
+    trace.mark("tables");
     uint64_t hs[8];
     HIP_CHECK(hipMemcpy(hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
@@ -261,6 +290,7 @@ void upload(gbwt_hip_index &ix) {
     if (end_len > 0) HIP_CHECK(hipMemcpy(ix.endmarker.ptr, endmarker.data(), end_len * sizeof(uint2), hipMemcpyHostToDevice));
     d.endmarker = ix.endmarker.as<uint2>();
     d.n_endmarker = end_len;
+    trace.mark("endmarker");
     // Lengths of all sequences and the sequence samples (GBWT_HIP_SEQ_LEN=0 skips both; extractions then go through the
     // pool of chained blocks and walk every sequence from one end).
     d.seq_len = nullptr;
@@ -348,6 +378,7 @@ void upload(gbwt_hip_index &ix) {
                 d.sample_interval = interval;
             }
         }
+        trace.mark("lengths + samples");
         ix.times.checkpoint_sampling = by_checkpoints ? 1u : 0u;
         ix.times.sample_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_samples).count();
     }
@@ -362,6 +393,7 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
     upload(*ix);
+    ix->host.finish();                    // the loader's background work (record bytes into `data`, node labels): needed from here on
     upload_label_lengths(*ix);
     const auto t_done = std::chrono::steady_clock::now();
     const auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
@@ -436,7 +468,7 @@ gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index 
     const auto t_open = std::chrono::steady_clock::now();
     std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
-    ix->host = load_index_file(path);
+    load_index_file_into(path, ix->host, true);
     return open_common(std::move(ix), out, t_open);
     GBWT_HIP_GUARD_END
 }

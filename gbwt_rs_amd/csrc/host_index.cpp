@@ -3,12 +3,20 @@
 #include "host_index.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <thread>
 
 namespace gbwt_hip {
 
@@ -86,34 +94,76 @@ void skip_option(Elements &in) {
     in.words(size);   // checked against the rest of the file
 }
 
-// SparseVector -> sorted values.  value_k = ((pos_k - k) << w) | low[k], pos_k = k-th set bit of high.
-std::vector<uint64_t> read_sparse(Elements &in, uint64_t &universe) {
-    universe = in.word();
-    uint64_t ones = in.word();
-    RawBits high = read_raw(in);
+// The large sections of a file -- the record starts, the record bytes, the node labels -- are LOCATED while the file is walked (a few
+// header words each) and DECODED afterwards, side by side on a few threads (Deferred): the Elias-Fano decode of two million starts,
+// the copy of the record bytes and the unpacking of a million labels were three quarters of the 36 ms the headline GBZ took to parse.
+struct Deferred {
+    std::vector<std::function<void()>> tasks, background;      // background: may still be running when the loader returns (HostIndex::pending)
+    void run() {
+        if (tasks.empty()) return;
+        const unsigned workers = std::min<unsigned>(static_cast<unsigned>(tasks.size()), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+        std::atomic<size_t> next{0};
+        std::exception_ptr failure;
+        std::atomic<bool> failed{false};
+        auto work = [&]() {
+            for (size_t k = next++; k < tasks.size(); k = next++) {
+                try { tasks[k](); }
+                catch (...) { if (!failed.exchange(true)) failure = std::current_exception(); }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < workers; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        tasks.clear();
+        if (failure) std::rethrow_exception(failure);
+    }
+};
+
+// SparseVector, located: value_k = ((pos_k - k) << w) | low[k], pos_k = k-th set bit of high.
+struct SparseView { uint64_t universe = 0, ones = 0; RawBits high; Packed low; };
+
+SparseView locate_sparse(Elements &in) {
+    SparseView v;
+    v.universe = in.word();
+    v.ones = in.word();
+    v.high = read_raw(in);
     skip_option(in); skip_option(in); skip_option(in);  // rank / select / select_zero supports
-    Packed low = read_packed(in);
-    if (low.len != ones) throw InvalidData("SparseVector: low length does not match the number of ones");
-    if (ones > high.len) throw InvalidData("SparseVector: more ones than bits in the high bitvector");   // also bounds the allocation
+    v.low = read_packed(in);
+    if (v.low.len != v.ones) throw InvalidData("SparseVector: low length does not match the number of ones");
+    if (v.ones > v.high.len) throw InvalidData("SparseVector: more ones than bits in the high bitvector");   // also bounds the allocation
+    return v;
+}
+
+std::vector<uint64_t> decode_sparse(const SparseView &v) {
+    // the declared number of ones must be the number of set bits BEFORE it sizes an allocation (a corrupt count would ask for up to
+    // 64 times the file size and surface as "out of host memory" instead of InvalidData)
+    uint64_t set = 0;
+    for (uint64_t wi = 0; wi < v.high.n_words; wi++) set += static_cast<uint64_t>(__builtin_popcountll(v.high.words[wi]));
+    if (set != v.ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
     std::vector<uint64_t> values;
-    values.reserve(ones + 1);
-    const uint64_t w = low.width;
+    values.reserve(v.ones + 1);
+    const uint64_t w = v.low.width;
     uint64_t k = 0;
-    for (uint64_t wi = 0; wi < high.n_words; wi++) {
-        uint64_t word = high.words[wi];
+    for (uint64_t wi = 0; wi < v.high.n_words; wi++) {
+        uint64_t word = v.high.words[wi];
         while (word) {
             uint64_t pos = wi * 64 + static_cast<uint64_t>(__builtin_ctzll(word));
             word &= word - 1;
-            if (k >= ones) throw InvalidData("SparseVector: too many ones in the high bitvector");
             const uint64_t upper = pos - k;
             if (w < 64 && upper != 0 && (upper >> (64 - w)) != 0) throw InvalidData("SparseVector: value does not fit 64 bits");
             uint64_t hi = (w >= 64) ? 0 : (upper << w);
-            values.push_back(hi | low.get(k));
+            values.push_back(hi | v.low.get(k));
             k++;
         }
     }
-    if (k != ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
     return values;
+}
+
+std::vector<uint64_t> read_sparse(Elements &in, uint64_t &universe) {
+    const SparseView v = locate_sparse(in);
+    universe = v.universe;
+    return decode_sparse(v);
 }
 
 void read_bytes(Elements &in, std::vector<uint8_t> &out) {
@@ -131,20 +181,23 @@ void finish_strings(Strings &s, std::vector<uint64_t> &&offsets) {
         if (s.offsets[i] < s.offsets[i - 1]) throw InvalidData("StringArray: offsets are not sorted");
 }
 
-// StringArray::load (packed form), src/support.rs:601-647
-void read_strings(Elements &in, Strings &s) {
-    uint64_t universe;
-    std::vector<uint64_t> offsets = read_sparse(in, universe);
+// StringArray::load (packed form), src/support.rs:601-647; with `later` the decoding is a deferred task
+void read_strings(Elements &in, Strings &s, Deferred *later = nullptr, bool background = false) {
+    const SparseView view = locate_sparse(in);
     std::vector<uint8_t> alphabet;
     read_bytes(in, alphabet);
-    Packed packed = read_packed(in);
-    s.bytes.resize(packed.len);
-    for (uint64_t i = 0; i < packed.len; i++) {
-        uint64_t x = packed.get(i);
-        if (x >= alphabet.size()) throw InvalidData("StringArray: packed character outside the alphabet");
-        s.bytes[i] = alphabet[x];
-    }
-    finish_strings(s, std::move(offsets));
+    const Packed packed = read_packed(in);
+    auto decode = [view, alphabet, packed, &s]() {
+        std::vector<uint64_t> offsets = decode_sparse(view);
+        s.bytes.resize(packed.len);
+        for (uint64_t i = 0; i < packed.len; i++) {
+            uint64_t x = packed.get(i);
+            if (x >= alphabet.size()) throw InvalidData("StringArray: packed character outside the alphabet");
+            s.bytes[i] = alphabet[x];
+        }
+        finish_strings(s, std::move(offsets));
+    };
+    if (later) (background ? later->background : later->tasks).push_back(decode); else decode();
 }
 
 // StringArray::decompress (zstd form, graph version >= 4), src/support.rs:543-571
@@ -272,7 +325,7 @@ void read_metadata(Elements &in, HostIndex &h) {
 }
 
 // GBWT::load, src/gbwt.rs:402-438 (+ BWT::load, src/bwt.rs:176-185)
-void read_gbwt(Elements &in, HostIndex &h) {
+void read_gbwt(Elements &in, HostIndex &h, Deferred &later) {
     uint64_t word0 = in.word();
     h.sequences = in.word(); h.size = in.word(); h.alphabet_offset = in.word(); h.alphabet_size = in.word();
     uint64_t flags = in.word();
@@ -283,14 +336,20 @@ void read_gbwt(Elements &in, HostIndex &h) {
     // path reads it, and keeping the file's value lets save_index_file() write a loaded file back unchanged.
     read_tags(in, h.tags);
 
-    uint64_t universe;
-    h.starts = read_sparse(in, universe);
-    read_bytes(in, h.data);
-    if (universe != h.data.size()) throw InvalidData("BWT: Index / data length mismatch");
-    for (size_t i = 0; i < h.starts.size(); i++)
-        if (h.starts[i] > h.data.size() || (i > 0 && h.starts[i] < h.starts[i - 1]))
-            throw InvalidData("BWT: record starts are not sorted offsets into the data");
-    h.starts.push_back(h.data.size());
+    const SparseView index = locate_sparse(in);
+    const uint64_t data_len = in.word();
+    if (data_len / 8 > in.remaining()) throw InvalidData("Vector<u8>: length exceeds the file");   // before rounding: (len + 7) / 8 wraps
+    const uint8_t *data = reinterpret_cast<const uint8_t *>(in.words(data_len / 8 + (data_len % 8 != 0 ? 1 : 0)));
+    if (index.universe != data_len) throw InvalidData("BWT: Index / data length mismatch");
+    h.file_data = data; h.file_data_len = data_len;
+    later.background.push_back([&h, data, data_len]() { h.data.assign(data, data + data_len); });
+    later.tasks.push_back([&h, index, data_len]() {
+        h.starts = decode_sparse(index);
+        for (size_t i = 0; i < h.starts.size(); i++)
+            if (h.starts[i] > data_len || (i > 0 && h.starts[i] < h.starts[i - 1]))
+                throw InvalidData("BWT: record starts are not sorted offsets into the data");
+        h.starts.push_back(data_len);
+    });
 
     uint64_t da_len = in.word();  // document array samples: opaque pass-through in the reference (417)
     const uint64_t *da = in.words(da_len);
@@ -309,7 +368,7 @@ void read_gbwt(Elements &in, HostIndex &h) {
 }
 
 // Graph::load, src/graph.rs:296-338
-void read_graph(Elements &in, HostIndex &h) {
+void read_graph(Elements &in, HostIndex &h, Deferred &later) {
     uint64_t word0 = in.word();
     uint64_t nodes = in.word();
     h.graph_nodes = nodes;
@@ -317,16 +376,23 @@ void read_graph(Elements &in, HostIndex &h) {
     check_header("GraphHeader", word0, flags, GRAPH_TAG, 3, 4, 0x3);
     if (!(flags & 2)) throw InvalidData("GraphHeader: SDSL format is not supported");
     h.has_translation = (flags & 1) != 0;
-    if ((word0 >> 32) >= 4) read_strings_zstd(in, h.sequences_labels); else read_strings(in, h.sequences_labels);
+    if ((word0 >> 32) >= 4) read_strings_zstd(in, h.sequences_labels); else read_strings(in, h.sequences_labels, &later, true);
     read_strings(in, h.segment_names);
     if (h.has_translation == (h.segment_names.size() == 0))
         throw InvalidData("Graph: Translation flag does not match the presence of segment names");
     h.segment_starts = read_sparse(in, h.mapping_len);
     if (h.has_translation) {
         if (h.mapping_len <= nodes) throw InvalidData("Graph: Node-to-segment mapping does not match the number of nodes");
-        if (h.mapping_len != h.sequences_labels.size() + 1) throw InvalidData("Graph: Node-to-segment mapping does not match the number of sequences");
         if (h.segment_starts.size() != h.segment_names.size()) throw InvalidData("Graph: Node-to-segment mapping does not match the number of segments");
     }
+}
+
+// the checks of Graph::load / GBZ::load that need the decoded node labels
+void check_graph(const HostIndex &h) {
+    if (h.has_translation && h.mapping_len != h.sequences_labels.size() + 1) throw InvalidData("Graph: Node-to-segment mapping does not match the number of sequences");
+    const uint64_t potential_nodes = (h.alphabet_size - (h.alphabet_offset + 1)) / 2;
+    if (h.sequences_labels.size() != potential_nodes)
+        throw InvalidData("GBZ: Mismatch between GBWT alphabet size and Graph sequence count");
 }
 
 }  // namespace
@@ -344,43 +410,113 @@ const std::string *HostIndex::tag(const std::string &key) const {
     return nullptr;
 }
 
-HostIndex load_index_file(const std::string &path) {
-    std::unique_ptr<FILE, int (*)(FILE *)> f(std::fopen(path.c_str(), "rb"), std::fclose);
-    if (!f) throw IoError("cannot open " + path);
-    std::fseek(f.get(), 0, SEEK_END);
-    long sz = std::ftell(f.get());
-    std::fseek(f.get(), 0, SEEK_SET);
-    if (sz < 0) throw IoError("cannot stat " + path);
-    if (sz % 8 != 0) throw InvalidData("file size is not a multiple of 8 bytes");
-    std::vector<uint64_t> buf(static_cast<size_t>(sz) / 8 + 1);
-    if (sz > 0 && std::fread(buf.data(), 1, static_cast<size_t>(sz), f.get()) != static_cast<size_t>(sz)) throw IoError("short read on " + path);
-    Elements in(buf.data(), static_cast<uint64_t>(sz) / 8);
+namespace {
+// The file, mapped (no copy, no zero-filled staging buffer) or -- where mmap does not work -- read into memory.
+struct FileImage {
+    const uint64_t *words = nullptr;
+    uint64_t n_words = 0;
+    void *mapping = nullptr;
+    size_t mapped = 0;
+    std::unique_ptr<uint64_t[]> owned;
+    FileImage() = default;
+    FileImage(const FileImage &) = delete;
+    FileImage &operator=(const FileImage &) = delete;
+    ~FileImage() { if (mapping) munmap(mapping, mapped); }
+};
 
-    HostIndex h;
+void open_image(const std::string &path, FileImage &image) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw IoError("cannot open " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); throw IoError("cannot stat " + path); }
+    const size_t sz = static_cast<size_t>(st.st_size);
+    if (sz % 8 != 0) { ::close(fd); throw InvalidData("file size is not a multiple of 8 bytes"); }
+    image.n_words = sz / 8;
+    if (sz == 0) { ::close(fd); return; }
+    void *m = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    if (m != MAP_FAILED) {
+        image.mapping = m; image.mapped = sz; image.words = static_cast<const uint64_t *>(m);
+        ::close(fd);
+        return;
+    }
+    image.owned.reset(new uint64_t[sz / 8]);
+    size_t got = 0;
+    while (got < sz) {
+        const ssize_t r = ::read(fd, reinterpret_cast<char *>(image.owned.get()) + got, sz - got);
+        if (r <= 0) { ::close(fd); throw IoError("short read on " + path); }
+        got += static_cast<size_t>(r);
+    }
+    ::close(fd);
+    image.words = image.owned.get();
+}
+}  // namespace
+
+struct HostIndex::Pending {
+    FileImage image;
+    std::thread worker;
+    std::exception_ptr failure;
+    ~Pending() { if (worker.joinable()) worker.join(); }
+};
+
+void HostIndex::finish() {
+    if (!pending) return;
+    std::shared_ptr<Pending> p = std::move(pending);          // record_bytes() now answers from `data`
+    pending.reset();
+    if (p->worker.joinable()) p->worker.join();
+    file_data = nullptr; file_data_len = 0;
+    if (p->failure) std::rethrow_exception(p->failure);
+    if (is_gbz) check_graph(*this);
+}
+
+void load_index_file_into(const std::string &path, HostIndex &h, bool background) {
+    h = HostIndex();
+    std::shared_ptr<HostIndex::Pending> pending = std::make_shared<HostIndex::Pending>();
+    open_image(path, pending->image);
+    Elements in(pending->image.words, pending->image.n_words);
+    Deferred later;
     uint32_t tag = static_cast<uint32_t>(in.peek());
     if (tag == GBZ_TAG) {
         // GBZ::load, src/gbz.rs:674-717
         uint64_t word0 = in.word(), flags = in.word();
         check_header("GBZHeader", word0, flags, GBZ_TAG, 1, 2, 0);
         read_tags(in, h.gbz_tags);
-        read_gbwt(in, h);
+        read_gbwt(in, h, later);
         if (!h.bidirectional) throw InvalidData("GBZ: The GBWT index is not bidirectional");
-        read_graph(in, h);
-        uint64_t potential_nodes = (h.alphabet_size - (h.alphabet_offset + 1)) / 2;
-        if (h.sequences_labels.size() != potential_nodes)
-            throw InvalidData("GBZ: Mismatch between GBWT alphabet size and Graph sequence count");
+        read_graph(in, h, later);
         h.is_gbz = true;
     } else {
-        read_gbwt(in, h);
+        read_gbwt(in, h, later);
     }
     if (!in.at_end()) throw InvalidData("trailing data after the index");
+    if (!background) {
+        for (auto &t : later.background) later.tasks.push_back(std::move(t));
+        later.background.clear();
+    }
+    later.run();
+    if (later.background.empty()) {
+        h.file_data = nullptr; h.file_data_len = 0;
+        if (h.is_gbz) check_graph(h);
+        return;
+    }
+    HostIndex::Pending *raw = pending.get();
+    std::vector<std::function<void()>> jobs = std::move(later.background);
+    raw->worker = std::thread([raw, jobs]() {
+        try { for (auto &job : jobs) job(); }
+        catch (...) { raw->failure = std::current_exception(); }
+    });
+    h.pending = std::move(pending);
+}
+
+HostIndex load_index_file(const std::string &path) {
+    HostIndex h;
+    load_index_file_into(path, h, false);
     return h;
 }
 
 std::vector<std::pair<uint32_t, uint32_t>> decompress_endmarker(const HostIndex &h, uint64_t limit) {
     std::vector<std::pair<uint32_t, uint32_t>> out;
     if (h.records() == 0 || h.starts[1] <= h.starts[0]) return out;
-    const uint8_t *p = h.data.data() + h.starts[0], *end = h.data.data() + h.starts[1];
+    const uint8_t *p = h.record_bytes() + h.starts[0], *end = h.record_bytes() + h.starts[1];
     auto varint = [&](uint64_t &v) -> bool {                  // ByteCodeIter::next, src/support.rs:1151-1164
         v = 0;
         unsigned shift = 0;

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -64,10 +65,24 @@ struct HostIndex {
     Strings segment_names;
     std::vector<uint64_t> segment_starts;  // node id of the first node of each segment (mapping ones)
     uint64_t mapping_len = 0;              // universe of the node-to-segment mapping
+
+    // load_index_file_into(..., background = true): the copy of the record bytes into `data` and the decoding of the node labels --
+    // nothing the device passes of an open need -- go on in a thread of their own while the caller uploads and builds on the GPU.
+    // Until finish() has returned, `data`, `sequences_labels` must not be touched; the record bytes are read through
+    // record_bytes() (the mapped file).  finish() joins the thread and throws what it threw; without a background it does nothing.
+    struct Pending;
+    std::shared_ptr<Pending> pending;
+    const uint8_t *file_data = nullptr;
+    uint64_t file_data_len = 0;
+    const uint8_t *record_bytes() const { return pending ? file_data : data.data(); }
+    uint64_t record_bytes_len() const { return pending ? file_data_len : data.size(); }
+    void finish();
 };
 
 // Parses a .gbwt or .gbz (detected by the header tag).  Throws InvalidData / IoError.
 HostIndex load_index_file(const std::string &path);
+// The same into `out`, which must stay where it is until out.finish() has returned when `background` is set (see HostIndex::pending).
+void load_index_file_into(const std::string &path, HostIndex &out, bool background);
 
 // Writes the index back in the simple-sds format (GBWT v5; GBZ v1 container with an uncompressed
 // graph, version 3), following the Serialize impls src/gbwt.rs:389-400, src/gbz.rs:662-672,

@@ -426,37 +426,34 @@ __global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, co
     }
     for (uint32_t k = lane; k < count; k += WAVE) {
         const uint4 P = ix.blocks[bb + k];
-        {   // full width
-            const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
-            const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
-            const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
-            uint64_t bits2 = 0;
-            uint32_t R[2] = {0, 0};
-            for (uint32_t a = 0; a < 2; a++) {
-                const uint64_t m = (a ? bits1 : ~bits1) & valid;
-                if (!s2.wblocks[a] || m == 0) continue;
-                const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
-                bits2 |= second_step_bits<uint64_t>(s2.wblocks[a], s2.wbase[a] + before, m, R[a]);
-            }
-            cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
-            cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
+        const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
+        const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
+        const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
+        uint64_t bits2 = 0, m_of[2] = {0, 0};
+        uint32_t R[2] = {0, 0};
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint64_t m = (a ? bits1 : ~bits1) & valid;
+            if (!s2.wblocks[a] || m == 0) continue;
+            m_of[a] = m;
+            const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
+            bits2 |= second_step_bits<uint64_t>(s2.wblocks[a], s2.wbase[a] + before, m, R[a]);
         }
+        cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
+        cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
         if (gblocks == nullptr) continue;
-        for (uint32_t h = 0; h < 2; h++) {
-            const uint32_t first = (k << RANK_BLOCK_SHIFT) + 32u * h;                      // first offset of this half
-            const uint32_t remaining = first > len ? 0u : len - first;
-            const uint32_t valid = remaining >= 32 ? ~0u : ((1u << remaining) - 1);
-            const uint32_t bits1 = h ? P.y : P.x;
-            const uint32_t ones1 = P.z + (h ? __popc(P.x) : 0u);
-            uint32_t bits2 = 0, R[2] = {0, 0};
-            for (uint32_t a = 0; a < 2; a++) {
-                const uint32_t m = (a ? bits1 : ~bits1) & valid;
-                if (!s2.wblocks[a] || m == 0) continue;
-                const uint32_t before = a ? ones1 : first - ones1;                            // a-paths of v before this half
-                bits2 |= second_step_bits<uint32_t>(s2.wblocks[a], s2.wbase[a] + before, m, R[a]);
-            }
-            gblocks[2 * static_cast<uint64_t>(bb + k) + h] = make_uint4(bits1, bits2, (ones1 & 0x1FFFFFu) | (R[0] << 21), ((R[0] >> 11) & 0x3FFu) | (R[1] << 10));
+        // the two halves of the same block: the bits are the same bits; the counts of the upper half start behind the lower half's
+        // positions (ones1) and behind the a-paths of the lower half that have value 1 in w_a (R_a).  A half without a-paths (or an
+        // edge without blocks behind it) carries R_a = 0, which nothing reads.
+        const uint32_t lo2 = static_cast<uint32_t>(bits2), hi2 = static_cast<uint32_t>(bits2 >> 32);
+        uint32_t Rlo[2], Rhi[2];
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint32_t mlo = static_cast<uint32_t>(m_of[a]), mhi = static_cast<uint32_t>(m_of[a] >> 32);
+            Rlo[a] = mlo ? R[a] : 0u;
+            Rhi[a] = mhi ? R[a] + __popc(lo2 & mlo) : 0u;
         }
+        const uint32_t ones_hi = P.z + __popc(P.x);
+        gblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, lo2, (P.z & 0x1FFFFFu) | (Rlo[0] << 21), ((Rlo[0] >> 11) & 0x3FFu) | (Rlo[1] << 10));
+        gblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.y, hi2, (ones_hi & 0x1FFFFFu) | (Rhi[0] << 21), ((Rhi[0] >> 11) & 0x3FFu) | (Rhi[1] << 10));
     }
 }
 
