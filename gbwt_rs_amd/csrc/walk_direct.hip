@@ -412,13 +412,63 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     uint32_t probe_uniform = 0, probe_vector = 0, probe_entries = 0, probe_mixed_entries = 0, probe_fell_out = 0;
 #endif
     bool full_blocks = a.packed_blocks == 0;    // wave-uniform
+    uint32_t catch_credit = 2, catch_pause = 0, catch_backoff = 8;   // wave-uniform: see CATCH-UP below
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
         if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
         // all lanes on one record: scalar descriptor fetch; otherwise every lane fetches its own
         // (the uniform loop finds out by itself, but only after it has issued a round of loads for nothing: in graphs whose rows do
         // not move in lock-step the waves are mixed at almost every entry)
-        const bool together = __ballot(rec != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rec))) == 0;
+        bool together = __ballot(rec != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rec))) == 0;
+        bool caught = false;
+        // CATCH-UP.  A wave that has left lock step is often only a step apart: the rows that took an insertion are one record behind
+        // the others.  Any lane may take an LF step at any time -- the order of the steps changes nothing in what is emitted -- so the
+        // lanes that are BEHIND take single steps (one-step descriptors + plain rank blocks, plain C++) until the wave stands on one
+        // record again and the uniform loop can have it back.  "Behind" is a guess from the orientation of the node the wave is on
+        // (forward nodes are walked in ascending id order in a graph whose ids are sorted topologically, as vg's are); where the guess
+        // is wrong, or the rows really have gone different ways, the attempt fails after four steps, the gather loop takes over as
+        // before, and the wave stops trying for a while.
+        if (!together && a.uniform_loop && a.catch_up && catch_pause == 0) {
+            const uint64_t walking = __ballot(rec != 0);
+            for (uint32_t tries = 0; tries < 4 && !together; tries++) {
+                const uint32_t any = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rec), __builtin_ctzll(walking)));
+                const bool ascending = ((any + ix.alphabet_offset) & 1u) == 0;
+                // the record furthest ahead among the walking lanes
+                uint32_t key = rec != 0 ? (ascending ? rec : ~rec) : 0u;
+                uint32_t front = key;
+                for (int d = 32; d > 0; d >>= 1) front = max(front, static_cast<uint32_t>(__shfl_xor(static_cast<int>(front), d)));
+                const bool behind = rec != 0 && key != front;
+                bool slow_here = false;
+                if (behind) {
+                    const uint4 *d1 = ix.desc + 4 * static_cast<uint64_t>(rec);
+                    const uint4 D = d1[2];
+                    slow_here = (D.x & DESC_SLOW) != 0;
+                    if (!slow_here) {
+                        const uint4 K = ix.blocks[bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT)];
+                        const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+                        const uint32_t bit = offset & 63u;
+                        const uint32_t value = static_cast<uint32_t>(bits >> bit) & 1u;
+                        const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << bit) - 1));
+                        const uint4 E = d1[value];
+                        const uint32_t flags = value ? D.w : D.y;
+                        rec = E.z; offset = E.y + (value ? ones : offset - ones); bb = E.w;
+                        sink.push(E.x, E.x != 0);
+                        sink.push(rec + ix.alphabet_offset, (flags & EDGE_EMIT2) != 0);
+                        if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+                    }
+                }
+                if (__ballot(slow_here) != 0) break;
+                together = __ballot(rec != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rec))) == 0;
+                if (__ballot(rec != 0) != walking) break;      // a lane has finished its segment: the wave will not be uniform again
+            }
+            lds_poke(my_mail + 3, sink.wr);
+            caught = together;
+            if (!together && --catch_credit == 0) { catch_pause = catch_backoff; catch_backoff = min(2 * catch_backoff, 256u); catch_credit = 1; }
+            // the single steps have used the slack the loops count on (they are entered with at least eight free slots and push four
+            // per iteration before they look again): back to the top, which waits for the helper if the ring is that full
+            if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - 8) != 0) continue;
+        } else if (catch_pause != 0) catch_pause--;
+        const uint32_t wr_entry = sink.wr;
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         const uint32_t wr0 = sink.wr;
         probe_entries++;
@@ -436,6 +486,13 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         if (!together) probe_mixed_entries++;
         if (slow_exit == 2 && together) probe_fell_out++;
 #endif
+        if (caught) {
+            // was it worth it?  Where the rows part again within a few iterations (indels at every other site) the single steps cost
+            // more than the uniform loop returns: such waves stop trying for a while (profiles/r03_catch_up.txt)
+            const uint32_t gained = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sink.wr - wr_entry)));
+            if (gained >= 24) { catch_credit = min(catch_credit + 1u, 4u); catch_backoff = 8; }
+            else if (--catch_credit == 0) { catch_pause = catch_backoff; catch_backoff = min(2 * catch_backoff, 256u); catch_credit = 1; }
+        }
         const bool mixed = slow_exit == 2;
         if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr)
                                            : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);

@@ -609,9 +609,12 @@ def test_chopped_chain_bit_exact(tmp_path, chop, extra, every):
     assert dev.path_lines(np.arange(1, 30, dtype=np.uint64), 1) == O.OracleGBZ(str(path)).path_lines(list(range(1, 30)), 1)
 
 
-def test_indel_chain_scale_properties():
-    """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix."""
-    s = S.Synth.chain(sites=60000, haplotypes=3000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=9, extra=2)
+@pytest.mark.parametrize("extra,every,sites", [(2, 1, 60000), (3, 64, 150000), (1, 8, 100000), (3, 4096, 150000)])
+def test_indel_chain_scale_properties(extra, every, sites):
+    """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix.  Dense
+    insertions (waves mixed for good: the gather loop), sparse ones (waves a step apart that catch up by single steps and return to the
+    uniform loop, with the ring filling up on the way) and in between (attempts that do not pay and back off)."""
+    s = S.Synth.chain(sites=sites, haplotypes=3000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=9, extra=extra, indel_every=every)
     dev = open_synth(s)
     ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
     out = dev.extract_device(ids)
@@ -817,6 +820,7 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "40", "GBWT_HIP_SERIAL_SAMPLES": "1"},   # ... both in one walk (samples every 40 nodes of each sequence)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CHECKPOINT_CAP": "5"},   # checkpoint sampling with hops of at most 5 + 3 nodes: many rounds of orphans
                 {"GBWT_HIP_SAMPLE_INTERVAL": "2048", "GBWT_HIP_CHECKPOINT_CAP": "100000"},   # ... with hardly any checkpoint: whole sequences in one hop
+                {"GBWT_HIP_SAMPLE_INTERVAL": "200", "GBWT_HIP_CATCH_UP": "0"},     # mixed waves go to the gather loop at once (no single steps of the lanes behind)
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
 
@@ -914,7 +918,8 @@ def _layered_paths(layers, haplotypes, seed):
 
 
 @pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "9", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
-                                 {"GBWT_HIP_WALK_TABLES": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_DIRECT": "0"}],
+                                 {"GBWT_HIP_WALK_TABLES": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_DIRECT": "0"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "11", "GBWT_HIP_CATCH_UP": "0"}],
                          ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
 def test_walk_tables(monkeypatch, env):
     """Walks over records with outdegree > 2 (walk tables: the plain LF entry with the step through a unary successor and
