@@ -64,9 +64,10 @@ def _ptr(a):
 class GBWT:
     """A GBWT index resident in HBM.  Mirrors gbwt::GBWT (src/gbwt.rs:95-385) for the hot path."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, owner=None):
         self._L = _lib.lib()
         self._h = handle
+        self._owner = owner                 # a view of another object's index (another_workspace): that object closes it
         self._ws = C.c_void_p()
         check(self._L.gbwt_hip_workspace_create(self._h, C.byref(self._ws)))
         self._stats = Stats()
@@ -95,14 +96,22 @@ class GBWT:
             self._L.gbwt_hip_workspace_destroy(self._ws)
             self._ws = None
         if getattr(self, "_h", None):
-            self._L.gbwt_hip_close(self._h)
+            if getattr(self, "_owner", None) is None:
+                self._L.gbwt_hip_close(self._h)
             self._h = None
+            self._owner = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    def another_workspace(self):
+        """The same index through a workspace of its own: what a second host thread uses (a handle is immutable after open and safe
+        for concurrent read-only calls as long as every thread has its own workspace; the reference shares &GBZ across rayon
+        workers, src/bin/gbunzip.rs:421-434).  The view keeps this object alive and never closes the index."""
+        return type(self)(self._h, owner=self)
 
     def new_workspace(self):
         """A fresh workspace: the GBWT_HIP_* extraction knobs are read when a workspace is created, not per call."""

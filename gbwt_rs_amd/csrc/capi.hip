@@ -38,6 +38,21 @@ void fill_stats(gbwt_hip_index &ix) {
     s.bidirectional = h.bidirectional; s.has_metadata = h.has_metadata; s.is_gbz = h.is_gbz; s.has_translation = h.has_translation;
 }
 
+// The full-width two-step blocks, built on first need (gbwt_hip_index::cblocks_once).
+void ensure_cblocks(const gbwt_hip_index *index) {
+    gbwt_hip_index *ix = const_cast<gbwt_hip_index *>(index);     // the lazily built part of an otherwise immutable handle
+    std::call_once(ix->cblocks_once, [ix]() {
+        if (ix->dev.cblocks != nullptr) return;
+        HIP_CHECK(hipSetDevice(ix->device));
+        ix->cblocks.reserve(std::max<uint64_t>(ix->dev.n_blocks, 1) * 2 * sizeof(uint4));
+        HIP_CHECK(hipMemsetAsync(ix->cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
+        if (ix->dev.n_blocks > 1) launch_fill_two_step_blocks(ix->dev, ix->cblocks.as<uint4>(), nullptr, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipGetLastError());
+        ix->dev.cblocks = ix->cblocks.as<uint4>();
+    });
+}
+
 // max / min / common number of samples per sequence from the host copy of sample_base
 void note_sample_counts(gbwt_hip_index &ix, const std::vector<uint64_t> &base) {
     uint64_t lo = ~uint64_t(0), hi = 0;
@@ -216,10 +231,8 @@ void upload(gbwt_hip_index &ix) {
             launch_link_lookahead(d, ix.desc.as<uint4>(), counts.as<uint32_t>(), hops, nullptr);
             // two-step walk: composed descriptors + two-step blocks
             ix.desc2.reserve(nr * 8 * sizeof(uint4));
-            ix.cblocks.reserve(n_blocks * 2 * sizeof(uint4));
-            HIP_CHECK(hipMemsetAsync(ix.cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.desc2 = ix.desc2.as<uint4>();
-            d.cblocks = ix.cblocks.as<uint4>();
+            d.cblocks = nullptr;
             uint32_t gather_limit = 1u << 21;     // the counts of the gather loop's packed blocks (tests lower it)
             if (const char *v = std::getenv("GBWT_HIP_GATHER_LIMIT")) gather_limit = static_cast<uint32_t>(std::min<long>(1l << 21, std::max<long>(0, std::atol(v))));
             if (n_blocks >= (uint64_t(1) << 31)) gather_limit = 0;   // half-block indices 2 bb + offset / 32 are 32-bit in the loops: beyond that, full-width blocks only
@@ -229,7 +242,17 @@ void upload(gbwt_hip_index &ix) {
             ix.gblocks.reserve((gather_limit ? n_blocks : 1) * 2 * sizeof(uint4));   // no record takes the packed path: only the zero block
             HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.gblocks = ix.gblocks.as<uint4>();
-            if (n_blocks > 1) launch_fill_two_step_blocks(d, counts.as<uint32_t>(), ix.cblocks.as<uint4>(), gather_limit ? ix.gblocks.as<uint4>() : nullptr, nullptr);
+            // both layouts in one pass when the full-width one is certain to be read: a record whose counts do not fit the packed blocks
+            // (k_link_desc2 clears GATHER_OK from 2^21 positions, for the record and for what lies behind its edges) or no packed blocks at all
+            uint64_t longest = 0;
+            HIP_CHECK(hipMemcpy(&longest, d_stats, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            const bool full_width_now = gather_limit == 0 || longest >= gather_limit;
+            if (full_width_now) {
+                ix.cblocks.reserve(n_blocks * 2 * sizeof(uint4));
+                HIP_CHECK(hipMemsetAsync(ix.cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
+            }
+            if (n_blocks > 1) launch_fill_two_step_blocks(d, full_width_now ? ix.cblocks.as<uint4>() : nullptr, gather_limit ? ix.gblocks.as<uint4>() : nullptr, nullptr);
+            if (full_width_now) std::call_once(ix.cblocks_once, [&]() { d.cblocks = ix.cblocks.as<uint4>(); });
             trace.mark("two-step descriptors + blocks");
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
@@ -325,6 +348,7 @@ void upload(gbwt_hip_index &ix) {
         const uint64_t pool_capacity = all_nodes / std::max<uint32_t>(interval, 1) + 2 * h.sequences + 1024;
         const char *two = std::getenv("GBWT_HIP_TWO_PASS_OPEN");
         bool one_walk = !by_checkpoints && sampled && !want_pairs && h.sequences <= 0xFFFFFFFFull && !(two && std::atoi(two) != 0);
+        if (!by_checkpoints) ensure_cblocks(&ix);               // the walks of every sequence below step on the full-width blocks (quiet_walk)
         if (one_walk) {
             pool.reserve(pool_capacity * sizeof(uint4)); tags.reserve(pool_capacity * sizeof(uint2));
             HIP_CHECK(hipMemset(d_stats + 2, 0, sizeof(uint64_t)));
@@ -639,6 +663,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.catch_up = knobs.catch_up >= 0 ? (knobs.catch_up ? 1u : 0u) : 1u;
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
             a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;
+            if (!a.packed_blocks) ensure_cblocks(ix);
             a.row_piece = knobs.row_piece >= 0 ? static_cast<uint32_t>(knobs.row_piece) : 32u;
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
             a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
@@ -656,6 +681,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         }
         uint32_t flags = 0;
         WalkArgs a{};
+        if (ws->walk_mode == WALK_TWO_STEP) ensure_cblocks(ix);   // the pool-output kernel walks on the full-width two-step blocks
         for (int attempt = 0; attempt < 8; attempt++) {
             if (pool_blocks >= POOL_NONE) return fail(GBWT_HIP_UNSUPPORTED, "path pool would exceed 2^32 blocks");
             ws->pool.reserve(pool_blocks * POOL_BLOCK_NODES * sizeof(uint32_t));

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <new>
@@ -203,6 +204,10 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceBuffer seg_seq_len;   // u64 per segment: length of the segment's sequence
     gbwt_hip::DeviceBuffer node_real;     // u8 per node id < mapping_len: GBZ::has_node
     gbwt_hip::DeviceIndex dev{};
+    // The full-width two-step blocks (cblocks, as large as gblocks: 1.7 GB on the headline index) are only read by the loops for records
+    // whose counts do not fit the packed half-blocks, by the pool-output kernel and by the serial walks at open: built at open when one of
+    // those is certain to run, else on the first request that needs them (ensure_cblocks; once, whichever thread comes first).
+    mutable std::once_flag cblocks_once;
     bool packed_blocks = true;        // gblocks was built (false: the index is too large for 32-bit half-block indices, or GBWT_HIP_GATHER_LIMIT=0)
     uint32_t max_samples = 0;         // the largest number of samples of a sequence
     std::vector<uint32_t> sample_counts;   // samples of every sequence (host copy: an extraction looks whether its rows all have the same number)

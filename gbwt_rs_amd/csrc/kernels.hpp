@@ -35,7 +35,7 @@ void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t
 void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t stream);
 // two-step walk (device_index.hpp): composed descriptors, two-step rank blocks, look-ahead targets
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, hipStream_t stream);   // gather_limit: Record::len below which the packed blocks can count
-void launch_fill_two_step_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, uint4 *d_gblocks /* or null */, hipStream_t stream);
+void launch_fill_two_step_blocks(const DeviceIndex &ix, uint4 *d_cblocks /* or null */, uint4 *d_gblocks /* or null */, hipStream_t stream);   // one of the two layouts, or both in one pass
 void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
 void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, const uint32_t *d_block_base, uint4 *d_blocks, hipStream_t stream);
 

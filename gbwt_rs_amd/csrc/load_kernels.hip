@@ -400,15 +400,15 @@ __device__ __forceinline__ Mask second_step_bits(const uint4 *wblocks, uint32_t 
     return bits2;
 }
 
-__global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, const uint32_t *block_counts, uint4 *cblocks, uint4 *gblocks) {
+__global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, uint4 *cblocks, uint4 *gblocks) {
     const uint64_t v = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     if (v >= ix.n_records) return;
-    const uint32_t count = block_counts[v];
-    if (count == 0) return;
+    const uint4 VB = ix.desc_raw[4 * v + 1];
+    if (VB.y == 0 || VB.y == DESC_UNARY || desc_class(VB.z) != 2) return;      // the records with rank blocks (k_build_desc)
+    const uint32_t len = VB.w, count = (len >> RANK_BLOCK_SHIFT) + 1;
     const uint4 *d1 = ix.desc;
     const uint4 D = d1[4 * v + 2];
-    const uint32_t len = ix.desc_raw[4 * v + 1].w;
     const uint32_t bb = ix.block_base[v];
     // per edge: landing record with blocks of its own, or none
     SecondStep s2{{nullptr, nullptr}, {0, 0}};
@@ -438,8 +438,10 @@ __global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, co
             const uint32_t before = a ? P.z : (k << RANK_BLOCK_SHIFT) - P.z;          // a-paths of v before this block
             bits2 |= second_step_bits<uint64_t>(s2.wblocks[a], s2.wbase[a] + before, m, R[a]);
         }
-        cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
-        cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
+        if (cblocks != nullptr) {
+            cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
+            cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
+        }
         if (gblocks == nullptr) continue;
         // the two halves of the same block: the bits are the same bits; the counts of the upper half start behind the lower half's
         // positions (ones1) and behind the a-paths of the lower half that have value 1 in w_a (R_a).  A half without a-paths (or an
@@ -545,9 +547,9 @@ void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_li
     hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, gather_limit);
 }
 
-void launch_fill_two_step_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, uint4 *d_cblocks, uint4 *d_gblocks, hipStream_t stream) {
-    if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_fill_two_step_blocks, dim3(grid_for(ix.n_records * WAVE, 256)), dim3(256), 0, stream, ix, d_block_counts, d_cblocks, d_gblocks);
+void launch_fill_two_step_blocks(const DeviceIndex &ix, uint4 *d_cblocks, uint4 *d_gblocks, hipStream_t stream) {
+    if (ix.n_records == 0 || (d_cblocks == nullptr && d_gblocks == nullptr)) return;
+    hipLaunchKernelGGL(k_fill_two_step_blocks, dim3(grid_for(ix.n_records * WAVE, 256)), dim3(256), 0, stream, ix, d_cblocks, d_gblocks);
 }
 
 void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {

@@ -1,0 +1,88 @@
+"""The RCCL exchange between real ranks: one process per GPU of the box, backend "nccl" (= RCCL), world size = the number of GPUs.
+Skipped on a one-GPU box, where tests/test_gpu_gfa.py::test_device_resident_lines_and_rccl_gather runs the same plumbing with world
+size 1 and tests/test_dist_cpu.py the N > 1 logic over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import gbwt_rs_amd as G
+from gbwt_rs_amd import dist as D, synth as S
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+device = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=device)
+# the same index on every rank (replicated, SURVEY 8e), paths dealt p -> rank p mod world
+s = S.Synth.chain(sites=SITES, haplotypes=HAPLOTYPES, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=5, extra=1, indel_every=7)
+dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, device=local)
+mine = np.arange(rank, s.paths, world, dtype=np.uint64)
+for attempt in range(4):                      # from the third request on the rows of a large batch are mapped from spread chunks (virtual-memory API)
+    out = dev.extract_device(2 * mine)
+offsets, nodes = D.paths_tensors(out, device)
+lengths = (offsets[1:] - offsets[:-1]).clone()
+# straight from the workspace's rows (no staging copy): RCCL point-to-point sends out of whatever memory the rows live in
+g_off, g_val = D.gather_rows(lengths, nodes, dst=0, interleaved=True)
+if rank == 0:
+    assert g_off.numel() == s.paths + 1
+    g_off = g_off.cpu().numpy()
+    for p in list(range(0, s.paths, max(1, s.paths // 37))) + [s.paths - 1]:
+        row = g_val[g_off[p]:g_off[p + 1]].cpu().numpy().astype(np.uint32)
+        assert np.array_equal(row, s.path(p)), p
+    assert int(g_off[-1]) == (s.size - s.sequences) // 2
+len_parts, val_parts = D.gather_parts(lengths, nodes, dst=0)
+if rank == 0:
+    assert sum(int(v.numel()) for v in val_parts) == (s.size - s.sequences) // 2
+    order = list(D.rows_in_path_order(len_parts))
+    assert len(order) == s.paths and order[1][0] == 1 % world
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("RCCL_RANKS_OK", world, int(out.total) * 4)
+'''
+
+
+def run_ranks(world, sites, haplotypes, timeout):
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = f"ROOT = {ROOT!r}; SITES = {sites}; HAPLOTYPES = {haplotypes}\n" + CHILD
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--no-python", sys.executable, "-c", script]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def gpus():
+    import torch
+    return torch.cuda.device_count()        # counting devices does not start the runtime in this process
+
+
+def test_rccl_gather_between_ranks():
+    """dist.gather_rows / gather_parts over RCCL with one rank per GPU: interleaved shards of one path set, rows back in path order on
+    rank 0, every 37th row against the generator."""
+    world = gpus()
+    if world < 2:
+        pytest.skip("one GPU on this box: ranks need devices of their own for RCCL point-to-point")
+    out = run_ranks(world, 3000, 700, 900)
+    assert out.returncode == 0 and "RCCL_RANKS_OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_rccl_send_from_a_mapped_rows_buffer():
+    """The same with a batch whose rows exceed 4 GiB per rank, i.e. rows that the workspace has rebuilt from 2 GiB chunks of the
+    virtual-memory API (capi_internal.hpp: DeviceBuffer): RCCL sends straight out of that mapping."""
+    world = gpus()
+    if world < 2:
+        pytest.skip("one GPU on this box: ranks need devices of their own for RCCL point-to-point")
+    out = run_ranks(world, 110000 * world, 5000, 3000)   # 5 000 / world paths of 236 000 x world nodes each: 4.7 GB of node ids per rank
+    assert out.returncode == 0 and "RCCL_RANKS_OK" in out.stdout, out.stderr[-3000:]
+    assert int(out.stdout.split("RCCL_RANKS_OK")[1].split()[1]) >= 4 << 30

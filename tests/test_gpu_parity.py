@@ -779,6 +779,95 @@ def test_config_c3_search_bit_exact(model, haplotypes):
         assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
 
 
+def test_config_c3_scale_states_against_the_oracle():
+    """Config 3 at a third of its full length (400 000 sites x 5 008 haplotypes, 1.2 M nodes; the full 1.1 M-site run is tools/search_bench.py):
+    a million queries go through the device, EVERY final state of a seeded sample of 30 000 of them is compared with the oracle
+    (unidirectional and bidirectional), and all of them satisfy the invariants a found state must satisfy."""
+    s = S.Synth.chain(sites=400000, haplotypes=5008, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=22)
+    dev, oracle = open_synth(s), oracle_of(s)
+    gen = np.random.default_rng(8)                                         # queries as make_queries cuts them, vectorised: a million of them
+    some = np.stack([s.path(int(h)) for h in gen.choice(s.paths, 48, replace=False)]).astype(np.uint64)
+    which, at = gen.integers(0, len(some), 1000000), gen.integers(0, some.shape[1] - 10, 1000000)
+    queries = some[which[:, None], at[:, None] + np.arange(10)]
+    flip = gen.random(len(queries)) < 0.5
+    queries[flip] = (queries[flip] ^ np.uint64(1))[:, ::-1]
+    bad = np.flatnonzero(gen.random(len(queries)) < 0.05)
+    queries[bad, gen.integers(0, 10, len(bad))] ^= np.uint64(2)
+    queries = np.ascontiguousarray(queries)
+    st, ok = dev.search(queries)
+    bd, bok = dev.bd_search(queries, 4)
+    assert 0.5 < ok.mean() <= 1.0 and np.array_equal(ok, bok)            # found one way = found the other way
+    assert np.array_equal(st["node"][ok], queries[ok][:, 9])
+    assert np.array_equal((st["end"] - st["start"])[ok], (bd["forward"]["end"] - bd["forward"]["start"])[ok])
+    pick = np.sort(np.random.default_rng(8).choice(len(queries), 30000, replace=False))
+    o_st, o_ok = oracle.search_batch(queries[pick], threads=8)
+    assert np.array_equal(ok[pick], o_ok)
+    got = np.stack([st["node"], st["start"], st["end"]], axis=1)[pick]
+    assert np.array_equal(got[o_ok], o_st[o_ok])
+    o_bd, o_bok = oracle.bd_search_batch(queries[pick], 4, threads=8)
+    assert np.array_equal(bok[pick], o_bok)
+    gbd = np.stack([bd["forward"]["node"], bd["forward"]["start"], bd["forward"]["end"],
+                    bd["reverse"]["node"], bd["reverse"]["start"], bd["reverse"]["end"]], axis=1)[pick]
+    assert np.array_equal(gbd[o_bok], o_bd[o_bok])
+
+
+def test_two_threads_two_workspaces_one_index(monkeypatch):
+    """A handle is shared by host threads, each with a workspace of its own (include/gbwt_hip.h; the reference shares &GBZ across
+    rayon workers, src/bin/gbunzip.rs:421-434): two threads extract different batches from one index at the same time, again and again --
+    one of them through the pool-output kernel, which makes it the one that builds the full-width two-step blocks on first use while
+    the other is already walking -- and a third searches.  Every result against the generator / the oracle."""
+    import threading
+    s = S.Synth.chain(sites=20000, haplotypes=900, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=31, extra=1, indel_every=5)
+    dev, oracle = open_synth(s), oracle_of(s)
+    views = [dev.another_workspace()]
+    monkeypatch.setenv("GBWT_HIP_DIRECT", "0")                             # the knobs are read when a workspace is created: this one takes the pool-output kernel
+    views.append(dev.another_workspace())
+    monkeypatch.delenv("GBWT_HIP_DIRECT")
+    errors = []
+    truth = [s.path_checksum(h) for h in range(s.paths)]
+
+    def extract(view, first, rounds, pool):
+        try:
+            for r in range(rounds):
+                ids = np.arange(first + (r % 3), s.sequences, 2 if not pool else 6, dtype=np.uint64)
+                offsets, nodes = view.sequences_csr(ids)
+                for k in (0, len(ids) // 2, len(ids) - 1):
+                    row = nodes[offsets[k]:offsets[k + 1]]
+                    p = int(ids[k]) // 2
+                    exp = s.path(p) if ids[k] % 2 == 0 else (s.path(p) ^ 1)[::-1]
+                    if not np.array_equal(row, exp):
+                        errors.append(("row", first, r, k))
+                if first == 0 and r % 3 == 0:
+                    out = view.extract_device(ids)
+                    sums = view.path_sums(len(ids))
+                    if any(int(sums[k]) != truth[int(ids[k]) // 2] for k in range(len(ids))) or int(out.total) != int(offsets[-1]):
+                        errors.append(("sums", r))
+        except Exception as e:                                              # noqa: BLE001
+            errors.append(repr(e))
+
+    def search():
+        try:
+            rng = random.Random(1)
+            for _ in range(6):
+                queries = make_queries(s, rng, 4000, 8)
+                st, ok = dev.search(queries)
+                o_st, o_ok = oracle.search_batch(queries, threads=2)
+                if not (np.array_equal(ok, o_ok) and np.array_equal(np.stack([st["node"], st["start"], st["end"]], axis=1)[ok], o_st[o_ok])):
+                    errors.append("search")
+        except Exception as e:                                              # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=extract, args=(views[0], 0, 9, False)), threading.Thread(target=extract, args=(views[1], 1, 6, True)),
+               threading.Thread(target=search)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    for v in views:
+        v.close()
+
+
 @pytest.mark.parametrize("env", [{"GBWT_HIP_DIRECT": "0"}, {"GBWT_HIP_BOTH_ENDS": "0"}, {"GBWT_HIP_SEQ_LEN": "0"}, {},
                                  {"GBWT_HIP_SAMPLE_INTERVAL": "0"},                                   # no samples: rows filled from both ends
                                  {"GBWT_HIP_SAMPLE_INTERVAL": "0", "GBWT_HIP_BOTH_ENDS": "0"},      #             ... from one end
