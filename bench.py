@@ -407,7 +407,7 @@ def main():
             "open": {
                 "open_ms": open_ms, "parse_ms": open_times["parse_ms"], "upload_ms": open_times["upload_ms"], "sample_ms": open_times["sample_ms"],
                 "samples": int(open_times["samples"]), "checkpoint_sampling": bool(open_times["checkpoint_sampling"]),
-                "checkpoint_walkers": int(open_times["checkpoint_walkers"]), "checkpoint_rounds": int(open_times["checkpoint_rounds"]),
+                "checkpoint_walkers": int(open_times["checkpoint_walkers"]), "checkpoint_orphans": int(open_times["checkpoint_orphans"]),
                 "first_pass_ms": first_pass_ms, "first_pass_kernel_ms": first_walk_ms, "runtime_init_ms": runtime_init_ms,
                 "note": "open_ms = GBZ.load of the .gbz (file read + parse, upload, rank blocks and descriptors, sequence samples) with the HIP "
                         "runtime already started (runtime_init_ms: what starting it cost, once per process); first_pass_ms includes the "

@@ -38,7 +38,7 @@ class Stats(C.Structure):
 
 class OpenTimes(C.Structure):
     _fields_ = [("parse_ms", C.c_double), ("upload_ms", C.c_double), ("sample_ms", C.c_double), ("total_ms", C.c_double),
-                ("samples", C.c_uint64), ("checkpoint_walkers", C.c_uint64), ("checkpoint_sampling", C.c_uint32),
+                ("samples", C.c_uint64), ("checkpoint_walkers", C.c_uint64), ("checkpoint_orphans", C.c_uint64), ("checkpoint_sampling", C.c_uint32),
                 ("checkpoint_rounds", C.c_uint32)]
 
 

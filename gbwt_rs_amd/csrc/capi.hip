@@ -70,15 +70,18 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     DeviceIndex &d = ix.dev;
     const uint64_t S = h.sequences, nr = d.n_records;
     if (nr == 0 || S == 0 || d.desc2 == nullptr) return false;
-    // a checkpoint per interval / 2 LF steps that end on a record that can be one (an LF step emits one node, two where it is fused with a
-    // unary successor), at most `cap` (+ 3) nodes per hop
-    const double q = std::min(0.5, 2.0 / interval);
+    // a checkpoint per `interval` LF steps that end on a record that can be one (an LF step emits one node, two where it is fused with a
+    // unary successor: every interval .. 2 x interval nodes), and at most `cap` = interval (+ 3) nodes per hop: most hops end at the cap,
+    // the checkpoints are where rows that have drifted apart meet again (profiles/r03_sampling_ab.txt)
+    double gap = 0.5 * interval;                                 // LF steps (that end on a record which can be a checkpoint) per checkpoint
+    if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_GAP")) gap = std::max(2.0, std::atof(v));
+    const double q = std::min(0.5, 1.0 / gap);
     CheckpointWalk w{};
     w.threshold = static_cast<uint32_t>(q * 4294967296.0);
     w.cap = interval;     // A/B on the headline (profiles/r03_sampling_ab.txt): cap = interval 4.31 ms per pass, 1.5 x 4.38, 2 x 4.46; the serial samples 4.34
     w.packed = ix.packed_blocks ? 1u : 0u;
     if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_CAP")) w.cap = static_cast<uint32_t>(std::max(1, std::atoi(v)));
-    DeviceBuffer counts, cp_first, scan_tmp, summaries, orphans, misc;
+    DeviceBuffer counts, cp_first, scan_tmp, summaries, misc;
     counts.reserve(nr * sizeof(uint64_t)); cp_first.reserve((nr + 1) * sizeof(uint64_t));
     launch_checkpoint_counts(d, w.threshold, counts.as<uint64_t>(), nullptr);
     const size_t tb = scan_temp_bytes(nr);
@@ -90,26 +93,18 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     const uint64_t orphan_capacity = 2 * (d.max_walk / w.cap) + S + 1024;
     const uint64_t n_summaries = S + positions + orphan_capacity;
     if (n_summaries >= 0xFFFFFFF0ull) return false;
-    summaries.reserve(n_summaries * sizeof(uint4)); orphans.reserve(orphan_capacity * sizeof(uint4));
+    summaries.reserve(n_summaries * sizeof(uint4));
     misc.reserve(2 * sizeof(uint64_t));
     HIP_CHECK(hipMemset(misc.ptr, 0, 2 * sizeof(uint64_t)));
-    w.cp_first = cp_first.as<uint64_t>(); w.summaries = summaries.as<uint4>(); w.orphans = orphans.as<uint4>();
+    w.cp_first = cp_first.as<uint64_t>(); w.summaries = summaries.as<uint4>();
     w.orphan_count = misc.as<uint64_t>(); w.orphan_capacity = orphan_capacity; w.positions = positions;
     w.flags = reinterpret_cast<uint32_t *>(misc.as<uint64_t>() + 1);
-    uint64_t first = 0, count = S + positions, orphans_seen = 0;
-    uint32_t rounds = 0;
-    for (;;) {
-        launch_checkpoint_walk(d, w, first, count, nullptr);
-        rounds++;
-        uint64_t state[2] = {0, 0};
-        HIP_CHECK(hipMemcpy(state, misc.ptr, sizeof(state), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipGetLastError());
-        if ((state[1] & 4u) || state[0] > orphan_capacity) return false;   // more orphans than a consistent index can have
-        if (state[0] == orphans_seen) break;
-        if (rounds > 4096) return false;                                    // walks in circles
-        first = S + positions + orphans_seen; count = state[0] - orphans_seen; orphans_seen = state[0];
-    }
-    ix.times.checkpoint_rounds = rounds; ix.times.checkpoint_walkers = S + positions + orphans_seen;
+    launch_checkpoint_walk(d, w, nullptr);
+    uint64_t state[2] = {0, 0};
+    HIP_CHECK(hipMemcpy(state, misc.ptr, sizeof(state), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    if ((state[1] & 4u) || state[0] > orphan_capacity) return false;   // more orphans than a consistent index can have (walks in circles)
+    ix.times.checkpoint_rounds = 1; ix.times.checkpoint_walkers = S + positions; ix.times.checkpoint_orphans = state[0];
     // the chase: count, scan, write
     ix.seq_len.reserve(S * sizeof(uint32_t));
     ix.sample_base.reserve((S + 1) * sizeof(uint64_t));

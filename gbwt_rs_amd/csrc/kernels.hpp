@@ -97,13 +97,13 @@ void launch_sample_counts(const uint32_t *d_seq_len, uint64_t n_sequences, uint3
 void launch_record_samples(const DeviceIndex &ix, const uint64_t *d_sample_base, uint32_t interval, uint4 *d_samples, hipStream_t stream);
 // checkpoint sampling (open_walks.hip): lengths and samples of all sequences without walking any sequence from end to end.
 // Records whose hashed index is below `threshold` are checkpoints; one walker per position of every checkpoint record and one per
-// sequence start walks to the next checkpoint (at most `cap` nodes, then it leaves an orphan = a walker of the next round) and stores
+// sequence start walks to the next checkpoint (at most `cap` nodes per hop: there it takes a summary slot for the position it has reached -- an
+// orphan -- and walks on) and stores
 // a summary {landing record, offset, nodes walked, summary index of the landing position}; launch_chase follows the summaries of
 // every sequence: with d_samples == nullptr it counts (d_seq_len, d_counts), otherwise it writes the samples at d_sample_base.
 struct CheckpointWalk {
     const uint64_t *cp_first;      // [n_records + 1] exclusive scan of launch_checkpoint_counts
     uint4 *summaries;              // [n_sequences + positions + orphan_capacity]
-    uint4 *orphans;                // [orphan_capacity]
     uint64_t *orphan_count;        // [1] zeroed by the caller
     uint64_t orphan_capacity, positions;
     uint32_t threshold, cap;
@@ -111,7 +111,7 @@ struct CheckpointWalk {
     uint32_t *flags;               // bit 2: orphan pool full
 };
 void launch_checkpoint_counts(const DeviceIndex &ix, uint32_t threshold, uint64_t *d_counts, hipStream_t stream);
-void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, uint64_t first, uint64_t count, hipStream_t stream);
+void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, hipStream_t stream);
 void launch_chase(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, uint32_t *d_seq_len, uint64_t *d_counts, const uint64_t *d_sample_base,
                   uint4 *d_samples, uint32_t *d_overflow, hipStream_t stream);
 // walker order of a segmented extraction: per-row segment counts -> rows sorted by count (descending, stable) and

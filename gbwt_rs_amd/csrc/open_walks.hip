@@ -178,8 +178,8 @@ __global__ void __launch_bounds__(256) k_check_orientation_pairs(const uint32_t 
 //   * one walker per BWT position of every checkpoint record, plus one per sequence start, walks forward -- the two-step walk of
 //     the extraction, counting instead of emitting -- until an iteration ends on a checkpoint record, the sequence ends, or `cap`
 //     nodes have been emitted.  Every BWT position is walked once by exactly one walker (LF is injective), at full occupancy;
-//   * a walker that reaches the cap leaves an ORPHAN: its position becomes a walker of the next round (a few short rounds: the
-//     number of walkers shrinks geometrically), so every gap between two hops is at most cap + 3 nodes;
+//   * a walker that reaches the cap ends its hop there, at a position nobody was started for -- an ORPHAN, which gets a summary slot
+//     of its own -- and walks on as the walker of that position; so every gap between two hops is at most cap + 3 nodes;
 //   * what a walker leaves is a SUMMARY {record, offset, nodes walked, summary index of the position it landed on}: the
 //     positions of one sequence form a linked list, about a thousand nodes per hop;
 //   * one lane per sequence then chases its list (k_chase: one 16-byte load per hop instead of a thousand LF steps) and writes
@@ -257,22 +257,19 @@ __device__ __forceinline__ bool counting_step(const DeviceIndex &ix, bool packed
 struct CheckpointArgs {
     const uint64_t *cp_first;      // [n_records + 1]: first checkpoint position of every record (exclusive scan of k_checkpoint_counts)
     uint4 *summaries;              // [sequences + positions + orphan capacity]
-    uint4 *orphans;                // [orphan capacity] {record, offset, block base, 0}
     unsigned long long *orphan_count;
     uint64_t orphan_capacity;
     uint64_t positions;            // checkpoint positions = cp_first[n_records]
-    uint64_t first, count;         // the walkers of this launch: summary indices first .. first + count
     uint32_t threshold, cap;
     uint32_t packed;               // the index has packed half-blocks (gblocks)
     uint32_t *flags;               // bit 2: the orphan pool is full (no samples from this pass)
 };
 
 __global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, CheckpointArgs c) {
-    const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    const uint64_t g = c.first + t;
     const uint64_t S = ix.n_sequences;
+    uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;       // the summary this walker is writing
     uint32_t rec = 0, offset = 0, bb = BLOCK_NONE;
-    bool active = t < c.count;
+    bool active = g < S + c.positions;
     if (active) {
         if (g < S) {                                           // a sequence start: the position after the start node (GBWT::start, src/gbwt.rs:213-219)
             if (g < ix.n_endmarker) {
@@ -280,7 +277,7 @@ __global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, Checkpo
                 offset = e.y;
                 if (e.x == 0 || !arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
             }
-        } else if (g < S + c.positions) {                      // position w of the checkpoint records: the last record with cp_first <= w
+        } else {                                               // position w of the checkpoint records: the last record with cp_first <= w
             const uint64_t w = g - S;
             uint64_t lo = 0, hi = ix.n_records;                // cp_first[lo] <= w < cp_first[hi]
             while (hi - lo > 1) {
@@ -288,9 +285,6 @@ __global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, Checkpo
                 if (c.cp_first[mid] <= w) lo = mid; else hi = mid;
             }
             rec = static_cast<uint32_t>(lo); offset = static_cast<uint32_t>(w - c.cp_first[lo]); bb = ix.block_base[lo];
-        } else {
-            const uint4 o = c.orphans[g - S - c.positions];
-            rec = o.x; offset = o.y; bb = o.z;
         }
         if (rec == 0) { c.summaries[g] = make_uint4(0u, 0u, 0u, CP_END); active = false; }
     }
@@ -306,10 +300,13 @@ __global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, Checkpo
                 active = false;
             } else {
                 if (between) bb = ix.block_base[rec];          // a hashed record that is no checkpoint after all (unary): the walk goes on from it
-                if (sink.wr >= c.cap) { orphan = true; active = false; }
+                orphan = sink.wr >= c.cap;
             }
         }
-        const uint64_t mask = __ballot(orphan);                // one atomic per wave: in a lock-step batch all 64 lanes reach the cap together
+        // The cap: the hop ends here, at a position no walker was started for -- an ORPHAN.  It gets a summary slot of its own and the
+        // same lane walks on as its walker (the state is in its registers).  One atomic per wave: in a lock-step batch all 64 lanes
+        // reach the cap together.
+        const uint64_t mask = __ballot(orphan);
         if (mask != 0) {
             const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1;
             unsigned long long base = 0;
@@ -318,11 +315,13 @@ __global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, Checkpo
             if (orphan) {
                 const uint64_t slot = base + __popcll(mask & ((uint64_t(1) << lane) - 1));
                 if (slot < c.orphan_capacity) {
-                    c.orphans[slot] = make_uint4(rec, offset, bb, 0u);
                     c.summaries[g] = make_uint4(rec, offset, sink.wr, static_cast<uint32_t>(S + c.positions + slot));
+                    g = S + c.positions + slot;
+                    sink.wr = 0;
                 } else {
                     c.summaries[g] = make_uint4(0u, 0u, sink.wr, CP_END);
                     atomicOr(c.flags, 4u);
+                    active = false;
                 }
             }
         }
@@ -402,11 +401,12 @@ void launch_checkpoint_counts(const DeviceIndex &ix, uint32_t threshold, uint64_
     if (ix.n_records) hipLaunchKernelGGL(k_checkpoint_counts, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, threshold, d_counts);
 }
 
-void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, uint64_t first, uint64_t count, hipStream_t stream) {
+void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, hipStream_t stream) {
+    const uint64_t count = ix.n_sequences + w.positions;
     if (count == 0) return;
     CheckpointArgs c{};
-    c.cp_first = w.cp_first; c.summaries = w.summaries; c.orphans = w.orphans; c.orphan_count = reinterpret_cast<unsigned long long *>(w.orphan_count);
-    c.orphan_capacity = w.orphan_capacity; c.positions = w.positions; c.first = first; c.count = count; c.threshold = w.threshold; c.cap = w.cap; c.packed = w.packed;
+    c.cp_first = w.cp_first; c.summaries = w.summaries; c.orphan_count = reinterpret_cast<unsigned long long *>(w.orphan_count);
+    c.orphan_capacity = w.orphan_capacity; c.positions = w.positions; c.threshold = w.threshold; c.cap = w.cap; c.packed = w.packed;
     c.flags = w.flags;
     hipLaunchKernelGGL(k_checkpoint_walk, dim3(grid_for(count, 256)), dim3(256), 0, stream, ix, c);
 }

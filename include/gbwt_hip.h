@@ -99,10 +99,10 @@ gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *
  * of it once per file): parse_ms = reading and validating the file (0 for gbwt_hip_open_records), upload_ms = host-to-device copies
  * and the per-record passes (descriptors, rank blocks, tables, endmarker), sample_ms = sequence lengths + sequence samples,
  * total_ms = the whole call.  samples = sequence samples built; checkpoint_sampling = 1 when they came from checkpoint sampling
- * (no sequence walked from end to end), with its number of rounds and walkers. */
+ * (no sequence walked from end to end), with its number of launches, walkers, and hops that ended at the length cap (orphans). */
 typedef struct {
     double parse_ms, upload_ms, sample_ms, total_ms;
-    uint64_t samples, checkpoint_walkers;
+    uint64_t samples, checkpoint_walkers, checkpoint_orphans;
     uint32_t checkpoint_sampling, checkpoint_rounds;
 } gbwt_hip_open_times;
 gbwt_hip_status gbwt_hip_get_open_times(const gbwt_hip_index *index, gbwt_hip_open_times *out);

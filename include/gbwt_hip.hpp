@@ -216,7 +216,16 @@ public:
         if (total) check(gbwt_hip_path_lines(index_.get(), ws_.get(), path_ids.data(), path_ids.size(), mode, text.data(), total, &total));
         return text;
     }
-    void write_gfa(const std::string &path) const { check(gbwt_hip_write_gfa(index_.get(), ws_.get(), path.c_str())); }
+    // gbunzip --paths MODE (PathMode, src/bin/gbunzip.rs:63-76): GBWT_HIP_PATHS_DEFAULT, _PAN_SN or _REF_ONLY
+    void write_gfa(const std::string &path, int path_mode = GBWT_HIP_PATHS_DEFAULT) const {
+        check(gbwt_hip_write_gfa_mode(index_.get(), ws_.get(), path.c_str(), path_mode));
+    }
+    // Metadata::pan_sn_path(path_id) (src/gbwt.rs:709-713) as gbunzip prints it: the name field of the PanSN P-line
+    std::string pan_sn_path(uint64_t path_id) const {
+        const std::string line = path_lines({path_id}, 2);                 // "P\t<name>\t..."
+        const size_t a = line.find('\t'), b = line.find('\t', a + 1);
+        return line.substr(a + 1, b - a - 1);
+    }
 
 private:
     std::optional<std::vector<BidirectionalState>> follow(const BidirectionalState &state, bool backward) const {

@@ -110,6 +110,9 @@ int main(int argc, char **argv) {
     REQUIRE(preds.size() == 2 && preds[0] == std::make_pair(uint64_t(12 * 100 + 15), uint64_t(2)) && preds[1] == std::make_pair(uint64_t(13 * 100 + 16), uint64_t(1)));
     REQUIRE(gbz.path_lines({0}, 0) == "P\tA\t11+,12+,14+,15+,17+\t*\n");
     REQUIRE(gbz.path_lines({2}, 1) == "W\tsample\t1\tA\t0\t5\t>11>12>14>15>17\n");
+    // Metadata::pan_sn_path, doc-test src/gbwt.rs:596-598
+    REQUIRE(gbz.pan_sn_path(3) == "sample#2#A");
+    REQUIRE(gbz.path_lines({3}, 2) == "P\tsample#2#A\t11+,13+,14+,16+,17+\t*\n");
     // a unidirectional index refuses what the reference asserts on (src/gbwt.rs:237,312)
     try {
         GBWT bad(dir + "/does-not-exist.gbwt");

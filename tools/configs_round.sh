@@ -10,7 +10,7 @@ mkdir -p "$out"; case "$out" in /*) ;; *) out="$PWD/$out" ;; esac
 cd "$root"
 run() { echo "## $*"; timeout 600 python3 "$@" 2>&1 | grep -v "amdgpu.ids"; }
 {
-echo "# Round 2, 1 x MI355X: the other configurations (walk-kernel time from HIP events; 'M steps/s' of sweep.py are G LF-steps/s)"
+echo "# Round 3, 1 x MI355X: the other configurations (walk-kernel time from HIP events; 'M steps/s' of sweep.py are G LF-steps/s)"
 run tools/sweep.py --sites 3333 --haplotypes 1000 --model mosaic --configs 0:64:16 --reps 3
 run tools/sweep.py --sites 3333 --haplotypes 1000 --model iid --configs 0:64:16 --reps 3
 run tools/sweep.py --sites 100000 --model mosaic --configs 0:64:16 --reps 3
@@ -21,7 +21,8 @@ run tools/sweep.py --sites 3000 --alleles 400 --model iid --configs 0:64:16 --re
 run tools/ragged_bench.py
 run tools/search_bench.py --sites 1100000 --haplotypes 5008
 run tools/gfa_bench.py --sites 20000
-run tools/indel_bench.py --extra 0,1 --indel-every 1,64 --repeats 3
+run tools/indel_bench.py --extra 0,1 --indel-every 1,64,4096 --repeats 3
+run tools/indel_bench.py --extra 0 --repeats 3 --chop 4
 } > "$out/other_configs.txt"
 # C5 under rocprofv3: kernel stats, then the two traffic passes
 cd /tmp && export TMPDIR=/tmp

@@ -59,7 +59,7 @@ for mode in args.modes.split(","):
         assert np.array_equal(dev.path_sums(len(ids)), truth), "extracted paths differ from the generator's ground truth"
         cold = steps / (times["total_ms"] * 1e-3 + t_first)
         print(f"{mode:24s} open {t_open * 1e3:8.1f} ms wall (upload {times['upload_ms']:.1f}, samples {times['sample_ms']:.1f} ms; {times['samples']} samples, "
-              f"{times['checkpoint_walkers']} walkers in {times['checkpoint_rounds']} rounds); first extraction {t_first * 1e3:.1f} ms (workspace sizing included); "
+              f"{times['checkpoint_walkers']} walkers, {times['checkpoint_orphans']} hops ended at the cap); first extraction {t_first * 1e3:.1f} ms (workspace sizing included); "
               f"walk kernel {np.mean(walk):.3f} ms ({min(walk):.3f} min) = {steps / np.mean(walk) / 1e6:.0f} G LF-steps/s; "
               f"cold (open + first pass) {cold / 1e9:.1f} G LF-steps/s", flush=True)
         dev.close()
