@@ -25,7 +25,7 @@ def test_fingerprint_follows_sources_and_knobs(monkeypatch):
 
 def test_committed_traffic_profile_names_its_build_and_workload():
     """profiles/*_hbm_traffic.json of this round carry the fingerprint and the workload bench.py matches them by."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
     t = json.load(open(path))
     assert len(t["source_fingerprint"]) == 16 and t["workload_key"] == "sites=333334 haplotypes=5000 model=mosaic seed=42"
     assert t["traffic_bytes_per_launch"] == 2 * t["fetch_bytes_raw"] + t["write_bytes"]
