@@ -212,6 +212,7 @@ struct gbwt_hip_index {
     uint32_t max_samples = 0;         // the largest number of samples of a sequence
     std::vector<uint32_t> sample_counts;   // samples of every sequence (host copy: an extraction looks whether its rows all have the same number)
     uint32_t uniform_samples = 0;     // every sequence has this many samples (0: they differ): the walkers of an extraction are then w = segment * n + row
+    bool record_bytes_uploaded = false;   // gbwt_hip_open_file has copied the record bytes to `data` while the loader was still decoding
     gbwt_hip_open_times times{};      // where the time of the open went (gbwt_hip_get_open_times)
     uint32_t uniform_len = 0;         // every sequence has this many nodes (0: lengths differ, or unknown): an extraction then knows its offsets without asking the device
     bool orientation_pairs = false;   // verified at open: sequence 2k + 1 is sequence 2k reversed (rows can be filled from both ends)

@@ -468,7 +468,7 @@ void HostIndex::finish() {
     if (is_gbz) check_graph(*this);
 }
 
-void load_index_file_into(const std::string &path, HostIndex &h, bool background) {
+void load_index_file_into(const std::string &path, HostIndex &h, bool background, const std::function<void(HostIndex &)> &on_located) {
     h = HostIndex();
     std::shared_ptr<HostIndex::Pending> pending = std::make_shared<HostIndex::Pending>();
     open_image(path, pending->image);
@@ -492,18 +492,25 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
         for (auto &t : later.background) later.tasks.push_back(std::move(t));
         later.background.clear();
     }
+    if (on_located) {
+        h.pending = pending;                               // record_bytes() answers from the mapping from here on
+        try { on_located(h); } catch (...) { h.pending.reset(); throw; }
+        h.pending.reset();
+    }
     later.run();
-    if (later.background.empty()) {
+    if (!background) {
         h.file_data = nullptr; h.file_data_len = 0;
         if (h.is_gbz) check_graph(h);
         return;
     }
+    // the mapping stays until finish(), whether or not anything is left to do in the background (a caller may still be copying from it)
     HostIndex::Pending *raw = pending.get();
     std::vector<std::function<void()>> jobs = std::move(later.background);
-    raw->worker = std::thread([raw, jobs]() {
-        try { for (auto &job : jobs) job(); }
-        catch (...) { raw->failure = std::current_exception(); }
-    });
+    if (!jobs.empty())
+        raw->worker = std::thread([raw, jobs]() {
+            try { for (auto &job : jobs) job(); }
+            catch (...) { raw->failure = std::current_exception(); }
+        });
     h.pending = std::move(pending);
 }
 

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -82,7 +83,9 @@ struct HostIndex {
 // Parses a .gbwt or .gbz (detected by the header tag).  Throws InvalidData / IoError.
 HostIndex load_index_file(const std::string &path);
 // The same into `out`, which must stay where it is until out.finish() has returned when `background` is set (see HostIndex::pending).
-void load_index_file_into(const std::string &path, HostIndex &out, bool background);
+// `on_located` (optional) runs once the file has been walked -- header fields set, record_bytes() valid -- and before anything is decoded:
+// an open starts the host-to-device copy of the record bytes there, next to the Elias-Fano decode of the starts.
+void load_index_file_into(const std::string &path, HostIndex &out, bool background, const std::function<void(HostIndex &)> &on_located = nullptr);
 
 // Writes the index back in the simple-sds format (GBWT v5; GBZ v1 container with an uncompressed
 // graph, version 3), following the Serialize impls src/gbwt.rs:389-400, src/gbz.rs:662-672,

@@ -23,11 +23,11 @@ __device__ __forceinline__ uint4 stream_bytes16(const uint8_t *data, uint64_t po
 
 // One lane per record: the RAW descriptor (device_index.hpp), the number of rank blocks the record gets, and the statistics of the
 // index: stats[0] = max Record::len, [1] = max outdegree, [2] = records without a readable outdegree, [3] = all BWT positions
-// (= GBWT::len of a consistent index; bounds the walks at open).  Reduced over the wave first: two million lanes on four addresses
+// (= GBWT::len of a consistent index; bounds the walks at open), [4] = class 0 records (the candidates for LF tables).  Reduced over the wave first: two million lanes on four addresses
 // took 25 ms of atomics on the headline index.
 __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc, uint32_t *block_counts, uint64_t *stats) {
     const uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    uint64_t stat_len = 0, stat_sigma = 0, stat_bad = 0;
+    uint64_t stat_len = 0, stat_sigma = 0, stat_bad = 0, stat_generic = 0;
     if (rec < ix.n_records) {
     uint64_t start, limit;
     record_bounds(ix, rec, start, limit);
@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
                 }
             }
             if (!classed) {  // class 0: B.w = 0 keeps the walk's fast path out; Record::len goes to C.y for find()
+                stat_generic = rec != 0 ? 1 : 0;            // (record 0, the endmarker, gets no table)
                 A = make_uint4(0, 0, 0, 0); C = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0;
                 ByteCursor c2(ix.data, start, limit);
                 uint64_t s2 = 0;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
     desc[4 * rec + 3] = D;
     block_counts[rec] = n_blocks;
     }
-    uint64_t max_len = stat_len, max_sigma = stat_sigma, sum = stat_len, bad = stat_bad;
+    uint64_t max_len = stat_len, max_sigma = stat_sigma, sum = stat_len, bad = stat_bad + (stat_generic << 32);   // two counts in one word: records < 2^30
     for (int d = WAVE / 2; d > 0; d >>= 1) {
         max_len = max(max_len, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_len), d)));
         max_sigma = max(max_sigma, static_cast<uint64_t>(__shfl_down(static_cast<unsigned long long>(max_sigma), d)));
@@ -104,7 +105,8 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
     if (threadIdx.x % WAVE != 0) return;
     if (max_len) atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(max_len));
     if (max_sigma) atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(max_sigma));
-    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), static_cast<unsigned long long>(bad));
+    if (bad & 0xFFFFFFFFull) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), static_cast<unsigned long long>(bad & 0xFFFFFFFFull));
+    if (bad >> 32) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 4), static_cast<unsigned long long>(bad >> 32));
     if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(sum));
 }
 
