@@ -88,6 +88,7 @@ SIGNATURES = {
     "gbwt_hip_copy_path": (_int, [_p, _p, _u64, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_last_kernel_ms": (_int, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gbwt_hip_last_query_ms": (_int, [_p, C.POINTER(C.c_float)]),
+    "gbwt_hip_device_memory": (_int, [_int, C.POINTER(_u64), C.POINTER(_u64)]),
 }
 
 _lib = None

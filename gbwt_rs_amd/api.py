@@ -50,6 +50,13 @@ def device_count():
     return _lib.lib().gbwt_hip_device_count()
 
 
+def device_memory(device=0):
+    """(free, total) bytes of a device (hipMemGetInfo)."""
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    check(_lib.lib().gbwt_hip_device_memory(device, C.byref(free), C.byref(total)))
+    return free.value, total.value
+
+
 def parse_file(path):
     """Host-only parse + validation (no GPU): the statistics serialize::load_from would yield."""
     st = Stats()
@@ -357,4 +364,4 @@ class GBZ(GBWT):
 
 
 __all__ = ["GBWT", "GBZ", "GbwtHipError", "Lines", "Paths", "FORWARD", "REVERSE", "PATHS_DEFAULT", "PATHS_PAN_SN", "PATHS_REF_ONLY", "POS_DTYPE", "STATE_DTYPE", "BD_DTYPE", "encode_node",
-           "decode_node", "flip_node", "encode_path", "device_count", "parse_file", "Pos", "State", "BdState"]
+           "decode_node", "flip_node", "encode_path", "device_count", "device_memory", "parse_file", "Pos", "State", "BdState"]

@@ -327,6 +327,10 @@ void upload(gbwt_hip_index &ix) {
         const uint64_t all_nodes = h.size >= h.sequences ? h.size - h.sequences : 0;
         uint32_t interval = 64;
         while (interval < 2048 && (all_nodes >> 22) > interval) interval *= 2;
+        // ... and at most about four thousand per sequence: the chain of one sequence is followed by ONE lane when the samples are put
+        // together (k_chase), a microsecond per hop -- ninety haplotypes of two million nodes at 128 nodes per hop were 23 000 hops,
+        // 2 x 23 ms of a 35 ms sampling pass (profiles/r03_open_c4.txt)
+        while (interval < 2048 && ((all_nodes / h.sequences) >> 12) > interval) interval *= 2;
         if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
         const bool sampled = interval >= 8;
         // Without samples an extraction fills every row from both ends, which needs the proof that sequence 2k + 1 is
@@ -544,6 +548,23 @@ gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *
     if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
     *out = index->stats;
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!free_bytes || !total_bytes) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(GBWT_HIP_NO_DEVICE, "no HIP device available");
+    try {
+        HIP_CHECK(hipSetDevice(device));
+        size_t f = 0, t = 0;
+        HIP_CHECK(hipMemGetInfo(&f, &t));
+        *free_bytes = f; *total_bytes = t;
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
     GBWT_HIP_GUARD_END
 }
 

@@ -242,6 +242,8 @@ gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *index, gbwt_hip_workspa
  * dominant kernel (the walk; bench.py's roofline object), *total_ms = everything the call put on the stream, from the
  * upload of the ids to the last kernel (lengths, offsets, walker order, walk; host waits in between included). */
 gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms);
+/* Free and total memory of a device in bytes (hipMemGetInfo): what the tests use to see that a workspace gives its rows back. */
+gbwt_hip_status gbwt_hip_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Kernel time (ms, HIP events on the workspace stream, host staging excluded) of the last navigation / search call
  * (start, forward, backward, find, extend, bd_*, search, bd_search) on `ws`. */
 gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kernel_ms);

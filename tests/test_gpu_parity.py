@@ -669,6 +669,23 @@ def test_headline_full_size():
     dev.extract_device(rev)
     for k, h in enumerate((1234, 0, 4999)):
         assert np.array_equal(dev.copy_path(k), (s.path(h) ^ 1)[::-1])
+    # The 13.3 GB of rows start as one hipMalloc and are rebuilt from spread 2 GiB chunks (virtual-memory API) when the workspace
+    # serves its third request of that size; every byte must come back when the workspace goes -- one hipMemUnmap per mapped chunk,
+    # hipMemAddressFree, hipMemRelease (capi_internal.hpp: DeviceBuffer::release) -- and when it regrows.
+    free_before = G.device_memory(0)[0]
+    view = dev.another_workspace()
+    for _ in range(4):                                     # the third one rebuilds the rows from spread chunks
+        out = view.extract_device(ids)
+    assert np.array_equal(view.path_sums(s.paths), truth)
+    used = free_before - G.device_memory(0)[0]
+    assert used >= 4 * int(out.total), used                # the rows are there ...
+    bigger = np.concatenate([ids, ids[:600]])              # ... a larger batch regrows them (release + a new hipMalloc) ...
+    out = view.extract_device(bigger)
+    assert int(out.total) == 5600 * 2 * 333334
+    assert free_before - G.device_memory(0)[0] < 4 * int(out.total) + (3 << 30), "the old rows were not given back when the buffer regrew"
+    view.close()
+    leaked = free_before - G.device_memory(0)[0]
+    assert leaked < (256 << 20), f"{leaked} bytes of VRAM did not come back with the workspace"
 
 
 # ---------------------------------------------------------------------------------------------
