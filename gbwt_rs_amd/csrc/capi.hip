@@ -38,19 +38,28 @@ void fill_stats(gbwt_hip_index &ix) {
     s.bidirectional = h.bidirectional; s.has_metadata = h.has_metadata; s.is_gbz = h.is_gbz; s.has_translation = h.has_translation;
 }
 
-// The full-width two-step blocks, built on first need (gbwt_hip_index::cblocks_once).
-void ensure_cblocks(const gbwt_hip_index *index) {
+// The full-width two-step blocks, built on first need (gbwt_hip_index::cblocks_once).  After open, `dev.cblocks` of a handle is never
+// written again -- other threads copy `dev` into their launches all the time -- so the pointer of a lazily built array lives in an atomic
+// of its own, and a launch that needs it takes a copy of `dev` with the pointer put in (with_cblocks).
+const uint4 *ensure_cblocks(const gbwt_hip_index *index) {
     gbwt_hip_index *ix = const_cast<gbwt_hip_index *>(index);     // the lazily built part of an otherwise immutable handle
+    if (ix->dev.cblocks != nullptr) return ix->dev.cblocks;        // built at open
     std::call_once(ix->cblocks_once, [ix]() {
-        if (ix->dev.cblocks != nullptr) return;
         HIP_CHECK(hipSetDevice(ix->device));
         ix->cblocks.reserve(std::max<uint64_t>(ix->dev.n_blocks, 1) * 2 * sizeof(uint4));
         HIP_CHECK(hipMemsetAsync(ix->cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
         if (ix->dev.n_blocks > 1) launch_fill_two_step_blocks(ix->dev, ix->cblocks.as<uint4>(), nullptr, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipGetLastError());
-        ix->dev.cblocks = ix->cblocks.as<uint4>();
+        ix->lazy_cblocks.store(ix->cblocks.as<uint4>(), std::memory_order_release);
     });
+    return ix->lazy_cblocks.load(std::memory_order_acquire);
+}
+
+DeviceIndex with_cblocks(const gbwt_hip_index *ix) {
+    DeviceIndex d = ix->dev;
+    d.cblocks = ensure_cblocks(ix);
+    return d;
 }
 
 // max / min / common number of samples per sequence from the host copy of sample_base
@@ -141,14 +150,30 @@ struct OpenTrace {
     }
 };
 
-// Uploads the host image and runs the load-time device passes.
-void upload(gbwt_hip_index &ix) {
+// The record starts to the device: narrowed to u32 where the record stream is shorter than 4 GiB.
+void upload_starts(gbwt_hip_index &ix) {
+    const HostIndex &h = ix.host;
+    const bool narrow = ix.stats.data_bytes < (uint64_t(1) << 32);
+    ix.starts.reserve(std::max<size_t>(h.starts.size(), 1) * (narrow ? sizeof(uint32_t) : sizeof(uint64_t)));
+    if (narrow) {
+        std::vector<uint32_t> s32(h.starts.begin(), h.starts.end());
+        if (s32.empty()) s32.push_back(0);
+        HIP_CHECK(hipMemcpy(ix.starts.ptr, s32.data(), s32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else if (!h.starts.empty()) {
+        HIP_CHECK(hipMemcpy(ix.starts.ptr, h.starts.data(), h.starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    ix.starts_uploaded = true;
+}
+
+// Uploads the host image and runs the load-time device passes.  `endmarker`: record 0 already decompressed by the caller (who is then free
+// to let another thread finish the loader's background work meanwhile: nothing below touches the record bytes of the host image), or null.
+void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>> *early_endmarker) {
     OpenTrace trace;
     HostIndex &h = ix.host;
     if (h.alphabet_size > (uint64_t(1) << 32)) throw InvalidData("alphabet_size > 2^32 is not supported (u32 node ids on device)");
     HIP_CHECK(hipSetDevice(ix.device));
     const uint64_t n_records = h.records();
-    const uint64_t data_bytes = h.record_bytes_len();      // read from the mapped file while the loader's background copy is still running
+    const uint64_t data_bytes = ix.stats.data_bytes;       // (fill_stats; the host image's own copy may still be on its way: HostIndex::pending)
     if (!ix.record_bytes_uploaded) {
         ix.data.reserve(data_bytes + DATA_PAD);
         HIP_CHECK(hipMemset(ix.data.ptr, 0, data_bytes + DATA_PAD));
@@ -161,23 +186,11 @@ void upload(gbwt_hip_index &ix) {
     d.n_sequences = h.sequences;
     d.alphabet_offset = static_cast<uint32_t>(h.alphabet_offset);
     d.first_node = static_cast<uint32_t>(h.alphabet_offset + 1);
-    // the record starts travel next to the record bytes (a thread of their own: narrowing two million offsets and staging them is 3 ms)
+    // the record starts: dense, u32 where the stream is shorter than 4 GiB (gbwt_hip_open_file has sent them already, under the tail of
+    // the copy of the record bytes)
     const bool narrow_starts = data_bytes < (uint64_t(1) << 32);
-    ix.starts.reserve(std::max<size_t>(h.starts.size(), 1) * (narrow_starts ? sizeof(uint32_t) : sizeof(uint64_t)));
-    std::atomic<int> starts_failed{0};
-    std::thread starts_thread([&]() {
-        if (hipSetDevice(ix.device) != hipSuccess) { starts_failed = 1; return; }
-        if (narrow_starts) {
-            std::vector<uint32_t> s32(h.starts.begin(), h.starts.end());
-            if (s32.empty()) s32.push_back(0);
-            if (hipMemcpy(ix.starts.ptr, s32.data(), s32.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) starts_failed = 1;
-        } else if (hipMemcpy(ix.starts.ptr, h.starts.data(), h.starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) starts_failed = 1;
-    });
-    // (slices on four threads, or the mapped pages pinned with hipHostRegister for the copy, measure the same 9 ms as this one call)
-    const hipError_t copied = (data_bytes && !ix.record_bytes_uploaded) ? hipMemcpy(ix.data.ptr, h.record_bytes(), data_bytes, hipMemcpyHostToDevice) : hipSuccess;
-    starts_thread.join();
-    if (copied != hipSuccess) throw HipError{copied, "hipMemcpy (record bytes)"};
-    if (starts_failed) throw HipError{hipErrorUnknown, "hipMemcpy (record starts)"};
+    if (!ix.starts_uploaded) upload_starts(ix);
+    if (!ix.record_bytes_uploaded && data_bytes) HIP_CHECK(hipMemcpy(ix.data.ptr, h.record_bytes(), data_bytes, hipMemcpyHostToDevice));
     if (narrow_starts) d.starts32 = ix.starts.as<uint32_t>(); else d.starts64 = ix.starts.as<uint64_t>();
     trace.mark("record bytes + starts to the device");
 
@@ -252,7 +265,7 @@ void upload(gbwt_hip_index &ix) {
                 HIP_CHECK(hipMemsetAsync(ix.cblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             }
             if (n_blocks > 1) launch_fill_two_step_blocks(d, full_width_now ? ix.cblocks.as<uint4>() : nullptr, gather_limit ? ix.gblocks.as<uint4>() : nullptr, nullptr);
-            if (full_width_now) std::call_once(ix.cblocks_once, [&]() { d.cblocks = ix.cblocks.as<uint4>(); });
+            if (full_width_now) d.cblocks = ix.cblocks.as<uint4>();
             trace.mark("two-step descriptors + blocks");
             launch_link_lookahead2(d, ix.desc2.as<uint4>(), counts.as<uint32_t>(), std::max<uint32_t>(1, (hops + 1) / 2), nullptr);
         }
@@ -306,7 +319,8 @@ void upload(gbwt_hip_index &ix) {
     d.max_walk = hs[3];
     // the endmarker: record 0 decompressed by the loader (host_index.cpp; the reference's GBWT::load does it on the CPU as well,
     // src/gbwt.rs:413-414) -- a single lane of the GPU took 6 ms for the 10 000 runs of the headline index, the host 0.1
-    const std::vector<std::pair<uint32_t, uint32_t>> endmarker = decompress_endmarker(h, std::max<uint64_t>(hs[0], 1));
+    const std::vector<std::pair<uint32_t, uint32_t>> endmarker =
+        early_endmarker ? *early_endmarker : decompress_endmarker(h, std::max<uint64_t>(hs[0], 1));
     const uint64_t end_len = endmarker.size();
     ix.endmarker.reserve(std::max<uint64_t>(end_len, 1) * sizeof(uint2));
     static_assert(sizeof(std::pair<uint32_t, uint32_t>) == sizeof(uint2), "pairs are uploaded as uint2");
@@ -352,7 +366,7 @@ void upload(gbwt_hip_index &ix) {
         const uint64_t pool_capacity = all_nodes / std::max<uint32_t>(interval, 1) + 2 * h.sequences + 1024;
         const char *two = std::getenv("GBWT_HIP_TWO_PASS_OPEN");
         bool one_walk = !by_checkpoints && sampled && !want_pairs && h.sequences <= 0xFFFFFFFFull && !(two && std::atoi(two) != 0);
-        if (!by_checkpoints) ensure_cblocks(&ix);               // the walks of every sequence below step on the full-width blocks (quiet_walk)
+        if (!by_checkpoints) d.cblocks = ensure_cblocks(&ix);   // the walks of every sequence below step on the full-width blocks (quiet_walk); still single-threaded here
         if (one_walk) {
             pool.reserve(pool_capacity * sizeof(uint4)); tags.reserve(pool_capacity * sizeof(uint2));
             HIP_CHECK(hipMemset(d_stats + 2, 0, sizeof(uint64_t)));
@@ -420,9 +434,30 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail(GBWT_HIP_NO_DEVICE, "no HIP device available (libgbwt_hip has no CPU fallback)");
-    upload(*ix);
-    ix->host.finish();                    // the loader's background work (record bytes into `data`, node labels): needed from here on
-    upload_label_lengths(*ix);
+    OpenTrace trace;
+    if (ix->host.pending && ix->record_bytes_uploaded) {
+        // The loader still has work in the background (the record bytes into the host image, the node labels) and the GFA tables need
+        // both: a thread waits for it and builds + uploads them while this one runs the device passes, which read nothing of either
+        // (the record bytes are on the device already; record 0 is decompressed here, from the mapping, before the thread starts).
+        const std::vector<std::pair<uint32_t, uint32_t>> endmarker = decompress_endmarker(ix->host, ix->host.sequences + 1);
+        std::exception_ptr tail_failure;
+        gbwt_hip_index *raw = ix.get();
+        std::thread tail([raw, &tail_failure]() {
+            try {
+                HIP_CHECK(hipSetDevice(raw->device));
+                raw->host.finish();
+                upload_label_lengths(*raw);
+            } catch (...) { tail_failure = std::current_exception(); }
+        });
+        try { upload(*ix, &endmarker); } catch (...) { tail.join(); throw; }
+        tail.join();
+        if (tail_failure) std::rethrow_exception(tail_failure);
+        trace.mark("(device passes + GFA tables)");
+    } else {
+        upload(*ix, nullptr);
+        ix->host.finish();                // the loader's background work, if any: needed from here on
+        upload_label_lengths(*ix);
+    }
     const auto t_done = std::chrono::steady_clock::now();
     const auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
     ix->times.parse_ms = ms(t_parsed - t_open);
@@ -520,7 +555,12 @@ gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index 
             if (early.result == hipSuccess) early.result = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
         });
     });
-    if (early.worker.joinable()) early.worker.join();
+    if (early.worker.joinable()) {
+        // the starts are decoded by now and the copy of the record bytes has a few milliseconds to go: the starts go out under them
+        fill_stats(*ix);
+        try { upload_starts(*ix); } catch (...) { early.worker.join(); throw; }
+        early.worker.join();
+    }
     if (early.result != hipSuccess) throw HipError{early.result, "hipMemcpy (record bytes, early)"};
     return open_common(std::move(ix), out, t_open);
     GBWT_HIP_GUARD_END
@@ -709,13 +749,13 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.catch_up = knobs.catch_up >= 0 ? (knobs.catch_up ? 1u : 0u) : 1u;
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
             a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;
-            if (!a.packed_blocks) ensure_cblocks(ix);
+            const DeviceIndex dev = a.packed_blocks ? ix->dev : with_cblocks(ix);
             a.row_piece = knobs.row_piece >= 0 ? static_cast<uint32_t>(knobs.row_piece) : 32u;
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
             a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
             a.both_ends = (ix->orientation_pairs && knobs.both_ends != 0) ? 1u : 0u;
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
-            launch_walk(ix->dev, a, s);
+            launch_walk(dev, a, s);
             HIP_CHECK(hipEventRecord(ws->ev[1], s));
             HIP_CHECK(hipEventRecord(ws->ev[2], s));
             HIP_CHECK(hipStreamSynchronize(s));
@@ -727,7 +767,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
         }
         uint32_t flags = 0;
         WalkArgs a{};
-        if (ws->walk_mode == WALK_TWO_STEP) ensure_cblocks(ix);   // the pool-output kernel walks on the full-width two-step blocks
+        const DeviceIndex dev = ws->walk_mode == WALK_TWO_STEP ? with_cblocks(ix) : ix->dev;   // the pool-output kernel walks on the full-width two-step blocks
         for (int attempt = 0; attempt < 8; attempt++) {
             if (pool_blocks >= POOL_NONE) return fail(GBWT_HIP_UNSUPPORTED, "path pool would exceed 2^32 blocks");
             ws->pool.reserve(pool_blocks * POOL_BLOCK_NODES * sizeof(uint32_t));
@@ -747,7 +787,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.wide_addresses = knobs.wide_addresses ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
-            launch_walk(ix->dev, a, s);
+            launch_walk(dev, a, s);
             HIP_CHECK(hipEventRecord(ws->ev[1], s));
             HIP_CHECK(hipMemcpyAsync(&flags, a.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             launch_scan(a.lengths, ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -208,10 +209,12 @@ struct gbwt_hip_index {
     // whose counts do not fit the packed half-blocks, by the pool-output kernel and by the serial walks at open: built at open when one of
     // those is certain to run, else on the first request that needs them (ensure_cblocks; once, whichever thread comes first).
     mutable std::once_flag cblocks_once;
+    std::atomic<const uint4 *> lazy_cblocks{nullptr};
     bool packed_blocks = true;        // gblocks was built (false: the index is too large for 32-bit half-block indices, or GBWT_HIP_GATHER_LIMIT=0)
     uint32_t max_samples = 0;         // the largest number of samples of a sequence
     std::vector<uint32_t> sample_counts;   // samples of every sequence (host copy: an extraction looks whether its rows all have the same number)
     uint32_t uniform_samples = 0;     // every sequence has this many samples (0: they differ): the walkers of an extraction are then w = segment * n + row
+    bool starts_uploaded = false;         // ... and the record starts
     bool record_bytes_uploaded = false;   // gbwt_hip_open_file has copied the record bytes to `data` while the loader was still decoding
     gbwt_hip_open_times times{};      // where the time of the open went (gbwt_hip_get_open_times)
     uint32_t uniform_len = 0;         // every sequence has this many nodes (0: lengths differ, or unknown): an extraction then knows its offsets without asking the device

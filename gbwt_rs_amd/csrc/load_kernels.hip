@@ -374,9 +374,10 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
 //   gblocks[2 * k + h] = {bits1 (32 values of v), bits2, ones1 | R_0 << 21, R_0 >> 11 | R_1 << 10}      (ones1, R_0 < 2^21, R_1 < 2^22)
 // for the offsets 64 k + 32 h ...; ones1 and R_a count up to the half's first offset / first a-path.  Records that do not fit the
 // counts have GATHER_OK cleared in their descriptor (k_link_desc2).
-// A WAVE per record, a lane per block: the blocks of a record are independent of each other once its plain rank blocks exist, and a
-// lane per record (79 blocks one after the other for a record of 5 000 positions, every one behind two dependent loads) made these two
-// arrays 12 of the 33 ms of kernel time of an open of the headline index.
+// A lane per BLOCK (the plain block says which record it belongs to): the blocks of a record are independent of each other once its plain
+// rank blocks exist.  A lane per record (79 blocks one after the other for a record of 5 000 positions, every one behind two dependent
+// loads) made these two arrays 12 of the 33 ms of kernel time of an open of the headline index; a wave per record still left two thirds
+// of the waves (unary records) and a fifth of the lanes (79 = 64 + 15 blocks) without work.
 struct SecondStep { const uint4 *wblocks[2]; uint32_t wbase[2]; };
 
 // the values in w_a of the a-paths selected by m (an ascending subset of 64 / 32 positions), and the count R_a before the first of them
@@ -403,15 +404,15 @@ __device__ __forceinline__ Mask second_step_bits(const uint4 *wblocks, uint32_t 
 }
 
 __global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, uint4 *cblocks, uint4 *gblocks) {
-    const uint64_t v = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) / WAVE;
-    const uint32_t lane = threadIdx.x % WAVE;
-    if (v >= ix.n_records) return;
-    const uint4 VB = ix.desc_raw[4 * v + 1];
-    if (VB.y == 0 || VB.y == DESC_UNARY || desc_class(VB.z) != 2) return;      // the records with rank blocks (k_build_desc)
-    const uint32_t len = VB.w, count = (len >> RANK_BLOCK_SHIFT) + 1;
+    const uint64_t b = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x + 1;      // block 0 is the shared zero block
+    if (b >= ix.n_blocks) return;
+    const uint4 P = ix.blocks[b];
+    const uint64_t v = P.w;                                                                   // the owner (k_fill_blocks)
     const uint4 *d1 = ix.desc;
     const uint4 D = d1[4 * v + 2];
+    const uint32_t len = ix.desc_raw[4 * v + 1].w;
     const uint32_t bb = ix.block_base[v];
+    const uint32_t k = static_cast<uint32_t>(b - bb);
     // per edge: landing record with blocks of its own, or none
     SecondStep s2{{nullptr, nullptr}, {0, 0}};
     if (!(D.x & DESC_SLOW)) {
@@ -426,8 +427,7 @@ __global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, ui
             s2.wbase[a] = E.y;
         }
     }
-    for (uint32_t k = lane; k < count; k += WAVE) {
-        const uint4 P = ix.blocks[bb + k];
+    {
         const uint64_t bits1 = (static_cast<uint64_t>(P.y) << 32) | P.x;
         const uint32_t remaining = len - (k << RANK_BLOCK_SHIFT) > len ? 0u : len - (k << RANK_BLOCK_SHIFT);   // k * 64 <= len
         const uint64_t valid = remaining >= 64 ? ~uint64_t(0) : ((uint64_t(1) << remaining) - 1);
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, ui
             cblocks[2 * static_cast<uint64_t>(bb + k)] = make_uint4(P.x, P.y, static_cast<uint32_t>(bits2), static_cast<uint32_t>(bits2 >> 32));
             cblocks[2 * static_cast<uint64_t>(bb + k) + 1] = make_uint4(P.z, R[0], R[1], 0u);
         }
-        if (gblocks == nullptr) continue;
+        if (gblocks == nullptr) return;
         // the two halves of the same block: the bits are the same bits; the counts of the upper half start behind the lower half's
         // positions (ones1) and behind the a-paths of the lower half that have value 1 in w_a (R_a).  A half without a-paths (or an
         // edge without blocks behind it) carries R_a = 0, which nothing reads.
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256) k_link_lookahead2(DeviceIndex ix, uint4 *
 }
 
 // One lane per outdegree-2 record: decode the runs ONCE and lay the record out as rank blocks (device_index.hpp):
-// block k = {64 values (one bit each), value-1 positions before the block}.  Record::lf (src/bwt.rs:480-496) at
+// block k = {64 values (one bit each), value-1 positions before the block, the record it belongs to}.  Record::lf (src/bwt.rs:480-496) at
 // offset i is then value = bit i, rank = ones-before or i - ones-before, without scanning any run.
 __global__ void __launch_bounds__(256) k_fill_blocks(DeviceIndex ix, const uint32_t *block_counts, const uint32_t *block_base, uint4 *blocks) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -502,13 +502,13 @@ __global__ void __launch_bounds__(256) k_fill_blocks(DeviceIndex ix, const uint3
             if (value) bits |= (take == 64 ? ~uint64_t(0) : ((uint64_t(1) << take) - 1)) << fill;
             fill += take; len -= take;
             if (fill == 64) {
-                out[k++] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
+                out[k++] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, static_cast<uint32_t>(rec));
                 ones += __popcll(bits);
                 bits = 0; fill = 0;
             }
         }
     }
-    if (k < count) out[k] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, 0u);
+    if (k < count) out[k] = make_uint4(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32), ones, static_cast<uint32_t>(rec));
 }
 
 }  // namespace
@@ -551,7 +551,8 @@ void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_li
 
 void launch_fill_two_step_blocks(const DeviceIndex &ix, uint4 *d_cblocks, uint4 *d_gblocks, hipStream_t stream) {
     if (ix.n_records == 0 || (d_cblocks == nullptr && d_gblocks == nullptr)) return;
-    hipLaunchKernelGGL(k_fill_two_step_blocks, dim3(grid_for(ix.n_records * WAVE, 256)), dim3(256), 0, stream, ix, d_cblocks, d_gblocks);
+    if (ix.n_blocks <= 1) return;
+    hipLaunchKernelGGL(k_fill_two_step_blocks, dim3(grid_for(ix.n_blocks - 1, 256)), dim3(256), 0, stream, ix, d_cblocks, d_gblocks);
 }
 
 void launch_link_lookahead2(const DeviceIndex &ix, uint4 *d_desc2, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream) {
