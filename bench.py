@@ -315,6 +315,7 @@ def main():
         if world == 1 and not args.no_extras:
             # (a) the same passes WITHOUT sequence samples: one walker per end of every row, the "one lane per active path" shape
             os.environ["GBWT_HIP_SAMPLE_INTERVAL"] = "0"
+            os.environ["GBWT_HIP_VMM"] = "0"      # four passes only: rebuilding the rows from spread chunks (at the third request) would be all they time
             try:
                 plain = G.GBZ.load(index_path, device=local_rank)
                 _, u_walk, _ = timed_passes(plain, ids, 1)
@@ -329,6 +330,7 @@ def main():
                 plain.close()
             finally:
                 del os.environ["GBWT_HIP_SAMPLE_INTERVAL"]
+                del os.environ["GBWT_HIP_VMM"]
             # (b) the same shape with an insertion allele at every site: the rows of a batch leave lock step at once (mixed waves)
             t0 = time.perf_counter()
             s2 = S.Synth.chain(sites=args.sites, haplotypes=args.haplotypes, alleles=2, model=model, founders=32, switch_rate=2e-3, seed=args.seed, extra=1)
