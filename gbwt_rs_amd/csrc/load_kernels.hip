@@ -80,10 +80,16 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
             if (!classed) {  // class 0: B.w = 0 keeps the walk's fast path out; Record::len goes to C.y for find()
                 stat_generic = rec != 0 ? 1 : 0;            // (record 0, the endmarker, gets no table)
                 A = make_uint4(0, 0, 0, 0); C = make_uint4(0, 0, 0, 0); D = make_uint4(0, 0, 0, 0); B.w = 0;
-                ByteCursor c2(ix.data, start, limit);
-                uint64_t s2 = 0;
-                c2.varint(s2);
-                const uint64_t total = record_len(c2, s2);
+                // Record::len by scanning the runs -- except for record 0, the endmarker, which has a run per sequence in a bidirectional
+                // index (10 000 on the headline: one lane scanning them was 2 of this kernel's 2.6 ms) and one position per sequence by
+                // definition (src/gbwt.rs:413-414; the loader decompresses it and stops at that many)
+                uint64_t total = ix.n_sequences;
+                if (rec != 0) {
+                    ByteCursor c2(ix.data, start, limit);
+                    uint64_t s2 = 0;
+                    c2.varint(s2);
+                    total = record_len(c2, s2);
+                }
                 stat_len = total;
                 C.y = total < 0xFFFFFFFFull ? static_cast<uint32_t>(total) : 0xFFFFFFFFu;
             }
