@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -99,9 +101,10 @@ void skip_option(Elements &in) {
 // the copy of the record bytes and the unpacking of a million labels were three quarters of the 36 ms the headline GBZ took to parse.
 struct Deferred {
     std::vector<std::function<void()>> tasks, background;      // background: may still be running when the loader returns (HostIndex::pending)
+    bool small = false;                                        // a file of a few megabytes: threads would cost more than they save
     void run() {
         if (tasks.empty()) return;
-        const unsigned workers = std::min<unsigned>(static_cast<unsigned>(tasks.size()), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+        const unsigned workers = small ? 1u : std::min<unsigned>(static_cast<unsigned>(tasks.size()), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
         std::atomic<size_t> next{0};
         std::exception_ptr failure;
         std::atomic<bool> failed{false};
@@ -135,28 +138,60 @@ SparseView locate_sparse(Elements &in) {
     return v;
 }
 
+// fn(piece, pieces) on a few threads (the caller's included); exceptions of the pieces are rethrown here
+template <class Fn>
+void run_pieces(unsigned pieces, Fn fn) {
+    std::exception_ptr failure;
+    std::atomic<bool> failed{false};
+    auto guarded = [&](unsigned p) {
+        try { fn(p); }
+        catch (...) { if (!failed.exchange(true)) failure = std::current_exception(); }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned p = 1; p < pieces; p++) pool.emplace_back(guarded, p);
+    guarded(0);
+    for (auto &t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
+}
+
+inline unsigned pieces_for(uint64_t items) {
+    return items >= (uint64_t(1) << 20) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+}
+
 std::vector<uint64_t> decode_sparse(const SparseView &v) {
-    // the declared number of ones must be the number of set bits BEFORE it sizes an allocation (a corrupt count would ask for up to
-    // 64 times the file size and surface as "out of host memory" instead of InvalidData)
-    uint64_t set = 0;
-    for (uint64_t wi = 0; wi < v.high.n_words; wi++) set += static_cast<uint64_t>(__builtin_popcountll(v.high.words[wi]));
-    if (set != v.ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
+    // A few threads, each with a stretch of the high bitvector (the rank of its first one comes from the popcounts before it): the
+    // 32 million record starts of a config-4-shaped GBZ were 110 ms on one thread.  The declared number of ones must be the number of
+    // set bits BEFORE it sizes an allocation (a corrupt count would ask for up to 64 times the file size and surface as "out of host
+    // memory" instead of InvalidData).
+    const uint64_t n_words = v.high.n_words;
+    const unsigned pieces = pieces_for(v.ones);
+    std::vector<uint64_t> first_word(pieces + 1), first_rank(pieces + 1, 0), count(pieces, 0);
+    for (unsigned p = 0; p <= pieces; p++) first_word[p] = n_words * p / pieces;
+    run_pieces(pieces, [&](unsigned p) {
+        uint64_t c = 0;
+        for (uint64_t wi = first_word[p]; wi < first_word[p + 1]; wi++) c += static_cast<uint64_t>(__builtin_popcountll(v.high.words[wi]));
+        count[p] = c;
+    });
+    for (unsigned p = 0; p < pieces; p++) first_rank[p + 1] = first_rank[p] + count[p];
+    if (first_rank[pieces] != v.ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
     std::vector<uint64_t> values;
-    values.reserve(v.ones + 1);
+    values.reserve(v.ones + 1);                               // the callers append a sentinel
+    values.resize(v.ones);
     const uint64_t w = v.low.width;
-    uint64_t k = 0;
-    for (uint64_t wi = 0; wi < v.high.n_words; wi++) {
-        uint64_t word = v.high.words[wi];
-        while (word) {
-            uint64_t pos = wi * 64 + static_cast<uint64_t>(__builtin_ctzll(word));
-            word &= word - 1;
-            const uint64_t upper = pos - k;
-            if (w < 64 && upper != 0 && (upper >> (64 - w)) != 0) throw InvalidData("SparseVector: value does not fit 64 bits");
-            uint64_t hi = (w >= 64) ? 0 : (upper << w);
-            values.push_back(hi | v.low.get(k));
-            k++;
+    run_pieces(pieces, [&](unsigned p) {
+        uint64_t k = first_rank[p];
+        for (uint64_t wi = first_word[p]; wi < first_word[p + 1]; wi++) {
+            uint64_t word = v.high.words[wi];
+            while (word) {
+                const uint64_t pos = wi * 64 + static_cast<uint64_t>(__builtin_ctzll(word));
+                word &= word - 1;
+                const uint64_t upper = pos - k;
+                if (w < 64 && upper != 0 && (upper >> (64 - w)) != 0) throw InvalidData("SparseVector: value does not fit 64 bits");
+                values[k] = ((w >= 64) ? 0 : (upper << w)) | v.low.get(k);
+                k++;
+            }
         }
-    }
+    });
     return values;
 }
 
@@ -190,11 +225,14 @@ void read_strings(Elements &in, Strings &s, Deferred *later = nullptr, bool back
     auto decode = [view, alphabet, packed, &s]() {
         std::vector<uint64_t> offsets = decode_sparse(view);
         s.bytes.resize(packed.len);
-        for (uint64_t i = 0; i < packed.len; i++) {
-            uint64_t x = packed.get(i);
-            if (x >= alphabet.size()) throw InvalidData("StringArray: packed character outside the alphabet");
-            s.bytes[i] = alphabet[x];
-        }
+        const unsigned pieces = pieces_for(packed.len);
+        run_pieces(pieces, [&](unsigned p) {
+            for (uint64_t i = packed.len * p / pieces, end = packed.len * (p + 1) / pieces; i < end; i++) {
+                uint64_t x = packed.get(i);
+                if (x >= alphabet.size()) throw InvalidData("StringArray: packed character outside the alphabet");
+                s.bytes[i] = alphabet[x];
+            }
+        });
         finish_strings(s, std::move(offsets));
     };
     if (later) (background ? later->background : later->tasks).push_back(decode); else decode();
@@ -468,12 +506,29 @@ void HostIndex::finish() {
     if (is_gbz) check_graph(*this);
 }
 
+namespace {
+// GBWT_HIP_TRACE_OPEN=1: the loader's phases on stderr, like the device side of an open (capi.hip: OpenTrace)
+struct LoadTrace {
+    bool on = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[load] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+}  // namespace
+
 void load_index_file_into(const std::string &path, HostIndex &h, bool background, const std::function<void(HostIndex &)> &on_located) {
+    LoadTrace trace;
     h = HostIndex();
     std::shared_ptr<HostIndex::Pending> pending = std::make_shared<HostIndex::Pending>();
     open_image(path, pending->image);
+    trace.mark("file mapped");
     Elements in(pending->image.words, pending->image.n_words);
     Deferred later;
+    later.small = pending->image.n_words < (uint64_t(1) << 19);          // < 4 MB
     uint32_t tag = static_cast<uint32_t>(in.peek());
     if (tag == GBZ_TAG) {
         // GBZ::load, src/gbz.rs:674-717
@@ -488,16 +543,18 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
         read_gbwt(in, h, later);
     }
     if (!in.at_end()) throw InvalidData("trailing data after the index");
-    if (!background) {
+    if (!background || later.small) {
         for (auto &t : later.background) later.tasks.push_back(std::move(t));
         later.background.clear();
     }
+    trace.mark("sections located");
     if (on_located) {
         h.pending = pending;                               // record_bytes() answers from the mapping from here on
         try { on_located(h); } catch (...) { h.pending.reset(); throw; }
         h.pending.reset();
     }
     later.run();
+    trace.mark("foreground decodes");
     if (!background) {
         h.file_data = nullptr; h.file_data_len = 0;
         if (h.is_gbz) check_graph(h);
@@ -508,7 +565,7 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
     std::vector<std::function<void()>> jobs = std::move(later.background);
     if (!jobs.empty())
         raw->worker = std::thread([raw, jobs]() {
-            try { for (auto &job : jobs) job(); }
+            try { run_pieces(static_cast<unsigned>(jobs.size()), [&](unsigned p) { jobs[p](); }); }   // the record bytes and the labels side by side
             catch (...) { raw->failure = std::current_exception(); }
         });
     h.pending = std::move(pending);
