@@ -440,16 +440,17 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 const bool behind = rec != 0 && key != front;
                 bool slow_here = false;
                 if (behind) {
+                    // everything the step can need in ONE round trip: both edges, the flags and the rank block
                     const uint4 *d1 = ix.desc + 4 * static_cast<uint64_t>(rec);
-                    const uint4 D = d1[2];
+                    const uint4 E0 = d1[0], E1 = d1[1], D = d1[2];
+                    const uint4 K = ix.blocks[bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT)];
                     slow_here = (D.x & DESC_SLOW) != 0;
                     if (!slow_here) {
-                        const uint4 K = ix.blocks[bb == BLOCK_NONE ? 0u : bb + (offset >> RANK_BLOCK_SHIFT)];
                         const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
                         const uint32_t bit = offset & 63u;
                         const uint32_t value = static_cast<uint32_t>(bits >> bit) & 1u;
                         const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << bit) - 1));
-                        const uint4 E = d1[value];
+                        const uint4 E = value ? E1 : E0;
                         const uint32_t flags = value ? D.w : D.y;
                         rec = E.z; offset = E.y + (value ? ones : offset - ones); bb = E.w;
                         sink.push(E.x, E.x != 0);
