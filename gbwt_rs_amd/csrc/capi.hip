@@ -62,6 +62,19 @@ DeviceIndex with_cblocks(const gbwt_hip_index *ix) {
     return d;
 }
 
+// GBWT_HIP_TRACE_OPEN=1: where the wall time of an open goes, phase by phase, on stderr (each mark waits for the device first)
+struct OpenTrace {
+    bool on = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[open] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = std::chrono::steady_clock::now();
+    }
+};
+
 // max / min / common number of samples per sequence from the host copy of sample_base
 void note_sample_counts(gbwt_hip_index &ix, const std::vector<uint64_t> &base) {
     uint64_t lo = ~uint64_t(0), hi = 0;
@@ -74,7 +87,7 @@ void note_sample_counts(gbwt_hip_index &ix, const std::vector<uint64_t> &base) {
 
 // Lengths and samples of all sequences by checkpoint sampling (open_walks.hip; kernels.hpp: CheckpointWalk).  d_flags[0] collects
 // the overflow bits of the chase like the serial walks do.  false: nothing usable was built (the caller walks every sequence).
-bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags) {
+bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags, OpenTrace &trace) {
     const HostIndex &h = ix.host;
     DeviceIndex &d = ix.dev;
     const uint64_t S = h.sequences, nr = d.n_records;
@@ -92,6 +105,7 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_CAP")) w.cap = static_cast<uint32_t>(std::max(1, std::atoi(v)));
     DeviceBuffer counts, cp_first, scan_tmp, summaries, misc;
     counts.reserve(nr * sizeof(uint64_t)); cp_first.reserve((nr + 1) * sizeof(uint64_t));
+    trace.mark("  (before the checkpoint passes)");
     launch_checkpoint_counts(d, w.threshold, counts.as<uint64_t>(), nullptr);
     const size_t tb = scan_temp_bytes(nr);
     scan_tmp.reserve(std::max<size_t>(tb, 16));
@@ -108,7 +122,9 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     w.cp_first = cp_first.as<uint64_t>(); w.summaries = summaries.as<uint4>();
     w.orphan_count = misc.as<uint64_t>(); w.orphan_capacity = orphan_capacity; w.positions = positions;
     w.flags = reinterpret_cast<uint32_t *>(misc.as<uint64_t>() + 1);
+    trace.mark("  checkpoint counts + scan + allocations");
     launch_checkpoint_walk(d, w, nullptr);
+    trace.mark("  k_checkpoint_walk");
     uint64_t state[2] = {0, 0};
     HIP_CHECK(hipMemcpy(state, misc.ptr, sizeof(state), hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
@@ -127,28 +143,17 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     HIP_CHECK(hipMemcpy(base.data(), ix.sample_base.ptr, base.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     uint32_t overflow = 0;
     HIP_CHECK(hipMemcpy(&overflow, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    trace.mark("  chase: counts + scan");
     if (overflow) return true;                                              // the caller reports it; no samples
     ix.samples.reserve(std::max<uint64_t>(base[S], 1) * sizeof(uint4));
     launch_chase(d, summaries.as<uint4>(), n_summaries, nullptr, nullptr, ix.sample_base.as<uint64_t>(), ix.samples.as<uint4>(), d_flags, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipGetLastError());
+    trace.mark("  chase: samples");
     ix.times.samples = base[S];
     note_sample_counts(ix, base);
     return true;
 }
-
-// GBWT_HIP_TRACE_OPEN=1: where the wall time of an open goes, phase by phase, on stderr (each mark waits for the device first)
-struct OpenTrace {
-    bool on = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
-    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
-    void mark(const char *what) {
-        if (!on) return;
-        (void)hipDeviceSynchronize();
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[open] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
-        last = std::chrono::steady_clock::now();
-    }
-};
 
 // The record starts to the device: narrowed to u32 where the record stream is shorter than 4 GiB.
 void upload_starts(gbwt_hip_index &ix) {
@@ -272,6 +277,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         // LF tables for the class 0 records, while they fit the budget (none in an index of outdegree <= 2 whose streams are all lean: nothing to count)
         d.tables = nullptr;
         d.wtables = nullptr;
+        d.wtables_deep = nullptr;
         if (n_records > 0 && generic_records > 0) {
             DeviceBuffer positions, sigmas, table_base, edge_base, edges;
             positions.reserve(n_records * sizeof(uint64_t)); sigmas.reserve(n_records * sizeof(uint64_t));
@@ -284,7 +290,14 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
             uint64_t total_positions = 0, total_edges = 0;
             HIP_CHECK(hipMemcpy(&total_positions, table_base.as<uint64_t>() + n_records, sizeof(uint64_t), hipMemcpyDeviceToHost));
             HIP_CHECK(hipMemcpy(&total_edges, edge_base.as<uint64_t>() + n_records, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            // 16 + 16 + 64 bytes per position of such a record (LF table, walk table, deep walk table): a quarter of the device's memory
+            // while half of what is free covers it (72 GiB of an MI355X's 288), or what GBWT_HIP_TABLE_BYTES says
             uint64_t budget = uint64_t(16) << 30;
+            {
+                size_t free_bytes = 0, total_bytes = 0;
+                if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) budget = std::min<uint64_t>(total_bytes / 4, free_bytes / 2);
+                else (void)hipGetLastError();
+            }
             if (const char *v = std::getenv("GBWT_HIP_TABLE_BYTES")) budget = std::strtoull(v, nullptr, 10);
             if (total_positions > 0 && total_positions < 0xFFFFFFFFull && total_positions * sizeof(uint4) <= budget) {
                 ix.tables.reserve(total_positions * sizeof(uint4));
@@ -302,6 +315,16 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
                     HIP_CHECK(hipDeviceSynchronize());
                     HIP_CHECK(hipGetLastError());
                     d.wtables = ix.wtables.as<uint4>();
+                    // ... and the deep walk tables (seven steps per 64-byte entry) while all three fit (GBWT_HIP_DEEP_TABLES=0: one step per load)
+                    const char *deep = std::getenv("GBWT_HIP_DEEP_TABLES");
+                    ix.table_positions = total_positions;
+                    if (6 * total_positions * sizeof(uint4) <= budget && !(deep && std::atoi(deep) == 0)) {
+                        ix.wtables_deep.reserve(total_positions * 4 * sizeof(uint4));
+                        launch_fill_wtables_deep(d, ix.wtables_deep.as<uint4>(), nullptr);
+                        HIP_CHECK(hipDeviceSynchronize());
+                        HIP_CHECK(hipGetLastError());
+                        d.wtables_deep = ix.wtables_deep.as<uint4>();
+                    }
                 }
             }
         }
@@ -345,6 +368,12 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         // together (k_chase), a microsecond per hop -- ninety haplotypes of two million nodes at 128 nodes per hop were 23 000 hops,
         // 2 x 23 ms of a 35 ms sampling pass (profiles/r03_open_c4.txt)
         while (interval < 2048 && ((all_nodes / h.sequences) >> 12) > interval) interval *= 2;
+        // walkers on deep walk tables take seven steps (up to fourteen nodes) per load: segments of 64 nodes would be five loads, a
+        // fifth of them past the end of the segment (config C5: 265 G LF-steps/s at 64 nodes, 359 G from 128 up)
+        // ... where most of the index is table records, and as long as about 64 000 walkers are left: the 7-allele chain of DESIGN section 4 walks
+        // at 331 G LF-steps/s with 128-node segments and at 407 G with 512; C5 at 339 and 357)
+        if (d.wtables_deep != nullptr && 3 * ix.table_positions >= h.size)   // (a star site is a table record and a unary one: half of the positions)
+            while (interval < 512 && (interval < 128 || (all_nodes >> 17) > interval)) interval *= 2;
         if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
         const bool sampled = interval >= 8;
         // Without samples an extraction fills every row from both ends, which needs the proof that sequence 2k + 1 is
@@ -359,7 +388,8 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         // Samples by checkpoint sampling (open_walks.hip): no sequence is walked from end to end.  GBWT_HIP_SERIAL_SAMPLES=1 (and
         // indexes it cannot number with 32 bits, or whose records send walks in circles) take the walk of every sequence instead.
         const char *serial = std::getenv("GBWT_HIP_SERIAL_SAMPLES");
-        bool by_checkpoints = sampled && !want_pairs && !(serial && std::atoi(serial) != 0) && checkpoint_samples(ix, interval, d_flags);
+        bool by_checkpoints = sampled && !want_pairs && !(serial && std::atoi(serial) != 0) && checkpoint_samples(ix, interval, d_flags, trace);
+        if (by_checkpoints) trace.mark("  temporaries freed");
         // serial: with samples and without fingerprints, lengths and samples come out of ONE walk (pooled samples, placed afterwards)
         DeviceBuffer pool, tags;
         uint64_t pooled = 0;

@@ -195,7 +195,8 @@ inline gbwt_hip_status status_of_current_exception() noexcept {
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
-    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks, gblocks, tables, wtables, seq_len, samples, sample_base;
+    uint64_t table_positions = 0;     // BWT positions in records with LF tables (outdegree > 2)
+    gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks, gblocks, tables, wtables, wtables_deep, seq_len, samples, sample_base;
     gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)
     // GBZ with a node-to-segment translation (src/graph.rs:186-218), flattened for the line formatter:
     gbwt_hip::DeviceBuffer seg_of;        // u32 per node id < mapping_len: segment holding the node (~0 before the first segment)

@@ -76,6 +76,7 @@ constexpr uint32_t LEAF_EMIT2 = 1u << 31;            // two-step descriptor: thi
 constexpr uint32_t DESC2_SLOW = 1u << 30;            // two-step descriptor, word E_a.z: generic decode
 constexpr uint32_t GATHER_OK = 1u;                   // two-step descriptor, word E_a.w: the record's packed blocks (gblocks) can count it
 constexpr uint32_t WT_TABLE = 1u << 30;              // walk table entry: the landing record is a table record, word 3 = its table base
+constexpr uint32_t WT_DEEP_STEPS = 7;                // deep walk table entry: this many table steps in 64 bytes
 constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANK_BLOCK_SHIFT = 6;   // 64 offsets per rank block
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start
@@ -92,6 +93,7 @@ struct DeviceIndex {
     const uint4 *desc2;        // 8 * n_records entries (two-step walk descriptors)
     const uint4 *tables;       // LF tables of the class 0 records (desc_raw C.z = first entry, C.w = 1), or null
     const uint4 *wtables;      // walk tables, same indexing: {node to emit, offset, landing record | LEAF_EMIT2 | WT_TABLE, its block / table base}, or null
+    const uint4 *wtables_deep; // deep walk tables: four uint4 per position = WT_DEEP_STEPS walk-table steps (load_kernels.hip: k_fill_wtables_deep), or null
     const uint32_t *seq_len;   // number of nodes of every sequence (counted once at open), or null
     const uint4 *samples;      // sequence samples {record, offset, block base, nodes emitted so far}, or null
     const uint64_t *sample_base;   // n_sequences + 1: first sample of every sequence

@@ -313,6 +313,43 @@ __global__ void __launch_bounds__(256) k_fill_wtables(DeviceIndex ix, uint4 *wta
     }
 }
 
+// Deep walk tables (DeviceIndex::wtables_deep): WT_DEEP_STEPS table steps of the walk folded into ONE 64-byte entry per position.  A table
+// step is one dependent load from a table far larger than the caches, so a walker spends its life waiting for HBM (config C5: 2 500 cycles
+// per step with 512 walkers per CU, rows not even stored); an entry that already holds the next seven steps -- what each of them emits and
+// where the last one lands -- makes that one wait per seven steps, and the 64 bytes are exactly the sector the single entry was fetched with.
+// Entry of position i of table record v, as four uint4: words 2 k, 2 k + 1 = step k {node to emit (0: nothing), landing record | LEAF_EMIT2},
+// k = 0 .. 6; word 14 = offset in the last landing record, word 15 = its table base (WT_TABLE set in word 13) or its block base.  The chain
+// stops early where the walk ends (record 0) or leaves the table records; the steps not taken repeat the last landing record and emit nothing.
+// The order of the LF steps (src/gbwt.rs:557-568) is untouched: the entry is the memo of seven of them.
+__global__ void __launch_bounds__(256) k_fill_wtables_deep(DeviceIndex ix, uint4 *deep) {
+    const uint64_t v = blockIdx.x;
+    if (v >= ix.n_records) return;
+    const uint4 C = ix.desc_raw[4 * v + 2];
+    if (C.w != 1u) return;
+    for (uint32_t i = threadIdx.x; i < C.y; i += blockDim.x) {
+        uint32_t w[16];
+        uint4 e = ix.wtables[static_cast<uint64_t>(C.z) + i];
+        bool going = true;
+#pragma unroll
+        for (uint32_t k = 0; k < WT_DEEP_STEPS; k++) {
+            if (going) {
+                if (k > 0) e = ix.wtables[static_cast<uint64_t>(e.w) + e.y];
+                w[2 * k] = e.x; w[2 * k + 1] = e.z & ~WT_TABLE;
+                going = (e.z & REC_MASK) != 0 && (e.z & WT_TABLE) != 0;
+            } else {
+                w[2 * k] = 0u; w[2 * k + 1] = e.z & REC_MASK;
+            }
+        }
+        if ((e.z & REC_MASK) != 0 && (e.z & WT_TABLE) != 0) w[2 * WT_DEEP_STEPS - 1] |= WT_TABLE;
+        w[14] = e.y; w[15] = e.w;
+        uint4 *out = deep + 4 * (static_cast<uint64_t>(C.z) + i);
+        out[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        out[2] = make_uint4(w[8], w[9], w[10], w[11]);
+        out[3] = make_uint4(w[12], w[13], w[14], w[15]);
+    }
+}
+
 // ---- two-step walk: descriptors and blocks -----------------------------------------------------------------
 // The single-step descriptor says, per edge of record v: what to emit and where the walk lands (record w, offset base).
 // The two-step descriptor composes that with the edges of w, so that one iteration of the walk -- one round trip to
@@ -548,6 +585,11 @@ void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t
 void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t stream) {
     if (ix.n_records == 0 || ix.n_records > 0x7FFFFFFFull) return;
     hipLaunchKernelGGL(k_fill_wtables, dim3(static_cast<unsigned>(ix.n_records)), dim3(256), 0, stream, ix, d_wtables);
+}
+
+void launch_fill_wtables_deep(const DeviceIndex &ix, uint4 *d_deep, hipStream_t stream) {
+    if (ix.n_records == 0 || ix.n_records > 0x7FFFFFFFull || ix.wtables == nullptr) return;
+    hipLaunchKernelGGL(k_fill_wtables_deep, dim3(static_cast<unsigned>(ix.n_records)), dim3(256), 0, stream, ix, d_deep);
 }
 
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, hipStream_t stream) {

@@ -516,8 +516,28 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                     const uint4 C = ix.desc_raw[4 * static_cast<uint64_t>(rec) + 2];
                     if (C.w == 1u && offset < C.y) { in_table = true; tb = C.z; generic = false; }   // offset >= Record::len: generic_step ends the walk (src/bwt.rs:481)
                 }
+                // With deep walk tables (k_fill_wtables_deep) a load brings the next seven steps: up to fourteen nodes, so the ring must have
+                // sixteen free slots (the loops above leave with as few as four).  Nodes past the end of the segment are staged like
+                // all others and never written (the row writers stop at the length of the row piece they serve).
+                const bool deep = ix.wtables_deep != nullptr && ring_mask + 1 >= 64;
+                const uint32_t table_slack = deep ? 16u : 8u;
                 while (__ballot(in_table) != 0) {
-                    if (in_table) {
+                    if (deep && __ballot(in_table && sink.wr - lds_peek(my_drained) > ring_mask + 1 - table_slack) != 0) { __builtin_amdgcn_s_sleep(2); continue; }
+                    if (in_table && deep) {
+                        const uint4 *e = ix.wtables_deep + 4 * (static_cast<uint64_t>(tb) + offset);
+                        const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
+                        const uint32_t ao = ix.alphabet_offset;
+                        sink.push(q0.x, q0.x != 0); sink.push((q0.y & REC_MASK) + ao, (q0.y & LEAF_EMIT2) != 0);
+                        sink.push(q0.z, q0.z != 0); sink.push((q0.w & REC_MASK) + ao, (q0.w & LEAF_EMIT2) != 0);
+                        sink.push(q1.x, q1.x != 0); sink.push((q1.y & REC_MASK) + ao, (q1.y & LEAF_EMIT2) != 0);
+                        sink.push(q1.z, q1.z != 0); sink.push((q1.w & REC_MASK) + ao, (q1.w & LEAF_EMIT2) != 0);
+                        sink.push(q2.x, q2.x != 0); sink.push((q2.y & REC_MASK) + ao, (q2.y & LEAF_EMIT2) != 0);
+                        sink.push(q2.z, q2.z != 0); sink.push((q2.w & REC_MASK) + ao, (q2.w & LEAF_EMIT2) != 0);
+                        sink.push(q3.x, q3.x != 0); sink.push((q3.y & REC_MASK) + ao, (q3.y & LEAF_EMIT2) != 0);
+                        rec = q3.y & REC_MASK; offset = q3.z;
+                        if (q3.y & WT_TABLE) tb = q3.w; else { bb = q3.w; in_table = false; }
+                        if (rec == 0 || sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; in_table = false; }
+                    } else if (in_table) {
                         const uint4 e = ix.wtables[static_cast<uint64_t>(tb) + offset];
                         sink.push(e.x, e.x != 0);
                         sink.push((e.z & REC_MASK) + ix.alphabet_offset, (e.z & LEAF_EMIT2) != 0);
@@ -528,7 +548,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                     lds_poke(my_mail + 3, sink.wr);
                     const uint64_t still = __ballot(in_table);
                     if (2 * __popcll(still) < __popcll(__ballot(rec != 0))) break;
-                    if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - 8) != 0) break;   // ring full: the outer loop waits for the helper
+                    if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - table_slack) != 0) break;   // ring full: the outer loop waits for the helper
                 }
                 if (in_table) bb = BLOCK_NONE;     // left on a table record (it has no blocks): back here after the next look at the ring
             }

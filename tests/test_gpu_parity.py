@@ -922,6 +922,7 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "128", "GBWT_HIP_WIDE_ADDRESSES": "1"},   # both loops with 64-bit addresses
                 {"GBWT_HIP_SAMPLE_INTERVAL": "1000", "GBWT_HIP_PATHS_PER_WAVE": "13"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_WALK_TABLES": "0"},   # outdegree > 2: plain table steps, one at a time
+                {"GBWT_HIP_SAMPLE_INTERVAL": "48", "GBWT_HIP_DEEP_TABLES": "0"},   # ... walk-table steps, one per load instead of seven
                 {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_SERIAL_SAMPLES": "1", "GBWT_HIP_TWO_PASS_OPEN": "1"},  # every sequence walked at open: lengths, then samples
                 {"GBWT_HIP_SAMPLE_INTERVAL": "40", "GBWT_HIP_SERIAL_SAMPLES": "1"},   # ... both in one walk (samples every 40 nodes of each sequence)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CHECKPOINT_CAP": "5"},   # checkpoint sampling with hops of at most 5 + 3 nodes: many rounds of orphans
@@ -1025,7 +1026,10 @@ def _layered_paths(layers, haplotypes, seed):
 
 @pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "9", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
                                  {"GBWT_HIP_WALK_TABLES": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_DIRECT": "0"},
-                                 {"GBWT_HIP_SAMPLE_INTERVAL": "11", "GBWT_HIP_CATCH_UP": "0"}],
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "11", "GBWT_HIP_CATCH_UP": "0"},
+                                 {"GBWT_HIP_DEEP_TABLES": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "13", "GBWT_HIP_DEEP_TABLES": "0"},   # one table step per load
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "10", "GBWT_HIP_RING_SLOTS": "128"}, {"GBWT_HIP_SAMPLE_INTERVAL": "21", "GBWT_HIP_ROW_PIECE": "0"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "0"}],   # whole sequences from both ends: seven steps at a time past the middle of the row
                          ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
 def test_walk_tables(monkeypatch, env):
     """Walks over records with outdegree > 2 (walk tables: the plain LF entry with the step through a unary successor and

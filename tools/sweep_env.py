@@ -15,20 +15,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gbwt_rs_amd as G
 from gbwt_rs_amd import synth as S
 
-OPEN_KNOBS = {"SAMPLE_INTERVAL", "LOOKAHEAD_HOPS", "SEQ_LEN", "TABLE_BYTES", "ORIENTATION_CHECK", "WALK_TABLES", "TWO_PASS_OPEN", "GATHER_LIMIT"}
+OPEN_KNOBS = {"SAMPLE_INTERVAL", "LOOKAHEAD_HOPS", "SEQ_LEN", "TABLE_BYTES", "ORIENTATION_CHECK", "WALK_TABLES", "DEEP_TABLES", "TWO_PASS_OPEN", "GATHER_LIMIT"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sites", type=int, default=333334)
 ap.add_argument("--haplotypes", type=int, default=5000)
 ap.add_argument("--model", default="mosaic")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--alleles", type=int, default=2)
 ap.add_argument("--configs", default="")
 ap.add_argument("--extra", type=int, default=0, help="allele 1 is an insertion of this many more nodes (walks leave lock step)")
 ap.add_argument("--indel-every", type=int, default=1, help="... at every k-th site only")
 ap.add_argument("--chop", type=int, default=1, help="every node a chain of this many nodes with consecutive ids")
 args = ap.parse_args()
 
-s = S.Synth.chain(args.sites, args.haplotypes, alleles=2, model=S.MOSAIC if args.model == "mosaic" else S.IID, seed=42, extra=args.extra, indel_every=args.indel_every, chop=args.chop)
+s = S.Synth.chain(args.sites, args.haplotypes, alleles=args.alleles, model=S.MOSAIC if args.model == "mosaic" else S.IID, seed=42, extra=args.extra, indel_every=args.indel_every, chop=args.chop)
 ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
 truth = np.array([s.path_checksum(h) for h in range(s.paths)], dtype=np.uint64)
 steps = (s.size - s.sequences) // 2
