@@ -11,7 +11,7 @@ its own contig of the same shape (seed 42 + rank).
 
 Next to the steady-state `value` the line carries the one-shot flow (open_ms, sample_walk_ms,
 first_pass_ms, value_cold), the same passes without sequence samples (value_unsampled) and a second
-workload whose rows do not move in lock step (secondary).
+workload whose rows do not move in lock step (secondary) and BASELINE config 5 (high_degree).
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE index (seed 42) replicated on every rank, path p walked by rank p mod N, whole CSR gathered on rank 0 "
                          "(SURVEY 8e; default); weak = every rank its own contig (seed 42 + rank)")
-    ap.add_argument("--no-extras", action="store_true", help="skip value_unsampled and the secondary (insertion chain) workload")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_unsampled, the secondary (insertion chain) and the high-degree (config 5) workloads")
     return ap.parse_args()
 
 
@@ -349,6 +349,24 @@ def main():
                                    "value": int(o2.total) * 5 / e2, "unit": "LF-steps/s", "kernel_ms": float(np.mean(w2)),
                                    "open_ms": dev2.open_times()["total_ms"], "seconds_incl_generator": round(time.perf_counter() - t0, 1)}
             dev2.close()
+            # (c) BASELINE config 5: a high-degree graph (300 alleles per site, outdegree >= 255: two-varint runs), walked on the deep walk tables
+            t0 = time.perf_counter()
+            s3 = S.Synth.chain(sites=3000, haplotypes=args.haplotypes, alleles=300, model=S.IID, seed=args.seed)
+            dev3 = G.GBWT.from_records(s3.data(), s3.starts(), s3.alphabet_offset, s3.alphabet_size, s3.sequences, s3.size, True, device=local_rank)
+            ids3 = np.arange(0, s3.sequences, 2, dtype=np.uint64)
+            timed_passes(dev3, ids3, 3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            o3, w3, _ = timed_passes(dev3, ids3, 10)
+            torch.cuda.synchronize()
+            e3 = time.perf_counter() - t1
+            truth3 = np.array([s3.path_checksum(h) for h in range(s3.paths)], dtype=np.uint64)
+            assert np.array_equal(dev3.path_sums(len(ids3)), truth3), "high-degree chain: extracted paths differ from the generator's ground truth"
+            extras["high_degree"] = {"workload": f"BASELINE config 5: {args.haplotypes} haplotypes x 3 000 sites with 300 alleles each, i.i.d. ({int(o3.total)} LF-steps; "
+                                                 f"max outdegree {dev3.stats.max_outdegree}: every site is a table record)",
+                                     "value": int(o3.total) * 10 / e3, "value_kernel": int(o3.total) / (float(np.mean(w3)) * 1e-3), "unit": "LF-steps/s",
+                                     "kernel_ms": float(np.mean(w3)), "open_ms": dev3.open_times()["total_ms"], "seconds_incl_generator": round(time.perf_counter() - t0, 1)}
+            dev3.close()
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/measure_round.sh -> profiles/*_hbm_traffic.json).  It is quoted only when those passes ran THIS build with
         # THESE knobs on THIS workload (fingerprint of the kernel sources + GBWT_HIP_* environment); a profile of another

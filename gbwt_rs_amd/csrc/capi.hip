@@ -254,14 +254,28 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
             if (n_blocks >= (uint64_t(1) << 31)) gather_limit = 0;   // half-block indices 2 bb + offset / 32 are 32-bit in the loops: beyond that, full-width blocks only
             ix.packed_blocks = gather_limit != 0;
             trace.mark("link + lookahead + allocations");
-            launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, nullptr);
+            // steps through runs of unary records with consecutive ids (k_link_desc2: CHAINS); GBWT_HIP_CHAINS=0: none, k: at most k more nodes per step
+            uint32_t chain_max = CHAIN_MAX;
+            if (const char *v = std::getenv("GBWT_HIP_CHAINS")) chain_max = static_cast<uint32_t>(std::min<long>(CHAIN_MAX, std::max<long>(0, std::atol(v))));
+            launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, chain_max | (h.bidirectional ? 0x100u : 0u), reinterpret_cast<uint32_t *>(d_stats + 5), nullptr);
             ix.gblocks.reserve((gather_limit ? n_blocks : 1) * 2 * sizeof(uint4));   // no record takes the packed path: only the zero block
             HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
             d.gblocks = ix.gblocks.as<uint4>();
             // both layouts in one pass when the full-width one is certain to be read: a record whose counts do not fit the packed blocks
             // (k_link_desc2 clears GATHER_OK from 2^21 positions, for the record and for what lies behind its edges) or no packed blocks at all
-            uint64_t early_stats[5] = {0, 0, 0, 0, 0};
+            uint64_t early_stats[6] = {0, 0, 0, 0, 0, 0};
             HIP_CHECK(hipMemcpy(early_stats, d_stats, sizeof(early_stats), hipMemcpyDeviceToHost));
+            d.chained = static_cast<uint32_t>(early_stats[5] & 0xFFFFFFFFu);      // (k_link_desc2's atomicMax on the low word; the high word counts the records)
+            // a handful of chained records (44 of two million on the headline index, where monomorphic sites meet) are not worth the ring
+            // headroom every walker then keeps free: below one record in a thousand the descriptors are linked again without chains
+            // (0.1 ms), unless GBWT_HIP_CHAINS asked for them
+            if (d.chained != 0 && std::getenv("GBWT_HIP_CHAINS") == nullptr && (early_stats[5] >> 32) * 1000 < n_records) {
+                HIP_CHECK(hipMemset(d_stats + 5, 0, sizeof(uint64_t)));
+                launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, h.bidirectional ? 0x100u : 0u, reinterpret_cast<uint32_t *>(d_stats + 5), nullptr);
+                d.chained = 0;
+            }
+            if (trace.on) std::fprintf(stderr, "[open] records with a chained step: %llu of %llu (up to %u nodes per iteration)\n",
+                                       static_cast<unsigned long long>(early_stats[5] >> 32), static_cast<unsigned long long>(n_records), d.chained);
             const uint64_t longest = early_stats[0];
             generic_records = early_stats[4];
             const bool full_width_now = gather_limit == 0 || longest >= gather_limit;

@@ -75,6 +75,10 @@ constexpr uint32_t REC_MASK = (1u << 30) - 1;       // record indices are < 2^30
 constexpr uint32_t LEAF_EMIT2 = 1u << 31;            // two-step descriptor: this step is fused with a unary successor
 constexpr uint32_t DESC2_SLOW = 1u << 30;            // two-step descriptor, word E_a.z: generic decode
 constexpr uint32_t GATHER_OK = 1u;                   // two-step descriptor, word E_a.w: the record's packed blocks (gblocks) can count it
+constexpr uint32_t E_CHAIN = 2u;                     // two-step descriptor, word E_a.w: the first step runs through a chain of unary records (below)
+constexpr uint32_t E_ANYCHAIN = 4u;                  // two-step descriptor, word E_0.w: some step of the record (E_0, E_1 or a leaf) is chained
+constexpr uint32_t LEAF_CHAIN = 1u << 30;            // two-step descriptor, leaf word z: the second step does
+constexpr uint32_t CHAIN_MAX = 6;                    // at most this many nodes between the first node of a step and its landing node
 constexpr uint32_t WT_TABLE = 1u << 30;              // walk table entry: the landing record is a table record, word 3 = its table base
 constexpr uint32_t WT_DEEP_STEPS = 7;                // deep walk table entry: this many table steps in 64 bytes
 constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
@@ -108,7 +112,14 @@ struct DeviceIndex {
     uint64_t max_walk;         // BWT positions in all records together: no sequence of a consistent index visits more (bounds the walks at open)
     uint32_t alphabet_offset;
     uint32_t first_node;       // alphabet_offset + 1
+    uint32_t chained;          // 0: no two-step descriptor has a chained step (E_CHAIN / LEAF_CHAIN); else the most nodes an iteration of the walk can stage (5 .. 16; 4 without chains)
 };
+
+// A chained step emits its first node x, the nodes between x and the node L of its landing record on the progression x + 2, x + 4, ...
+// (x - 2, ... for reverse nodes), then L: a run of unary records with consecutive ids in one orientation, as a GFA segment chopped into
+// nodes is (k_link_desc2).  A lane runs `n = x + d; n != L; n += d`.
+__host__ __device__ inline uint32_t chain_stride(uint32_t x, uint32_t L) { return L > x ? 2u : 0xFFFFFFFEu; }
+__host__ __device__ inline uint32_t chain_mids(uint32_t x, uint32_t L) { return (L > x ? L - x : x - L) / 2 - 1; }
 
 __host__ __device__ inline uint32_t desc_body_offset(uint32_t meta) { return meta & 0xFFFFu; }
 __host__ __device__ inline uint32_t desc_class(uint32_t meta) { return (meta >> 16) & 3u; }

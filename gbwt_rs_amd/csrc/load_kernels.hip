@@ -363,14 +363,57 @@ __global__ void __launch_bounds__(256) k_fill_wtables_deep(DeviceIndex ix, uint4
 // (bits2) and the number of value-1 positions of w_a before the landing offset of the block's first a-path (R_a), so
 // the rank inside w_a is again one popcount.  Where the second step is not real (w_a generic, sequence ending, v
 // unary and w_a branching) the leaf (a, 0) is the identity: "emit nothing, stay in w_a at the offset reached".
-__global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, uint32_t gather_limit) {
+// CHAINS.  A fused step emits the successor x and the node of the record w behind it (a unary record stepped through).  Where w is
+// unary as well, and the node behind it is the next id in the same direction (x, x + 2 = node of w, x + 4, ...: a GFA segment chopped
+// into nodes, an insertion that got consecutive ids), the step runs on: every further unary record costs an addition of its o0 to the
+// offset base -- Record::lf of an outdegree-1 record is (n0, o0 + i), src/bwt.rs:480-496 -- and one more node to emit, which the walk
+// derives from x and the landing node (chain_stride / chain_mids, device_index.hpp).  The same tests as for the first fusion apply at
+// every record (the landing record exists, is not empty, and holds every offset the step can produce).  Rows that took alleles of
+// different lengths then land on the SAME record after one step and the wave stays in the uniform loop; a chopped segment is one step.
+// `count` = positions that can take the step; returns the number of records added (at most `room`).
+__device__ __forceinline__ uint32_t extend_chain(const DeviceIndex &ix, uint32_t x, uint32_t &w, uint64_t &base, uint64_t count, uint32_t room, bool bidirectional) {
+    const uint4 *raw = ix.desc_raw;
+    const uint32_t first = w + ix.alphabet_offset;
+    if (first != x + 2u && first != x - 2u) return 0;
+    const uint32_t d = chain_stride(x, first);
+    uint32_t added = 0;
+    while (added < room) {
+        const uint4 WA = raw[4 * static_cast<uint64_t>(w)], WB = raw[4 * static_cast<uint64_t>(w) + 1];
+        if (WB.y != DESC_UNARY || WA.x == 0 || WA.x != w + ix.alphabet_offset + d) break;
+        // ... and never THROUGH a record where paths merge: rows that arrive over different alleles must all stop there, or the chain of
+        // the one allele whose ids happen to run on into the merge node would carry its rows past the others.  In a bidirectional index
+        // the predecessors of a node are the successors of its reverse (src/gbwt.rs:229-241): one predecessor = the reverse record is unary.
+        if (bidirectional) {
+            uint64_t rev = 0;
+            if (!landing_record(ix, (w + ix.alphabet_offset) ^ 1u, rev) || raw[4 * rev + 1].y != DESC_UNARY) break;
+        }
+        uint64_t next = 0;
+        if (!landing_record(ix, WA.x, next)) break;
+        const uint4 NB = raw[4 * next + 1];
+        const uint64_t base2 = base + WA.y;
+        if (NB.y == 0 || base2 + count > 0xFFFFFFFFull || !(desc_class(NB.z) == 0 || base2 + count <= NB.w)) break;
+        w = static_cast<uint32_t>(next); base = base2; added++;
+    }
+    return added;
+}
+
+// positions of record r that take edge e (0 for an edge it does not have)
+__device__ __forceinline__ uint64_t edge_positions(const DeviceIndex &ix, uint64_t r, uint32_t e) {
+    const uint4 B = ix.desc_raw[4 * r + 1], C = ix.desc_raw[4 * r + 2];
+    const uint32_t cls = B.y != 0 ? desc_class(B.z) : 0u;
+    if (cls == 2) return e ? B.w - C.x : C.x;
+    return cls == 1 && e == 0 ? B.w : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, uint32_t gather_limit, uint32_t chain_max, uint32_t *chained) {
     uint64_t v = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (v >= ix.n_records) return;
     const uint4 *d1 = ix.desc;
     const uint4 D = d1[4 * v + 2];
     const uint4 VB = ix.desc_raw[4 * v + 1];
     const uint32_t cls_v = VB.y != 0 ? desc_class(VB.z) : 0u;
-    uint32_t n1[2] = {0, 0}, base[2] = {0, 0}, wword[2] = {0, 0};
+    uint32_t n1[2] = {0, 0}, base[2] = {0, 0}, wword[2] = {0, 0}, chain[2] = {0, 0};
+    bool any_chain = false;
     uint4 leaf[4] = {make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE), make_uint4(0, 0, 0, BLOCK_NONE)};
     const bool slow = (D.x & DESC_SLOW) != 0;
     if (!slow) {
@@ -379,18 +422,29 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
             const uint32_t f = a ? D.w : D.y;
             n1[a] = E.x; base[a] = E.y;
             if (!(f & EDGE_CONT)) continue;                       // the walk ends behind this edge: both leaves park it
-            const uint32_t w = E.z;
+            uint32_t w = E.z, wbb = E.w;
+            if ((f & EDGE_EMIT2) && chain_max != 0) {
+                uint64_t chained_base = base[a];
+                if (extend_chain(ix, E.x, w, chained_base, edge_positions(ix, v, a), chain_max & 0xFFu, (chain_max >> 8) != 0) != 0) {
+                    base[a] = static_cast<uint32_t>(chained_base); wbb = ix.block_base[w]; chain[a] = E_CHAIN; any_chain = true;
+                }
+            }
             wword[a] = w | ((f & EDGE_EMIT2) ? LEAF_EMIT2 : 0u);
             const uint4 WD = d1[4 * static_cast<uint64_t>(w) + 2];
             const uint4 WB = ix.desc_raw[4 * static_cast<uint64_t>(w) + 1];
             const uint32_t cls_w = WB.y != 0 ? desc_class(WB.z) : 0u;
             const bool real = !(WD.x & DESC_SLOW) && (cls_w == 1 || (cls_w == 2 && cls_v == 2));
-            if (!real) { leaf[2 * a] = make_uint4(0u, 0u, w, E.w); continue; }   // identity
+            if (!real) { leaf[2 * a] = make_uint4(0u, 0u, w, wbb); continue; }   // identity
             for (uint32_t b = 0; b < cls_w; b++) {
                 const uint4 WE = d1[4 * static_cast<uint64_t>(w) + b];
                 const uint32_t wf = b ? WD.w : WD.y;
                 const bool cont = (wf & EDGE_CONT) != 0;
-                leaf[2 * a + b] = make_uint4(WE.x, WE.y, cont ? (WE.z | ((wf & EDGE_EMIT2) ? LEAF_EMIT2 : 0u)) : 0u, cont ? WE.w : BLOCK_NONE);
+                uint32_t land = WE.z, lbb = WE.w, lflag = 0;
+                uint64_t lbase = WE.y;
+                if (cont && (wf & EDGE_EMIT2) && chain_max != 0 && extend_chain(ix, WE.x, land, lbase, edge_positions(ix, w, b), chain_max & 0xFFu, (chain_max >> 8) != 0) != 0) {
+                    lbb = ix.block_base[land]; lflag = LEAF_CHAIN; any_chain = true;
+                }
+                leaf[2 * a + b] = make_uint4(WE.x, static_cast<uint32_t>(lbase), cont ? (land | lflag | ((wf & EDGE_EMIT2) ? LEAF_EMIT2 : 0u)) : 0u, cont ? lbb : BLOCK_NONE);
             }
         }
     }
@@ -399,8 +453,21 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
     for (uint32_t a = 0; a < 2; a++)
         if (wword[a] & REC_MASK) packed = packed && ix.desc_raw[4 * static_cast<uint64_t>(wword[a] & REC_MASK) + 1].w < gather_limit;
     uint4 *o = out + 8 * v;
-    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), packed ? GATHER_OK : 0u);
-    o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), packed ? GATHER_OK : 0u);
+    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[0] | (any_chain ? E_ANYCHAIN : 0u));
+    o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[1]);
+    if (any_chain && chained != nullptr) {
+        // the most nodes one iteration of the walk can stage on this record: what the rings must have free when a loop is entered
+        uint32_t most = 0;
+        for (uint32_t a = 0; a < 2; a++) {
+            const uint32_t first = 2u + (chain[a] ? chain_mids(n1[a], (wword[a] & REC_MASK) + ix.alphabet_offset) : 0u);
+            for (uint32_t b = 0; b < 2; b++) {
+                const uint4 l = leaf[2 * a + b];
+                most = max(most, first + 2u + ((l.z & LEAF_CHAIN) ? chain_mids(l.x, (l.z & REC_MASK) + ix.alphabet_offset) : 0u));
+            }
+        }
+        if (*chained < most) atomicMax(chained, most);
+        atomicAdd(chained + 1, 1u);                                            // records with a chained step
+    }
     o[2] = leaf[0]; o[3] = leaf[1]; o[4] = leaf[2]; o[5] = leaf[3];
     o[6] = make_uint4(0u, 0u, 0u, 0u);
     o[7] = make_uint4(0u, 0u, 0u, 0u);
@@ -460,10 +527,11 @@ __global__ void __launch_bounds__(256) k_fill_two_step_blocks(DeviceIndex ix, ui
     SecondStep s2{{nullptr, nullptr}, {0, 0}};
     if (!(D.x & DESC_SLOW)) {
         for (uint32_t a = 0; a < 2; a++) {
-            const uint32_t f = a ? D.w : D.y;
-            if (!(f & EDGE_CONT)) continue;
-            const uint4 E = d1[4 * v + a];
-            const uint64_t w = E.z;
+            // where the first step lands and with which offset base: the two-step descriptor's word (k_link_desc2 may have run the step
+            // through a chain of unary records, further than the one-step descriptor goes)
+            const uint4 E = ix.desc2[8 * v + a];
+            const uint64_t w = E.z & REC_MASK;
+            if (w == 0) continue;                                             // the walk ends behind this edge
             const uint4 WB = ix.desc_raw[4 * w + 1];
             if ((d1[4 * w + 2].x & DESC_SLOW) || WB.y == 0 || desc_class(WB.z) != 2) continue;
             s2.wblocks[a] = ix.blocks + ix.block_base[w];
@@ -592,9 +660,9 @@ void launch_fill_wtables_deep(const DeviceIndex &ix, uint4 *d_deep, hipStream_t 
     hipLaunchKernelGGL(k_fill_wtables_deep, dim3(static_cast<unsigned>(ix.n_records)), dim3(256), 0, stream, ix, d_deep);
 }
 
-void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, hipStream_t stream) {
+void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, uint32_t chain_max, uint32_t *d_chained, hipStream_t stream) {
     if (ix.n_records == 0) return;
-    hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, gather_limit);
+    hipLaunchKernelGGL(k_link_desc2, dim3(grid_for(ix.n_records, 256)), dim3(256), 0, stream, ix, d_desc2, gather_limit, chain_max, d_chained);
 }
 
 void launch_fill_two_step_blocks(const DeviceIndex &ix, uint4 *d_cblocks, uint4 *d_gblocks, hipStream_t stream) {

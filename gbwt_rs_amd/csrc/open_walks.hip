@@ -245,12 +245,12 @@ __device__ __forceinline__ bool counting_step(const DeviceIndex &ix, bool packed
         ones_w_base = a ? K1.z : K1.y; mw = __popcll(m & bits2);
     }
     const uint32_t j = E.y + rank_a, w = E.z & REC_MASK;
-    sink.wr += (E.x != 0 ? 1u : 0u) + ((E.z & LEAF_EMIT2) ? 1u : 0u);
+    sink.wr += (E.x != 0 ? 1u : 0u) + ((E.z & LEAF_EMIT2) ? 1u : 0u) + ((E.w & E_CHAIN) ? chain_mids(E.x, w + ix.alphabet_offset) : 0u);
     if (hashed_checkpoint(w, threshold)) { rec = w; offset = j; bb = BLOCK_NONE; return true; }
     const uint4 leaf = d[2 + 2 * a + b];
     const uint32_t ones_w = ones_w_base + mw;
     rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
-    sink.wr += (leaf.x != 0 ? 1u : 0u) + ((leaf.z & LEAF_EMIT2) ? 1u : 0u);
+    sink.wr += (leaf.x != 0 ? 1u : 0u) + ((leaf.z & LEAF_EMIT2) ? 1u : 0u) + ((leaf.z & LEAF_CHAIN) ? chain_mids(leaf.x, rec + ix.alphabet_offset) : 0u);
     return false;
 }
 

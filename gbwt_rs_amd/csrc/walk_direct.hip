@@ -411,11 +411,19 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE   // measurement only: nodes staged by each of the two loops, for a few workgroups (profiles/r02_walk_bounds.txt #16)
     uint32_t probe_uniform = 0, probe_vector = 0, probe_entries = 0, probe_mixed_entries = 0, probe_fell_out = 0;
 #endif
+    // Free ring slots a loop needs when it is entered, and leaves below.  A loop looks at the ring AFTER an iteration, so whatever follows it
+    // (the other loop, a table or generic step) may start with one iteration's nodes fewer.  Without chained steps an iteration stages four
+    // nodes and the headroom of eight covers two of them.  With chained steps an iteration stages up to ix.chained nodes (5 .. 16): the
+    // headroom covers ONE iteration and what follows a loop looks at the ring first (`recheck`) -- usable slots are worth more than the
+    // look: 48 of 64 instead of 56 cost the lock-step chain a tenth of its speed, and the insertion chain walks at 490 G LF-steps/s with a
+    // headroom of 8 and the look, at 460 G with a headroom of 14 without it.
+    const bool recheck = ix.chained != 0;
+    const uint32_t headroom = max(8u, ix.chained);
     bool full_blocks = a.packed_blocks == 0;    // wave-uniform
     uint32_t catch_credit = 2, catch_pause = 0, catch_backoff = 8;   // wave-uniform: see CATCH-UP below
     while (__ballot(rec != 0) != 0) {
         const uint32_t drained = lds_peek(my_drained);
-        if (__ballot(sink.wr - drained > ring_mask + 1 - 8) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
+        if (__ballot(sink.wr - drained > ring_mask + 1 - headroom) != 0) { __builtin_amdgcn_s_sleep(2); continue; }   // ring full: let the helper catch up
         // all lanes on one record: scalar descriptor fetch; otherwise every lane fetches its own
         // (the uniform loop finds out by itself, but only after it has issued a round of loads for nothing: in graphs whose rows do
         // not move in lock-step the waves are mixed at almost every entry)
@@ -467,7 +475,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             if (!together && --catch_credit == 0) { catch_pause = catch_backoff; catch_backoff = min(2 * catch_backoff, 256u); catch_credit = 1; }
             // the single steps have used the slack the loops count on (they are entered with at least eight free slots and push four
             // per iteration before they look again): back to the top, which waits for the helper if the ring is that full
-            if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - 8) != 0) continue;
+            if (__ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - headroom) != 0) continue;
         } else if (catch_pause != 0) catch_pause--;
         const uint32_t wr_entry = sink.wr;
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
@@ -477,9 +485,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         uint32_t slow_exit = 2;
         if (a.uniform_loop && together) {
             // on the packed half-blocks until the wave meets a record they cannot count (reason 3), on the full-width blocks from then on
-            if (!full_blocks) slow_exit = walk2_uniform_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+            if (!full_blocks) slow_exit = walk2_uniform_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom);
             if (slow_exit == 3) full_blocks = true;
-            if (full_blocks) slow_exit = walk2_uniform_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+            if (full_blocks) slow_exit = walk2_uniform_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom);
         }
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         const uint32_t wr1 = sink.wr;
@@ -495,11 +503,14 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             else if (--catch_credit == 0) { catch_pause = catch_backoff; catch_backoff = min(2 * catch_backoff, 256u); catch_credit = 1; }
         }
         const bool mixed = slow_exit == 2;
-        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr)
-                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr);
+        // (chained steps: the loop may have left with less than the headroom free -- back to the top, which waits for the helper)
+        if (recheck && slow_exit != 0 && __ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - headroom) != 0) continue;
+        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom)
+                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom);
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif
+        if (recheck && mixed && slow_exit != 0 && __ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - headroom) != 0) continue;   // (the gather loop has run)
         if (slow_exit) {
             const uint4 here = ix.desc2[8 * static_cast<uint64_t>(rec)];
             bool generic = rec != 0 && (here.z & DESC2_SLOW) != 0;   // lanes on a slow record
@@ -520,7 +531,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 // sixteen free slots (the loops above leave with as few as four).  Nodes past the end of the segment are staged like
                 // all others and never written (the row writers stop at the length of the row piece they serve).
                 const bool deep = ix.wtables_deep != nullptr && ring_mask + 1 >= 64;
-                const uint32_t table_slack = deep ? 16u : 8u;
+                const uint32_t table_slack = deep ? 16u : headroom;
                 while (__ballot(in_table) != 0) {
                     if (deep && __ballot(in_table && sink.wr - lds_peek(my_drained) > ring_mask + 1 - table_slack) != 0) { __builtin_amdgcn_s_sleep(2); continue; }
                     if (in_table && deep) {

@@ -136,6 +136,13 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_two(DeviceIndex ix, WalkArgs 
     // SGPR base + 32-bit byte offsets while both arrays are below 4 GiB, 64-bit addresses otherwise
     const bool narrow = !a.wide_addresses && ix.n_records * 128 <= 0xFFFFFFFFull && ix.n_blocks * 32 <= 0xFFFFFFFFull;
     while (__ballot(rec != 0) != 0) {
+        if (ix.chained) {
+            // chained steps (up to sixteen nodes per iteration) are known to k_walk_direct's loops and to the plain C++ step; this kernel --
+            // the pool output for indexes without sequence lengths -- takes the latter where an index has them
+            if (rec != 0) two_step(ix, sink, rec, offset, bb);
+            while (sink.needs_flush()) sink.flush16(a);
+            continue;
+        }
         const uint32_t slow_exit = walk2_hot_loop(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, sink.flushed, narrow, 0xFFFFFFFFu, RING2 - 1, WAVE, rec, offset, bb, sink.wr);
         if (slow_exit) {
             const bool slow = rec != 0 && (ix.desc2[8 * static_cast<uint64_t>(rec)].z & DESC2_SLOW) != 0;

@@ -101,15 +101,17 @@ struct gbwt_synth {
         if (alleles == 2) { if (a) bits[s * row_words + (h >> 6)] |= uint64_t(1) << (h & 63); }
         else choices[s * haplotypes + h] = static_cast<uint16_t>(a);
     }
-    // node ids of site s, ascending: the `chop` pieces of the anchor (the last one branches), the first pieces of the A alleles, then the
-    // tails: the remaining pieces of allele 0 (chop - 1), of allele 1 (chop * (1 + extra) - 1 where it is an insertion), of allele 2, ...
+    // node ids of site s, ascending: the `chop` pieces of the anchor (the last one branches), then allele by allele its pieces -- the first
+    // one and its tails: chop - 1 for allele 0, chop * (1 + extra) - 1 for the others (an insertion site uses all of them) -- so that the
+    // pieces of every logical node have consecutive ids, as the nodes of a chopped GFA segment have
     inline uint64_t tails_max(uint32_t a) const { return a == 0 ? chop - 1 : chop * (1 + extra) - 1; }
     inline uint64_t tails_before(uint32_t a) const { return a == 0 ? 0 : (chop - 1) + (a - 1) * (chop * (1 + extra) - 1); }
     inline uint64_t stride() const { return chop + alleles + tails_before(static_cast<uint32_t>(alleles)); }
     inline uint64_t anchor_first(uint64_t s) const { return s * stride() + 1; }
     inline uint64_t anchor_last(uint64_t s) const { return s * stride() + chop; }
-    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * stride() + chop + 1 + a; }
-    inline uint64_t tail_id(uint64_t s, uint32_t a, uint64_t e) const { return s * stride() + chop + 1 + alleles + tails_before(a) + e; }
+    inline uint64_t allele_slot(uint32_t a) const { return chop + a + tails_before(a); }            // slot of the first piece within the site (slot k <-> id s * stride + k + 1)
+    inline uint64_t allele_id(uint64_t s, uint32_t a) const { return s * stride() + allele_slot(a) + 1; }
+    inline uint64_t tail_id(uint64_t s, uint32_t a, uint64_t e) const { return allele_id(s, a) + 1 + e; }
     inline uint64_t extra_at(uint64_t s) const { return s % indel_every == 0 ? extra : 0; }
     inline uint64_t tails_at(uint64_t s, uint32_t a) const { return a == 0 ? chop - 1 : chop * (1 + extra_at(s)) - 1; }   // pieces behind the first one
     inline uint64_t last_id(uint64_t s, uint32_t a) const { const uint64_t t = tails_at(s, a); return t == 0 ? allele_id(s, a) : tail_id(s, a, t - 1); }
@@ -243,7 +245,7 @@ void forward_sweep(const gbwt_synth &g, Pool &pool) {
         // allele a: first piece, then its tails; the last piece has one edge to the next anchor (or the ENDMARKER at the last site) --
         // the next anchor's visits are ordered by predecessor = last piece of the allele, ascending with the allele
         for (uint32_t a = 0; a < A; a++) {
-            const uint64_t tails = st.cnt[a] ? g.tails_at(s, a) : 0, first_slot = base + K + a, tail_slot = base + K + A + g.tails_before(a);
+            const uint64_t tails = st.cnt[a] ? g.tails_at(s, a) : 0, first_slot = base + g.allele_slot(a), tail_slot = first_slot + 1;
             for (uint64_t e = tails; e < g.tails_max(a); e++) pool.empty(tail_slot + e);          // tails this site does not use
             if (!st.cnt[a]) { pool.empty(first_slot); continue; }
             const uint64_t out = s + 1 < S ? 2 * g.anchor_first(s + 1) : 0, out_offset = s + 1 < S ? before[a] : 0;
@@ -302,7 +304,7 @@ void reverse_sweep(const gbwt_synth &g, Pool &pool) {
         // alleles, reverse: the first piece has one edge to the reverse last piece of this site's anchor, every tail one back towards it
         uint64_t before = 0;
         for (uint32_t a = 0; a < A; a++) {
-            const uint64_t tails = st.cnt[a] ? g.tails_at(s, a) : 0, first_slot = base + K + a, tail_slot = base + K + A + g.tails_before(a);
+            const uint64_t tails = st.cnt[a] ? g.tails_at(s, a) : 0, first_slot = base + g.allele_slot(a), tail_slot = first_slot + 1;
             for (uint64_t e = tails; e < g.tails_max(a); e++) pool.empty(tail_slot + e);
             if (!st.cnt[a]) { pool.empty(first_slot); continue; }
             unary(first_slot, 2 * g.anchor_last(s) + 1, before, st.cnt[a]);
@@ -396,11 +398,11 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
         for (uint64_t k = 0; k < W; k++) {
             if (s * W + k + 1 > g.last_id(S - 1, top)) break;  // ids past the largest visited node
             bool exists = k < K;                                     // anchor pieces
-            if (!exists && k < K + A) exists = st.cnt[k - K] != 0;   // first pieces of the alleles
-            if (!exists && k >= K + A) {                             // tails: which allele, which piece
-                uint32_t a = 0;
-                while (a + 1 < A && k - K - A >= g.tails_before(a + 1)) a++;
-                exists = st.cnt[a] != 0 && k - K - A - g.tails_before(a) < g.tails_at(s, a);
+            if (!exists) {                                           // which allele, which piece (0 = the first one)
+                const uint64_t q = k - K, wide = K * (1 + g.extra);
+                const uint32_t a = q < K ? 0u : static_cast<uint32_t>(1 + (q - K) / wide);
+                const uint64_t piece = q < K ? q : (q - K) % wide;
+                exists = a < A && st.cnt[a] != 0 && piece <= g.tails_at(s, a);
             }
             if (exists) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
             ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());

@@ -592,10 +592,14 @@ def test_walk_loop_variants(monkeypatch, env):
             assert np.array_equal(dev.copy_path(h), s.path(h))
 
 
-@pytest.mark.parametrize("chop,extra,every", [(3, 0, 1), (4, 1, 2), (2, 2, 1)])
-def test_chopped_chain_bit_exact(tmp_path, chop, extra, every):
+@pytest.mark.parametrize("chains", ["6", "0", "1", "3"])
+@pytest.mark.parametrize("chop,extra,every", [(3, 0, 1), (4, 1, 2), (2, 2, 1), (9, 5, 3), (1, 7, 1)])
+def test_chopped_chain_bit_exact(tmp_path, monkeypatch, chop, extra, every, chains):
     """Every node a chain of `chop` nodes with consecutive ids -- most records unary, as in a GBZ built from a GFA with long
-    segments -- with and without insertions: forward and reverse sequences and W-lines against the oracle."""
+    segments -- with and without insertions: forward and reverse sequences and W-lines against the oracle.  GBWT_HIP_CHAINS: steps
+    that run through up to that many more unary records with consecutive ids (k_link_desc2; 0 = fused pairs only, 6 = the default);
+    chains longer than the limit are taken in several steps, reverse sequences walk them with descending ids."""
+    monkeypatch.setenv("GBWT_HIP_CHAINS", chains)
     s = S.Synth.chain(sites=1200, haplotypes=500, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=41, extra=extra, indel_every=every, chop=chop)
     path = tmp_path / "chopped.gbz"
     s.save(str(path), as_gbz=True)
@@ -927,6 +931,8 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "40", "GBWT_HIP_SERIAL_SAMPLES": "1"},   # ... both in one walk (samples every 40 nodes of each sequence)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CHECKPOINT_CAP": "5"},   # checkpoint sampling with hops of at most 5 + 3 nodes: many rounds of orphans
                 {"GBWT_HIP_SAMPLE_INTERVAL": "2048", "GBWT_HIP_CHECKPOINT_CAP": "100000"},   # ... with hardly any checkpoint: whole sequences in one hop
+                {"GBWT_HIP_SAMPLE_INTERVAL": "90", "GBWT_HIP_CHAINS": "0"},        # no chained steps: fused pairs only
+                {"GBWT_HIP_SAMPLE_INTERVAL": "19", "GBWT_HIP_CHAINS": "2", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "200", "GBWT_HIP_CATCH_UP": "0"},     # mixed waves go to the gather loop at once (no single steps of the lanes behind)
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
