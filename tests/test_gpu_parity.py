@@ -592,14 +592,16 @@ def test_walk_loop_variants(monkeypatch, env):
             assert np.array_equal(dev.copy_path(h), s.path(h))
 
 
-@pytest.mark.parametrize("chains", ["6", "0", "1", "3"])
+@pytest.mark.parametrize("chains", ["6", "0", "1", "3", "6 pool"])
 @pytest.mark.parametrize("chop,extra,every", [(3, 0, 1), (4, 1, 2), (2, 2, 1), (9, 5, 3), (1, 7, 1)])
 def test_chopped_chain_bit_exact(tmp_path, monkeypatch, chop, extra, every, chains):
     """Every node a chain of `chop` nodes with consecutive ids -- most records unary, as in a GBZ built from a GFA with long
     segments -- with and without insertions: forward and reverse sequences and W-lines against the oracle.  GBWT_HIP_CHAINS: steps
     that run through up to that many more unary records with consecutive ids (k_link_desc2; 0 = fused pairs only, 6 = the default);
     chains longer than the limit are taken in several steps, reverse sequences walk them with descending ids."""
-    monkeypatch.setenv("GBWT_HIP_CHAINS", chains)
+    monkeypatch.setenv("GBWT_HIP_CHAINS", chains.split()[0])
+    if chains.endswith("pool"):
+        monkeypatch.setenv("GBWT_HIP_DIRECT", "0")       # the pool-output kernel: chained steps in plain C++ (k_walk_two)
     s = S.Synth.chain(sites=1200, haplotypes=500, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=41, extra=extra, indel_every=every, chop=chop)
     path = tmp_path / "chopped.gbz"
     s.save(str(path), as_gbz=True)
