@@ -95,7 +95,13 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     // a checkpoint per `interval` LF steps that end on a record that can be one (an LF step emits one node, two where it is fused with a
     // unary successor: every interval .. 2 x interval nodes), and at most `cap` = interval (+ 3) nodes per hop: most hops end at the cap,
     // the checkpoints are where rows that have drifted apart meet again (profiles/r03_sampling_ab.txt)
-    double gap = 0.5 * interval;                                 // LF steps (that end on a record which can be a checkpoint) per checkpoint
+    // LF steps (that end on a record which can be a checkpoint) per checkpoint.  Where rows move in lock step a hop that ends at the cap
+    // ends on the same record for all of them; where they do not (indexes with chained steps: insertions, chopped nodes) it ends a few
+    // sites apart and the wave that takes up those segments stays mixed to their end -- there most hops should end at a checkpoint, which
+    // every row passes: gap = interval / 8 (insertion chain 486 -> 650 G LF-steps/s, insertions at every 8th site 580 -> 680 G, chopped
+    // nodes with insertions 510 -> 650 G; the lock-step chain is indifferent down to interval / 8 and loses a tenth at interval / 16, but
+    // pays four times the hops of the chase at open: profiles/r03_chained_steps.txt)
+    double gap = (d.chained != 0 ? 0.125 : 0.5) * interval;
     if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_GAP")) gap = std::max(2.0, std::atof(v));
     const double q = std::min(0.5, 1.0 / gap);
     CheckpointWalk w{};

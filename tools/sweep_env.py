@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gbwt_rs_amd as G
 from gbwt_rs_amd import synth as S
 
-OPEN_KNOBS = {"SAMPLE_INTERVAL", "LOOKAHEAD_HOPS", "SEQ_LEN", "TABLE_BYTES", "ORIENTATION_CHECK", "WALK_TABLES", "DEEP_TABLES", "CHAINS", "TWO_PASS_OPEN", "GATHER_LIMIT"}
+OPEN_KNOBS = {"SAMPLE_INTERVAL", "LOOKAHEAD_HOPS", "SEQ_LEN", "TABLE_BYTES", "ORIENTATION_CHECK", "WALK_TABLES", "DEEP_TABLES", "CHAINS", "CHECKPOINT_GAP", "CHECKPOINT_CAP", "TWO_PASS_OPEN", "GATHER_LIMIT"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sites", type=int, default=333334)
