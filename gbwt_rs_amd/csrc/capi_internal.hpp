@@ -228,7 +228,7 @@ struct gbwt_hip_index {
 // index at the same time, each with its own workspace -- include/gbwt_hip.h).  -1 = not set: the library's default for the batch.
 struct ExtractKnobs {
     int direct = 1, segments = 1, both_ends = 1;             // GBWT_HIP_DIRECT / _SEGMENTS / _BOTH_ENDS (0 switches the feature off)
-    int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1;
+    int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
     uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
     unsigned copy_threads = 4;                                // GBWT_HIP_COPY_THREADS
@@ -241,6 +241,7 @@ struct ExtractKnobs {
         k.helper_naps = std::max(-1, num("GBWT_HIP_HELPER_NAPS", -1));
         k.xcd_map = num("GBWT_HIP_XCD_MAP", -1); k.uniform_loop = num("GBWT_HIP_UNIFORM_LOOP", -1); k.packed_blocks = num("GBWT_HIP_PACKED_BLOCKS", -1);
         k.catch_up = num("GBWT_HIP_CATCH_UP", -1);
+        k.headroom = std::min(32, std::max(0, num("GBWT_HIP_HEADROOM", 0)));
         k.row_piece = num("GBWT_HIP_ROW_PIECE", -1); if (k.row_piece != 0 && k.row_piece != 16 && k.row_piece != 32) k.row_piece = -1;
         k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;
         k.debug = static_cast<uint32_t>(num("GBWT_HIP_DEBUG_DRY_ROWS", 0));

@@ -67,6 +67,7 @@ struct WalkArgs {
     uint32_t row_piece;        // segmented extraction: nodes per cooperative row write (16 = 64 bytes, 32 = 128 bytes; 0 = every lane writes its own row)
     uint32_t xcd_map;          // k_walk_direct: XCD x (workgroups x, x + 8, ...) takes the x-th eighth of the walkers
     uint32_t uniform_loop;     // k_walk_direct: try the wave-uniform loop (scalar descriptor fetch) first
+    uint32_t headroom;         // k_walk_direct: ring slots a loop keeps free (0 = by the index: 8, or the longest chained iteration; measurements)
     uint32_t catch_up;         // k_walk_direct: a mixed wave first lets the lanes that are behind take single steps (walk_direct.hip: CATCH-UP)
     uint32_t packed_blocks;    // k_walk_direct: the uniform loop starts on the packed half-blocks (0: on the full-width blocks at once; measurements)
     uint32_t debug;            // measurement switches of k_walk_direct (GBWT_HIP_DEBUG_DRY_ROWS; never set by the library itself; the output is

@@ -417,8 +417,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     // headroom covers ONE iteration and what follows a loop looks at the ring first (`recheck`) -- usable slots are worth more than the
     // look: 48 of 64 instead of 56 cost the lock-step chain a tenth of its speed, and the insertion chain walks at 490 G LF-steps/s with a
     // headroom of 8 and the look, at 460 G with a headroom of 14 without it.
-    const bool recheck = ix.chained != 0;
-    const uint32_t headroom = max(8u, ix.chained);
+    const uint32_t most = ix.chained != 0 ? ix.chained : 4u;               // nodes an iteration can stage
+    bool recheck = ix.chained != 0;
+    uint32_t headroom = max(8u, ix.chained);
+    if (a.headroom != 0) { headroom = max(a.headroom, most); recheck = recheck || headroom < 2 * most; }   // GBWT_HIP_HEADROOM (measurements)
     bool full_blocks = a.packed_blocks == 0;    // wave-uniform
     uint32_t catch_credit = 2, catch_pause = 0, catch_backoff = 8;   // wave-uniform: see CATCH-UP below
     while (__ballot(rec != 0) != 0) {
@@ -436,7 +438,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         // (forward nodes are walked in ascending id order in a graph whose ids are sorted topologically, as vg's are); where the guess
         // is wrong, or the rows really have gone different ways, the attempt fails after four steps, the gather loop takes over as
         // before, and the wave stops trying for a while.
-        if (!together && a.uniform_loop && a.catch_up && catch_pause == 0) {
+        if (!together && a.uniform_loop && a.catch_up && catch_pause == 0 && __ballot(sink.wr - drained > ring_mask + 1 - 8) == 0) {   // (its single steps stage up to eight nodes)
             const uint64_t walking = __ballot(rec != 0);
             for (uint32_t tries = 0; tries < 4 && !together; tries++) {
                 const uint32_t any = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rec), __builtin_ctzll(walking)));
