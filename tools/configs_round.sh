@@ -21,8 +21,8 @@ run tools/sweep.py --sites 3000 --alleles 400 --model iid --configs 0:64:16 --re
 run tools/ragged_bench.py
 run tools/search_bench.py --sites 1100000 --haplotypes 5008
 run tools/gfa_bench.py --sites 20000
-run tools/indel_bench.py --extra 0,1 --indel-every 1,64,4096 --repeats 3
-run tools/indel_bench.py --extra 0 --repeats 3 --chop 4
+run tools/indel_bench.py --extra 0,1,3 --indel-every 1,8,64,4096 --repeats 3
+run tools/indel_bench.py --extra 0,1 --repeats 3 --chop 4
 } > "$out/other_configs.txt"
 # C5 under rocprofv3: kernel stats, then the two traffic passes
 cd /tmp && export TMPDIR=/tmp
