@@ -615,6 +615,55 @@ def test_chopped_chain_bit_exact(tmp_path, monkeypatch, chop, extra, every, chai
     assert dev.path_lines(np.arange(1, 30, dtype=np.uint64), 1) == O.OracleGBZ(str(path)).path_lines(list(range(1, 30)), 1)
 
 
+def _segment_paths(segments, haplotypes, seed):
+    """Paths over GFA-like segments chopped into 1 .. 12 nodes with consecutive ids: a path takes a segment forwards (ids ascending,
+    orientation +) or backwards (ids descending, orientation -), skips some, ends inside some -- runs of unary records in both
+    orientations, longer and shorter than a chained step can hold, with merges and branches in between."""
+    rng = random.Random(seed)
+    first, ids = [], 1
+    for _ in range(segments):
+        n = rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 12])
+        first.append((ids, n))
+        ids += n + rng.choice([0, 0, 1])            # sometimes the next segment's ids run on, sometimes there is a gap
+    paths = []
+    for h in range(haplotypes):
+        p = []
+        for k, (f, n) in enumerate(first):
+            r = rng.random()
+            if r < 0.15:
+                continue
+            if r < 0.25:
+                p.extend(2 * (f + n - 1 - i) + 1 for i in range(n))      # the segment backwards
+            else:
+                p.extend(2 * (f + i) for i in range(n))
+        if h % 11 == 0 and p:
+            p = p[:rng.randint(1, len(p))]
+        paths.append(p)
+    return [p for p in paths if p]
+
+
+@pytest.mark.parametrize("bidirectional", [True, False], ids=["bidirectional", "unidirectional"])
+@pytest.mark.parametrize("env", [{}, {"GBWT_HIP_CHAINS": "6"}, {"GBWT_HIP_CHAINS": "2", "GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_CHAINS": "6", "GBWT_HIP_SAMPLE_INTERVAL": "0"},
+                                 {"GBWT_HIP_CHAINS": "5", "GBWT_HIP_UNIFORM_LOOP": "0", "GBWT_HIP_SAMPLE_INTERVAL": "17"},
+                                 {"GBWT_HIP_CHAINS": "6", "GBWT_HIP_GATHER_LIMIT": "0", "GBWT_HIP_SAMPLE_INTERVAL": "33"}],
+                         ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
+def test_chained_steps_over_chopped_segments(monkeypatch, env, bidirectional):
+    """Chained steps (k_link_desc2: a step runs through a run of unary records with consecutive ids, forwards with ascending and backwards with
+    descending ids; never through a record with two predecessors in a bidirectional index, anywhere in a unidirectional one) against the oracle:
+    every sequence, forward() from every position, find / extend over the same records (which know nothing of chains)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for seed, (segments, haplotypes) in enumerate([(40, 30), (300, 400), (25, 1200)]):
+        s = S.Synth.from_paths(_segment_paths(segments, haplotypes, 70 + seed), bidirectional=bidirectional)
+        dev, oracle = open_synth(s), oracle_of(s)
+        ids = np.arange(0, s.sequences, dtype=np.uint64)
+        o_off, o_nodes = oracle.extract(ids, threads=4)
+        offsets, nodes = dev.sequences_csr(ids)
+        assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes), (env, seed)
+        if seed == 0:
+            check_all_positions(dev, oracle)
+
+
 @pytest.mark.parametrize("extra,every,sites", [(2, 1, 60000), (3, 64, 150000), (1, 8, 100000), (3, 4096, 150000)])
 def test_indel_chain_scale_properties(extra, every, sites):
     """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix.  Dense
