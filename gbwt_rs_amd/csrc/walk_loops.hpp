@@ -1148,7 +1148,16 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "s_cbranch_scc1 .Lgbwt_walk2u_out_%=\n\t"           /* everyone has parked */ \
         "s_cmp_eq_u64 s[46:47], 0\n\t" \
         "s_cbranch_scc1 .Lgbwt_walk2u_loop_%=\n\t" \
-        "s_branch .Lgbwt_walk2u_out_%=\n\t" \
+        ".Lgbwt_walk2u_full_%=:\n\t"                        /* a ring is full: wait HERE for the helper -- the loads of the next position are out and stay */ \
+        "s_sleep 2\n\t"                                     /* valid; leaving meant a wasted round of loads and another one on the way back in */ \
+        "ds_read_b32 v45, %[drained]\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_sub_u32_e32 v47, v44, v45\n\t" \
+        "v_cmp_lt_u32_e64 s[46:47], %[slack], v47\n\t" \
+        "s_nop 1\n\t" \
+        "s_cmp_eq_u64 s[46:47], 0\n\t" \
+        "s_cbranch_scc0 .Lgbwt_walk2u_full_%=\n\t" \
+        "s_branch .Lgbwt_walk2u_loop_%=\n\t" \
         ".Lgbwt_walk2u_chained_%=:\n\t"                     /* the same with the nodes between; v62 = a */ \
         "v_mov_b32_e32 v82, s83\n\t" \
         "v_mov_b32_e32 v86, s84\n\t" \
