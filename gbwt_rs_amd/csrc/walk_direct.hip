@@ -507,8 +507,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const bool mixed = slow_exit == 2;
         // (chained steps: the loop may have left with less than the headroom free -- back to the top, which waits for the helper)
         if (recheck && slow_exit != 0 && __ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - headroom) != 0) continue;
-        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom)
-                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom);
+        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)))
+                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)));
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif

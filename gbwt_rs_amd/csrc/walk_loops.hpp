@@ -618,7 +618,7 @@ __device__ __forceinline__ uint32_t walk2_hot_loop(const uint4 *desc2, const uin
 // to walk2_gather_loop_full).
 __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const uint4 *gblocks, uint32_t alphabet_offset, uint32_t ring_base,
                                                       uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
-                                                      uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8) {
+                                                      uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8, uint32_t drained_addr = 0) {
 #ifdef GBWT_HIP_CXX_LOOP
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
     __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
@@ -788,7 +788,15 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
         "s_cmp_eq_u64 s[42:43], 0\n\t" \
         "s_cbranch_scc1 .Lgbwt_gather_out_%=\n\t" \
         "s_cbranch_vccz .Lgbwt_gather_loop_%=\n\t" \
-        "s_branch .Lgbwt_gather_out_%=\n\t" \
+        ".Lgbwt_gather_full_%=:\n\t"                          /* over the limit the loop was entered with: how far has the helper come?  A ring that */ \
+        "ds_read_b32 v45, %[drained]\n\t"                    /* is still full is waited for here (leaving costs the way out and back in) */ \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_add_u32_e32 v45, %[room], v45\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v45, v44\n\t" \
+        "s_nop 1\n\t" \
+        "s_cbranch_vccz .Lgbwt_gather_loop_%=\n\t" \
+        "s_sleep 2\n\t" \
+        "s_branch .Lgbwt_gather_full_%=\n\t" \
         ".Lgbwt_gather_slow_%=:\n\t" \
         "s_mov_b32 %[reason], 1\n\t" \
         ".Lgbwt_gather_out_%=:\n\t" \
@@ -799,6 +807,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
         "v_mov_b32_e32 %[wr], v44\n\t" \
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
         : [desc2] "s"(desc2), [gblocks] "s"(gblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
+          [drained] "v"(drained_addr), [room] "s"(ring_mask + 1 - headroom), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", "s80", "s81", \
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", \
@@ -817,7 +826,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
 // record whose counts do not fit the packed half-blocks (2^21 positions or more).  Registers v40-v87.
 __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
                                                       uint32_t mail_slot, uint32_t flushed, bool narrow, uint32_t quota, uint32_t ring_mask, uint32_t ring_stride,
-                                                      uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8) {
+                                                      uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8, uint32_t drained_addr = 0) {
 #ifdef GBWT_HIP_CXX_LOOP
     __attribute__((address_space(3))) uint32_t *ring = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)ring_base;
     __attribute__((address_space(3))) uint32_t *mail = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)mail_slot;
@@ -991,7 +1000,15 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "s_cmp_eq_u64 s[42:43], 0\n\t" \
         "s_cbranch_scc1 .Lgbwt_gatherf_out_%=\n\t" \
         "s_cbranch_vccz .Lgbwt_gatherf_loop_%=\n\t" \
-        "s_branch .Lgbwt_gatherf_out_%=\n\t" \
+        ".Lgbwt_gatherf_full_%=:\n\t"                          /* over the limit the loop was entered with: how far has the helper come?  A ring that */ \
+        "ds_read_b32 v45, %[drained]\n\t"                    /* is still full is waited for here (leaving costs the way out and back in) */ \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_add_u32_e32 v45, %[room], v45\n\t" \
+        "v_cmp_lt_u32_e32 vcc, v45, v44\n\t" \
+        "s_nop 1\n\t" \
+        "s_cbranch_vccz .Lgbwt_gatherf_loop_%=\n\t" \
+        "s_sleep 2\n\t" \
+        "s_branch .Lgbwt_gatherf_full_%=\n\t" \
         ".Lgbwt_gatherf_slow_%=:\n\t" \
         "s_mov_b32 %[reason], 1\n\t" \
         ".Lgbwt_gatherf_out_%=:\n\t" \
@@ -1002,6 +1019,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "v_mov_b32_e32 %[wr], v44\n\t" \
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
         : [desc2] "s"(desc2), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [limit] "v"(limit), [quota] "v"(quota), [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), \
+          [drained] "v"(drained_addr), [room] "s"(ring_mask + 1 - headroom), \
           "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s42", "s43", "s44", "s45", "s46", "s47", "s80", "s81", \
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", \
