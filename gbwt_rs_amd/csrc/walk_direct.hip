@@ -507,8 +507,14 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const bool mixed = slow_exit == 2;
         // (chained steps: the loop may have left with less than the headroom free -- back to the top, which waits for the helper)
         if (recheck && slow_exit != 0 && __ballot(sink.wr - lds_peek(my_drained) > ring_mask + 1 - headroom) != 0) continue;
-        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)))
-                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)));
+        // How long the gather loop stays once it has used up the ring slots it was entered with: it can wait for the helper where it stands
+        // (cheaper than the way out and back in), but only out here can a wave that is one step apart be brought together again -- so while
+        // catch-up is being tried the loop comes back as it always did, while catch-up is backing off it stays for as long as the pause
+        // would have lasted, and without catch-up it stays.
+        const uint32_t patience = (a.catch_up && a.uniform_loop) ? 8u * catch_pause : 0x7FFFFFFFu;
+        if (mixed && patience != 0 && catch_pause != 0) catch_pause = 1;      // (the stay replaces the pause: one more outer round, then a new attempt)
+        if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), patience)
+                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), patience);
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif
