@@ -190,6 +190,7 @@ struct CoopRows {
     bool dry;
     bool plain_stores;           // row pieces as ordinary stores instead of non-temporal ones (measurement switch)
     bool skip_reads;             // measurement switch: nothing is read from the ring or stored
+    bool pipelined;              // coop_drain fetches the next group's state under this group's nodes (measurement switch 256 of WalkArgs::debug: off)
 };
 __device__ __forceinline__ uint32_t lds_word(uint32_t byte_address) { return *(const volatile lds_u32_t *)static_cast<uintptr_t>(byte_address); }
 
@@ -254,6 +255,53 @@ __device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane,
     const uint32_t mis = ((st.x >> 2) + st.w) & (PIECE - 1);
     const uint64_t todo = __ballot(pend >= PIECE - mis || (done && pend != 0));
     const uint64_t left = __ballot(pend != 0);
+    if (todo != 0 && c.pipelined && !done && !c.dry && !c.skip_reads && !c.plain_stores) {
+        // The groups one after the other as below, but the count and state of the NEXT group are fetched while this group's nodes are on
+        // their way out of the ring: a visit is two dependent LDS round trips, and sixteen of them in a row are what a round of the helper
+        // takes -- the helper's lag is what the walkers' rings fill up behind (section 3 item 23).  Plain loads, so that the compiler can
+        // count them down (lgkmcnt) instead of waiting for all; rows that are not at a piece boundary take the visit.
+        typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
+        typedef __attribute__((address_space(1))) uint32_t global_u32_t;
+        typedef __attribute__((address_space(1))) u32x4_t global_u32x4_t;
+        const uint32_t p = lane % LPR;
+        uint32_t staged_next = 0;
+        u32x4_t st_next = {0, 0, 0, 0};
+        const bool on0 = (todo & ((uint64_t(1) << ROWS) - 1)) != 0;
+        if (on0) {
+            staged_next = *(const lds_u32_t *)static_cast<uintptr_t>(c.mail + 16 * rows[0] + 12);
+            st_next = *(const lds_u32x4_t *)static_cast<uintptr_t>(c.state + 16 * rows[0]);
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < LPR; g++) {
+            const bool on = ((todo >> (g * ROWS)) & ((uint64_t(1) << ROWS) - 1)) != 0;                       // wave-uniform
+            const uint32_t staged = staged_next;
+            const u32x4_t st = st_next;
+            if (g + 1 < LPR && ((todo >> ((g + 1) * ROWS)) & ((uint64_t(1) << ROWS) - 1)) != 0) {
+                staged_next = *(const lds_u32_t *)static_cast<uintptr_t>(c.mail + 16 * rows[g + 1] + 12);
+                st_next = *(const lds_u32x4_t *)static_cast<uintptr_t>(c.state + 16 * rows[g + 1]);
+            }
+            if (!on) continue;
+            const uint32_t drained = st.w, waiting = staged - drained;
+            const uint32_t off = ((st.x >> 2) + drained) & (PIECE - 1);
+            const bool ready = waiting >= PIECE - off;
+            const bool fast = ready && off == 0 && drained + PIECE <= st.z;
+            if (fast) {
+                const uint32_t col = c.ring + 4 * rows[g], k = drained + 4 * p;
+                u32x4_t out;
+                out.x = *(const lds_u32_t *)static_cast<uintptr_t>(col + __umul24((k + 0) & c.mask, 4 * RING_PITCH));
+                out.y = *(const lds_u32_t *)static_cast<uintptr_t>(col + __umul24((k + 1) & c.mask, 4 * RING_PITCH));
+                out.z = *(const lds_u32_t *)static_cast<uintptr_t>(col + __umul24((k + 2) & c.mask, 4 * RING_PITCH));
+                out.w = *(const lds_u32_t *)static_cast<uintptr_t>(col + __umul24((k + 3) & c.mask, 4 * RING_PITCH));
+                global_u32_t *dst = (global_u32_t *)((static_cast<uint64_t>(st.y) << 32) | st.x) + drained;
+                global_u32x4_t *at = (global_u32x4_t *)dst + p;
+                asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(out) : "memory");
+                if (p == 0) *(volatile lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * rows[g] + 12) = drained + PIECE;   // only after the nodes have left the ring
+            } else if (ready) {
+                coop_visit<LPR>(c, rows[g], p, done);
+            }
+        }
+        return left;
+    }
     if (todo != 0) {
 #pragma unroll
         for (uint32_t g = 0; g < LPR; g++)                           // wave-uniform tests; rows[g] stays in a register
@@ -328,7 +376,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
         const auto lds_address = [](const void *q) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(q)); };
         const CoopRows rows{lds_address(ring_lds), lds_address(mailbox), lds_address(row_state), ring_mask, (a.debug & 1u) != 0, (a.debug & 4u) != 0,
-                            (a.debug & 64u) != 0};
+                            (a.debug & 64u) != 0, (a.debug & 256u) == 0};
         uint32_t mine = lane;                                        // the row this lane watches
         uint32_t served[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // the row this lane serves in group g
         if (piece) {
