@@ -122,6 +122,17 @@ def test_chopped_chain_matches_bruteforce_builder(alleles, model, extra, every, 
     for h, p in enumerate(paths):
         assert sum(p) == s.path_checksum(h)
         assert all(b - a == 2 for a, b in zip(p[:chop], p[1:chop]))           # the anchor's pieces: consecutive ids, forward
+        # ... and so are the pieces of every allele (a chopped GFA segment): a path is made of runs of consecutive ids, one per logical
+        # node -- the anchor (chop pieces), then the allele (chop, or chop * (1 + extra) where it is an insertion) -- or longer where the
+        # ids of an allele happen to run on into the next anchor
+        runs, k = [], 0
+        while k < len(p):
+            j = k + 1
+            while j < len(p) and p[j] - p[j - 1] == 2:
+                j += 1
+            runs.append(j - k)
+            k = j
+        assert all(r % chop == 0 for r in runs) and len(runs) <= 2 * 7
     b = S.Synth.from_paths(paths, bidirectional=True)
     assert bytes(s.data()) == bytes(b.data())
     assert list(s.starts()) == list(b.starts())
