@@ -42,6 +42,11 @@ class OpenTimes(C.Structure):
                 ("checkpoint_rounds", C.c_uint32)]
 
 
+class Memory(C.Structure):
+    _fields_ = [("index_device_bytes", C.c_uint64), ("index_host_bytes", C.c_uint64), ("workspace_device_bytes", C.c_uint64),
+                ("rows_bytes", C.c_uint64), ("text_bytes", C.c_uint64)]
+
+
 class Paths(C.Structure):
     _fields_ = [("d_offsets", C.c_void_p), ("d_nodes", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
 
@@ -61,6 +66,8 @@ SIGNATURES = {
     "gbwt_hip_close": (None, [_p]),
     "gbwt_hip_get_stats": (_int, [_p, C.POINTER(Stats)]),
     "gbwt_hip_get_open_times": (_int, [_p, C.POINTER(OpenTimes)]),
+    "gbwt_hip_memory_usage": (_int, [_p, _p, C.POINTER(Memory)]),
+    "gbwt_hip_last_lines_ms": (_int, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gbwt_hip_workspace_create": (_int, [_p, C.POINTER(_p)]),
     "gbwt_hip_workspace_destroy": (None, [_p]),
     "gbwt_hip_workspace_stream": (_p, [_p]),

@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import BdState, GbwtHipError, Lines, OpenTimes, Paths, Pos, State, Stats, check
+from ._lib import BdState, GbwtHipError, Lines, Memory, OpenTimes, Paths, Pos, State, Stats, check
 
 FORWARD, REVERSE = 0, 1  # support::Orientation, src/support.rs:30-47
 PATHS_DEFAULT, PATHS_PAN_SN, PATHS_REF_ONLY = 0, 1, 2  # gbunzip's PathMode, src/bin/gbunzip.rs:63-76
@@ -132,6 +132,12 @@ class GBWT:
         t = OpenTimes()
         check(self._L.gbwt_hip_get_open_times(self._h, C.byref(t)))
         return {name: getattr(t, name) for name, _ in OpenTimes._fields_}
+
+    def memory_usage(self):
+        """Bytes held by the index (device, host) and by this object's workspace (gbwt_hip_memory_usage): a dict."""
+        m = Memory()
+        check(self._L.gbwt_hip_memory_usage(self._h, self._ws, C.byref(m)))
+        return {name: getattr(m, name) for name, _ in Memory._fields_}
 
     # ---- statistics (src/gbwt.rs:105-175) -----------------------------------------------------
     def len(self):
@@ -345,6 +351,12 @@ class GBZ(GBWT):
         buf = C.create_string_buffer(max(1, total.value))
         check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, buf, total.value, C.byref(total)))
         return buf.raw[: total.value]
+
+    def last_lines_ms(self):
+        """(walk kernel ms, everything behind the walk ms) of the last path_lines / path_lines_device request (HIP events)."""
+        walk, fmt = C.c_float(0), C.c_float(0)
+        check(self._L.gbwt_hip_last_lines_ms(self._ws, C.byref(walk), C.byref(fmt)))
+        return walk.value, fmt.value
 
     def write_gfa(self, path, path_mode=PATHS_DEFAULT):
         """The file `gbunzip -t 1 --paths MODE` writes for this GBZ (src/bin/gbunzip.rs:205-226; PathMode 63-76)."""

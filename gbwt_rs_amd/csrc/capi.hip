@@ -181,7 +181,7 @@ void upload_starts(gbwt_hip_index &ix) {
 void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>> *early_endmarker) {
     OpenTrace trace;
     HostIndex &h = ix.host;
-    if (h.alphabet_size > (uint64_t(1) << 32)) throw InvalidData("alphabet_size > 2^32 is not supported (u32 node ids on device)");
+    if (h.alphabet_size > (uint64_t(1) << 32)) throw Unsupported("alphabet_size > 2^32 is not supported (u32 node ids on device)");
     HIP_CHECK(hipSetDevice(ix.device));
     const uint64_t n_records = h.records();
     const uint64_t data_bytes = ix.stats.data_bytes;       // (fill_stats; the host image's own copy may still be on its way: HostIndex::pending)
@@ -226,8 +226,8 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         uint64_t n_blocks = 1;  // block 0: all zero, read by the records that have no blocks of their own
         uint64_t generic_records = n_records;   // class 0 records (k_build_desc's count, read below)
         if (n_records > 0) {
-            if (n_records >= (uint64_t(1) << 30)) throw InvalidData("more than 2^30 records are not supported");
-            if ((h.size >> RANK_BLOCK_SHIFT) + n_records >= 0xFFFFFFF0ull) throw InvalidData("index too large for 32-bit rank block indices");
+            if (n_records >= (uint64_t(1) << 30)) throw Unsupported("more than 2^30 records are not supported");
+            if ((h.size >> RANK_BLOCK_SHIFT) + n_records >= 0xFFFFFFF0ull) throw Unsupported("index too large for 32-bit rank block indices");
             size_t tb = block_scan_temp_bytes(n_records);
             scan_tmp.reserve(std::max<size_t>(tb, 16));
             launch_block_scan(counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), n_records, scan_tmp.ptr, tb, nullptr);
@@ -358,7 +358,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
     ix.stats.max_record_len = hs[0];
     ix.stats.max_outdegree = hs[1];
     if (hs[2] != 0) throw InvalidData("BWT: record without a readable outdegree");
-    if (hs[0] >= (uint64_t(1) << 32)) throw InvalidData("record longer than 2^32 positions is not supported");
+    if (hs[0] >= (uint64_t(1) << 32)) throw Unsupported("a record with 2^32 or more positions is not supported (u32 offsets on device)");
     d.max_walk = hs[3];
     // the endmarker: record 0 decompressed by the loader (host_index.cpp; the reference's GBWT::load does it on the CPU as well,
     // src/gbwt.rs:413-414) -- a single lane of the GPU took 6 ms for the 10 000 runs of the headline index, the host 0.1
@@ -436,7 +436,8 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
             d.seq_len = ix.seq_len.as<uint32_t>();
             ix.orientation_pairs = want_pairs && !flags[2];
             {   // all sequences of one length?  (haplotypes over one reference frame: the headline's shape)
-                std::vector<uint32_t> lens(h.sequences);
+                std::vector<uint32_t> &lens = ix.host_seq_len;
+                lens.resize(h.sequences);
                 HIP_CHECK(hipMemcpy(lens.data(), ix.seq_len.ptr, h.sequences * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 const auto mm = std::minmax_element(lens.begin(), lens.end());
                 ix.uniform_len = (*mm.first == *mm.second) ? *mm.first : 0u;
@@ -658,6 +659,35 @@ gbwt_hip_status gbwt_hip_device_memory(int device, uint64_t *free_bytes, uint64_
     GBWT_HIP_GUARD_END
 }
 
+gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hip_workspace *ws, gbwt_hip_memory *out) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!index || !out || (ws && ws->index != index)) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    *out = gbwt_hip_memory{};
+    const auto sum = [](std::initializer_list<const DeviceBuffer *> buffers) { uint64_t b = 0; for (const DeviceBuffer *q : buffers) b += q->bytes; return b; };
+    const gbwt_hip_index &ix = *index;
+    out->index_device_bytes = sum({&ix.data, &ix.starts, &ix.endmarker, &ix.desc, &ix.desc_raw, &ix.block_base, &ix.blocks, &ix.desc2, &ix.gblocks, &ix.tables,
+                                   &ix.wtables, &ix.wtables_deep, &ix.seq_len, &ix.samples, &ix.sample_base, &ix.label_len, &ix.seg_of, &ix.seg_start,
+                                   &ix.seg_name_off, &ix.seg_names, &ix.seg_seq_len, &ix.node_real, &ix.line_prefix[0], &ix.line_prefix[1], &ix.line_prefix[2],
+                                   &ix.line_prefix_off[0], &ix.line_prefix_off[1], &ix.line_prefix_off[2], &ix.line_fragment});
+    // (the full-width two-step blocks: at open, or by the first request that needs them -- the atomic says when they are there)
+    if (ix.dev.cblocks != nullptr || ix.lazy_cblocks.load(std::memory_order_acquire) != nullptr) out->index_device_bytes += ix.cblocks.bytes;
+    const HostIndex &h = ix.host;
+    out->index_host_bytes = h.data.size() + h.starts.size() * sizeof(uint64_t) + h.da_samples.size() * sizeof(uint64_t) + h.path_names.size() * sizeof(PathName) +
+                            h.sample_names.bytes.size() + h.contig_names.bytes.size() + h.sequences_labels.bytes.size() + h.sequences_labels.offsets.size() * sizeof(uint64_t) +
+                            h.segment_names.bytes.size() + h.segment_names.offsets.size() * sizeof(uint64_t) + h.segment_starts.size() * sizeof(uint64_t) +
+                            ix.sample_counts.size() * sizeof(uint32_t);
+    if (ws) {
+        out->workspace_device_bytes = sum({&ws->seq_ids, &ws->lengths, &ws->offsets, &ws->head, &ws->pool, &ws->next, &ws->counters, &ws->nodes, &ws->scan_temp,
+                                           &ws->order_keys, &ws->order_rows, &ws->order_counts, &ws->order_level, &ws->order_temp, &ws->in_a, &ws->in_b, &ws->out_a,
+                                           &ws->out_valid, &ws->follow_off, &ws->gfa_a, &ws->gfa_b, &ws->gfa_c, &ws->gfa_text, &ws->gfa_text2, &ws->gfa_valid, &ws->gfa_chunk_first,
+                                           &ws->gfa_chunks});
+        out->rows_bytes = ws->nodes.bytes;
+        out->text_bytes = ws->gfa_text.bytes + ws->gfa_text2.bytes;
+    }
+    return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
+}
+
 gbwt_hip_status gbwt_hip_get_open_times(const gbwt_hip_index *index, gbwt_hip_open_times *out) {
     GBWT_HIP_GUARD_BEGIN
     if (!index || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
@@ -803,6 +833,9 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             const DeviceIndex dev = a.packed_blocks ? ix->dev : with_cblocks(ix);
             a.row_piece = knobs.row_piece >= 0 ? static_cast<uint32_t>(knobs.row_piece) : 32u;
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
+            // GBWT_HIP_HEADROOM: the walkers wait while more than ring - headroom nodes are pending, the cooperative helper moves whole pieces only:
+            // a headroom above ring - piece would leave a row with fewer than a piece pending and its walker waiting for ever
+            if (a.headroom > a.ring_slots - std::max(a.row_piece, 1u)) a.headroom = a.ring_slots - std::max(a.row_piece, 1u);
             a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
             a.both_ends = (ix->orientation_pairs && knobs.both_ends != 0) ? 1u : 0u;
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
@@ -870,7 +903,9 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
     GBWT_HIP_GUARD_END
 }
 
-namespace {
+}  // extern "C"
+
+namespace gbwt_hip {
 
 // Device -> pageable host memory for the large results (13 GB of node ids on the headline index).  A plain hipMemcpy
 // stages through one pinned buffer on one thread and also pays the first-touch page faults of a fresh destination on
@@ -906,7 +941,9 @@ void copy_to_host(int device, void *dst, const void *src, size_t bytes, unsigned
     if (failed) HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));   // whatever went wrong: the plain way, which reports it
 }
 
-}  // namespace
+}  // namespace gbwt_hip
+
+extern "C" {
 
 gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                  uint64_t *out_offsets, uint32_t *out_nodes, uint64_t capacity, uint64_t *total) {

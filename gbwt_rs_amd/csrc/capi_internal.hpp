@@ -51,9 +51,10 @@ struct VmmPolicy { size_t chunk = size_t(2048) << 20, min = size_t(4) << 30; uns
 inline VmmPolicy vmm_policy_from_env() {
     VmmPolicy p;
     if (const char *v = std::getenv("GBWT_HIP_VMM")) {
-        unsigned long chunk = 0, spread = 0, min = 4096;
-        const int got = std::sscanf(v, "%lu:%lu:%lu", &chunk, &spread, &min);
+        unsigned long chunk = 0, spread = 0, min = 4096, after = 2;
+        const int got = std::sscanf(v, "%lu:%lu:%lu:%lu", &chunk, &spread, &min, &after);
         if (got >= 1) { p.chunk = chunk << 20; p.spread = static_cast<unsigned>(spread); p.min = min << 20; }
+        if (got >= 4) p.after = static_cast<unsigned>(after);
     }
     return p;
 }
@@ -175,6 +176,8 @@ inline gbwt_hip_status status_of_current_exception() noexcept {
         return fail(GBWT_HIP_INVALID_DATA, e.what());
     } catch (const IoError &e) {
         return fail(GBWT_HIP_IO_ERROR, e.what());
+    } catch (const Unsupported &e) {
+        return fail(GBWT_HIP_UNSUPPORTED, e.what());
     } catch (const HipError &e) {
         return status_of(e);
     } catch (const std::bad_alloc &) {
@@ -187,6 +190,9 @@ inline gbwt_hip_status status_of_current_exception() noexcept {
         return fail(GBWT_HIP_DEVICE_ERROR, "unexpected exception");
     }
 }
+// Device -> pageable host memory on `threads` threads, each with a pinned staging buffer and a stream of its own (capi.hip)
+void copy_to_host(int device, void *dst, const void *src, size_t bytes, unsigned threads);
+
 #define GBWT_HIP_GUARD_BEGIN try {
 #define GBWT_HIP_GUARD_END } catch (...) { return gbwt_hip::status_of_current_exception(); }
 
@@ -205,6 +211,14 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceBuffer seg_names;     // segment names, concatenated
     gbwt_hip::DeviceBuffer seg_seq_len;   // u64 per segment: length of the segment's sequence
     gbwt_hip::DeviceBuffer node_real;     // u8 per node id < mapping_len: GBZ::has_node
+    // GFA line headers, one table per line mode (0 = P-line named by the contig, 1 = W-line, 2 = P-line with the PanSN name): for every path of
+    // the metadata the bytes of its line up to the node tokens -- for a W-line up to and including "<fragment>\t"; the end coordinate
+    // (fragment + summed label lengths, path_to_w_line, src/bin/gbunzip.rs:532-540) is only known once the path has been walked and is
+    // appended by the device.  Built once at open (gfa.hip: upload_label_lengths), so that a request formats its lines without the host.
+    gbwt_hip::DeviceBuffer line_prefix[3], line_prefix_off[3], line_fragment;
+    std::vector<char> host_line_prefix[3];
+    std::vector<uint64_t> host_line_prefix_off[3];
+    std::vector<uint32_t> host_seq_len;   // host copy of seq_len (empty when the lengths are not known): sizes byte-bounded batches of a whole-file write
     gbwt_hip::DeviceIndex dev{};
     // The full-width two-step blocks (cblocks, as large as gblocks: 1.7 GB on the headline index) are only read by the loops for records
     // whose counts do not fit the packed half-blocks, by the pool-output kernel and by the serial walks at open: built at open when one of
@@ -256,24 +270,26 @@ struct gbwt_hip_workspace {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t qev[2] = {nullptr, nullptr};   // around the kernel(s) of the last navigation / search call
-    bool timed = false, query_timed = false;
+    hipEvent_t gev[2] = {nullptr, nullptr};   // around the formatting of the last GFA lines request (behind its walk)
+    bool timed = false, query_timed = false, lines_timed = false;
     uint64_t last_n = 0, last_total = 0;   // shape of the last device-resident extraction
     uint32_t walk_mode = gbwt_hip::WALK_TWO_STEP, paths_per_wave = 0, small_record = 16;   // paths_per_wave 0 = automatic
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     gbwt_hip::DeviceBuffer order_keys, order_rows, order_counts, order_level, order_temp;   // walker order of a segmented extraction
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid, follow_off;  // search staging
-    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_valid, gfa_chunk_first, gfa_chunks;  // GFA line formatting
+    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_text2, gfa_valid, gfa_chunk_first, gfa_chunks;  // GFA line formatting (gfa_text2: the second text buffer of a pipelined whole-file write)
     // What the device-resident results answer.  The C idiom "size query, then the same call with a buffer" (gbwt_hip_extract,
     // _follow, _path_lines) must not compute twice: a call that repeats the request of the results still in the workspace
     // copies them out.  Keys are host copies of the ids / states of the request.
     bool extract_cached = false, follow_cached = false, lines_cached = false;
     std::vector<uint64_t> extract_key, lines_key;
     std::vector<uint8_t> follow_key;
-    int follow_backward = 0, lines_mode = 0;
+    int follow_backward = 0, lines_mode = 0, lines_slot = 0;
     uint64_t follow_total = 0, lines_total = 0;
     ~gbwt_hip_workspace() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : qev) if (e) (void)hipEventDestroy(e);
+        for (auto &e : gev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };

@@ -16,9 +16,12 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,6 +40,22 @@ __device__ __forceinline__ uint32_t decimal_digits(uint32_t v) {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) +
            (v >= 100000000u) + (v >= 1000000000u);
 }
+
+__device__ __forceinline__ uint32_t decimal_digits64(uint64_t v) {
+    uint32_t d = 1;
+    while (v >= 10u) { v /= 10u; d++; }
+    return d;
+}
+
+// The headers of one line mode as the kernels see them (gbwt_hip_index::line_prefix): everything in front of the node tokens, per path of
+// the metadata.  W-lines (fragment != null) end in "<fragment>\t<fragment + summed label lengths>\t" (path_to_w_line,
+// src/bin/gbunzip.rs:532-540): the table holds the line up to and including "<fragment>\t", the end coordinate and its tab are
+// appended where the line is formatted.
+struct LineHeaders {
+    const uint8_t *prefix;
+    const uint64_t *prefix_off;    // [paths + 1]
+    const uint32_t *fragment;      // [paths], or null: no end coordinate (P-lines)
+};
 
 // Lines are formatted in chunks of LINE_CHUNK path positions, so that the work is as parallel for ninety haplotypes of two
 // million nodes as it is for fifty thousand short walks (one workgroup per LINE had 0.6 G nodes/s on the former, 50 on the
@@ -72,12 +91,15 @@ __device__ __forceinline__ ChunkRange chunk_range(const uint64_t *chunk_first, u
 
 // One wave per chunk: text bytes of its node tokens and the summed label lengths (W-line end coordinate,
 // src/bin/gbunzip.rs:532-536: sequence_len(node).unwrap_or(0)).
-__global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, uint64_t chunks,
+// The number of chunks of a request is known on the device only (chunk_first[n]); the host launches for its upper bound
+// (total / LINE_CHUNK + n) and the chunks past the end count nothing, so that the scans over the bound are those over the chunks.
+__global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, uint64_t chunks_cap,
                                                       const uint32_t *label_len, uint64_t n_labels, uint32_t first_node, int p_lines, uint64_t *chunk_text,
                                                       uint64_t *chunk_seq) {
     const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
-    if (c >= chunks) return;
+    if (c >= chunks_cap) return;
+    if (c >= chunk_first[n]) { if (lane == 0) { chunk_text[c] = 0; chunk_seq[c] = 0; } return; }
     const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
     uint64_t text = 0, labels = 0;
     for (uint64_t k0 = r.lo + 4 * lane; k0 < r.hi; k0 += 4 * WAVE) {   // four consecutive positions per lane: the loads and the label gathers of a round overlap
@@ -96,16 +118,38 @@ __global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, co
     if (lane == 0) { chunk_text[c] = text; chunk_seq[c] = labels; }
 }
 
-// Per path, from the scans over the chunks: text bytes of the tokens, summed label lengths, and -- translation graphs --
-// whether every position fitted a whole segment (bad_before = scan of the chunks' bad flags, or null).
-__global__ void __launch_bounds__(256) k_path_totals(const uint64_t *chunk_first, uint64_t n, const uint64_t *text_before, const uint64_t *seq_before,
-                                                      const uint64_t *bad_before, uint64_t *text_len, uint64_t *seq_len, uint8_t *valid) {
+// Per path, from the scans over the chunks: the length of its line -- header (prefix from the table + for W-lines the end coordinate and
+// its tab), node tokens, trailer -- the end coordinate itself, and for translation graphs whether every position fitted a whole segment
+// (bad_before = scan of the chunks' bad flags, or null).  A flagged line gets length 0 here: the host replays it and puts its length in.
+__global__ void __launch_bounds__(256) k_line_sizes(const uint64_t *seq_ids, const uint64_t *chunk_first, uint64_t n, const uint64_t *text_before,
+                                                     const uint64_t *seq_before, const uint64_t *bad_before, LineHeaders hdr, int p_lines, uint64_t *line_len,
+                                                     uint64_t *line_end, uint8_t *valid) {
     const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (p >= n) return;
     const uint64_t a = chunk_first[p], b = chunk_first[p + 1];
-    text_len[p] = text_before[b] - text_before[a];
-    seq_len[p] = seq_before[b] - seq_before[a];
-    if (valid) valid[p] = bad_before[b] == bad_before[a] ? 1 : 0;
+    const uint64_t text = text_before[b] - text_before[a], labels = seq_before[b] - seq_before[a];
+    const uint64_t path = seq_ids[p] >> 1;                              // the forward sequence of path p is sequence 2p (support::encode_path)
+    uint64_t header = hdr.prefix_off[path + 1] - hdr.prefix_off[path], end = 0;
+    if (hdr.fragment) { end = hdr.fragment[path] + labels; header += decimal_digits64(end) + 1; }
+    const bool ok = bad_before == nullptr || bad_before[b] == bad_before[a];
+    line_end[p] = end;
+    line_len[p] = ok ? header + text + (p_lines ? 3u : 1u) : 0u;        // "\t*\n" / "\n"
+    if (valid) valid[p] = ok ? 1 : 0;
+}
+
+// The header of a line, written by the workgroup of its first chunk; every chunk needs its length.
+__device__ __forceinline__ uint64_t line_header(const LineHeaders &hdr, uint64_t path, const uint64_t *line_end, uint64_t row, bool write, uint8_t *line, uint32_t t,
+                                                uint32_t threads) {
+    const uint64_t h0 = hdr.prefix_off[path], plen = hdr.prefix_off[path + 1] - h0;
+    if (write) for (uint64_t k = t; k < plen; k += threads) line[k] = hdr.prefix[h0 + k];
+    if (hdr.fragment == nullptr) return plen;
+    uint64_t end = line_end[row];
+    const uint32_t digits = decimal_digits64(end);
+    if (write && t == 0) {
+        for (uint32_t d = 0; d < digits; d++) { line[plen + digits - 1 - d] = static_cast<uint8_t>('0' + end % 10u); end /= 10u; }
+        line[plen + digits] = '\t';
+    }
+    return plen + digits + 1;
 }
 
 // One workgroup per chunk: the header (first chunk of a line), the node tokens of the chunk, the trailer (last chunk).
@@ -115,17 +159,17 @@ __global__ void __launch_bounds__(256) k_path_totals(const uint64_t *chunk_first
 constexpr uint32_t TOKEN_MAX = 12;   // ',' + ten digits + '+' (P-lines); '>' + ten digits (W-lines)
 constexpr uint32_t PER_THREAD = 4;   // consecutive positions per thread and batch (one scan and two barriers per 1 024 positions)
 __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
-                                                                   const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint8_t *headers,
-                                                                   const uint64_t *header_off, uint8_t *out) {
+                                                                   const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint64_t *seq_ids,
+                                                                   LineHeaders hdr, const uint64_t *line_end, uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
     __shared__ __attribute__((aligned(16))) uint8_t stage[FORMAT_THREADS * PER_THREAD * TOKEN_MAX + 32];
+    if (blockIdx.x >= chunk_first[n]) return;                           // (launched for the host's upper bound of the chunk count)
     const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
     const uint32_t t = threadIdx.x;
     uint8_t *line = out + line_start[r.path];
-    const uint64_t h0 = header_off[r.path], h1 = header_off[r.path + 1];
-    if (r.first) for (uint64_t k = t; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
-    uint64_t cursor = (h1 - h0) + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    const uint64_t header_len = line_header(hdr, seq_ids[r.path] >> 1, line_end, r.path, r.first, line, t, FORMAT_THREADS);
+    uint64_t cursor = header_len + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
     for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS * PER_THREAD) {
         const uint64_t k0 = base + PER_THREAD * t;
         uint32_t node[PER_THREAD], digits[PER_THREAD], len = 0;
@@ -211,11 +255,12 @@ __device__ __forceinline__ uint32_t classify_position(const SegmentTables &t, co
 
 // One wave per chunk, translation graphs: text bytes of the segment tokens, summed segment lengths, positions that fit no segment.
 __global__ void __launch_bounds__(256) k_chunk_stats_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
-                                                               uint64_t chunks, SegmentTables t, int p_lines, uint64_t *chunk_text, uint64_t *chunk_seq,
+                                                               uint64_t chunks_cap, SegmentTables t, int p_lines, uint64_t *chunk_text, uint64_t *chunk_seq,
                                                                uint64_t *chunk_bad) {
     const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
-    if (c >= chunks) return;
+    if (c >= chunks_cap) return;
+    if (c >= chunk_first[n]) { if (lane == 0) { chunk_text[c] = 0; chunk_seq[c] = 0; chunk_bad[c] = 0; } return; }
     const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
     uint64_t text = 0, labels = 0;
     uint32_t bad = 0;
@@ -235,17 +280,17 @@ __global__ void __launch_bounds__(256) k_chunk_stats_segments(const uint64_t *of
 // One workgroup per chunk, translation graphs.  Lines of flagged paths are left to the host.
 __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
                                                                             const uint64_t *text_before, SegmentTables t, int p_lines, const uint8_t *valid,
-                                                                            const uint64_t *line_start, const uint8_t *headers, const uint64_t *header_off,
-                                                                            uint8_t *out) {
+                                                                            const uint64_t *line_start, const uint64_t *seq_ids, LineHeaders hdr,
+                                                                            const uint64_t *line_end, uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
+    if (blockIdx.x >= chunk_first[n]) return;
     const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
     if (!valid[r.path]) return;
     const uint32_t tid = threadIdx.x;
     uint8_t *line = out + line_start[r.path];
-    const uint64_t h0 = header_off[r.path], h1 = header_off[r.path + 1];
-    if (r.first) for (uint64_t k = tid; k < h1 - h0; k += FORMAT_THREADS) line[k] = headers[h0 + k];
-    uint64_t cursor = (h1 - h0) + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    const uint64_t header_len = line_header(hdr, seq_ids[r.path] >> 1, line_end, r.path, r.first, line, tid, FORMAT_THREADS);
+    uint64_t cursor = header_len + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
     for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS) {
         const uint64_t k = base + tid;
         uint32_t len = 0, s = 0, name_len = 0;
@@ -275,12 +320,6 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const
         if (p_lines) { line[cursor] = '\t'; line[cursor + 1] = '*'; line[cursor + 2] = '\n'; }
         else line[cursor] = '\n';
     }
-}
-
-std::string name_or_id(const Strings &names, bool has_names, uint64_t id) {
-    // Metadata::sample_name / contig_name fall back to the number (src/gbwt.rs:744-761, 792-809)
-    if (has_names && id < names.size()) return names.str(id);
-    return std::to_string(id);
 }
 
 void require_gfa_capable(const gbwt_hip_index *ix) {
@@ -375,6 +414,59 @@ SegmentTables segment_tables(const gbwt_hip_index *ix) {
 
 namespace gbwt_hip {
 
+// The header of every path's line in the three line modes, up to the node tokens (path_to_p_line / path_to_pan_sn / path_to_w_line,
+// src/bin/gbunzip.rs:480-524; Metadata::pan_sn_path, src/gbwt.rs:709-713; sample_name / contig_name fall back to the number,
+// src/gbwt.rs:744-761, 792-809).  A W-line's end coordinate follows its fragment field and is appended on the device.
+static void upload_line_headers(gbwt_hip_index &ix) {
+    const HostIndex &h = ix.host;
+    if (!h.has_metadata || h.path_names.empty()) return;
+    const bool sample_names = (h.metadata_flags & 2) != 0, contig_names = (h.metadata_flags & 4) != 0;
+    const uint64_t n = h.path_names.size();
+    std::vector<uint32_t> fragment(n);
+    for (uint64_t p = 0; p < n; p++) fragment[p] = h.path_names[p].fragment;
+    auto build = [&](int mode) {
+        std::vector<char> &out = ix.host_line_prefix[mode];
+        std::vector<uint64_t> &off = ix.host_line_prefix_off[mode];
+        out.clear(); out.reserve(32 * n);
+        off.assign(n + 1, 0);
+        auto text = [&](const char *t) { while (*t) out.push_back(*t++); };
+        auto number = [&](uint64_t v) {
+            char digits[24];
+            int len = 0;
+            do { digits[len++] = static_cast<char>('0' + v % 10); v /= 10; } while (v != 0);
+            while (len > 0) out.push_back(digits[--len]);
+        };
+        auto name = [&](const Strings &names, bool has_names, uint64_t id) {
+            if (has_names && id < names.size()) out.insert(out.end(), names.bytes.begin() + names.offsets[id], names.bytes.begin() + names.offsets[id + 1]);
+            else number(id);
+        };
+        for (uint64_t p = 0; p < n; p++) {
+            const PathName &pn = h.path_names[p];
+            if (mode == 0) { text("P\t"); name(h.contig_names, contig_names, pn.contig); out.push_back('\t'); }
+            else if (mode == 2) {
+                text("P\t"); name(h.sample_names, sample_names, pn.sample); out.push_back('#'); number(pn.phase); out.push_back('#');
+                name(h.contig_names, contig_names, pn.contig); out.push_back('\t');
+            } else {
+                text("W\t"); name(h.sample_names, sample_names, pn.sample); out.push_back('\t'); number(pn.phase); out.push_back('\t');
+                name(h.contig_names, contig_names, pn.contig); out.push_back('\t'); number(pn.fragment); out.push_back('\t');
+            }
+            off[p + 1] = out.size();
+        }
+    };
+    std::thread others[2] = {std::thread(build, 0), std::thread(build, 2)};    // (tens of thousands of walks in a config-4-shaped GBZ)
+    build(1);
+    for (auto &t : others) t.join();
+    for (int mode = 0; mode < 3; mode++) {
+        ix.line_prefix[mode].reserve(std::max<size_t>(ix.host_line_prefix[mode].size(), 16));
+        ix.line_prefix_off[mode].reserve((n + 1) * sizeof(uint64_t));
+        if (!ix.host_line_prefix[mode].empty())
+            HIP_CHECK(hipMemcpy(ix.line_prefix[mode].ptr, ix.host_line_prefix[mode].data(), ix.host_line_prefix[mode].size(), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(ix.line_prefix_off[mode].ptr, ix.host_line_prefix_off[mode].data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    ix.line_fragment.reserve(n * sizeof(uint32_t));
+    HIP_CHECK(hipMemcpy(ix.line_fragment.ptr, fragment.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
 // Uploads the label length of every potential node (0 where GBZ::has_node is false, src/gbz.rs:286-289).
 void upload_label_lengths(gbwt_hip_index &ix) {
     const HostIndex &h = ix.host;
@@ -399,6 +491,7 @@ void upload_label_lengths(gbwt_hip_index &ix) {
     }
     ix.label_len.reserve(len.size() * sizeof(uint32_t));
     HIP_CHECK(hipMemcpy(ix.label_len.ptr, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    upload_line_headers(ix);
     if (!h.has_translation || h.segment_starts.empty()) return;
     // node-to-segment translation, flattened (Graph::node_to_segment is a predecessor query on a sparse vector in the
     // reference, src/graph.rs:186-198; here every node id gets its segment)
@@ -430,15 +523,22 @@ void upload_label_lengths(gbwt_hip_index &ix) {
 
 }  // namespace gbwt_hip
 
-// The lines of a batch of paths, formatted ONCE into device memory (ws->gfa_text, line k at [line_start[k], line_start[k + 1]),
-// offsets also on the device in ws->gfa_b).  The request is remembered in the workspace: the fill call that follows a size
-// query, and the copy-out of gbwt_hip_path_lines after gbwt_hip_path_lines_device, find the text there.
-static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode) {
+// The lines of a batch of paths, formatted ONCE into device memory (the text buffer of `slot`: ws->gfa_text or gfa_text2; line k at
+// [line_start[k], line_start[k + 1]), offsets also on the device in ws->gfa_b).  The request is remembered in the workspace: the fill call that
+// follows a size query, and the copy-out of gbwt_hip_path_lines after gbwt_hip_path_lines_device, find the text there.
+//
+// Everything between the walk and the text stays on the device (round 4): chunk counts, per-chunk sizes, their scans, the line lengths --
+// headers included, from the per-path header tables built at open and the end coordinate the walk yields -- and the scan that places the
+// lines.  The host waits ONCE, for the total that sizes the text buffer (and, with a node-to-segment translation, for the flags of the
+// paths it has to replay).  Until round 3 it built every header itself, between two more synchronisations: 0.9 ms per request whatever its
+// size -- config 4's 32 000 walks in rounds of 512 spent 58 ms there.
+static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode, int slot = 0) {
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !path_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null path_ids");
     if (mode < 0 || mode > 2) return fail(GBWT_HIP_BAD_ARGUMENT, "mode must be 0 (P-lines), 1 (W-lines) or 2 (P-lines with PanSN names)");
     const int p_lines = mode != 1 ? 1 : 0;
-    if (ws->lines_cached && ws->lines_mode == mode && ws->lines_key.size() == n && (n == 0 || std::memcmp(ws->lines_key.data(), path_ids, n * sizeof(uint64_t)) == 0))
+    if (ws->lines_cached && ws->lines_mode == mode && ws->lines_slot == slot && ws->lines_key.size() == n &&
+        (n == 0 || std::memcmp(ws->lines_key.data(), path_ids, n * sizeof(uint64_t)) == 0))
         return GBWT_HIP_OK;
     ws->lines_cached = false;
     try {
@@ -449,7 +549,7 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
             if (path_ids[k] >= h.path_names.size()) return fail(GBWT_HIP_BAD_ARGUMENT, "path id out of range");
         ws->lines_total = 0;
         if (n == 0) {
-            ws->lines_key.clear(); ws->lines_mode = mode; ws->lines_cached = true;
+            ws->lines_key.clear(); ws->lines_mode = mode; ws->lines_slot = slot; ws->lines_cached = true;
             return GBWT_HIP_OK;
         }
         // 1. forward sequences of the paths (GBZ::path(id, Forward), src/bin/gbunzip.rs:462, 532)
@@ -460,63 +560,62 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         if (st != GBWT_HIP_OK) return st;
         HIP_CHECK(hipSetDevice(ix->device));
         hipStream_t s = ws->stream;
-        // 2. size of every line: chunks of LINE_CHUNK positions, a wave per chunk, scans over the chunks
-        const size_t tb_n = scan_temp_bytes(n);
+        for (auto &e : ws->gev) if (!e) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(ws->gev[0], s));
+        const uint64_t *d_seq_ids = ws->seq_ids.as<uint64_t>();         // (the extraction has left the ids on the device)
+        // 2. size of every line: chunks of LINE_CHUNK positions, a wave per chunk, scans over the chunks.  Every row has at least one chunk
+        // and at most len / LINE_CHUNK + 1: the launches and scans below run over that bound, the kernels read the count from the device.
+        const uint64_t chunks_cap = paths.total / LINE_CHUNK + n;
+        if (chunks_cap > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "too many line chunks in one batch: format fewer paths per call");
+        const size_t tb = scan_temp_bytes(std::max(n, chunks_cap));
         ws->gfa_a.reserve(2 * n * sizeof(uint64_t));
+        ws->gfa_b.reserve((n + 1) * sizeof(uint64_t));
         ws->gfa_chunk_first.reserve(2 * (n + 1) * sizeof(uint64_t));
-        ws->scan_temp.reserve(std::max<size_t>(tb_n, 16));
-        uint64_t *d_text_len = ws->gfa_a.as<uint64_t>(), *d_seq_len = d_text_len + n;
+        ws->gfa_chunks.reserve((3 * chunks_cap + 3 * (chunks_cap + 1)) * sizeof(uint64_t));
+        ws->scan_temp.reserve(std::max<size_t>(tb, 16));
+        ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
+        uint64_t *d_line_len = ws->gfa_a.as<uint64_t>(), *d_line_end = d_line_len + n, *d_line_start = ws->gfa_b.as<uint64_t>();
         uint64_t *d_chunk_first = ws->gfa_chunk_first.as<uint64_t>(), *d_chunk_counts = d_chunk_first + (n + 1);
+        uint64_t *d_chunk_text = ws->gfa_chunks.as<uint64_t>(), *d_chunk_seq = d_chunk_text + chunks_cap, *d_chunk_bad = d_chunk_seq + chunks_cap;
+        uint64_t *d_text_before = d_chunk_bad + chunks_cap, *d_seq_before = d_text_before + (chunks_cap + 1), *d_bad_before = d_seq_before + (chunks_cap + 1);
+        uint8_t *d_valid = translated ? ws->gfa_valid.as<uint8_t>() : nullptr;
+        const LineHeaders hdr{ix->line_prefix[mode].as<uint8_t>(), ix->line_prefix_off[mode].as<uint64_t>(), mode == 1 ? ix->line_fragment.as<uint32_t>() : nullptr};
         hipLaunchKernelGGL(k_chunk_counts, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_counts);
-        launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb_n, s);
-        uint64_t chunks = 0;
-        HIP_CHECK(hipMemcpyAsync(&chunks, d_chunk_first + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        if (chunks > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "too many line chunks in one batch: format fewer paths per call");
-        const size_t tb_c = scan_temp_bytes(chunks);
-        ws->gfa_chunks.reserve((3 * chunks + 3 * (chunks + 1)) * sizeof(uint64_t));
-        ws->scan_temp.reserve(std::max<size_t>(tb_c, 16));
-        uint64_t *d_chunk_text = ws->gfa_chunks.as<uint64_t>(), *d_chunk_seq = d_chunk_text + chunks, *d_chunk_bad = d_chunk_seq + chunks;
-        uint64_t *d_text_before = d_chunk_bad + chunks, *d_seq_before = d_text_before + (chunks + 1), *d_bad_before = d_seq_before + (chunks + 1);
-        std::vector<uint8_t> valid(n, 1);
-        const unsigned stat_blocks = static_cast<unsigned>((chunks + 3) / 4);
+        launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb, s);
+        const unsigned stat_blocks = static_cast<unsigned>((chunks_cap + 3) / 4);
         if (translated) {
-            ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
-            hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks,
+            hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks_cap,
                                segment_tables(ix), p_lines, d_chunk_text, d_chunk_seq, d_chunk_bad);
-            launch_scan(d_chunk_bad, d_bad_before, chunks, ws->scan_temp.ptr, tb_c, s);
+            launch_scan(d_chunk_bad, d_bad_before, chunks_cap, ws->scan_temp.ptr, tb, s);
         } else {
-            hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks,
+            hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks_cap,
                                ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
                                static_cast<uint32_t>(h.alphabet_offset + 1), p_lines, d_chunk_text, d_chunk_seq);
         }
-        launch_scan(d_chunk_text, d_text_before, chunks, ws->scan_temp.ptr, tb_c, s);
-        launch_scan(d_chunk_seq, d_seq_before, chunks, ws->scan_temp.ptr, tb_c, s);
-        hipLaunchKernelGGL(k_path_totals, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_chunk_first, n, d_text_before, d_seq_before,
-                           translated ? d_bad_before : nullptr, d_text_len, d_seq_len, translated ? ws->gfa_valid.as<uint8_t>() : nullptr);
-        if (translated) HIP_CHECK(hipMemcpyAsync(valid.data(), ws->gfa_valid.ptr, n, hipMemcpyDeviceToHost, s));
-        std::vector<uint64_t> lens(2 * n);
-        HIP_CHECK(hipMemcpyAsync(lens.data(), d_text_len, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        launch_scan(d_chunk_text, d_text_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+        launch_scan(d_chunk_seq, d_seq_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+        hipLaunchKernelGGL(k_line_sizes, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_seq_ids, d_chunk_first, n, d_text_before, d_seq_before,
+                           translated ? d_bad_before : nullptr, hdr, p_lines, d_line_len, d_line_end, d_valid);
+        launch_scan(d_line_len, d_line_start, n, ws->scan_temp.ptr, tb, s);
+        uint64_t total = 0;
+        std::vector<uint8_t> valid;
+        HIP_CHECK(hipMemcpyAsync(&total, d_line_start + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        if (translated) { valid.resize(n); HIP_CHECK(hipMemcpyAsync(valid.data(), d_valid, n, hipMemcpyDeviceToHost, s)); }
+        HIP_CHECK(hipStreamSynchronize(s));                             // the one wait of a request
         HIP_CHECK(hipGetLastError());
-        const bool sample_names = (h.metadata_flags & 2) != 0, contig_names = (h.metadata_flags & 4) != 0;
-        auto line_header = [&](uint64_t k, uint64_t seq_len) {
-            const PathName &pn = h.path_names[path_ids[k]];
-            if (mode == 0) return "P\t" + name_or_id(h.contig_names, contig_names, pn.contig) + "\t";
-            if (mode == 2) return "P\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "#" + std::to_string(pn.phase) + "#" +
-                                  name_or_id(h.contig_names, contig_names, pn.contig) + "\t";   // Metadata::pan_sn_path, src/gbwt.rs:709-713
-            return "W\t" + name_or_id(h.sample_names, sample_names, pn.sample) + "\t" + std::to_string(pn.phase) + "\t" +
-                   name_or_id(h.contig_names, contig_names, pn.contig) + "\t" + std::to_string(pn.fragment) + "\t" +
-                   std::to_string(static_cast<uint64_t>(pn.fragment) + seq_len) + "\t";
-        };
-        // 2b. paths that are not concatenations of whole segments: the reference's iterator stops somewhere inside them;
-        // the host replays it on the extracted node ids
-        std::vector<std::string> host_lines(translated ? n : 0);
+        // 2b. paths that are not concatenations of whole segments: the reference's iterator stops somewhere inside them; the host replays
+        // it on the extracted node ids, puts the lengths of those lines in and places the lines again
+        std::vector<std::string> host_lines;
+        std::vector<uint64_t> line_start;
         if (translated && std::find(valid.begin(), valid.end(), uint8_t(0)) != valid.end()) {
-            std::vector<uint64_t> offs(n + 1);
+            host_lines.resize(n);
+            std::vector<uint64_t> offs(n + 1), lens(n);
             HIP_CHECK(hipMemcpy(offs.data(), paths.d_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(lens.data(), d_line_len, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
             std::vector<uint32_t> nodes;
             std::vector<std::pair<uint64_t, bool>> tokens;
+            const std::vector<char> &prefix = ix->host_line_prefix[mode];
+            const std::vector<uint64_t> &prefix_off = ix->host_line_prefix_off[mode];
             for (uint64_t k = 0; k < n; k++) {
                 if (valid[k]) continue;
                 nodes.resize(offs[k + 1] - offs[k]);
@@ -524,75 +623,41 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
                 uint64_t seq_len = 0;
                 host_segment_path(h, nodes.data(), nodes.size(), tokens, seq_len);
                 std::string &line = host_lines[k];
-                line = line_header(k, seq_len);
+                line.assign(prefix.data() + prefix_off[path_ids[k]], prefix_off[path_ids[k] + 1] - prefix_off[path_ids[k]]);
+                if (mode == 1) line += std::to_string(static_cast<uint64_t>(h.path_names[path_ids[k]].fragment) + seq_len) + "\t";
                 for (size_t j = 0; j < tokens.size(); j++) {
                     const std::string name = h.segment_names.str(tokens[j].first);
                     if (p_lines) line += (j ? "," : "") + name + (tokens[j].second ? "-" : "+");
                     else line += (tokens[j].second ? "<" : ">") + name;
                 }
                 line += p_lines ? "\t*\n" : "\n";
+                lens[k] = line.size();
             }
+            line_start.assign(n + 1, 0);
+            for (uint64_t k = 0; k < n; k++) line_start[k + 1] = line_start[k] + lens[k];
+            total = line_start[n];
+            HIP_CHECK(hipMemcpyAsync(d_line_start, line_start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         }
-        // 3. headers (path_to_p_line / path_to_pan_sn / path_to_w_line, src/bin/gbunzip.rs:480-524)
-        // (appended in place: five thousand headers put together from temporaries were a sixth of a call that formats a gigabyte)
-        std::string headers;
-        headers.reserve(64 * n);
-        auto append_number = [&](uint64_t v) {
-            char digits[24];
-            int len = 0;
-            do { digits[len++] = static_cast<char>('0' + v % 10); v /= 10; } while (v != 0);
-            while (len > 0) headers.push_back(digits[--len]);
-        };
-        auto append_name = [&](const Strings &names, bool has_names, uint64_t id) {
-            if (has_names && id < names.size()) headers.append(reinterpret_cast<const char *>(names.bytes.data()) + names.offsets[id], names.offsets[id + 1] - names.offsets[id]);
-            else append_number(id);                          // Metadata::sample_name / contig_name fall back to the number
-        };
-        auto append_header = [&](uint64_t k, uint64_t seq_len) {
-            const PathName &pn = h.path_names[path_ids[k]];
-            if (mode == 0) { headers += "P\t"; append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t'); return; }
-            if (mode == 2) {                                 // sample#phase#contig (Metadata::pan_sn_path, src/gbwt.rs:709-713)
-                headers += "P\t"; append_name(h.sample_names, sample_names, pn.sample); headers.push_back('#');
-                append_number(pn.phase); headers.push_back('#');
-                append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t');
-                return;
-            }
-            headers += "W\t"; append_name(h.sample_names, sample_names, pn.sample); headers.push_back('\t');
-            append_number(pn.phase); headers.push_back('\t');
-            append_name(h.contig_names, contig_names, pn.contig); headers.push_back('\t');
-            append_number(pn.fragment); headers.push_back('\t');
-            append_number(static_cast<uint64_t>(pn.fragment) + seq_len); headers.push_back('\t');
-        };
-        std::vector<uint64_t> header_off(n + 1, 0), line_start(n + 1, 0);
-        for (uint64_t k = 0; k < n; k++) {
-            if (valid[k]) append_header(k, lens[n + k]);
-            header_off[k + 1] = headers.size();
-            line_start[k + 1] = line_start[k] + (valid[k] ? (header_off[k + 1] - header_off[k]) + lens[k] + (p_lines ? 3 : 1) : host_lines[k].size());
-        }
-        const uint64_t total = line_start[n];
-        // 4. format on the device; the lines the host had to replay are copied into their places
-        ws->gfa_b.reserve((2 * (n + 1)) * sizeof(uint64_t));
-        ws->gfa_c.reserve(std::max<size_t>(headers.size(), 16));
-        ws->gfa_text.reserve(std::max<uint64_t>(total, 16));
-        uint64_t *d_line_start = ws->gfa_b.as<uint64_t>(), *d_header_off = d_line_start + (n + 1);
-        HIP_CHECK(hipMemcpyAsync(d_line_start, line_start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(d_header_off, header_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(ws->gfa_c.ptr, headers.data(), headers.size(), hipMemcpyHostToDevice, s));
+        // 3. format on the device; the lines the host had to replay are copied into their places
+        DeviceBuffer &text = slot == 0 ? ws->gfa_text : ws->gfa_text2;
+        text.reserve(std::max<uint64_t>(total, 16));
         if (translated)
-            hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_text_before, segment_tables(ix), p_lines, ws->gfa_valid.as<uint8_t>(), d_line_start,
-                               ws->gfa_c.as<uint8_t>(), d_header_off, ws->gfa_text.as<uint8_t>());
+            hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               d_chunk_first, d_text_before, segment_tables(ix), p_lines, d_valid, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
         else
-            hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_text_before, p_lines, d_line_start, ws->gfa_c.as<uint8_t>(), d_header_off,
-                               ws->gfa_text.as<uint8_t>());
+            hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
+                               d_chunk_first, d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
-        for (uint64_t k = 0; k < n; k++)
+        for (uint64_t k = 0; k < host_lines.size(); k++)
             if (!valid[k] && !host_lines[k].empty())
-                HIP_CHECK(hipMemcpyAsync(ws->gfa_text.as<char>() + line_start[k], host_lines[k].data(), host_lines[k].size(), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipStreamSynchronize(s));   // host_lines / headers / line_start go out of scope
+                HIP_CHECK(hipMemcpyAsync(text.as<char>() + line_start[k], host_lines[k].data(), host_lines[k].size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(ws->gev[1], s));
+        HIP_CHECK(hipStreamSynchronize(s));   // the text is there when the call returns (and host_lines / line_start go out of scope)
+        ws->lines_timed = true;
         ws->lines_total = total;
         ws->lines_key.assign(path_ids, path_ids + n);
         ws->lines_mode = mode;
+        ws->lines_slot = slot;
         ws->lines_cached = true;
         return GBWT_HIP_OK;
     } catch (const InvalidData &e) {
@@ -602,65 +667,34 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
     }
 }
 
-// gbwt_hip_path_lines; with `grow` the text goes into that vector (sized here) instead of `out`.
+// gbwt_hip_path_lines: formats (or finds) the lines and copies them to the host buffer -- over several threads with pinned staging
+// buffers (copy_to_host), as the CSR of gbwt_hip_extract is: one pageable hipMemcpy moved a gigabyte of W-lines at 2.4 GB/s.
 static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
-                                       char *out, uint64_t capacity, uint64_t *total, std::vector<char> *grow) {
+                                       char *out, uint64_t capacity, uint64_t *total) {
     if (!total) return fail(GBWT_HIP_BAD_ARGUMENT, "null total");
     *total = 0;
     const gbwt_hip_status st = path_lines_compute(ix, ws, path_ids, n, mode);
     if (st != GBWT_HIP_OK) return st;
     *total = ws->lines_total;
-    if (grow) { grow->resize(*total); out = grow->data(); capacity = *total; }
     if (!out || *total == 0) return GBWT_HIP_OK;
     if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the lines");
     try {
         HIP_CHECK(hipSetDevice(ix->device));
-        HIP_CHECK(hipMemcpyAsync(out, ws->gfa_text.ptr, *total, hipMemcpyDeviceToHost, ws->stream));
-        HIP_CHECK(hipStreamSynchronize(ws->stream));
+        copy_to_host(ix->device, out, ws->gfa_text.ptr, *total, ws->knobs.copy_threads);
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
     }
 }
 
-extern "C" {
+namespace {
 
-gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
-                                    char *out, uint64_t capacity, uint64_t *total) {
-    GBWT_HIP_GUARD_BEGIN
-    return path_lines_impl(ix, ws, path_ids, n, mode, out, capacity, total, nullptr);
-    GBWT_HIP_GUARD_END
-}
-
-gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
-                                           gbwt_hip_lines *out) {
-    GBWT_HIP_GUARD_BEGIN
-    if (!out) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
-    *out = gbwt_hip_lines{nullptr, nullptr, 0, 0};
-    const gbwt_hip_status st = path_lines_compute(ix, ws, path_ids, n, mode);
-    if (st != GBWT_HIP_OK) return st;
-    out->d_text = n ? ws->gfa_text.as<char>() : nullptr;
-    out->d_line_offsets = n ? ws->gfa_b.as<uint64_t>() : nullptr;
-    out->total = ws->lines_total;
-    out->n = n;
-    return GBWT_HIP_OK;
-    GBWT_HIP_GUARD_END
-}
-
-gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path) {
-    return gbwt_hip_write_gfa_mode(ix, ws, path, GBWT_HIP_PATHS_DEFAULT);
-}
-
-gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path, int path_mode) {
-    GBWT_HIP_GUARD_BEGIN
-    if (!ix || !ws || ws->index != ix || !path) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
-    if (path_mode < GBWT_HIP_PATHS_DEFAULT || path_mode > GBWT_HIP_PATHS_REF_ONLY) return fail(GBWT_HIP_BAD_ARGUMENT, "unknown path mode");
-    try {
-        require_gfa_capable(ix);
-        const HostIndex &h = ix->host;
-        const bool translated = h.has_translation && !h.segment_starts.empty();
-        std::unique_ptr<FILE, int (*)(FILE *)> f(std::fopen(path, "wb"), std::fclose);
-        if (!f) return fail(GBWT_HIP_IO_ERROR, std::string("cannot create ") + path);
+// H-, S- and L-lines of the whole graph (write_gfa_header / write_segments / write_links, src/bin/gbunzip.rs:193-317): serial host work in
+// the reference as well.  Written through `emit` in pieces of about 8 MiB (the reference's BufWriter, src/bin/gbunzip.rs:96).
+template <class Emit>
+void host_graph_lines(const HostIndex &h, bool translated, Emit emit) {
+    auto flush = [&](std::string &text) { emit(text.data(), text.size()); text.clear(); };
+    {
         std::string text;
         // header (write_gfa_header, src/bin/gbunzip.rs:193-203)
         if (const std::string *rs = h.tag("reference_samples")) text = "H\tVN:Z:1.1\tRS:Z:" + *rs + "\n";
@@ -683,7 +717,7 @@ gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_works
                 text += "S\t" + h.segment_names.str(id) + "\t";
                 text.append(reinterpret_cast<const char *>(h.sequences_labels.bytes.data()) + h.sequences_labels.offsets[seg.start - 1], host_segment_seq_len(h, seg));
                 text += "\n";
-                if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+                if (text.size() > (8u << 20)) flush(text);
             }
             for (uint64_t id = 0; id < n_seg; id++) {
                 const HostSegment seg = host_segment(h, id);
@@ -703,14 +737,14 @@ gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_works
                         text += "L\t" + name + (rev ? "\t-\t" : "\t+\t") + h.segment_names.str(to.id) + (succ_rev ? "\t-\t*\n" : "\t+\t*\n");
                     }
                 }
-                if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+                if (text.size() > (8u << 20)) flush(text);
             }
         }
         for (uint64_t seq = 0; seq < potential && !translated; seq++) {
             if (!real(seq)) continue;
             const uint64_t node_id = (2 * seq + first) / 2;
             text += "S\t" + std::to_string(node_id) + "\t" + h.sequences_labels.str(seq) + "\n";
-            if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+            if (text.size() > (8u << 20)) flush(text);
         }
         for (uint64_t seq = 0; seq < potential && !translated; seq++) {
             if (!real(seq)) continue;
@@ -726,9 +760,171 @@ gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_works
                     text += "L\t" + std::to_string(node_id) + (rev ? "\t-\t" : "\t+\t") + std::to_string(succ) + (succ_rev ? "\t-\t*\n" : "\t+\t*\n");
                 }
             }
-            if (text.size() > (8u << 20)) { std::fwrite(text.data(), 1, text.size(), f.get()); text.clear(); }
+            if (text.size() > (8u << 20)) flush(text);
         }
-        std::fwrite(text.data(), 1, text.size(), f.get());
+        flush(text);
+    }
+}
+
+// The writer's side of a whole-file write: one thread that first puts out the graph lines (which precede the paths in the file), then
+// takes finished batches of path lines -- device text -- and moves them to the file through two pinned buffers: the copy of piece i + 1
+// runs under the fwrite of piece i, and the main thread formats the next batch into the other device text buffer meanwhile.
+struct GfaWriter {
+    static constexpr size_t PIECE = size_t(64) << 20;
+    struct Job { const char *text; uint64_t bytes; int slot; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    bool closing = false, slot_busy[2] = {false, false};
+    gbwt_hip_status status = GBWT_HIP_OK;
+    std::string message;
+    std::thread worker;
+    FILE *file;
+    int device;
+
+    void fail_with(gbwt_hip_status st, const std::string &msg) {
+        std::lock_guard<std::mutex> lock(m);
+        if (status == GBWT_HIP_OK) { status = st; message = msg; }
+        cv.notify_all();
+    }
+    bool put(const char *data, size_t bytes) {
+        if (bytes != 0 && std::fwrite(data, 1, bytes, file) != bytes) { fail_with(GBWT_HIP_IO_ERROR, "short write"); return false; }
+        return true;
+    }
+    template <class Graph>
+    void run(Graph graph_lines) {
+        void *pinned[2] = {nullptr, nullptr};
+        hipStream_t stream = nullptr;
+        hipEvent_t landed[2] = {nullptr, nullptr};
+        try {
+            graph_lines([this](const char *data, size_t bytes) { (void)put(data, bytes); });
+            HIP_CHECK(hipSetDevice(device));
+            HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) { HIP_CHECK(hipHostMalloc(&pinned[i], PIECE, hipHostMallocDefault)); HIP_CHECK(hipEventCreate(&landed[i])); }
+            for (;;) {
+                Job job;
+                {
+                    std::unique_lock<std::mutex> lock(m);
+                    cv.wait(lock, [&] { return !jobs.empty() || closing || status != GBWT_HIP_OK; });
+                    if (status != GBWT_HIP_OK || jobs.empty()) break;
+                    job = jobs.front(); jobs.pop_front();
+                }
+                const uint64_t pieces = (job.bytes + PIECE - 1) / PIECE;
+                auto fetch = [&](uint64_t i) {
+                    const uint64_t at = i * PIECE, len = std::min<uint64_t>(PIECE, job.bytes - at);
+                    HIP_CHECK(hipMemcpyAsync(pinned[i % 2], job.text + at, len, hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipEventRecord(landed[i % 2], stream));
+                };
+                if (pieces) fetch(0);
+                for (uint64_t i = 0; i < pieces; i++) {
+                    HIP_CHECK(hipEventSynchronize(landed[i % 2]));
+                    if (i + 1 < pieces) fetch(i + 1);
+                    else {   // the device text of this batch has left: the formatter may have the slot back
+                        std::lock_guard<std::mutex> lock(m);
+                        slot_busy[job.slot] = false;
+                        cv.notify_all();
+                    }
+                    if (!put(static_cast<const char *>(pinned[i % 2]), std::min<uint64_t>(PIECE, job.bytes - i * PIECE))) break;
+                }
+                if (pieces == 0) { std::lock_guard<std::mutex> lock(m); slot_busy[job.slot] = false; cv.notify_all(); }
+            }
+        } catch (const HipError &e) {
+            fail_with(GBWT_HIP_DEVICE_ERROR, std::string(e.what) + ": " + hipGetErrorString(e.err));
+        } catch (const std::exception &e) {
+            fail_with(GBWT_HIP_DEVICE_ERROR, std::string("GFA writer: ") + e.what());
+        }
+        for (int i = 0; i < 2; i++) { if (pinned[i]) (void)hipHostFree(pinned[i]); if (landed[i]) (void)hipEventDestroy(landed[i]); }
+        if (stream) (void)hipStreamDestroy(stream);
+        std::lock_guard<std::mutex> lock(m);
+        closing = true; slot_busy[0] = slot_busy[1] = false;
+        cv.notify_all();
+    }
+    // the formatter's side: wait until the device text buffer of `slot` has been read out; false when the writer has failed
+    bool acquire(int slot) {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return !slot_busy[slot] || status != GBWT_HIP_OK; });
+        if (status != GBWT_HIP_OK) return false;
+        slot_busy[slot] = true;
+        return true;
+    }
+    void submit(const char *text, uint64_t bytes, int slot) {
+        std::lock_guard<std::mutex> lock(m);
+        jobs.push_back(Job{text, bytes, slot});
+        cv.notify_all();
+    }
+    gbwt_hip_status finish() {
+        { std::lock_guard<std::mutex> lock(m); closing = true; cv.notify_all(); }
+        if (worker.joinable()) worker.join();
+        return status;
+    }
+    ~GfaWriter() { (void)finish(); }
+};
+
+}  // namespace
+
+extern "C" {
+
+gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
+                                    char *out, uint64_t capacity, uint64_t *total) {
+    GBWT_HIP_GUARD_BEGIN
+    return path_lines_impl(ix, ws, path_ids, n, mode, out, capacity, total);
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *path_ids, uint64_t n, int mode,
+                                           gbwt_hip_lines *out) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!out) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
+    *out = gbwt_hip_lines{nullptr, nullptr, 0, 0};
+    const gbwt_hip_status st = path_lines_compute(ix, ws, path_ids, n, mode);
+    if (st != GBWT_HIP_OK) return st;
+    out->d_text = n ? ws->gfa_text.as<char>() : nullptr;
+    out->d_line_offsets = n ? ws->gfa_b.as<uint64_t>() : nullptr;
+    out->total = ws->lines_total;
+    out->n = n;
+    return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_last_lines_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *format_ms) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!ws || !ws->lines_timed || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no timed GFA lines request on this workspace");
+    float a = 0, b = 0;
+    if (hipEventElapsedTime(&a, ws->ev[0], ws->ev[1]) != hipSuccess || hipEventElapsedTime(&b, ws->gev[0], ws->gev[1]) != hipSuccess)
+        return fail(GBWT_HIP_DEVICE_ERROR, "hipEventElapsedTime failed");
+    if (walk_ms) *walk_ms = a;
+    if (format_ms) *format_ms = b;
+    return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path) {
+    return gbwt_hip_write_gfa_mode(ix, ws, path, GBWT_HIP_PATHS_DEFAULT);
+}
+
+// The reference builds the lines of the paths in parallel and hands them to a writer under a mutex, behind an 8 MiB BufWriter
+// (src/bin/gbunzip.rs:96, 205-226, 421-434).  Here: batches bounded by BYTES of text (GBWT_HIP_GFA_BATCH_MIB, default 1 GiB: config 4's
+// 32 000 walks are four batches, the headline's 5 000 paths of 4.5 MB each a few hundred), formatted on the device into two text
+// buffers in turn, while a writer thread moves the previous batch to the file through two 64 MiB pinned buffers (GfaWriter) -- and
+// writes the H-, S- and L-lines of the graph, host work, while the first batch is walked.
+gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const char *path, int path_mode) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!ix || !ws || ws->index != ix || !path) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (path_mode < GBWT_HIP_PATHS_DEFAULT || path_mode > GBWT_HIP_PATHS_REF_ONLY) return fail(GBWT_HIP_BAD_ARGUMENT, "unknown path mode");
+    try {
+        require_gfa_capable(ix);
+        const HostIndex &h = ix->host;
+        const bool translated = h.has_translation && !h.segment_starts.empty();
+        std::unique_ptr<FILE, int (*)(FILE *)> f(std::fopen(path, "wb"), std::fclose);
+        if (!f) return fail(GBWT_HIP_IO_ERROR, std::string("cannot create ") + path);
+        std::vector<char> file_buffer(size_t(8) << 20);
+        (void)std::setvbuf(f.get(), file_buffer.data(), _IOFBF, file_buffer.size());
+        GfaWriter writer;
+        writer.file = f.get();
+        writer.device = ix->device;
+        writer.worker = std::thread([&writer, &h, translated]() {
+            writer.run([&h, translated](auto emit) { host_graph_lines(h, translated, emit); });
+        });
         // write_gfa_impl's match on the path mode (src/bin/gbunzip.rs:212-222), ascending path id (-t 1 order):
         //   default: paths of the generic sample as P-lines, then the others as W-lines (write_paths / write_walks, 343-417)
         //   pan-sn : every path as a P-line with its PanSN name (write_pan_sn, 371-393)
@@ -743,20 +939,40 @@ gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_works
             if (have_ref) passes.push_back(Pass{0, 0});
             if (path_mode == GBWT_HIP_PATHS_DEFAULT) passes.push_back(Pass{1, 1});
         }
+        // a path of `len` nodes prints at most len tokens of (digits of the largest node id, or the longest segment name) + 2 bytes
+        uint64_t token = 2 + std::to_string(h.alphabet_size / 2).size();
+        if (translated) { token = 2; for (size_t i = 0; i < h.segment_names.size(); i++) token = std::max<uint64_t>(token, 2 + h.segment_names.len(i)); }
+        uint64_t budget = uint64_t(1) << 30;
+        if (const char *v = std::getenv("GBWT_HIP_GFA_BATCH_MIB")) budget = std::max<uint64_t>(1, std::strtoull(v, nullptr, 10)) << 20;
+        const uint64_t fallback_batch = 4096;                // without sequence lengths: by count, as until round 3
+        int slot = 0;
+        gbwt_hip_status st = GBWT_HIP_OK;
         for (const Pass &pass : passes) {
             std::vector<uint64_t> ids;
             for (uint64_t p = 0; p < h.path_names.size(); p++)
                 if (pass.which == 2 || (h.path_names[p].sample == ref_sample) == (pass.which == 0)) ids.push_back(p);
-            const uint64_t batch = 4096;
-            std::vector<char> buf;
-            for (uint64_t b0 = 0; b0 < ids.size(); b0 += batch) {
-                const uint64_t nb = std::min<uint64_t>(batch, ids.size() - b0);
-                uint64_t total = 0;
-                gbwt_hip_status st = path_lines_impl(ix, ws, ids.data() + b0, nb, pass.line_mode, nullptr, 0, &total, &buf);
-                if (st != GBWT_HIP_OK) return st;
-                if (std::fwrite(buf.data(), 1, total, f.get()) != total) return fail(GBWT_HIP_IO_ERROR, "short write");
+            for (uint64_t b0 = 0; b0 < ids.size() && st == GBWT_HIP_OK;) {
+                uint64_t nb = 0, bytes = 0;
+                while (b0 + nb < ids.size()) {
+                    const uint64_t seq = 2 * ids[b0 + nb];
+                    const uint64_t est = seq < ix->host_seq_len.size() ? 128 + token * ix->host_seq_len[seq] : 0;
+                    if (nb != 0 && (ix->host_seq_len.empty() ? nb >= fallback_batch : bytes + est > budget)) break;
+                    bytes += est; nb++;
+                }
+                if (!writer.acquire(slot)) { st = GBWT_HIP_IO_ERROR; break; }
+                st = path_lines_compute(ix, ws, ids.data() + b0, nb, pass.line_mode, slot);
+                if (st != GBWT_HIP_OK) break;
+                writer.submit((slot == 0 ? ws->gfa_text : ws->gfa_text2).as<char>(), ws->lines_total, slot);
+                slot ^= 1;
+                b0 += nb;
             }
+            if (st != GBWT_HIP_OK) break;
         }
+        const gbwt_hip_status wst = writer.finish();
+        ws->lines_cached = false;                            // (both text buffers have been reused)
+        if (st == GBWT_HIP_OK && wst != GBWT_HIP_OK) return fail(wst, writer.message);
+        if (st != GBWT_HIP_OK) return wst != GBWT_HIP_OK ? fail(wst, writer.message) : st;
+        if (std::fflush(f.get()) != 0) return fail(GBWT_HIP_IO_ERROR, "short write");
         return GBWT_HIP_OK;
     } catch (const InvalidData &e) {
         return fail(GBWT_HIP_BAD_ARGUMENT, e.what());

@@ -551,13 +551,17 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
     }
     trace.mark("sections located");
     if (on_located) {
-        h.pending = pending;                               // record_bytes() answers from the mapping from here on
-        try { on_located(h); } catch (...) { h.pending.reset(); throw; }
-        h.pending.reset();
+        // record_bytes() answers from the mapping from here on.  `h` keeps its share of the mapping across the decodes below as well:
+        // what on_located started (gbwt_hip_open_file: a thread copying the record bytes to the device) may still be reading the file
+        // when a decode throws, and the caller can only stop it after this function has unwound -- the mapping then goes with `h`,
+        // which the caller destroys after that thread.
+        h.pending = pending;
+        on_located(h);
     }
     later.run();
     trace.mark("foreground decodes");
     if (!background) {
+        h.pending.reset();
         h.file_data = nullptr; h.file_data_len = 0;
         if (h.is_gbz) check_graph(h);
         return;

@@ -19,6 +19,8 @@ namespace gbwt_hip {
 // Raised for anything the reference reports as io::ErrorKind::InvalidData.
 struct InvalidData : std::runtime_error { using std::runtime_error::runtime_error; };
 struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+// A well-formed index beyond the 32-bit widths of the device side (include/gbwt_hip.h: "Widths"): GBWT_HIP_UNSUPPORTED.
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // gbwt::PathName, src/gbwt.rs:912-926
 struct PathName { uint32_t sample, contig, phase, fragment; };

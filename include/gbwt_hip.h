@@ -17,6 +17,18 @@
  *     where the reference asserts/panics (non-bidirectional index in bd_* calls) -> GBWT_HIP_BAD_ARGUMENT.
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
  *     GBWT_HIP_NO_DEVICE / GBWT_HIP_DEVICE_ERROR.
+ *
+ * Widths.  The reference is usize (u64) everywhere (bwt::Pos, src/bwt.rs:63-69); this ABI carries u64 in every struct, but the
+ * device side computes in u32: node ids, record indices, offsets inside a record and rank-block indices.  An index outside that
+ * range is refused AT OPEN with GBWT_HIP_UNSUPPORTED (never truncated, never a wrong answer later):
+ *     alphabet_size > 2^32                          (node ids; SURVEY 8b allows u32 node ids iff alphabet_size <= 2^32)
+ *     2^30 records or more                          (bits 30-31 of a record word carry flags)
+ *     a record with 2^32 or more positions          (Record::len: offsets inside a record are u32; counted by the device pass at open)
+ *     (size >> 6) + records >= 2^32 - 16            (rank-block indices)
+ * Sequence lengths are u32 as well: an index in which one sequence has 2^32 - 16 or more nodes opens without sequence lengths and
+ * samples (extractions then take the pool-output kernel).  Record byte streams and CSR outputs are 64-bit throughout (an index
+ * whose rank blocks exceed 4 GiB is walked with 64-bit block addresses).  Query inputs are u64 and compared as such: a node or
+ * offset that does not fit u32 cannot exist in an index that was opened, and yields "not found" (valid = 0).
  */
 #ifndef GBWT_HIP_H
 #define GBWT_HIP_H
@@ -94,6 +106,17 @@ gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, co
                                       gbwt_hip_index **out);
 void gbwt_hip_close(gbwt_hip_index *index);
 gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *out);
+
+/* What a handle and a workspace hold (bytes).  index_device_bytes: every array of the handle in HBM -- the record bytes, starts,
+ * descriptors, rank blocks, tables, samples, GFA tables; the full-width two-step blocks are counted once they have been built (on first
+ * need).  An index is replicated per GPU, so this is also the cost of one more rank.  index_host_bytes: the host image (record
+ * bytes, starts, names, node labels).  workspace_device_bytes (0 for ws == NULL): all scratch of the workspace, of which rows_bytes are
+ * the extracted rows (the CSR node ids) and text_bytes the formatted GFA lines. */
+typedef struct {
+    uint64_t index_device_bytes, index_host_bytes;
+    uint64_t workspace_device_bytes, rows_bytes, text_bytes;
+} gbwt_hip_memory;
+gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hip_workspace *ws, gbwt_hip_memory *out);
 
 /* Where the time of gbwt_hip_open_* went (host clock, milliseconds; the one-shot flow of gbunzip, src/bin/gbunzip.rs:24-59, pays all
  * of it once per file): parse_ms = reading and validating the file (0 for gbwt_hip_open_records), upload_ms = host-to-device copies
@@ -242,6 +265,9 @@ gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *index, gbwt_hip_workspa
  * dominant kernel (the walk; bench.py's roofline object), *total_ms = everything the call put on the stream, from the
  * upload of the ids to the last kernel (lengths, offsets, walker order, walk; host waits in between included). */
 gbwt_hip_status gbwt_hip_last_kernel_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *total_ms);
+/* The same for the last GFA lines request (gbwt_hip_path_lines / _device) on `ws`: *walk_ms = the walk kernel of its extraction,
+ * *format_ms = everything behind the walk on the stream -- sizes, scans, the one host wait for the total, the formatting kernel. */
+gbwt_hip_status gbwt_hip_last_lines_ms(const gbwt_hip_workspace *ws, float *walk_ms, float *format_ms);
 /* Free and total memory of a device in bytes (hipMemGetInfo): what the tests use to see that a workspace gives its rows back. */
 gbwt_hip_status gbwt_hip_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Kernel time (ms, HIP events on the workspace stream, host staging excluded) of the last navigation / search call
