@@ -52,7 +52,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE index (seed 42) replicated on every rank, path p walked by rank p mod N, whole CSR gathered on rank 0 "
                          "(SURVEY 8e; default); weak = every rank its own contig (seed 42 + rank)")
-    ap.add_argument("--no-extras", action="store_true", help="skip value_unsampled, the secondary (insertion chain) and the high-degree (config 5) workloads")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_unsampled and the other BASELINE configs (secondary = insertion chain, high_degree = config 5, search = config 3, config4)")
+    ap.add_argument("--no-search", action="store_true", help="skip the config 3 search object (its 1.1 M-site index takes half a minute to generate)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config 4 object")
     return ap.parse_args()
 
 
@@ -127,6 +129,37 @@ def source_fingerprint():
         if k.startswith("GBWT_HIP_") and k != "GBWT_HIP_LIB":
             h.update(f"{k}={os.environ[k]};".encode())
     return h.hexdigest()[:16]
+
+
+def lookup_traffic(workload_key, kernel=None):
+    """HBM bytes per launch of `kernel` (default: the profile's first kernel) from a rocprofv3 PMC profile under profiles/ that was taken
+    with THESE kernel sources and knobs on THIS workload (tools/hbm_traffic.py stores both); (None, why) otherwise."""
+    import glob
+    fingerprint = source_fingerprint()
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(tpath))
+        except (OSError, ValueError):
+            continue
+        if tj.get("source_fingerprint") != fingerprint or tj.get("workload_key") != workload_key:
+            continue
+        entry = tj if kernel is None else tj.get("kernels", {}).get(kernel)
+        if entry is None:
+            continue
+        return entry["traffic_bytes_per_launch"], (f"profiles/{os.path.basename(tpath)} (same kernel sources and knobs, fingerprint {fingerprint}): "
+                                                   "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes")
+    return None, "no PMC profile of this build / workload under profiles/"
+
+
+def config_roofline(obj, key, definition):
+    """The roofline object of a secondary workload: algorithmic bytes / kernel time against the HBM peak, and the measured traffic."""
+    seconds = obj["kernel_ms"] * 1e-3
+    achieved = obj["algorithmic_bytes"] / seconds / 1e9
+    traffic, source = lookup_traffic(key)
+    obj["roofline"] = {"bound": "hbm", "definition": definition, "kernel": obj["kernel"], "kernel_ms": obj["kernel_ms"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "traffic_frac": None if traffic is None else traffic / seconds / 1e9 / HBM_PEAK_GBS, "traffic_source": source}
+    return obj
 
 
 def shard_paths(n_paths, rank, world):
@@ -219,7 +252,6 @@ def main():
     path_len = (index.len() - index.sequences()) // 2 // n_paths if n_paths else 0   # every path of this generator visits every site
     expected_steps = len(my_paths) * path_len
     steps_done = int(out.total)
-    value_cold = steps_done / ((open_ms + first_pass_ms) * 1e-3)
 
     # ---- steady state: the index resident, the same batch again and again
     for _ in range(args.warmup):
@@ -239,13 +271,18 @@ def main():
         assert np.array_equal(index.copy_path(k), s.path(int(my_paths[k])))
 
     gather_info = None
+    cold_ms = open_ms + first_pass_ms              # the one-shot flow of the slowest rank
+    rank_kernel_ms = [float(np.mean(walk_ms))]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
+        t = torch.tensor([elapsed, cold_ms], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, cold_ms = float(t[0].item()), float(t[1].item())
         tot = torch.tensor([steps_done], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         all_steps = float(tot.item())
+        per_rank = torch.zeros(world, dtype=torch.float64, device=comm_device)
+        dist.all_gather_into_tensor(per_rank, torch.tensor([float(np.mean(walk_ms))], dtype=torch.float64, device=comm_device))
+        rank_kernel_ms = [float(x) for x in per_rank.cpu().tolist()]
         # The one exchange of the job (outside the timed region, src/bin/gbunzip.rs:421-434: the writer's mutex): the extracted rows
         # travel to rank 0 over RCCL point-to-point sends, one group (gbwt_rs_amd/dist.py), every peer over its own xGMI link.
         # Strong scaling: the WHOLE CSR of the rank's shard (rows + lengths; 13.3 GB / N per rank); weak scaling (every rank a
@@ -314,6 +351,7 @@ def main():
         extras = {}
         if world == 1 and not args.no_extras:
             # (a) the same passes WITHOUT sequence samples: one walker per end of every row, the "one lane per active path" shape
+            saved = {k: os.environ.get(k) for k in ("GBWT_HIP_SAMPLE_INTERVAL", "GBWT_HIP_VMM")}
             os.environ["GBWT_HIP_SAMPLE_INTERVAL"] = "0"
             os.environ["GBWT_HIP_VMM"] = "0"      # four passes only: rebuilding the rows from spread chunks (at the third request) would be all they time
             try:
@@ -329,61 +367,32 @@ def main():
                                        "note": "GBWT_HIP_SAMPLE_INTERVAL=0: no sequence samples, every row walked by one lane from each of its two ends"}
                 plain.close()
             finally:
-                del os.environ["GBWT_HIP_SAMPLE_INTERVAL"]
-                del os.environ["GBWT_HIP_VMM"]
-            # (b) the same shape with an insertion allele at every site: the rows of a batch leave lock step at once (mixed waves)
-            t0 = time.perf_counter()
-            s2 = S.Synth.chain(sites=args.sites, haplotypes=args.haplotypes, alleles=2, model=model, founders=32, switch_rate=2e-3, seed=args.seed, extra=1)
-            dev2 = G.GBWT.from_records(s2.data(), s2.starts(), s2.alphabet_offset, s2.alphabet_size, s2.sequences, s2.size, True, device=local_rank)
-            ids2 = np.arange(0, s2.sequences, 2, dtype=np.uint64)
-            timed_passes(dev2, ids2, 3)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            o2, w2, _ = timed_passes(dev2, ids2, 5)
-            torch.cuda.synchronize()
-            e2 = time.perf_counter() - t1
-            truth2 = np.array([s2.path_checksum(h) for h in range(s2.paths)], dtype=np.uint64)
-            assert np.array_equal(dev2.path_sums(len(ids2)), truth2), "insertion chain: extracted paths differ from the generator's ground truth"
-            extras["secondary"] = {"workload": f"the same bubble chain with a one-node insertion as allele 1 of every site ({int(o2.total)} LF-steps; rows of a batch "
-                                               "leave lock step after the first site: every wave is mixed)",
-                                   "value": int(o2.total) * 5 / e2, "unit": "LF-steps/s", "kernel_ms": float(np.mean(w2)),
-                                   "open_ms": dev2.open_times()["total_ms"], "seconds_incl_generator": round(time.perf_counter() - t0, 1)}
-            dev2.close()
-            # (c) BASELINE config 5: a high-degree graph (300 alleles per site, outdegree >= 255: two-varint runs), walked on the deep walk tables
-            t0 = time.perf_counter()
-            s3 = S.Synth.chain(sites=3000, haplotypes=args.haplotypes, alleles=300, model=S.IID, seed=args.seed)
-            dev3 = G.GBWT.from_records(s3.data(), s3.starts(), s3.alphabet_offset, s3.alphabet_size, s3.sequences, s3.size, True, device=local_rank)
-            ids3 = np.arange(0, s3.sequences, 2, dtype=np.uint64)
-            timed_passes(dev3, ids3, 3)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            o3, w3, _ = timed_passes(dev3, ids3, 10)
-            torch.cuda.synchronize()
-            e3 = time.perf_counter() - t1
-            truth3 = np.array([s3.path_checksum(h) for h in range(s3.paths)], dtype=np.uint64)
-            assert np.array_equal(dev3.path_sums(len(ids3)), truth3), "high-degree chain: extracted paths differ from the generator's ground truth"
-            extras["high_degree"] = {"workload": f"BASELINE config 5: {args.haplotypes} haplotypes x 3 000 sites with 300 alleles each, i.i.d. ({int(o3.total)} LF-steps; "
-                                                 f"max outdegree {dev3.stats.max_outdegree}: every site is a table record)",
-                                     "value": int(o3.total) * 10 / e3, "value_kernel": int(o3.total) / (float(np.mean(w3)) * 1e-3), "unit": "LF-steps/s",
-                                     "kernel_ms": float(np.mean(w3)), "open_ms": dev3.open_times()["total_ms"], "seconds_incl_generator": round(time.perf_counter() - t0, 1)}
-            dev3.close()
+                for k, v in saved.items():       # a run launched with one of the knobs set keeps it for what follows (and for the fingerprint)
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            # (b)-(e) the other BASELINE configs, each with a roofline object of its own (tools/configs.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import configs as K
+            emitted = "emitted bytes: the u32 node id every LF-step writes (4 B per step) / kernel time; index reads show up in `traffic`"
+            extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank), "secondary", emitted)
+            extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank), "high_degree", emitted)
+            if not args.no_search:
+                extras["search"] = config_roofline(K.search(device=local_rank), "search",
+                                                   "bytes a query must move in this layout: its nodes in, its state out, and per step one 64-byte record descriptor + "
+                                                   "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)")
+            if not args.no_config4:
+                extras["config4"] = config_roofline(K.config4(device=local_rank), "config4",
+                                                    "bytes moved by walk + format: node ids written by the walk, read by the sizing pass and by the formatter, "
+                                                    "+ the text written / wall time of the two requests (P-lines, W-lines), host side included")
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/measure_round.sh -> profiles/*_hbm_traffic.json).  It is quoted only when those passes ran THIS build with
         # THESE knobs on THIS workload (fingerprint of the kernel sources + GBWT_HIP_* environment); a profile of another
         # build says nothing about this run.
-        traffic, traffic_source = None, "no PMC profile of this build / workload under profiles/"
         fingerprint = source_fingerprint()
         workload_key = f"sites={args.sites} haplotypes={args.haplotypes} model={args.model} seed={args.seed}"
-        import glob
-        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
-            try:
-                tj = json.load(open(tpath))
-            except (OSError, ValueError):
-                continue
-            if tj.get("source_fingerprint") == fingerprint and tj.get("workload_key") == workload_key and world == 1:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_source = f"profiles/{os.path.basename(tpath)} (same kernel sources and knobs, fingerprint {fingerprint}): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
-                break
+        traffic, traffic_source = lookup_traffic(workload_key) if world == 1 else (None, "N > 1: no profile")
         seconds = walk_avg_ms * 1e-3
         # What this kernel must move per LF-step whatever happens in the caches: the emitted u32 node id.  (The index it
         # reads -- two-step blocks and descriptors -- is shared by the 64+ steps of a block and mostly survives in L2 /
@@ -407,7 +416,10 @@ def main():
             "dtype": "u32",   # device arithmetic: record indices, offsets and node ids are 32-bit (the C ABI widens to u64 where the reference has usize)
             "data": "synthetic",
             # the one-shot flow (load, extract once) next to the steady state `value` is quoted on
-            "value_cold": value_cold * (world if strong else 1),
+            # LF-steps of all ranks / (open + first pass) of the slowest rank; value_cold_incl_init also counts what starting the HIP runtime cost
+            "value_cold": all_steps / (cold_ms * 1e-3),
+            "value_cold_incl_init": all_steps / ((cold_ms + runtime_init_ms) * 1e-3),
+            "kernel_ms_per_rank": rank_kernel_ms,
             "open_ms": open_ms,
             "sample_walk_ms": open_times["sample_ms"],
             "first_pass_ms": first_pass_ms,
@@ -435,6 +447,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
+                "definition": "emitted bytes: the u32 node id every LF-step writes (4 B per step) / kernel time -- a STORE roofline; SURVEY 8(d)'s per-step "
+                              "figure (what the reference's scan reads) is priced in `cold` (with the open, where the run-length decode happens) and in `survey_8d`",
                 "kernel": "k_walk_direct",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -455,6 +469,12 @@ def main():
                             "run-length decode is done once, at open (rank blocks, open.upload_ms), and the timed step is a popcount on a "
                             "16-byte packed half-block -- an algorithmic gain, not a fraction of the roofline",
                     "sample": f"exact over {sampled_steps} LF-steps of {min(args.bytes_sample, n_paths)} paths, scaled to {steps_done}",
+                },
+                "cold": {
+                    "bytes": b_per_step * all_steps, "ms": cold_ms, "achieved": b_per_step * all_steps / (cold_ms * 1e-3) / 1e9,
+                    "frac": b_per_step * all_steps / (cold_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                    "note": "SURVEY 8(d)'s algorithmic bytes (H + P + 4 per step) / (open_ms + first_pass_ms) / peak: the one figure that contains ALL the work "
+                            "8(d) prices -- the run-length decode into rank blocks and the sampling walk at open, then one extraction",
                 },
                 "kernel_ms": walk_avg_ms,
                 "extract_ms": float(np.mean(total_ms)),

@@ -44,7 +44,7 @@ class OpenTimes(C.Structure):
 
 class Memory(C.Structure):
     _fields_ = [("index_device_bytes", C.c_uint64), ("index_host_bytes", C.c_uint64), ("workspace_device_bytes", C.c_uint64),
-                ("rows_bytes", C.c_uint64), ("text_bytes", C.c_uint64)]
+                ("rows_bytes", C.c_uint64), ("text_bytes", C.c_uint64), ("rows_chunks", C.c_uint64)]
 
 
 class Paths(C.Structure):

@@ -682,6 +682,7 @@ gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hi
                                            &ws->out_valid, &ws->follow_off, &ws->gfa_a, &ws->gfa_b, &ws->gfa_c, &ws->gfa_text, &ws->gfa_text2, &ws->gfa_valid, &ws->gfa_chunk_first,
                                            &ws->gfa_chunks});
         out->rows_bytes = ws->nodes.bytes;
+        out->rows_chunks = ws->nodes.chunks.size();
         out->text_bytes = ws->gfa_text.bytes + ws->gfa_text2.bytes;
     }
     return GBWT_HIP_OK;

@@ -115,6 +115,7 @@ gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *
 typedef struct {
     uint64_t index_device_bytes, index_host_bytes;
     uint64_t workspace_device_bytes, rows_bytes, text_bytes;
+    uint64_t rows_chunks;   /* physical chunks the rows are mapped from (virtual-memory API, GBWT_HIP_VMM); 0 = one hipMalloc */
 } gbwt_hip_memory;
 gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hip_workspace *ws, gbwt_hip_memory *out);
 

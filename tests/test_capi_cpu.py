@@ -106,6 +106,47 @@ def mutated_files(tmp_path, names=None, values=MUTATIONS):
                 yield os.path.basename(path), w, value, target
 
 
+def mutated_large_file(tmp_path, per_region=40, values=(0xFFFFFFFFFFFFFFFF, 0, 1 << 40)):
+    """The same for a generated GBZ of several MiB -- large enough for the threaded paths of an open (the early host-to-device copy of
+    the record bytes out of the mapped file, the deferred decodes on threads, the background copy + label decode behind finish()):
+    seeded word positions in the head of the file (headers, tags, the Elias-Fano index of the record starts), in its tail (node
+    labels, translation) and in between (record bytes, metadata)."""
+    import numpy as np
+    from gbwt_rs_amd import synth as S
+    s = S.Synth.chain(sites=40000, haplotypes=600, alleles=2, model=S.MOSAIC, founders=16, switch_rate=0.01, seed=77)
+    source, target = str(tmp_path / "large.gbz"), str(tmp_path / "large_mutated.gbz")
+    s.save(source, as_gbz=True)
+    raw = open(source, "rb").read()
+    words = len(raw) // 8
+    assert len(raw) > (2 << 20)
+    rng = np.random.default_rng(99)
+    picks = np.concatenate([rng.integers(0, words // 12, per_region), rng.integers(words - words // 10, words, per_region),
+                            rng.integers(words // 12, words - words // 10, per_region // 2), np.arange(0, 24)])
+    for w in sorted(set(int(x) for x in picks)):
+        for value in values:
+            if raw[8 * w:8 * w + 8] == value.to_bytes(8, "little"):
+                continue
+            bad = bytearray(raw)
+            bad[8 * w:8 * w + 8] = value.to_bytes(8, "little")
+            with open(target, "wb") as f:
+                f.write(bad)
+            yield w, value, target
+
+
+def test_corrupt_words_of_a_large_file_are_invalid_data(tmp_path):
+    accepted = rejected = 0
+    reasons = set()
+    for w, value, path in mutated_large_file(tmp_path):
+        try:
+            G.parse_file(path)
+            accepted += 1
+        except G.GbwtHipError as e:
+            assert e.status == _lib.INVALID_DATA, (w, hex(value), str(e))
+            rejected += 1
+            reasons.add(str(e).split(":")[1].strip()[:40])
+    assert rejected > 40 and accepted > 20 and len(reasons) >= 4, (accepted, rejected, reasons)
+
+
 def test_corrupt_words_are_invalid_data_never_an_abort(tmp_path):
     """A corrupt length word must come back as GBWT_HIP_INVALID_DATA (io::ErrorKind::InvalidData in the reference's
     loaders), not as an exception crossing the C ABI (std::terminate) or an out-of-bounds read.  Runs in-process: an

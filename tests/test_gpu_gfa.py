@@ -175,6 +175,91 @@ def test_config_c4_shape_whole_file(tmp_path):
         assert np.array_equal(nodes[offsets[2 * p]:offsets[2 * p + 1]], g.path(p))
 
 
+def test_whole_file_in_many_batches(tmp_path):
+    """The pipelined writer (gbwt_hip_write_gfa_mode: byte-bounded batches, two device text buffers in turn, a writer thread with two
+    pinned buffers) with a budget so small that every pass takes dozens of batches: the same bytes as the oracle's gbunzip restatement in
+    the three path modes, and as the file written in one batch."""
+    import subprocess
+    import sys
+    g = S.Synth.genome(contigs=6, fragments=4, haplotypes=24, sites=400, seed=5)
+    path = tmp_path / "batches.gbz"
+    g.save(str(path), as_gbz=True)
+    oracle = O.OracleGBZ(str(path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import gbwt_rs_amd as G\n"
+            f"dev = G.GBZ.load({str(path)!r})\n"
+            f"for mode in (0, 1, 2): dev.write_gfa({str(tmp_path)!r} + '/small_' + str(mode) + '.gfa', mode)\n")
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, GBWT_HIP_GFA_BATCH_MIB="1"), timeout=600)
+    dev = G.GBZ.load(str(path))
+    for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+        exp = oracle.gfa(mode)
+        assert len(exp) > (3 << 20) or mode == G.PATHS_REF_ONLY       # several 1 MiB batches
+        assert (tmp_path / f"small_{mode}.gfa").read_bytes() == exp, mode
+        out = tmp_path / f"one_{mode}.gfa"
+        dev.write_gfa(str(out), mode)
+        assert out.read_bytes() == exp, mode
+
+
+def test_config_c4_full_size():
+    """Config 4 at the size bench.py's `config4` object is quoted on: Synth.genome 24 contigs x 20 components, 90 haplotypes -- 32 286
+    ragged walks, 0.50 G LF-steps, 4.5 GB of GFA.  The whole file through the pipelined writer (1 GiB batches, 64 MiB pieces), checked
+    piece by piece:
+      * H-, S-, L- and P-lines: byte-identical to the oracle's gbunzip restatement in ref-only mode (src/bin/gbunzip.rs:205-332);
+      * the W-lines: identical to the text of ONE device request for all walks; a seeded sample of 2 048 of them byte-identical to the
+        oracle's path_to_w_line (src/bin/gbunzip.rs:495-550); EVERY line's header fields and length against the generator's ground truth
+        (sample, phase, contig, fragment, fragment + length, one token per node);
+      * the extraction behind it: per-path checksums of all 32 286 forward sequences against the generator."""
+    g = S.Synth.genome(contigs=24, fragments=20, haplotypes=90, sites=6000, seed=42)
+    assert g.paths > 30000
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path, out = os.path.join(tmp, "gbwt_c4_full.gbz"), os.path.join(tmp, "gbwt_c4_full.gfa")
+    try:
+        g.save(path, as_gbz=True)
+        dev, oracle = G.GBZ.load(path), O.OracleGBZ(path)
+        generic = np.array(g.generic_paths(), dtype=np.uint64)
+        walks = np.setdiff1d(np.arange(g.paths, dtype=np.uint64), generic)
+        # the extraction: every forward sequence against the generator
+        ids = 2 * np.arange(g.paths, dtype=np.uint64)
+        res = dev.extract_device(ids)
+        assert int(res.total) == (g.size - g.sequences) // 2
+        truth = np.array([g.path_checksum(p) for p in range(g.paths)], dtype=np.uint64)
+        assert np.array_equal(dev.path_sums(len(ids)), truth)
+        # the whole file
+        dev.write_gfa(out)
+        head = oracle.gfa(G.PATHS_REF_ONLY)
+        whole = np.memmap(out, dtype=np.uint8, mode="r")
+        assert len(whole) > len(head) and bytes(whole[:len(head)]) == head, "H/S/L/P lines differ from the oracle"
+        text = dev.path_lines(walks, 1)                        # one request for all walks
+        assert len(whole) == len(head) + len(text)
+        tail = np.frombuffer(text, dtype=np.uint8)
+        step = 1 << 28
+        for lo in range(0, len(tail), step):
+            assert np.array_equal(whole[len(head) + lo:len(head) + lo + step], tail[lo:lo + step]), "the batched file differs from the single request"
+        ends = np.concatenate([np.flatnonzero(tail[lo:lo + step] == 10) + lo for lo in range(0, len(tail), step)])
+        assert len(ends) == len(walks)
+        starts = np.concatenate([[0], ends[:-1] + 1])
+        # every line: header fields and length from the generator's ground truth
+        samples = [f"s{k}" for k in range((90 + 1) // 2)] + ["_gbwt_ref"]
+        pow10 = 10 ** np.arange(1, 10, dtype=np.uint64)
+        for k, p in enumerate(walks):
+            nodes = g.path(int(p))
+            sample, contig, phase, fragment = (int(x) for x in g.path_names[int(p)])
+            header = f"W\t{samples[sample]}\t{phase}\tchr{contig + 1}\t{fragment}\t{fragment + len(nodes)}\t".encode()
+            lo, hi = int(starts[k]), int(ends[k])
+            assert text[lo:lo + len(header)] == header, (k, int(p))
+            digits = 1 + np.searchsorted(pow10, (nodes >> 1).astype(np.uint64), side="right")
+            assert hi - lo == len(header) + int(digits.sum()) + len(nodes), (k, int(p))
+        # a seeded sample of lines against the oracle, byte for byte
+        rng = np.random.default_rng(2024)
+        for k in np.sort(rng.choice(len(walks), 2048, replace=False)):
+            assert text[int(starts[k]):int(ends[k]) + 1] == oracle.path_lines([int(walks[k])], 1), int(walks[k])
+        del whole
+    finally:
+        for f in (path, out):
+            if os.path.exists(f):
+                os.remove(f)
+
+
 def test_bare_gbwt_has_no_gfa():
     dev = G.GBZ.load(os.path.join(O.GOLDEN, "example.gbwt"))
     with pytest.raises(G.GbwtHipError):

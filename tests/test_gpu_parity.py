@@ -1224,3 +1224,45 @@ print("MUTATIONS_OK")
 '''
     out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}; TMP = {str(tmp_path)!r}\n" + code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "MUTATIONS_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_corrupt_large_files_through_the_threaded_open(tmp_path):
+    """The same for a GBZ of several MiB, which takes the threaded paths of gbwt_hip_open_file: the record bytes start for the device out
+    of the mapped file while the loader still decodes (a decode that throws must not unmap the file under that copy: round 3 did), the
+    deferred decodes run on threads, node labels and the host copy of the record bytes in the background behind finish().  Corrupt
+    starts, labels, lengths: GBWT_HIP_INVALID_DATA (or an index that opens and answers), never a fault.  Child process with a deadline."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import gbwt_rs_amd as G
+from test_capi_cpu import mutated_large_file
+import pathlib
+opened = rejected = 0
+reasons = set()
+for w, value, path in mutated_large_file(pathlib.Path(TMP), per_region=60):
+    try:
+        dev = G.GBZ.load(path)
+    except G.GbwtHipError as e:
+        assert e.status in (G._lib.INVALID_DATA, G._lib.UNSUPPORTED), (w, hex(value), str(e))
+        rejected += 1
+        reasons.add(str(e)[:60])
+        continue
+    opened += 1
+    off, nodes = dev.sequences_csr(np.arange(0, min(dev.sequences(), 64), dtype=np.uint64))
+    assert int(off[-1]) == len(nodes)
+    if dev.stats.is_gbz and dev.has_metadata() and dev.stats.paths:
+        try:
+            dev.path_lines(np.arange(min(dev.stats.paths, 4), dtype=np.uint64), 1)
+        except G.GbwtHipError as e:
+            assert e.status in (G._lib.BAD_ARGUMENT, G._lib.INVALID_DATA), str(e)
+    dev.close()
+print("opened", opened, "rejected", rejected, sorted(reasons))
+assert opened > 30 and rejected > 60 and any("starts" in r or "bitvector" in r or "Elias" in r or "sparse" in r.lower() for r in reasons), reasons
+print("MUTATIONS_OK")
+'''
+    out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}; TMP = {str(tmp_path)!r}\n" + code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "MUTATIONS_OK" in out.stdout, (out.stdout[-800:], out.stderr[-3000:])

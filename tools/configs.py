@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""The BASELINE configs next to the headline, each as one function that returns the object bench.py puts on its line
+(N = 1 only) and as a command `python3 tools/configs.py NAME` for the rocprofv3 passes of tools/measure_round.sh:
+
+  secondary    the headline's shape with a one-node insertion as allele 1 of every site (rows leave lock step at once)
+  high_degree  BASELINE config 5: 300 alleles per site (outdegree >= 255: two-varint runs), walked on the deep walk tables
+  search       BASELINE config 3: 1.1 M sites x 5 008 haplotypes, 1 M queries of 10 nodes as src/bin/benchmark.rs:124-169 builds
+               them (seeded), find + 9 x extend in one launch and the bidirectional form
+  config4      BASELINE config 4's shape on one GPU (tools/c4_bench.py)
+
+Every object carries {workload, value, unit, kernel, kernel_ms, algorithmic_bytes}; bench.py adds the roofline fraction and the
+measured HBM traffic of a PMC profile taken with the same sources and knobs (profiles/*_hbm_traffic.json, key = the config's name).
+Results are checked against the generator's ground truth (extraction) or against invariants (search); parity with the oracle is
+tests/'s business."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _timed_passes(index, ids, passes):
+    walk, total, out = [], [], None
+    for _ in range(passes):
+        out = index.extract_device(ids)
+        w, t = index.last_kernel_ms()
+        walk.append(w)
+        total.append(t)
+    return out, walk, total
+
+
+def _extraction(s, passes, warm, device):
+    import gbwt_rs_amd as G
+    import torch
+    dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, device=device)
+    ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
+    _timed_passes(dev, ids, warm)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out, walk, _ = _timed_passes(dev, ids, passes)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    truth = np.array([s.path_checksum(h) for h in range(s.paths)], dtype=np.uint64)
+    assert np.array_equal(dev.path_sums(len(ids)), truth), "extracted paths differ from the generator's ground truth"
+    steps = int(out.total)
+    res = {"value": steps * passes / elapsed, "unit": "LF-steps/s", "kernel": "k_walk_direct", "kernel_ms": float(np.mean(walk)),
+           "value_kernel": steps / (float(np.mean(walk)) * 1e-3), "lf_steps": steps, "algorithmic_bytes": 4.0 * steps,
+           "open_ms": dev.open_times()["total_ms"], "memory": dev.memory_usage()}
+    dev.close()
+    return res
+
+
+def secondary(sites=333334, haplotypes=5000, model=0, seed=42, passes=5, device=0):
+    from gbwt_rs_amd import synth as S
+    t0 = time.perf_counter()
+    s = S.Synth.chain(sites=sites, haplotypes=haplotypes, alleles=2, model=model, founders=32, switch_rate=2e-3, seed=seed, extra=1)
+    res = _extraction(s, passes, 3, device)
+    res["workload"] = (f"the headline's bubble chain with a one-node insertion as allele 1 of every site ({res['lf_steps']} LF-steps; rows of a batch "
+                       "leave lock step after the first site: every wave is mixed)")
+    res["seconds_incl_generator"] = round(time.perf_counter() - t0, 1)
+    return res
+
+
+def high_degree(haplotypes=5000, seed=42, passes=10, device=0):
+    from gbwt_rs_amd import synth as S
+    t0 = time.perf_counter()
+    s = S.Synth.chain(sites=3000, haplotypes=haplotypes, alleles=300, model=S.IID, seed=seed)
+    res = _extraction(s, passes, 3, device)
+    res["workload"] = (f"BASELINE config 5: {haplotypes} haplotypes x 3 000 sites with 300 alleles each, i.i.d. Zipf(1.2) ({res['lf_steps']} LF-steps; "
+                       "every site is a table record of outdegree >= 255, two-varint runs)")
+    res["seconds_incl_generator"] = round(time.perf_counter() - t0, 1)
+    return res
+
+
+def make_benchmark_queries(dev, first, alphabet, n_queries, length, seed):
+    """Queries as src/bin/benchmark.rs:124-153 builds them: a start node uniform in [first_node, alphabet_size), an offset uniform in its
+    record, extended with GBWT::forward; discarded when the sequence ends early -- with a seeded generator (the reference's is not)."""
+    import gbwt_rs_amd as G
+    rng = np.random.default_rng(seed)
+    want = int(n_queries * 1.3) + 1024
+    nodes = rng.integers(first, alphabet, size=want, dtype=np.uint64)
+    states, ok = dev.find(nodes)
+    lens = (states["end"] - states["start"]).astype(np.uint64)
+    keep = ok & (lens > 0)
+    nodes, lens = nodes[keep], lens[keep]
+    offsets = (rng.random(nodes.size) * lens).astype(np.uint64)
+    pos = np.zeros(nodes.size, dtype=G.POS_DTYPE)
+    pos["node"], pos["offset"] = nodes, offsets
+    rows = [pos["node"].copy()]
+    alive = np.ones(nodes.size, dtype=bool)
+    for _ in range(length - 1):
+        pos, ok = dev.forward(pos)
+        alive &= ok & (pos["node"] != 0)
+        rows.append(pos["node"].copy())
+    return np.stack(rows, axis=1)[alive][:n_queries].astype(np.uint64)
+
+
+def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7, passes=5, device=0, keep=None):
+    import gbwt_rs_amd as G
+    from gbwt_rs_amd import synth as S
+    t0 = time.perf_counter()
+    s = S.Synth.chain(sites, haplotypes, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=42)
+    dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, device=device)
+    queries = make_benchmark_queries(dev, s.alphabet_offset + 1, s.alphabet_size, n_queries, length, seed)
+    n = queries.shape[0]
+    res = {"workload": f"BASELINE config 3: bubble chain {sites} sites x {haplotypes} haplotypes (mosaic, seed 42), {n} queries of {length} nodes built as "
+                       f"src/bin/benchmark.rs:124-153 does (seed {seed}); find + {length - 1} x extend per query in one launch, and bd_find + alternating "
+                       "extend_forward / extend_backward",
+           "queries": int(n), "unit": "queries/s"}
+    for name, kernel, fn in (("unidirectional", "k_search", lambda: dev.search(queries)), ("bidirectional", "k_bd_search", lambda: dev.bd_search(queries, length // 2))):
+        fn()
+        ks, ws = [], []
+        for _ in range(passes):
+            t1 = time.perf_counter()
+            out, ok = fn()
+            ws.append((time.perf_counter() - t1) * 1e3)
+            ks.append(dev.last_query_ms())
+        assert ok.all(), "a query cut out of the index itself was not found"
+        fwd = out if name == "unidirectional" else out["forward"]
+        assert ((fwd["end"] > fwd["start"]) & (fwd["node"] == queries[:, -1 if name == "unidirectional" else length - 1])).all()
+        k = float(np.mean(ks))
+        # what a query must move in this layout: its nodes in (8 B each), its state out (24 / 48 B + 1), and per step the 64-byte descriptor of
+        # the record + two 16-byte rank blocks (range start and end)
+        bytes_q = 8 * length + (24 if name == "unidirectional" else 48) + 1 + length * (64 + 2 * 16)
+        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.mean(ws)), "value": n / (k * 1e-3), "steps_per_s": n * length / (k * 1e-3),
+                     "algorithmic_bytes": float(bytes_q * n), "found": int(ok.sum())}
+    res["value"] = res["unidirectional"]["value"]
+    res["kernel"], res["kernel_ms"], res["algorithmic_bytes"] = "k_search", res["unidirectional"]["kernel_ms"], res["unidirectional"]["algorithmic_bytes"]
+    res["memory"] = dev.memory_usage()
+    res["seconds_incl_generator"] = round(time.perf_counter() - t0, 1)
+    if keep is not None:
+        keep.update(dev=dev, synth=s, queries=queries)
+    else:
+        dev.close()
+    return res
+
+
+def config4(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import c4_bench
+    try:
+        res = c4_bench.run(passes=passes, out=out, device=device)
+    finally:
+        if out and os.path.exists(out):
+            os.remove(out)
+    wf = res["walk_format"]
+    res.update({"value": wf["value"], "unit": "LF-steps/s", "kernel": "k_walk_direct + k_chunk_stats + k_format_chunks", "kernel_ms": wf["ms"],
+                "algorithmic_bytes": float(wf["bytes_moved"])})
+    return res
+
+
+if __name__ == "__main__":
+    import json
+    name = sys.argv[1]
+    fn = {"secondary": secondary, "high_degree": high_degree, "search": search, "config4": config4}[name]
+    print(json.dumps(fn()), flush=True)

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
-"""HBM traffic of the walk kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass)
+"""HBM traffic of one or more kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass)
 -> the JSON kept under profiles/ and quoted by bench.py as roofline.traffic.
 
-usage: hbm_traffic.py FETCH_DIR WRITE_DIR KERNEL "workload text" OUTPUT_BYTES [bench.py arguments] > profiles/rNN_x_hbm_traffic.json
-The JSON carries bench.py's fingerprint of the kernel sources + GBWT_HIP_* knobs and the workload key: bench.py quotes
-the traffic only for a run of the same build, knobs and workload.
+usage: hbm_traffic.py FETCH_DIR WRITE_DIR KERNEL[,KERNEL...] "workload text" ALGORITHMIC_BYTES [--key KEY] [--pick last|max] [bench.py arguments]
+           > profiles/rNN_x_hbm_traffic.json
+--key: the workload key bench.py looks the profile up by (default: the headline's "sites=... haplotypes=... model=... seed=...";
+the other configs: "secondary", "high_degree", "search", "config4").  --pick: which dispatch of a kernel counts -- the last one
+(default: the timed launch behind the warm-ups) or the largest (commands whose launches differ in size).  With several kernels the
+top-level figures are their SUM (the workload's traffic); every kernel's own are under "kernels".
+The JSON carries bench.py's fingerprint of the kernel sources + GBWT_HIP_* knobs: bench.py quotes the traffic only for a run of the
+same build, knobs and workload.
 Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes of
 16 B/lane loads -> doubled; WRITE_SIZE is uncalibrated and taken as is.  Both are in KiB."""
 import csv
 import glob
 import json
+import os
 import sys
 
 
@@ -24,27 +30,43 @@ def dispatches(directory, counter, kernel):
     return vals
 
 
-import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 
-fetch_dir, write_dir, kernel, workload, algorithmic = sys.argv[1:6]
-sys.argv = [sys.argv[0]] + sys.argv[6:]
+fetch_dir, write_dir, kernels, workload, algorithmic = sys.argv[1:6]
+rest, key, pick = sys.argv[6:], None, "last"
+while rest and rest[0] in ("--key", "--pick"):
+    if rest[0] == "--key":
+        key = rest[1]
+    else:
+        pick = rest[1]
+    rest = rest[2:]
+sys.argv = [sys.argv[0]] + rest
 bench_args = bench.parse_args()
-fetch, write = dispatches(fetch_dir, "FETCH_SIZE", kernel), dispatches(write_dir, "WRITE_SIZE", kernel)
-f_raw, w_raw = fetch[-1] * 1024, write[-1] * 1024      # the last launch = the timed one (the first is the warm-up)
+choose = (lambda v: v[-1]) if pick == "last" else max
+per_kernel, f_sum, w_sum = {}, 0.0, 0.0
+for kernel in kernels.split(","):
+    fetch, write = dispatches(fetch_dir, "FETCH_SIZE", kernel), dispatches(write_dir, "WRITE_SIZE", kernel)
+    f_raw, w_raw = choose(fetch) * 1024, choose(write) * 1024
+    per_kernel[kernel] = {"dispatches": {"FETCH_SIZE_KiB": fetch[-8:], "WRITE_SIZE_KiB": write[-8:]}, "fetch_bytes_raw": f_raw, "fetch_bytes_corrected": 2 * f_raw,
+                          "write_bytes": w_raw, "traffic_bytes_per_launch": 2 * f_raw + w_raw}
+    f_sum += f_raw
+    w_sum += w_raw
+first = per_kernel[kernels.split(",")[0]]
 print(json.dumps({
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline",
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes of the same command)",
     "workload": workload,
-    "kernel": kernel,
+    "kernel": kernels,
     "unit_note": "FETCH_SIZE / WRITE_SIZE are in KiB",
-    "dispatches": {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write},
-    "fetch_bytes_raw": f_raw,
-    "fetch_bytes_corrected": 2 * f_raw,
+    "dispatches": first["dispatches"],
+    "fetch_bytes_raw": f_sum,
+    "fetch_bytes_corrected": 2 * f_sum,
     "correction": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane loads -> doubled; WRITE_SIZE uncalibrated, taken as is",
-    "write_bytes": w_raw,
-    "traffic_bytes_per_launch": 2 * f_raw + w_raw,
+    "write_bytes": w_sum,
+    "traffic_bytes_per_launch": 2 * f_sum + w_sum,
     "algorithmic_bytes_per_launch": float(algorithmic),
+    "kernels": per_kernel,
+    "pick": pick,
     "source_fingerprint": bench.source_fingerprint(),
-    "workload_key": f"sites={bench_args.sites} haplotypes={bench_args.haplotypes} model={bench_args.model} seed={bench_args.seed}",
+    "workload_key": key or f"sites={bench_args.sites} haplotypes={bench_args.haplotypes} model={bench_args.model} seed={bench_args.seed}",
 }, indent=1))
