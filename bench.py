@@ -291,32 +291,56 @@ def main():
             from gbwt_rs_amd import dist as D
             device = torch.device("cuda", local_rank)
             if strong:
-                offsets, nodes = D.paths_tensors(out, device)
-                lengths = (offsets[1:] - offsets[:-1]).clone()
-                # the rows of a workspace may be mapped from spread chunks (virtual-memory API); they are staged through an ordinary
-                # allocation for the send (RCCL registers / IPC-exports what it sends from)
-                payload = nodes.clone()
-                if comm_device == "cpu":
-                    lengths, payload = lengths.cpu(), payload.cpu()
-                barrier()
-                tg = time.perf_counter()
-                len_parts, val_parts = D.gather_parts(lengths, payload, dst=0)
-                if comm_device == "cuda":
-                    torch.cuda.synchronize()
-                gather_ms = (time.perf_counter() - tg) * 1e3
-                gather_info = {"ms": gather_ms, "backend": backend, "payload": "the whole CSR: node ids (u32) + row lengths of every rank's shard, gathered on rank 0"}
-                if rank == 0:
-                    got = sum(int(p.numel()) for p in val_parts)
-                    assert got == int(all_steps), (got, all_steps)
-                    for r in range(world):                     # first and last row of every rank's part against the generator
-                        paths_r = shard_paths(n_paths, r, world)
-                        ends = torch.cumsum(len_parts[r], 0)
-                        for k in (0, len(paths_r) - 1):
-                            lo = int(ends[k - 1]) if k else 0
-                            row = val_parts[r][lo:int(ends[k])].cpu().numpy().astype(np.uint32)
-                            assert np.array_equal(row, s.path(int(paths_r[k]))), f"row {k} of rank {r} changed on the way"
-                    gather_info["bytes"] = 4 * got + 8 * n_paths
-                    gather_info["GB_per_s"] = gather_info["bytes"] / 1e9 / (gather_ms * 1e-3)
+                # through the C ABI (gbwt_hip_comm_*: RCCL called by the library, rows placed in path order by kernels on rank 0); the
+                # torch.distributed form is the fallback (and what the gloo rehearsal on one shared GPU takes), reported as such
+                via, comm = "gbwt_hip_comm (C ABI, RCCL)", None
+                try:
+                    if comm_device != "cuda":
+                        raise RuntimeError("not an RCCL run")
+                    comm = D.Comm(rank, world, local_rank)
+                    comm.gather_rows(index, root=0, interleaved=True)          # untimed: connections, buffers
+                    barrier()
+                    tg = time.perf_counter()
+                    got = comm.gather_rows(index, root=0, interleaved=True)
+                    barrier()
+                    gather_ms = (time.perf_counter() - tg) * 1e3
+                    gather_info = {"ms": gather_ms, "backend": backend, "via": via, "rank_stats": comm.last(),
+                                   "payload": "the whole CSR: node ids (u32) + row lengths of every rank's shard, gathered on rank 0 in path order"}
+                    if rank == 0:
+                        assert int(got.total) == int(all_steps) and int(got.n) == n_paths, (int(got.total), all_steps)
+                        g_off, g_nodes = D.paths_tensors(got, device)
+                        for p_id in list(range(min(world, n_paths))) + list(range(max(0, n_paths - world), n_paths)):   # first and last row of every rank
+                            row = g_nodes[int(g_off[p_id]):int(g_off[p_id + 1])].cpu().numpy().astype(np.uint32)
+                            assert np.array_equal(row, s.path(p_id)), f"row {p_id} changed on the way"
+                        gather_info["bytes"] = 4 * int(got.total) + 8 * n_paths
+                        gather_info["GB_per_s"] = gather_info["bytes"] / 1e9 / (gather_ms * 1e-3)
+                except Exception as first:
+                    if comm is not None:
+                        comm.close()
+                    offsets, nodes = D.paths_tensors(out, device)
+                    lengths = (offsets[1:] - offsets[:-1]).clone()
+                    payload = nodes.clone()                                     # (rows may be mapped from spread chunks: staged for the send)
+                    if comm_device == "cpu":
+                        lengths, payload = lengths.cpu(), payload.cpu()
+                    barrier()
+                    tg = time.perf_counter()
+                    len_parts, val_parts = D.gather_parts(lengths, payload, dst=0)
+                    barrier()
+                    gather_ms = (time.perf_counter() - tg) * 1e3
+                    gather_info = {"ms": gather_ms, "backend": backend, "via": "torch.distributed batch_isend_irecv (fallback: " + repr(first)[:200] + ")",
+                                   "payload": "the whole CSR: node ids (u32) + row lengths of every rank's shard, gathered on rank 0"}
+                    if rank == 0:
+                        got_n = sum(int(p.numel()) for p in val_parts)
+                        assert got_n == int(all_steps), (got_n, all_steps)
+                        for r in range(world):                     # first and last row of every rank's part against the generator
+                            paths_r = shard_paths(n_paths, r, world)
+                            ends = torch.cumsum(len_parts[r], 0)
+                            for k in (0, len(paths_r) - 1):
+                                lo = int(ends[k - 1]) if k else 0
+                                row = val_parts[r][lo:int(ends[k])].cpu().numpy().astype(np.uint32)
+                                assert np.array_equal(row, s.path(int(paths_r[k]))), f"row {k} of rank {r} changed on the way"
+                        gather_info["bytes"] = 4 * got_n + 8 * n_paths
+                        gather_info["GB_per_s"] = gather_info["bytes"] / 1e9 / (gather_ms * 1e-3)
             else:
                 sample = np.arange(min(args.gather_paths, n_paths), dtype=np.uint64)
                 lines = index.path_lines_device(sample, 1)
@@ -420,6 +444,8 @@ def main():
             "value_cold": all_steps / (cold_ms * 1e-3),
             "value_cold_incl_init": all_steps / ((cold_ms + runtime_init_ms) * 1e-3),
             "kernel_ms_per_rank": rank_kernel_ms,
+            # N > 1: one pass + the gather of its rows on rank 0 (the only collective of the job, outside `value`'s timed region)
+            "value_incl_gather": None if not (gather_info and "ms" in gather_info) else all_steps / ((elapsed / args.steps) + gather_info["ms"] * 1e-3),
             "open_ms": open_ms,
             "sample_walk_ms": open_times["sample_ms"],
             "first_pass_ms": first_pass_ms,

@@ -47,6 +47,14 @@ class Memory(C.Structure):
                 ("rows_bytes", C.c_uint64), ("text_bytes", C.c_uint64), ("rows_chunks", C.c_uint64)]
 
 
+class UniqueId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
+class CommStats(C.Structure):
+    _fields_ = [("ms", C.c_double), ("bytes", C.c_uint64), ("staged_send", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Paths(C.Structure):
     _fields_ = [("d_offsets", C.c_void_p), ("d_nodes", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
 
@@ -96,6 +104,12 @@ SIGNATURES = {
     "gbwt_hip_last_kernel_ms": (_int, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gbwt_hip_last_query_ms": (_int, [_p, C.POINTER(C.c_float)]),
     "gbwt_hip_device_memory": (_int, [_int, C.POINTER(_u64), C.POINTER(_u64)]),
+    "gbwt_hip_comm_unique_id": (_int, [C.POINTER(UniqueId)]),
+    "gbwt_hip_comm_create": (_int, [C.POINTER(UniqueId), _int, _int, _int, C.POINTER(_p)]),
+    "gbwt_hip_comm_destroy": (None, [_p]),
+    "gbwt_hip_gather_rows": (_int, [_p, _p, _p, _int, _int, C.POINTER(Paths)]),
+    "gbwt_hip_gather_lines": (_int, [_p, _p, _p, _int, _int, C.POINTER(Lines)]),
+    "gbwt_hip_comm_last": (_int, [_p, C.POINTER(CommStats)]),
 }
 
 _lib = None

@@ -14,9 +14,71 @@ path order on one rank.  That is
        copy at all: gather_parts + rows_in_path_order hand a writer the rows in path order where they arrived
 
 Works on HIP tensors over RCCL and on CPU tensors over gloo (the CPU form is what the tests run).
+
+Since round 4 the same exchange also exists BEHIND THE C ABI (include/gbwt_hip.h: gbwt_hip_comm_*, csrc/comm.hip: RCCL called
+directly, rows placed in path order by kernels) -- what a Rust `gbunzip` linking libgbwt_hip.so would call; `Comm` below is its
+Python face and what bench.py --gpus N and tools/gfa_sharded.py use on GPUs.  The torch.distributed functions stay: they are the
+form that runs over gloo on CPU tensors (tests/test_dist_cpu.py) and the fallback when RCCL cannot be loaded by the library.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+
+class Comm:
+    """gbwt_hip_comm: one communicator per process, created collectively by the `world` ranks.  The 128-byte unique id is made by
+    rank 0 and reaches the others through `broadcast` -- by default torch.distributed's broadcast_object_list over the default group
+    (any backend), or any callable `bytes-or-None -> bytes`."""
+
+    def __init__(self, rank, world, device, broadcast=None):
+        self._L = _lib.lib()
+        uid = _lib.UniqueId()
+        if rank == 0:
+            _lib.check(self._L.gbwt_hip_comm_unique_id(C.byref(uid)))
+        if world > 1:
+            raw = bytes(uid.bytes) if rank == 0 else None
+            if broadcast is None:
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = broadcast(raw)
+            C.memmove(C.byref(uid), raw, 128)
+        self._c = C.c_void_p()
+        self.rank, self.world, self.device = rank, world, device
+        _lib.check(self._L.gbwt_hip_comm_create(C.byref(uid), rank, world, device, C.byref(self._c)))
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._L.gbwt_hip_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_rows(self, gbwt, root=0, interleaved=False):
+        """The rows of the last gbwt.extract_device() of every rank, in path order on `root`: a Paths struct (device memory of the
+        communicator, valid until its next gather) there, None elsewhere."""
+        out = _lib.Paths()
+        _lib.check(self._L.gbwt_hip_gather_rows(self._c, gbwt._h, gbwt._ws, root, int(interleaved), C.byref(out)))
+        return out if self.rank == root else None
+
+    def gather_lines(self, gbz, root=0, interleaved=False):
+        """The GFA lines of the last gbz.path_lines_device() of every rank, in path order on `root`: a Lines struct there."""
+        out = _lib.Lines()
+        _lib.check(self._L.gbwt_hip_gather_lines(self._c, gbz._h, gbz._ws, root, int(interleaved), C.byref(out)))
+        return out if self.rank == root else None
+
+    def last(self):
+        st = _lib.CommStats()
+        _lib.check(self._L.gbwt_hip_comm_last(self._c, C.byref(st)))
+        return {"ms": st.ms, "bytes": st.bytes, "staged_send": bool(st.staged_send)}
 
 
 def shard_bounds(n, rank, world):

@@ -253,6 +253,37 @@ gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *index, gbwt_hip_workspa
 enum { GBWT_HIP_PATHS_DEFAULT = 0, GBWT_HIP_PATHS_PAN_SN = 1, GBWT_HIP_PATHS_REF_ONLY = 2 };
 gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const char *path, int path_mode);
 
+/* ---- multi-GPU: the one exchange of a sharded extraction -------------------------------------------------------------
+ * The reference's parallel axis is the path: rayon workers pull path ids and hand their finished lines to ONE writer behind a mutex
+ * (src/bin/gbunzip.rs:27, 421-434).  Sharded over GPUs -- one process per GPU, the index replicated, path p on rank p mod world
+ * (interleaved) or in contiguous blocks, no collective inside the walk -- that writer becomes an ordered gather on one rank, over RCCL:
+ * an all-gather of the per-rank counts, ONE group of point-to-point sends (every peer streams to the root over its own xGMI link at
+ * once), and kernels on the root that put the rows into path order.
+ *
+ * gbwt_hip_comm_unique_id: called by one rank; the 128 bytes travel to the others by whatever channel the host program has (a file,
+ * a socket, MPI, a torch store).  gbwt_hip_comm_create: collective over the `world` ranks (ncclCommInitRank), each with its device.
+ * RCCL is loaded at run time; without it these calls return GBWT_HIP_UNSUPPORTED and everything else works. */
+typedef struct { char bytes[128]; } gbwt_hip_unique_id;
+typedef struct gbwt_hip_comm gbwt_hip_comm;
+gbwt_hip_status gbwt_hip_comm_unique_id(gbwt_hip_unique_id *out);
+gbwt_hip_status gbwt_hip_comm_create(const gbwt_hip_unique_id *id, int rank, int world, int device, gbwt_hip_comm **out);
+void gbwt_hip_comm_destroy(gbwt_hip_comm *comm);
+/* gbwt_hip_gather_rows: the rows of the last gbwt_hip_extract_device on `ws` of EVERY rank (collective), gathered on `root` in path
+ * order: with interleaved != 0 row k of rank r is global row k * world + r (the ranks' row counts must be those of p -> rank p mod
+ * world), otherwise the rows of rank 0, then of rank 1, ...  On the root *out describes the result -- device memory of the
+ * communicator, valid until its next gather: d_offsets[rows + 1], d_nodes[total] --, elsewhere it is zeroed.
+ * gbwt_hip_gather_lines: the same for the GFA lines of the last gbwt_hip_path_lines_device on `ws` (d_text, d_line_offsets): the final
+ * GFA concatenation of north_star. */
+gbwt_hip_status gbwt_hip_gather_rows(gbwt_hip_comm *comm, const gbwt_hip_index *index, gbwt_hip_workspace *ws, int root, int interleaved,
+                                     gbwt_hip_paths *out);
+gbwt_hip_status gbwt_hip_gather_lines(gbwt_hip_comm *comm, const gbwt_hip_index *index, gbwt_hip_workspace *ws, int root, int interleaved,
+                                      gbwt_hip_lines *out);
+/* The last gather on `comm`, as this rank saw it: wall time from the first collective to the last kernel, bytes sent (peers) or
+ * gathered (root), and whether the payload was staged through an ordinary allocation before the send (rows mapped from spread chunks;
+ * GBWT_HIP_COMM_DIRECT=1 sends from the mapping). */
+typedef struct { double ms; uint64_t bytes; uint32_t staged_send, reserved; } gbwt_hip_comm_stats;
+gbwt_hip_status gbwt_hip_comm_last(const gbwt_hip_comm *comm, gbwt_hip_comm_stats *out);
+
 /* ---- checking hooks for device-resident results -------------------------------------------------
  * Per-path sums of the node ids of the last gbwt_hip_extract_device call on `ws` (a wave-per-path
  * reduction on the device), copied to out_sums[n]: a cheap full-size checksum of the extraction. */

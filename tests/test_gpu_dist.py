@@ -51,6 +51,100 @@ if rank == 0:
 '''
 
 
+# The same exchange through the C ABI (gbwt_hip_comm_*: RCCL called by libgbwt_hip.so itself, rows placed by kernels): rows and GFA lines,
+# interleaved and contiguous shards, against the generator and against one rank formatting everything alone.
+CHILD_CAPI = r'''
+import os, sys, hashlib
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import gbwt_rs_amd as G
+from gbwt_rs_amd import dist as D, synth as S
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+device = torch.device("cuda", local)
+dist.init_process_group("nccl" if world > 1 else "gloo", **({"device_id": device} if world > 1 else {}))
+comm = D.Comm(rank, world, local)
+path = os.path.join(TMP, "capi_ranks.gbz")
+if rank == 0:
+    g = S.Synth.genome(contigs=6, fragments=3, haplotypes=30, sites=SITES, seed=9)
+    g.save(path + ".tmp", as_gbz=True)
+    os.replace(path + ".tmp", path)
+dist.barrier()
+gbz = G.GBZ.load(path, device=local)
+n_paths = gbz.stats.paths
+everything = np.arange(n_paths, dtype=np.uint64)
+for interleaved in (True, False):
+    mine = D.shard_ids(everything, rank, world, interleaved=interleaved)
+    for attempt in range(ATTEMPTS):           # from the third request on large rows are mapped from spread chunks (GBWT_HIP_VMM)
+        out = gbz.extract_device(2 * mine)
+    got = comm.gather_rows(gbz, root=0, interleaved=interleaved)
+    stats = comm.last()
+    if rank == 0:
+        off, nodes = D.paths_tensors(got, device)
+        off, nodes = off.cpu().numpy(), nodes.cpu().numpy().astype(np.uint32)
+        w_off, w_nodes = gbz.sequences_csr(2 * everything)
+        assert np.array_equal(off, w_off.astype(np.int64)) and np.array_equal(nodes, w_nodes), interleaved
+    else:
+        assert got is None and stats["bytes"] == 4 * int(out.total) + 8 * len(mine)
+    lines = gbz.path_lines_device(mine, 1)
+    got = comm.gather_lines(gbz, root=0, interleaved=interleaved)
+    if rank == 0:
+        off, text = D.lines_tensors(got, device)
+        alone = gbz.path_lines(everything, 1)
+        assert bytes(text.cpu().numpy().tobytes()) == alone and int(off[-1]) == len(alone) and off.numel() == n_paths + 1, interleaved
+dist.barrier()
+comm.close()
+dist.destroy_process_group()
+if rank == world - 1:
+    print("PEER_STATS", stats, flush=True)      # (the last rank is a peer whenever there is one: did its rows go through a staging copy?)
+if rank == 0:
+    print("CAPI_RANKS_OK", world, int(out.total) * 4, flush=True)
+'''
+
+
+def run_capi_ranks(world, sites, attempts, tmp, timeout, extra_env=None):
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = f"ROOT = {ROOT!r}; SITES = {sites}; ATTEMPTS = {attempts}; TMP = {str(tmp)!r}\n" + CHILD_CAPI
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--no-python", sys.executable, "-c", script]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.parametrize("self_send", [False, True])
+def test_capi_comm_on_one_gpu(tmp_path, self_send):
+    """gbwt_hip_comm_* with world size 1 on the one GPU of a box: RCCL loaded by the library, a communicator, the all-gather of the
+    counts, the placement kernels (interleaved and contiguous, node ids and ragged GFA lines at every byte alignment) -- and, with
+    GBWT_HIP_COMM_SELF_SEND, the root's own part through ncclSend / ncclRecv in one group.  The peers are what is missing."""
+    out = run_capi_ranks(1, 300, 1, tmp_path, 600, {"GBWT_HIP_COMM_SELF_SEND": "1"} if self_send else None)
+    assert out.returncode == 0 and "CAPI_RANKS_OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_capi_comm_between_ranks(tmp_path):
+    """The same with one rank per GPU: the point-to-point group over xGMI, every rank's rows and lines in path order on rank 0."""
+    world = gpus()
+    if world < 2:
+        pytest.skip("one GPU on this box: ranks need devices of their own for RCCL point-to-point")
+    out = run_capi_ranks(world, 3000, 4, tmp_path, 900)
+    assert out.returncode == 0 and "CAPI_RANKS_OK" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_capi_comm_sends_from_mapped_rows(tmp_path, direct):
+    """Rows that the workspace has rebuilt from chunks of the virtual-memory API (GBWT_HIP_VMM with a 64 MiB threshold, so that a test-size
+    batch is mapped): staged through an ordinary allocation before the send (default), or sent straight out of the mapping
+    (GBWT_HIP_COMM_DIRECT=1) -- the mode a multi-GPU box has to prove before it becomes the default (INTEGRATION.md)."""
+    world = gpus()
+    if world < 2:
+        pytest.skip("one GPU on this box: ranks need devices of their own for RCCL point-to-point")
+    out = run_capi_ranks(world, 40000, 4, tmp_path, 1800, {"GBWT_HIP_VMM": "64:2:64:2", "GBWT_HIP_COMM_DIRECT": direct})
+    assert out.returncode == 0 and "CAPI_RANKS_OK" in out.stdout, out.stderr[-3000:]
+    peer = [l for l in out.stdout.splitlines() if l.startswith("PEER_STATS")][-1]
+    assert ("'staged_send': True" in peer) == (direct == "0"), peer
+
+
 def run_ranks(world, sites, haplotypes, timeout):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))

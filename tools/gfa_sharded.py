@@ -38,6 +38,7 @@ ap.add_argument("--backend", default="nccl")
 ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (rehearsal on a one-GPU box; with --backend gloo)")
 ap.add_argument("--check", action="store_true", help="rank 0 also formats all paths alone and compares the hashes")
 ap.add_argument("--out", default="", help="write the lines to this file (rank 0)")
+ap.add_argument("--torch-gather", action="store_true", help="gather through torch.distributed (dist.gather_parts) instead of the C ABI's gbwt_hip_comm (default with --backend nccl)")
 args = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,6 +59,7 @@ if world > 1:
     else:
         dist.init_process_group(args.backend)
 comm = device if args.backend == "nccl" else torch.device("cpu")
+capi = D.Comm(rank, world, local) if (args.backend == "nccl" and world > 1 and not args.torch_gather) else None   # gbwt_hip_comm_*: RCCL behind the C ABI
 
 # the same file on every rank (rank 0 writes it, the others wait for it)
 path = os.path.join(tempfile.gettempdir(), f"gfa_sharded_{args.contigs}_{args.fragments}_{args.sites}_{args.haplotypes}.gbz")
@@ -106,6 +108,20 @@ for q in range(rounds):
     offsets, text = D.lines_tensors(lines, device)
     walk_ms += (time.perf_counter() - t0) * 1e3
     lengths = offsets[1:] - offsets[:-1]
+    if capi is not None:
+        t0 = time.perf_counter()
+        got = capi.gather_lines(gbz, root=0, interleaved=True)       # the round's lines of all ranks, in path order on rank 0
+        gather_ms += (time.perf_counter() - t0) * 1e3
+        if rank == 0:
+            _, gathered = D.lines_tensors(got, device)
+            chunk = gathered.cpu().numpy().tobytes()
+            sha.update(chunk)
+            total += len(chunk)
+            if out:
+                out.write(chunk)
+            if whole is not None:
+                whole.append(chunk)
+        continue
     if world > 1:
         t0 = time.perf_counter()
         if comm.type == "cpu":
