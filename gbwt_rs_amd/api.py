@@ -352,6 +352,17 @@ class GBZ(GBWT):
         check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, buf, total.value, C.byref(total)))
         return buf.raw[: total.value]
 
+    def path_lines_array(self, path_ids, mode, out=None):
+        """The same lines as a numpy uint8 array -- into `out` when it is large enough (a reused buffer has its pages already) --
+        without the zero-filled ctypes buffer and the second copy `path_lines` pays for a bytes object."""
+        ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, None, 0, C.byref(total)))
+        if out is None or out.size < total.value:
+            out = np.empty(max(1, total.value), dtype=np.uint8)
+        check(self._L.gbwt_hip_path_lines(self._h, self._ws, _ptr(ids), ids.size, mode, out.ctypes.data, out.size, C.byref(total)))
+        return out[: total.value]
+
     def last_lines_ms(self):
         """(walk kernel ms, everything behind the walk ms) of the last path_lines / path_lines_device request (HIP events)."""
         walk, fmt = C.c_float(0), C.c_float(0)

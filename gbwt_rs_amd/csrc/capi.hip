@@ -908,38 +908,69 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
 
 namespace gbwt_hip {
 
-// Device -> pageable host memory for the large results (13 GB of node ids on the headline index).  A plain hipMemcpy
-// stages through one pinned buffer on one thread and also pays the first-touch page faults of a fresh destination on
-// that thread (0.5 - 1.1 s for 13.3 GB).  Here a few threads take alternate chunks, each with a pinned buffer and a
-// stream of its own: the copies over PCIe, the copies out of the pinned buffers and the page faults run side by side.
-void copy_to_host(int device, void *dst, const void *src, size_t bytes, unsigned threads) {
-    constexpr size_t CHUNK = size_t(32) << 20;
+// Device -> pageable host memory for the large results (13 GB of node ids on the headline index, gigabytes of GFA lines).  A plain
+// hipMemcpy stages through one pinned buffer on one thread and also pays the first-touch page faults of a fresh destination on that
+// thread (0.5 - 1.1 s for 13.3 GB; 2.4 GB/s for a gigabyte of W-lines).  Here a few threads take alternate 16 MiB chunks, each with two
+// pinned buffers and a stream of its own: the copy of a thread's next chunk over PCIe runs under its memcpy of the present one out of
+// the pinned buffer, and the threads' page faults run side by side.  Buffers and streams belong to the workspace (HostCopier) and are
+// made once: allocating pinned memory per call cost as much as copying a gigabyte.
+HostCopier::~HostCopier() {
+    for (Lane &l : lanes) {
+        for (void *p : l.pinned) if (p) (void)hipHostFree(p);
+        for (hipEvent_t e : l.landed) if (e) (void)hipEventDestroy(e);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+}
+
+bool HostCopier::ensure(int device, unsigned threads) {
+    if (hipSetDevice(device) != hipSuccess) return false;
+    while (lanes.size() < threads) {
+        Lane l;
+        bool ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; b < 2 && ok; b++) ok = hipHostMalloc(&l.pinned[b], CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&l.landed[b], hipEventDisableTiming) == hipSuccess;
+        lanes.push_back(l);            // (its destructor frees whatever a failed lane got)
+        if (!ok) { (void)hipGetLastError(); return false; }
+    }
+    return true;
+}
+
+void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes) {
+    constexpr size_t CHUNK = HostCopier::CHUNK;
+    const int device = ws->index->device;
+    const unsigned threads = ws->knobs.copy_threads;
     if (bytes < 4 * CHUNK || threads < 2) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return; }
+    std::lock_guard<std::mutex> guard(ws->copier.busy);
+    if (!ws->copier.ensure(device, threads)) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return; }
     const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
-    auto work = [&]() {
-        void *pinned = nullptr;
-        hipStream_t stream = nullptr;
-        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pinned, CHUNK, hipHostMallocDefault) != hipSuccess ||
-            hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
-            failed = 1;
-        } else {
-            for (size_t c = next++; c < chunks && !failed; c = next++) {
-                const size_t at = c * CHUNK, len = std::min(CHUNK, bytes - at);
-                if (hipMemcpyAsync(pinned, static_cast<const char *>(src) + at, len, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-                    hipStreamSynchronize(stream) != hipSuccess) { failed = 1; break; }
-                std::memcpy(static_cast<char *>(dst) + at, pinned, len);
-            }
+    auto work = [&](unsigned t) {
+        HostCopier::Lane &l = ws->copier.lanes[t];
+        if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
+        auto issue = [&](size_t c, int b) {
+            const size_t at = c * CHUNK, len = std::min(CHUNK, bytes - at);
+            return hipMemcpyAsync(l.pinned[b], static_cast<const char *>(src) + at, len, hipMemcpyDeviceToHost, l.stream) == hipSuccess &&
+                   hipEventRecord(l.landed[b], l.stream) == hipSuccess;
+        };
+        size_t cur = next++;
+        int b = 0;
+        if (cur >= chunks) return;
+        if (!issue(cur, b)) { failed = 1; return; }
+        while (!failed) {
+            const size_t nxt = next++;
+            if (nxt < chunks && !issue(nxt, b ^ 1)) { failed = 1; break; }
+            if (hipEventSynchronize(l.landed[b]) != hipSuccess) { failed = 1; break; }
+            std::memcpy(static_cast<char *>(dst) + cur * CHUNK, l.pinned[b], std::min(CHUNK, bytes - cur * CHUNK));
+            if (nxt >= chunks) break;
+            cur = nxt; b ^= 1;
         }
-        if (stream) (void)hipStreamDestroy(stream);
-        if (pinned) (void)hipHostFree(pinned);
+        (void)hipStreamSynchronize(l.stream);
     };
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t + 1 < threads; t++) pool.emplace_back(work);
-    work();
+    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
     for (auto &t : pool) t.join();
-    if (failed) HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));   // whatever went wrong: the plain way, which reports it
+    if (failed) { (void)hipGetLastError(); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }   // whatever went wrong: the plain way, which reports it
 }
 
 }  // namespace gbwt_hip
@@ -964,7 +995,7 @@ gbwt_hip_status gbwt_hip_extract(const gbwt_hip_index *ix, gbwt_hip_workspace *w
         *total = p.total;
         if (!out_nodes) return GBWT_HIP_OK;
         if (capacity < p.total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(p.total));
-        if (p.total) copy_to_host(ix->device, out_nodes, p.d_nodes, p.total * sizeof(uint32_t), ws->knobs.copy_threads);
+        if (p.total) copy_to_host(ws, out_nodes, p.d_nodes, p.total * sizeof(uint32_t));
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
@@ -991,7 +1022,7 @@ gbwt_hip_status gbwt_hip_copy_result(const gbwt_hip_index *ix, gbwt_hip_workspac
     if (out_offsets) HIP_CHECK(hipMemcpy(out_offsets, ws->offsets.ptr, (ws->last_n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (out_nodes) {
         if (capacity < ws->last_total) return fail(GBWT_HIP_CAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ws->last_total));
-        if (ws->last_total) copy_to_host(ix->device, out_nodes, ws->nodes.ptr, ws->last_total * sizeof(uint32_t), ws->knobs.copy_threads);
+        if (ws->last_total) copy_to_host(ws, out_nodes, ws->nodes.ptr, ws->last_total * sizeof(uint32_t));
     }
     return GBWT_HIP_OK;
     GBWT_HIP_GUARD_END

@@ -190,8 +190,18 @@ inline gbwt_hip_status status_of_current_exception() noexcept {
         return fail(GBWT_HIP_DEVICE_ERROR, "unexpected exception");
     }
 }
-// Device -> pageable host memory on `threads` threads, each with a pinned staging buffer and a stream of its own (capi.hip)
-void copy_to_host(int device, void *dst, const void *src, size_t bytes, unsigned threads);
+// The pinned staging buffers and streams of a workspace's device-to-host copies (capi.hip: copy_to_host), made on first use.
+struct HostCopier {
+    static constexpr size_t CHUNK = size_t(16) << 20;
+    struct Lane { void *pinned[2] = {nullptr, nullptr}; hipEvent_t landed[2] = {nullptr, nullptr}; hipStream_t stream = nullptr; };
+    std::vector<Lane> lanes;
+    std::mutex busy;
+    HostCopier() = default;
+    HostCopier(const HostCopier &) = delete;
+    HostCopier &operator=(const HostCopier &) = delete;
+    ~HostCopier();
+    bool ensure(int device, unsigned threads);
+};
 
 #define GBWT_HIP_GUARD_BEGIN try {
 #define GBWT_HIP_GUARD_END } catch (...) { return gbwt_hip::status_of_current_exception(); }
@@ -245,7 +255,7 @@ struct ExtractKnobs {
     int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
     uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
-    unsigned copy_threads = 4;                                // GBWT_HIP_COPY_THREADS
+    unsigned copy_threads = 8;                                // GBWT_HIP_COPY_THREADS
     static ExtractKnobs from_env() {
         ExtractKnobs k;
         const auto num = [](const char *name, int unset) { const char *v = std::getenv(name); return v ? std::atoi(v) : unset; };
@@ -259,7 +269,7 @@ struct ExtractKnobs {
         k.row_piece = num("GBWT_HIP_ROW_PIECE", -1); if (k.row_piece != 0 && k.row_piece != 16 && k.row_piece != 32) k.row_piece = -1;
         k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;
         k.debug = static_cast<uint32_t>(num("GBWT_HIP_DEBUG_DRY_ROWS", 0));
-        k.copy_threads = static_cast<unsigned>(std::max(1, num("GBWT_HIP_COPY_THREADS", 4)));
+        k.copy_threads = static_cast<unsigned>(std::min(64, std::max(1, num("GBWT_HIP_COPY_THREADS", 8))));
         return k;
     }
 };
@@ -285,6 +295,7 @@ struct gbwt_hip_workspace {
     std::vector<uint64_t> extract_key, lines_key;
     std::vector<uint8_t> follow_key;
     int follow_backward = 0, lines_mode = 0, lines_slot = 0;
+    gbwt_hip::HostCopier copier;      // pinned staging of the large device-to-host copies
     uint64_t follow_total = 0, lines_total = 0;
     ~gbwt_hip_workspace() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -293,3 +304,9 @@ struct gbwt_hip_workspace {
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
+
+namespace gbwt_hip {
+// Device -> pageable host memory over the workspace's copy threads (GBWT_HIP_COPY_THREADS, default 8), each with two pinned staging
+// buffers and a stream of its own (capi.hip)
+void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes);
+}

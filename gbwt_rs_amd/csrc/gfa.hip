@@ -680,7 +680,7 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
     if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the lines");
     try {
         HIP_CHECK(hipSetDevice(ix->device));
-        copy_to_host(ix->device, out, ws->gfa_text.ptr, *total, ws->knobs.copy_threads);
+        copy_to_host(ws, out, ws->gfa_text.ptr, *total);
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
