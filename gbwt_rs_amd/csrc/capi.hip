@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <atomic>
 #include <chrono>
@@ -118,11 +119,15 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     launch_scan(counts.as<uint64_t>(), cp_first.as<uint64_t>(), nr, scan_tmp.ptr, tb, nullptr);
     uint64_t positions = 0;
     HIP_CHECK(hipMemcpy(&positions, cp_first.as<uint64_t>() + nr, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    trace.mark("    checkpoint counts + scan");
     // every orphan stands for a finished walk of at least `cap` nodes, and no two walkers share a BWT position
-    const uint64_t orphan_capacity = 2 * (d.max_walk / w.cap) + S + 1024;
+    // (every node of a sequence is one BWT position: at most max_walk / cap hops end at the cap.  A quarter more for the hops of up to cap + 3
+    // nodes; 2 x until round 4 -- 50 MB of summaries more on the headline index, and every allocation of an open is paid in milliseconds)
+    const uint64_t orphan_capacity = d.max_walk / w.cap + d.max_walk / w.cap / 4 + S + 1024;
     const uint64_t n_summaries = S + positions + orphan_capacity;
     if (n_summaries >= 0xFFFFFFF0ull) return false;
     summaries.reserve(n_summaries * sizeof(uint4));
+    trace.mark("    summaries allocated");
     misc.reserve(2 * sizeof(uint64_t));
     HIP_CHECK(hipMemset(misc.ptr, 0, 2 * sizeof(uint64_t)));
     w.cp_first = cp_first.as<uint64_t>(); w.summaries = summaries.as<uint4>();
@@ -601,6 +606,10 @@ gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index 
         const uint8_t *src = h.record_bytes();
         void *dst = raw->data.ptr;
         const int dev = raw->device;
+        // (one hipMemcpy from the mapping: 9 ms = 6.7 GB/s for the headline's 60 MB.  Measured and not kept, rounds 3 and 4: four threads
+        // with slices, registered pages, and -- round 4 -- four threads staging 4 MiB chunks through pinned buffers and streams of their
+        // own, made once per process in the background: 16-25 ms, and a first extraction that waited 370 ms behind the pinned
+        // allocations; NOTEBOOK.md, round 4)
         early.worker = std::thread([&early, src, dst, bytes, dev]() {
             early.result = hipSetDevice(dev);
             if (early.result == hipSuccess) early.result = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
