@@ -102,7 +102,11 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     // every row passes: gap = interval / 8 (insertion chain 486 -> 650 G LF-steps/s, insertions at every 8th site 580 -> 680 G, chopped
     // nodes with insertions 510 -> 650 G; the lock-step chain is indifferent down to interval / 8 and loses a tenth at interval / 16, but
     // pays four times the hops of the chase at open: profiles/r03_chained_steps.txt)
-    double gap = (d.chained != 0 ? 0.125 : 0.5) * interval;
+    // (... of an interval of 2 048 nodes.  The shorter intervals of smaller indexes keep at least 128 LF steps between checkpoints, or half
+    // the interval: with interval / 8 of 256 a config-4-shaped index -- 90 haplotypes over 480 components -- was cut into segments of 30 to
+    // 60 nodes, ten million walkers of a dozen iterations each, and walked at 2.53 ms where a gap of 128 takes 2.07; round 4,
+    // profiles/r04_walk_experiments.txt)
+    double gap = d.chained != 0 ? std::max(0.125 * interval, std::min(128.0, 0.5 * interval)) : 0.5 * interval;
     if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_GAP")) gap = std::max(2.0, std::atof(v));
     const double q = std::min(0.5, 1.0 / gap);
     CheckpointWalk w{};
@@ -809,8 +813,29 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
                 a.segments = common;
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
+            } else if (segmented && knobs.walker_order != 0 && n <= 0x7FFFFFFFull) {
+                // (GBWT_HIP_WALKER_ORDER=1; measured in round 4 and NOT the default: profiles/r04_walker_order.txt)  Rows with different numbers of
+                // segments (ragged walks, a subset of the paths): walkers in the order of the RECORD their segment starts on.  The samples lie where sequences pass checkpoint records (open_walks.hip), so the walkers that start on
+                // one record are the rows that travel together there -- whichever rows they are: a batch of 32 000 walks over 480 graph
+                // components, sorted by row length until round 4, had every wave on 64 different records (201 G LF-steps/s in the gather
+                // loop; profiles/r04_walker_order.txt).
+                ws->order_counts.reserve(n * sizeof(uint64_t)); ws->order_level.reserve((n + 1) * sizeof(uint64_t));
+                launch_walker_counts(ix->dev, ws->seq_ids.as<uint64_t>(), n, ws->order_counts.as<uint64_t>(), s);
+                launch_scan(ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+                HIP_CHECK(hipMemcpyAsync(&walkers, ws->order_level.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (walkers >= 0xFFFFFFF0ull) return fail(GBWT_HIP_UNSUPPORTED, "more than 2^32 walkers in one extraction: extract fewer sequences per call");
+                const size_t ob = walker_list_temp_bytes(std::max<uint64_t>(walkers, 1));
+                ws->order_keys.reserve(2 * std::max<uint64_t>(walkers, 1) * sizeof(uint32_t)); ws->order_rows.reserve(2 * std::max<uint64_t>(walkers, 1) * sizeof(uint32_t));
+                ws->order_temp.reserve(std::max<size_t>(ob, 16));
+                const uint32_t *sorted = nullptr;
+                if (walkers) launch_walker_list(ix->dev, ws->seq_ids.as<uint64_t>(), n, ws->order_level.as<uint64_t>(), walkers, ws->order_keys.as<uint32_t>(),
+                                                ws->order_rows.as<uint32_t>(), ws->order_temp.ptr, ob, &sorted, s);
+                a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
+                a.walker_list = walkers ? sorted : nullptr; a.row_first = ws->order_level.as<uint64_t>();
+                if (walkers == 0) { a.segments = 0; walkers = ix->orientation_pairs ? 2 * n : n; }      // (nothing but empty rows)
             } else if (segmented) {
-                // walker order: segment by segment over the rows that have the segment (rows sorted by their segment count)
+                // (GBWT_HIP_WALKER_ORDER=0, rounds 1-3) walker order: segment by segment over the rows that have the segment (rows sorted by their segment count)
                 const size_t ob = walker_order_temp_bytes(n), sb = scan_temp_bytes(a.segments);
                 ws->order_keys.reserve(2 * n * sizeof(uint32_t)); ws->order_rows.reserve(2 * n * sizeof(uint32_t));
                 ws->order_counts.reserve(a.segments * sizeof(uint64_t)); ws->order_level.reserve((a.segments + 1ull) * sizeof(uint64_t));
@@ -837,6 +862,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.xcd_map = knobs.xcd_map >= 0 ? (knobs.xcd_map ? 1u : 0u) : (segmented ? 1u : 0u);
             a.uniform_loop = knobs.uniform_loop >= 0 ? (knobs.uniform_loop ? 1u : 0u) : 1u;
             a.catch_up = knobs.catch_up >= 0 ? (knobs.catch_up ? 1u : 0u) : 1u;
+            a.align_segments = (segmented && knobs.align_segments != 0) ? 1u : 0u;
             a.headroom = static_cast<uint32_t>(knobs.headroom);
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
             a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;

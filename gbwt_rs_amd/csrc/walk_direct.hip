@@ -30,6 +30,7 @@ struct RowTarget {
     uint64_t len = 0;            // nodes in the row
     bool backward = false;       // this walker comes from the other end: node k goes to row[len - 1 - k], flipped
     uint32_t share = 0;          // nodes this walker has to deliver
+    uint32_t skip = 0;           // line-aligned segments: the first `skip` of them lie in front of this walker's first piece boundary and are written by the walker before
 };
 
 __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
@@ -59,7 +60,16 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
         if (a.level[mid] <= w) lo = mid; else hi = mid;
     }
     uint64_t j = lo, k = 0;
-    if (a.level == nullptr) { j = w / a.n; k = w % a.n; }           // every row has every segment: w = j * n + k
+    if (a.walker_list != nullptr) {                                // walkers in the order of their start records: t-th (row, segment) pair
+        const uint64_t t = a.walker_list[w];
+        uint64_t first = 0, last = a.n;                            // row_first[first] <= t < row_first[last]
+        while (last - first > 1) {
+            const uint64_t mid = (first + last) / 2;
+            if (a.row_first[mid] <= t) first = mid; else last = mid;
+        }
+        k = first; j = t - a.row_first[first];
+    }
+    else if (a.level == nullptr) { j = w / a.n; k = w % a.n; }      // every row has every segment: w = j * n + k
     else k = a.sorted_rows[w - a.level[lo]];
     const uint64_t id = a.seq_ids[k];
     if (id >= ix.n_sequences) return s;                      // GBWT::sequence: no such sequence -> an empty row
@@ -70,9 +80,23 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     const uint64_t from = j == 0 ? 0 : here.w;                // segment 0 starts with the start node (sample 0 is the state after it)
     const uint64_t to = j + 1 < count ? ix.samples[base + j + 1].w : len;
     t.row = a.out_nodes + a.out_offsets[k] + from;
+    t.len = to > from ? to - from : 0;
+    // LINE-ALIGNED SEGMENTS (round 4).  Samples lie where sequences pass checkpoint records, rows start wherever the rows before them
+    // end: a segment begins and ends anywhere in a 128-byte line of the row's memory, and both ends used to go out as partial lines --
+    // single stores, five times as expensive per byte as whole lines under `nt` (NOTEBOOK.md, r02 #4), two of the nine lines of a
+    // 256-node segment.  Now the boundary between two walkers of a row is the first piece boundary AT OR BEHIND the sample: a walker
+    // walks on past the next sample to the end of that line (any lane may take any LF step: the nodes are the same), and the walker
+    // that starts there stages the nodes in front of the boundary like all others but does not write them (`skip`).  Up to
+    // piece - 1 more LF steps per segment; only the two ends of a ROW are partial lines.
+    if (a.align_segments && t.len != 0) {
+        const uint32_t piece = a.row_piece ? a.row_piece : RING_FLUSH;
+        const uint64_t phase_from = (reinterpret_cast<uintptr_t>(t.row) >> 2) & (piece - 1), phase_to = (reinterpret_cast<uintptr_t>(t.row + t.len) >> 2) & (piece - 1);
+        if (j > 0 && phase_from != 0) t.skip = static_cast<uint32_t>(piece - phase_from);
+        if (j + 1 < count && phase_to != 0) t.len = min(t.len + (piece - phase_to), len - from);       // never past the end of the row
+        if (t.skip >= t.len) { t.len = 0; t.skip = 0; }             // a segment inside one line: the walker before writes all of it
+    }
     if (a.debug & 2u) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
     if (a.debug & 128u) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
-    t.len = to > from ? to - from : 0;
     t.backward = false;
     t.share = static_cast<uint32_t>(t.len);
     s.rec = here.x; s.offset = here.y; s.bb = here.z;
@@ -119,7 +143,7 @@ struct RowWriter {
     bool dry = false;            // measurement switch (GBWT_HIP_DEBUG_DRY_ROWS): read the ring, store nothing
     __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * RING_PITCH]; }
     __device__ __forceinline__ void put(uint32_t k) {
-        if (k >= t.len || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row
+        if (k >= t.len || k < t.skip || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row (or in front of this walker's part of it)
         if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
     }
     __device__ __forceinline__ void chunk() {   // 16 nodes = 64 bytes
@@ -159,6 +183,10 @@ struct RowWriter {
     // piece is one aligned cache-line half (unaligned pieces would go out as sixteen 4-byte stores each and reach HBM as
     // partial lines: 22.7 GB written for 13.3 GB of node ids before this).
     __device__ __forceinline__ void drain(uint32_t staged) {
+        if (drained < t.skip) {                                   // (line-aligned segments: t.skip = the nodes up to the first 64-byte boundary)
+            if (staged < t.skip) return;
+            drained = t.skip;
+        }
         if (!t.backward) {
             const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(t.row + drained) >> 2) & (RING_FLUSH - 1));
             if (mis != 0) {
@@ -200,12 +228,13 @@ __device__ __forceinline__ void coop_visit(const CoopRows &c, uint32_t r, uint32
     constexpr uint32_t PIECE = 4 * LPR;
     const uint32_t staged = lds_word(c.mail + 16 * r + 12);
     const u32x4_t st = lds_peek4((const lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r));   // waits for both
-    const uint32_t drained = st.w, len = st.z;
+    const uint32_t drained = st.w, len = st.z & 0x7FFFFFFFu;
     const uint32_t pend = staged - drained;
     const uint32_t mis = ((st.x >> 2) + drained) & (PIECE - 1);      // nodes past the last piece boundary of the row's memory
     uint32_t n = PIECE - mis;                                        // nodes up to the next boundary
     if (pend < n) { if (!done || pend == 0) return; n = pend; }      // short pieces only once the walk is over
     volatile lds_u32_t *const publish = (volatile lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r + 12);   // only after the nodes have left the ring
+    if (drained == 0 && (st.z & 0x80000000u)) { if (p == 0) *publish = n; return; }   // line-aligned segments: the nodes in front of the first boundary are the previous walker's
     if (c.skip_reads) { if (p == 0) *publish = drained + n; return; }   // measurement switch: the ring is emptied unread
     // a pointer rebuilt from integers is a generic one: say that it is global memory, or the stores become flat_store
     // (which also count in lgkmcnt, so that every LDS wait of the helper would wait for its row writes as well)
@@ -284,7 +313,7 @@ __device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane,
             const uint32_t drained = st.w, waiting = staged - drained;
             const uint32_t off = ((st.x >> 2) + drained) & (PIECE - 1);
             const bool ready = waiting >= PIECE - off;
-            const bool fast = ready && off == 0 && drained + PIECE <= st.z;
+            const bool fast = ready && off == 0 && drained + PIECE <= (st.z & 0x7FFFFFFFu);
             if (fast) {
                 const uint32_t col = c.ring + 4 * rows[g], k = drained + 4 * p;
                 u32x4_t out;
@@ -383,7 +412,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
             lds_poke(lds_ptr(&row_state[lane].x), static_cast<uint32_t>(at));
             lds_poke(lds_ptr(&row_state[lane].y), static_cast<uint32_t>(at >> 32));
-            lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0xFFFFFFF0u)));
+            lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0x7FFFFFF0u)) | (target.skip ? 0x80000000u : 0u));
             // order = the rows sorted by (address phase within a piece, row): rank by counting, once per workgroup
             const uint32_t phase = (static_cast<uint32_t>(at) >> 2) & (piece - 1);
             uint32_t rank = 0;
@@ -657,6 +686,49 @@ __global__ void __launch_bounds__(256) k_level_counts(const uint32_t *sorted_key
         if (sorted_keys[mid] > j) lo = mid + 1; else hi = mid;
     }
     counts[j] = lo;
+}
+
+// counts[k] = segments of row k = samples of its sequence
+__global__ void __launch_bounds__(256) k_walker_counts(const uint64_t *sample_base, uint64_t n_sequences, const uint64_t *ids, uint64_t n, uint64_t *counts) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t id = ids[k];
+    counts[k] = id < n_sequences ? sample_base[id + 1] - sample_base[id] : 0u;
+}
+
+// keys[t] = the record the t-th (row, segment) pair starts on, vals[t] = t
+__global__ void __launch_bounds__(256) k_walker_keys(const uint4 *samples, const uint64_t *sample_base, const uint64_t *ids, uint64_t n, const uint64_t *row_first,
+                                                      uint64_t walkers, uint32_t *keys, uint32_t *vals) {
+    const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (t >= walkers) return;
+    uint64_t first = 0, last = n;
+    while (last - first > 1) {
+        const uint64_t mid = (first + last) / 2;
+        if (row_first[mid] <= t) first = mid; else last = mid;
+    }
+    keys[t] = samples[sample_base[ids[first]] + (t - row_first[first])].x;
+    vals[t] = static_cast<uint32_t>(t);
+}
+
+void launch_walker_counts(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_counts, hipStream_t stream) {
+    hipLaunchKernelGGL(k_walker_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, ix.n_sequences, d_ids, n, d_counts);
+}
+
+size_t walker_list_temp_bytes(uint64_t walkers) {
+    size_t bytes = 0;
+    hipcub::DoubleBuffer<uint32_t> keys(nullptr, nullptr), vals(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, vals, static_cast<int>(walkers));
+    return bytes;
+}
+
+void launch_walker_list(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, const uint64_t *d_row_first, uint64_t walkers, uint32_t *d_keys, uint32_t *d_vals,
+                        void *d_temp, size_t temp_bytes, const uint32_t **d_sorted, hipStream_t stream) {
+    hipLaunchKernelGGL(k_walker_keys, dim3(grid_for(walkers, 256)), dim3(256), 0, stream, ix.samples, ix.sample_base, d_ids, n, d_row_first, walkers, d_keys, d_vals);
+    int bits = 1;
+    while (bits < 32 && (ix.n_records >> bits) != 0) bits++;       // record indices have this many bits
+    hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + walkers), vals(d_vals, d_vals + walkers);
+    (void)hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, keys, vals, static_cast<int>(walkers), 0, bits, stream);   // stable: walkers on one record stay in (row, segment) order
+    *d_sorted = vals.Current();
 }
 
 size_t walker_order_temp_bytes(uint64_t n) {

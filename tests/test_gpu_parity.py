@@ -985,6 +985,10 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "90", "GBWT_HIP_CHAINS": "0"},        # no chained steps: fused pairs only
                 {"GBWT_HIP_SAMPLE_INTERVAL": "19", "GBWT_HIP_CHAINS": "2", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "200", "GBWT_HIP_CATCH_UP": "0"},     # mixed waves go to the gather loop at once (no single steps of the lanes behind)
+                {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_ALIGN_SEGMENTS": "1"},  # line-aligned segments (round 4): walkers hand over at line boundaries of the row's memory; segments shorter than a line
+                {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "0"},   # ... with the lane-per-row writer (64-byte boundaries)
+                {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16", "GBWT_HIP_WALKER_ORDER": "1"},   # ... and walkers in the order of their start records
+                {"GBWT_HIP_SAMPLE_INTERVAL": "2048", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
 
@@ -1032,7 +1036,8 @@ def test_segmented_extraction(monkeypatch, env):
             assert np.array_equal(c_off, o_off) and np.array_equal(c_nodes, o_nodes), env
 
 
-@pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "50", "GBWT_HIP_XCD_MAP": "0"}],
+@pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "50", "GBWT_HIP_XCD_MAP": "0"},
+                                 {"GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1", "GBWT_HIP_ALIGN_SEGMENTS": "1"}],
                          ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
 def test_walker_order_with_ragged_rows(monkeypatch, env):
     """A few long haplotypes and thousands of short walks (a fragmented assembly): the walkers of a segmented extraction
