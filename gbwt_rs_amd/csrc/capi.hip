@@ -814,11 +814,11 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
             } else if (segmented && knobs.walker_order != 0 && n <= 0x7FFFFFFFull) {
-                // (GBWT_HIP_WALKER_ORDER=1; measured in round 4 and NOT the default: profiles/r04_walker_order.txt)  Rows with different numbers of
+                // (GBWT_HIP_WALKER_ORDER=1; measured in round 4 and NOT the default: profiles/r04_walk_experiments.txt)  Rows with different numbers of
                 // segments (ragged walks, a subset of the paths): walkers in the order of the RECORD their segment starts on.  The samples lie where sequences pass checkpoint records (open_walks.hip), so the walkers that start on
                 // one record are the rows that travel together there -- whichever rows they are: a batch of 32 000 walks over 480 graph
                 // components, sorted by row length until round 4, had every wave on 64 different records (201 G LF-steps/s in the gather
-                // loop; profiles/r04_walker_order.txt).
+                // loop; profiles/r04_walk_experiments.txt).
                 ws->order_counts.reserve(n * sizeof(uint64_t)); ws->order_level.reserve((n + 1) * sizeof(uint64_t));
                 launch_walker_counts(ix->dev, ws->seq_ids.as<uint64_t>(), n, ws->order_counts.as<uint64_t>(), s);
                 launch_scan(ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
