@@ -244,7 +244,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
             HIP_CHECK(hipMemcpy(&last_base, ix.block_base.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
             HIP_CHECK(hipMemcpy(&last_count, counts.as<uint32_t>() + (n_records - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
             n_blocks += static_cast<uint64_t>(last_base) + last_count;
-            launch_finish_block_base(counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), n_records, nullptr);
+            launch_finish_block_base(counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), n_records, ix.desc_raw.as<uint4>(), nullptr);
         }
         ix.blocks.reserve(n_blocks * sizeof(uint4));
         HIP_CHECK(hipMemsetAsync(ix.blocks.ptr, 0, sizeof(uint4), nullptr));

@@ -15,7 +15,7 @@
 //                     meta = body offset (bits 0-15) | class (bits 16-17) | start (bits 32-39 of it, in bits 24-31)
 //                     class 1 / 2 = outdegree 1 / 2 (class 1 is always unary, class 2 has rank blocks) with the edges in A and "body offset" = where the run stream
 //                     starts inside the record; class 0 = any other non-empty record (generic lane-serial decode)
-//                 C = {value-0 positions of the record, Record::len, first LF table entry, 1 if the record has an LF table}
+//                 C = {value-0 positions of the record, Record::len, first LF table entry (class 0) / first rank block (class 2), 1 if the record has an LF table}
 //                 D = the first 16 bytes of the run stream, so short records need no second load
 //               empty / None record : B.y = 0
 //               unary record        : B.y = DESC_UNARY.  "Unary" = outdegree 1 (every node on a linear stretch of

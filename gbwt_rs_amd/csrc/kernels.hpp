@@ -24,7 +24,7 @@ constexpr uint32_t FLAG_POOL_OVERFLOW = 1u;
 void launch_build_desc(const DeviceIndex &ix, uint4 *d_desc, uint32_t *d_block_counts, uint64_t *d_stats, hipStream_t stream);
 size_t block_scan_temp_bytes(uint64_t n);
 void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t stream);
-void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream);
+void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, uint4 *d_desc_raw /* class 2 records also get their block base in C.z */, hipStream_t stream);
 void launch_link_desc(const DeviceIndex &ix, uint4 *d_desc, hipStream_t stream);
 void launch_link_lookahead(const DeviceIndex &ix, uint4 *d_desc, const uint32_t *d_block_counts, uint32_t hops, hipStream_t stream);
 // LF tables of the class 0 records (device_index.hpp): per-record positions / outdegrees, then the fill

@@ -683,9 +683,15 @@ void launch_fill_blocks(const DeviceIndex &ix, const uint32_t *d_block_counts, c
 
 // exclusive scan of the per-record block counts, then block_base = 1 + scan (block 0 is the shared all-zero block)
 // or BLOCK_NONE where the count is 0
-__global__ void __launch_bounds__(256) k_finish_block_base(const uint32_t *counts, uint32_t *block_base, uint64_t n) {
+// ... and, for the records that have blocks (class 2), a copy in the raw descriptor's word C.z, which only class 0 records use otherwise
+// (first LF table entry): a search step then finds the block base in the descriptor line it has fetched anyway, instead of behind one
+// more dependent load from one more cache line (config 3: k_search 0.58 -> 0.49 ms for a million queries of ten nodes, k_bd_search 0.59 -> 0.51; NOTEBOOK.md round 4)
+__global__ void __launch_bounds__(256) k_finish_block_base(const uint32_t *counts, uint32_t *block_base, uint64_t n, uint4 *desc_raw) {
     uint64_t rec = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (rec < n) block_base[rec] = counts[rec] == 0 ? BLOCK_NONE : block_base[rec] + 1;
+    if (rec >= n) return;
+    const uint32_t bb = counts[rec] == 0 ? BLOCK_NONE : block_base[rec] + 1;
+    block_base[rec] = bb;
+    if (bb != BLOCK_NONE && desc_raw != nullptr) reinterpret_cast<uint32_t *>(desc_raw + 4 * rec + 2)[2] = bb;
 }
 
 size_t block_scan_temp_bytes(uint64_t n) {
@@ -699,8 +705,8 @@ void launch_block_scan(const uint32_t *d_counts, uint32_t *d_block_base, uint64_
     (void)hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_counts, d_block_base, static_cast<int>(n), stream);
 }
 
-void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_finish_block_base, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_block_base, n);
+void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, uint64_t n, uint4 *d_desc_raw, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_finish_block_base, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_block_base, n, d_desc_raw);
 }
 
 size_t scan_temp_bytes(uint64_t n) {

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_
                 const uint32_t i = static_cast<uint32_t>(p.offset);
                 uint32_t value = 0, rank = i;
                 if (cls == 2) {
-                    const uint4 K = ix.blocks[ix.block_base[rec] + (i >> RANK_BLOCK_SHIFT)];
+                    const uint4 K = ix.blocks[d.C.z + (i >> RANK_BLOCK_SHIFT)];   // (class 2: C.z = the record's first rank block, k_finish_block_base)
                     const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
                     value = static_cast<uint32_t>(bits >> (i & 63u)) & 1u;
                     const uint32_t ones = K.z + __popcll(bits & ((uint64_t(1) << (i & 63u)) - 1));
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_forward(DeviceIndex ix, const gbwt_hip_
 __device__ __forceinline__ uint32_t count0_before(const DeviceIndex &ix, const RawDesc &d, uint64_t rec, uint32_t p) {
     if (desc_class(d.B.z) == 1) return p;
     if (p >= d.B.w) return d.C.x;
-    const uint4 K = ix.blocks[ix.block_base[rec] + (p >> RANK_BLOCK_SHIFT)];
+    const uint4 K = ix.blocks[d.C.z + (p >> RANK_BLOCK_SHIFT)];
     const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
     return p - (K.z + __popcll(bits & ((uint64_t(1) << (p & 63u)) - 1)));
 }
@@ -200,7 +200,7 @@ __device__ __forceinline__ bool dev_offset_to(const DeviceIndex &ix, uint64_t pr
     if (k >= total) return false;
     if (cls == 1) { out = k; return true; }
     // largest block whose running count of `value` is <= k
-    const uint4 *blocks = ix.blocks + ix.block_base[rec];
+    const uint4 *blocks = ix.blocks + d.C.z;
     uint32_t lo = 0, hi = d.B.w >> RANK_BLOCK_SHIFT;            // last block index
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo + 1) / 2;
