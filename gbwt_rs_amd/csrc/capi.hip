@@ -863,6 +863,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.uniform_loop = knobs.uniform_loop >= 0 ? (knobs.uniform_loop ? 1u : 0u) : 1u;
             a.catch_up = knobs.catch_up >= 0 ? (knobs.catch_up ? 1u : 0u) : 1u;
             a.align_segments = (segmented && knobs.align_segments != 0) ? 1u : 0u;
+            a.all4 = knobs.all4 != 0 ? 1u : 0u;
             a.headroom = static_cast<uint32_t>(knobs.headroom);
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
             a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;

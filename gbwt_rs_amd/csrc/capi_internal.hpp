@@ -253,6 +253,7 @@ struct gbwt_hip_index {
 struct ExtractKnobs {
     int direct = 1, segments = 1, both_ends = 1;             // GBWT_HIP_DIRECT / _SEGMENTS / _BOTH_ENDS (0 switches the feature off)
     int align_segments = 0;                                   // GBWT_HIP_ALIGN_SEGMENTS: 1 = the boundary between two walkers of a row is a line boundary of the row's memory (round 4: measured, 2.4 % slower on the headline: not the default)
+    int all4 = 1;                                             // GBWT_HIP_ALL4: 0 = the uniform loop counts every node it stages (rounds 1-3)
     int walker_order = 0;                                     // GBWT_HIP_WALKER_ORDER: 1 = ragged batches in the order of the walkers' start records (round 4: measured, not the default), 0 = by number of segments
     int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
@@ -269,6 +270,7 @@ struct ExtractKnobs {
         k.catch_up = num("GBWT_HIP_CATCH_UP", -1);
         k.walker_order = num("GBWT_HIP_WALKER_ORDER", 0);
         k.align_segments = num("GBWT_HIP_ALIGN_SEGMENTS", 0);
+        k.all4 = num("GBWT_HIP_ALL4", 1);
         k.headroom = std::min(32, std::max(0, num("GBWT_HIP_HEADROOM", 0)));
         k.row_piece = num("GBWT_HIP_ROW_PIECE", -1); if (k.row_piece != 0 && k.row_piece != 16 && k.row_piece != 32) k.row_piece = -1;
         k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;

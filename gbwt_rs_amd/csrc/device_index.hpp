@@ -76,6 +76,7 @@ constexpr uint32_t LEAF_EMIT2 = 1u << 31;            // two-step descriptor: thi
 constexpr uint32_t DESC2_SLOW = 1u << 30;            // two-step descriptor, word E_a.z: generic decode
 constexpr uint32_t GATHER_OK = 1u;                   // two-step descriptor, word E_a.w: the record's packed blocks (gblocks) can count it
 constexpr uint32_t E_CHAIN = 2u;                     // two-step descriptor, word E_a.w: the first step runs through a chain of unary records (below)
+constexpr uint32_t E_ALL4 = 8u;                      // two-step descriptor, word E_0.w: whichever edge and leaf a lane takes here, the iteration emits four nodes (no ENDMARKER, both steps fused, nothing chained)
 constexpr uint32_t E_ANYCHAIN = 4u;                  // two-step descriptor, word E_0.w: some step of the record (E_0, E_1 or a leaf) is chained
 constexpr uint32_t LEAF_CHAIN = 1u << 30;            // two-step descriptor, leaf word z: the second step does
 constexpr uint32_t CHAIN_MAX = 6;                    // at most this many nodes between the first node of a step and its landing node

@@ -68,6 +68,7 @@ struct WalkArgs {
     uint32_t xcd_map;          // k_walk_direct: XCD x (workgroups x, x + 8, ...) takes the x-th eighth of the walkers
     uint32_t uniform_loop;     // k_walk_direct: try the wave-uniform loop (scalar descriptor fetch) first
     uint32_t headroom;         // k_walk_direct: ring slots a loop keeps free (0 = by the index: 8, or the longest chained iteration; measurements)
+    uint32_t all4;             // k_walk_direct: the uniform loop stages the four nodes of an iteration in a row on E_ALL4 records (0: counts every node; measurements)
     uint32_t align_segments;   // k_walk_direct, segmented: the boundary between two walkers of a row is a piece boundary of the row's memory (walk_direct.hip: LINE-ALIGNED SEGMENTS)
     uint32_t catch_up;         // k_walk_direct: a mixed wave first lets the lanes that are behind take single steps (walk_direct.hip: CATCH-UP)
     uint32_t packed_blocks;    // k_walk_direct: the uniform loop starts on the packed half-blocks (0: on the full-width blocks at once; measurements)

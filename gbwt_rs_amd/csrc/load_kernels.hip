@@ -452,8 +452,18 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
     bool packed = VB.w < gather_limit;
     for (uint32_t a = 0; a < 2; a++)
         if (wword[a] & REC_MASK) packed = packed && ix.desc_raw[4 * static_cast<uint64_t>(wword[a] & REC_MASK) + 1].w < gather_limit;
+    // E_ALL4: every edge this record has emits a node and is fused (two nodes), and so does every leaf behind it: the uniform loop then
+    // stages four nodes per lane and iteration without counting them (walk_loops.hpp)
+    bool all4 = !slow && !any_chain && cls_v != 0;
+    for (uint32_t a = 0; a < cls_v && all4; a++) {
+        all4 = n1[a] != 0 && (wword[a] & LEAF_EMIT2) != 0;
+        const uint4 WB = ix.desc_raw[4 * static_cast<uint64_t>(wword[a] & REC_MASK) + 1];
+        const uint32_t cls_w = WB.y != 0 ? desc_class(WB.z) : 0u;
+        all4 = all4 && cls_w != 0;
+        for (uint32_t b = 0; b < cls_w && all4; b++) all4 = leaf[2 * a + b].x != 0 && (leaf[2 * a + b].z & LEAF_EMIT2) != 0;
+    }
     uint4 *o = out + 8 * v;
-    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[0] | (any_chain ? E_ANYCHAIN : 0u));
+    o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[0] | (any_chain ? E_ANYCHAIN : 0u) | (all4 ? E_ALL4 : 0u));
     o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[1]);
     if (any_chain && chained != nullptr) {
         // the most nodes one iteration of the walk can stage on this record: what the rings must have free when a loop is entered

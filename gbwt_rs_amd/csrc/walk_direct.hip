@@ -123,6 +123,7 @@ __device__ __forceinline__ u32x4_t lds_peek4(const lds_u32_t *p) {   // one ds_r
 // lane fall into different LDS banks: the cooperative row writes read several slots of the same lane in one
 // instruction (with a pitch of 64 they were all in one bank: 60 % of the LDS cycles of the kernel were bank conflicts).
 constexpr uint32_t RING_PITCH = WAVE + 1;
+static_assert(RING_PITCH == 65, "walk_loops.hpp: the four-in-a-row staging of the uniform loop (E_ALL4) writes at byte offsets k * 4 * 65");
 
 // Staging only: the walking wave's side of the ring.
 struct StageSink {
@@ -564,9 +565,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         uint32_t slow_exit = 2;
         if (a.uniform_loop && together) {
             // on the packed half-blocks until the wave meets a record they cannot count (reason 3), on the full-width blocks from then on
-            if (!full_blocks) slow_exit = walk2_uniform_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom);
+            if (!full_blocks) slow_exit = walk2_uniform_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, a.all4 != 0);
             if (slow_exit == 3) full_blocks = true;
-            if (full_blocks) slow_exit = walk2_uniform_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom);
+            if (full_blocks) slow_exit = walk2_uniform_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, a.all4 != 0);
         }
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         const uint32_t wr1 = sink.wr;

@@ -1126,7 +1126,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
         "s_bitcmp1_b32 s50, 30\n\t"                         /* DESC2_SLOW */ \
         "s_cbranch_scc1 .Lgbwt_walk2u_slow_%=\n\t" \
-        "s_and_b32 s82, s51, 4\n\t"                         /* E_ANYCHAIN: some step of this record is chained (kept, with the flag words of the two edges: */ \
+        "s_and_b32 s82, s51, %[flagmask]\n\t"               /* E_ANYCHAIN: some step of this record is chained; E_ALL4: every iteration on it stages four nodes (kept, with the flag words of the two edges: */ \
         "s_mov_b32 s83, s51\n\t"                            /*  the SGPRs are reloaded before the nodes are staged) */ \
         "s_mov_b32 s84, s55\n\t" \
         GBWT_WALK2U_FLAG_CHECK \
@@ -1156,8 +1156,9 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         GBWT_WALK2U_ISSUE(KLOAD, "")                        /* the loads of the next position go out now; staging the nodes runs underneath them */ \
         "s_nop 1\n\t" \
         "s_mov_b64 s[44:45], vcc\n\t"                       /* lanes that are not on the record of lane 0 */ \
-        "s_cmp_lg_u32 s82, 0\n\t"                          /* a record with chained steps stages its nodes out of line (below) */ \
-        "s_cbranch_scc1 .Lgbwt_walk2u_chained_%=\n\t" \
+        "s_cmp_lg_u32 s82, 0\n\t"                          /* a record with chained steps, or one whose iterations all stage four nodes: out of line (below) */ \
+        "s_cbranch_scc1 .Lgbwt_walk2u_special_%=\n\t" \
+        ".Lgbwt_walk2u_plain_%=:\n\t" \
         GBWT_WALK2U_STAGE("", "") \
         ".Lgbwt_walk2u_staged_%=:\n\t" \
         "v_cmp_lt_u32_e32 vcc, v44, %[quota]\n\t"           /* a walker that has emitted its share parks */ \
@@ -1186,6 +1187,25 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "s_cmp_eq_u64 s[46:47], 0\n\t" \
         "s_cbranch_scc0 .Lgbwt_walk2u_full_%=\n\t" \
         "s_branch .Lgbwt_walk2u_loop_%=\n\t" \
+        ".Lgbwt_walk2u_special_%=:\n\t" \
+        "s_bitcmp1_b32 s82, 2\n\t"                          /* E_ANYCHAIN */ \
+        "s_cbranch_scc1 .Lgbwt_walk2u_chained_%=\n\t" \
+        /* E_ALL4 (k_link_desc2): whichever edge and leaf a lane takes on this record, it emits four nodes -- neither an ENDMARKER nor an unfused \
+           step -- so nothing has to be counted: four consecutive ring slots (unless they wrap), one address, wr += 4.  6 VALU instead of 18. */ \
+        "v_and_b32_e32 v47, %[ringmask], v44\n\t" \
+        "v_cmp_lt_u32_e64 s[46:47], %[wrapmax], v47\n\t"    /* slot > slots - 4: the four would wrap */ \
+        "s_nop 1\n\t" \
+        "s_cmp_lg_u64 s[46:47], 0\n\t" \
+        "s_cbranch_scc1 .Lgbwt_walk2u_plain_%=\n\t" \
+        "v_mad_u32_u24 v47, v47, %[stride], %[ring]\n\t" \
+        "v_add_u32_e32 v78, s41, v78\n\t"                 /* node of w_a */ \
+        "v_add_u32_e32 v79, s41, v40\n\t"                  /* node of the landing record */ \
+        "ds_write_b32 v47, v72\n\t" \
+        "ds_write_b32 v47, v78 offset:260\n\t"              /* (slot + k) * 4 * RING_PITCH: the pitch is 65 dwords (walk_direct.hip; flagmask drops E_ALL4 for any other) */ \
+        "ds_write_b32 v47, v80 offset:520\n\t" \
+        "ds_write_b32 v47, v79 offset:780\n\t" \
+        "v_add_u32_e32 v44, 4, v44\n\t" \
+        "s_branch .Lgbwt_walk2u_staged_%=\n\t" \
         ".Lgbwt_walk2u_chained_%=:\n\t"                     /* the same with the nodes between; v62 = a */ \
         "v_mov_b32_e32 v82, s83\n\t" \
         "v_mov_b32_e32 v86, s84\n\t" \
@@ -1210,7 +1230,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "v_mov_b32_e32 %[wr], v44\n\t" \
         : [rec] "+v"(rec), [offset] "+v"(offset), [bb] "+v"(bb), [wr] "+v"(wr), [reason] "=&s"(reason) \
         : [dlo] "s"(dlo), [dhi] "s"(dhi), [cblocks] "s"(cblocks), [ring] "v"(ring_base), [mail] "v"(mail_slot), [drained] "v"(drained_addr), [slack] "s"(slack), [quota] "v"(quota), \
-          [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), "{s41}"(alphabet_offset) \
+          [ringmask] "s"(ring_mask), [stride] "s"(4 * ring_stride), [flagmask] "s"(flagmask), [wrapmax] "s"(ring_mask - 3), "{s41}"(alphabet_offset) \
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
           "v40", "v42", "v43", "v44", "v45", "v46", "v61", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v47", "v62", "v63", \
@@ -1219,6 +1239,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
 #define GBWT_WALK2U_BODY \
     uint32_t reason; \
     const uint32_t slack = ring_mask + 1 - headroom;   /* leave with more than slots - headroom nodes waiting in a ring (8; 16 where steps are chained) */ \
+    const uint32_t flagmask = (ring_stride == 65u && all4) ? (E_ANYCHAIN | E_ALL4) : E_ANYCHAIN;   /* the four-in-a-row staging hardcodes the ring pitch */ \
     const uint32_t dlo = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2)), dhi = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(desc2) >> 32); \
     /* the loop re-reads how far the helper has emptied the ring every iteration (working with the count it was entered with, it had to \
        leave after (slots - 8 - waiting) / 4 iterations: 180 exits per 1 024 iterations, each with a wasted round of loads) */ \
@@ -1267,7 +1288,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
 #endif
 __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const uint4 *cblocks /* = gblocks */, uint32_t alphabet_offset, uint32_t ring_base,
                                                        uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
-                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8) {
+                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8, bool all4 = true) {
 #ifdef GBWT_HIP_CXX_LOOP
     return 2;
 #else
@@ -1328,7 +1349,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop(const uint4 *desc2, const
 #endif
 __device__ __forceinline__ uint32_t walk2_uniform_loop_full(const uint4 *desc2, const uint4 *cblocks, uint32_t alphabet_offset, uint32_t ring_base,
                                                        uint32_t mail_slot, uint32_t drained_addr, bool narrow, uint32_t quota, uint32_t ring_mask,
-                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8) {
+                                                       uint32_t ring_stride, uint32_t &rec, uint32_t &offset, uint32_t &bb, uint32_t &wr, uint32_t headroom = 8, bool all4 = true) {
 #ifdef GBWT_HIP_CXX_LOOP
     return 2;
 #else
