@@ -13,9 +13,13 @@
 // other position must continue its predecessor).  A path that is not makes the reference's iterator stop at an
 // input-dependent place; such paths are flagged by the device and formatted by the host with the reference's state
 // machine, from the node ids the device extracted.
+#include <fcntl.h>
 #include <hipcub/hipcub.hpp>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -689,37 +693,104 @@ static gbwt_hip_status path_lines_impl(const gbwt_hip_index *ix, gbwt_hip_worksp
 
 namespace {
 
-// H-, S- and L-lines of the whole graph (write_gfa_header / write_segments / write_links, src/bin/gbunzip.rs:193-317): serial host work in
-// the reference as well.  Written through `emit` in pieces of about 8 MiB (the reference's BufWriter, src/bin/gbunzip.rs:96).
-template <class Emit>
-void host_graph_lines(const HostIndex &h, bool translated, Emit emit) {
-    auto flush = [&](std::string &text) { emit(text.data(), text.size()); text.clear(); };
-    {
-        std::string text;
-        // header (write_gfa_header, src/bin/gbunzip.rs:193-203)
-        if (const std::string *rs = h.tag("reference_samples")) text = "H\tVN:Z:1.1\tRS:Z:" + *rs + "\n";
-        else text = "H\tVN:Z:1.1\n";
-        // segments + links over the real nodes (write_segments / write_links, src/bin/gbunzip.rs:230-317)
-        const uint64_t first = h.alphabet_offset + 1, potential = h.sequences_labels.size();
-        auto real = [&](uint64_t seq) {
-            const uint64_t rec = 2 * seq + first - h.alphabet_offset;
-            return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;
+// A file written at positions: every producer knows (or is told, in order) where its bytes go, so several threads write at once --
+// one thread moved config 4's 4.5 GB to /dev/shm at 2.4 GB/s, most of it spent in the page cache's per-page work.
+struct PositionalFile {
+    int fd = -1;
+    std::atomic<int> failed{0};
+    ~PositionalFile() { if (fd >= 0) ::close(fd); }
+    bool write_at(const char *data, size_t bytes, uint64_t at) {
+        while (bytes != 0) {
+            const ssize_t w = ::pwrite(fd, data, bytes, static_cast<off_t>(at));
+            if (w <= 0) { failed = 1; return false; }
+            data += w; bytes -= static_cast<size_t>(w); at += static_cast<uint64_t>(w);
+        }
+        return true;
+    }
+};
+
+// H-, S- and L-lines of the whole graph (write_gfa_header / write_segments / write_links, src/bin/gbunzip.rs:193-317).  Serial host work in
+// the reference; here the node ids are cut into ranges that a few threads turn into text side by side (the S-lines of all ranges, then
+// the L-lines of all ranges: the order of the file).  A range's place in the file is behind the ranges before it, so a thread that has
+// its text waits for its turn to take the next stretch of the file (a counter, no I/O under it) and then writes it on its own:
+// config 4's 462 MB of S- and L-lines: 1 090 ms on one thread.  At most `threads` ranges of text exist at a time.  Returns the bytes written
+// from `cursor` on.  Graphs with a node-to-segment translation (segment names, links between segments) take one thread, as before.
+struct GraphLineRanges {
+    const HostIndex &h;
+    PositionalFile &file;
+    uint64_t cursor = 0;                   // next free byte of the file
+    GraphLineRanges(const HostIndex &index, PositionalFile &f) : h(index), file(f) {}
+    std::mutex turn_lock;
+    std::condition_variable turn_cv;
+    uint64_t turn = 0;                     // the range whose text goes next
+
+    template <class Make>
+    void phase(uint64_t items, uint64_t per_range, unsigned threads, Make make) {
+        const uint64_t ranges = (items + per_range - 1) / per_range;
+        std::atomic<uint64_t> next{0};
+        turn = 0;
+        auto work = [&]() {
+            std::string text;
+            for (uint64_t r = next++; r < ranges; r = next++) {
+                text.clear();
+                make(r * per_range, std::min(items, (r + 1) * per_range), text);
+                uint64_t at;
+                {
+                    std::unique_lock<std::mutex> lock(turn_lock);
+                    turn_cv.wait(lock, [&] { return turn == r; });
+                    at = cursor; cursor += text.size(); turn = r + 1;
+                }
+                turn_cv.notify_all();
+                (void)file.write_at(text.data(), text.size(), at);
+            }
         };
-        std::vector<std::pair<uint64_t, uint64_t>> edges;
-        if (translated) {
-            // GBZ::segment_iter keeps the segments whose first node exists (src/gbz.rs:927-929); links go from the last
-            // node of the segment in the orientation of travel (segment_successors, src/gbz.rs:402-415) and are named by
-            // the segment of the successor; LinkIter ends at a successor without a segment (src/gbz.rs:996-999)
-            const uint64_t n_seg = h.segment_starts.size();
-            for (uint64_t id = 0; id < n_seg; id++) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    }
+};
+
+void append_number(std::string &text, uint64_t v) {
+    char digits[24];
+    int len = 0;
+    do { digits[len++] = static_cast<char>('0' + v % 10); v /= 10; } while (v != 0);
+    while (len > 0) text.push_back(digits[--len]);
+}
+
+uint64_t host_graph_lines(const HostIndex &h, bool translated, PositionalFile &file) {
+    GraphLineRanges out(h, file);
+    {   // header (write_gfa_header, src/bin/gbunzip.rs:193-203)
+        std::string head;
+        if (const std::string *rs = h.tag("reference_samples")) head = "H\tVN:Z:1.1\tRS:Z:" + *rs + "\n";
+        else head = "H\tVN:Z:1.1\n";
+        (void)file.write_at(head.data(), head.size(), 0);
+        out.cursor = head.size();
+    }
+    // segments + links over the real nodes (write_segments / write_links, src/bin/gbunzip.rs:230-317)
+    const uint64_t first = h.alphabet_offset + 1, potential = h.sequences_labels.size();
+    auto real = [&](uint64_t seq) {
+        const uint64_t rec = 2 * seq + first - h.alphabet_offset;
+        return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;
+    };
+    const unsigned threads = potential >= (uint64_t(1) << 18) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+    if (translated) {
+        // GBZ::segment_iter keeps the segments whose first node exists (src/gbz.rs:927-929); links go from the last
+        // node of the segment in the orientation of travel (segment_successors, src/gbz.rs:402-415) and are named by
+        // the segment of the successor; LinkIter ends at a successor without a segment (src/gbz.rs:996-999)
+        const uint64_t n_seg = h.segment_starts.size();
+        out.phase(n_seg, uint64_t(1) << 15, threads, [&](uint64_t lo, uint64_t hi, std::string &text) {
+            for (uint64_t id = lo; id < hi; id++) {
                 const HostSegment seg = host_segment(h, id);
                 if (!host_has_node(h, seg.start)) continue;
-                text += "S\t" + h.segment_names.str(id) + "\t";
+                text += "S\t"; text += h.segment_names.str(id); text += "\t";
                 text.append(reinterpret_cast<const char *>(h.sequences_labels.bytes.data()) + h.sequences_labels.offsets[seg.start - 1], host_segment_seq_len(h, seg));
                 text += "\n";
-                if (text.size() > (8u << 20)) flush(text);
             }
-            for (uint64_t id = 0; id < n_seg; id++) {
+        });
+        out.phase(n_seg, uint64_t(1) << 15, threads, [&](uint64_t lo, uint64_t hi, std::string &text) {
+            std::vector<std::pair<uint64_t, uint64_t>> edges;
+            for (uint64_t id = lo; id < hi; id++) {
                 const HostSegment seg = host_segment(h, id);
                 if (!host_has_node(h, seg.start)) continue;
                 const std::string name = h.segment_names.str(id);
@@ -737,16 +808,21 @@ void host_graph_lines(const HostIndex &h, bool translated, Emit emit) {
                         text += "L\t" + name + (rev ? "\t-\t" : "\t+\t") + h.segment_names.str(to.id) + (succ_rev ? "\t-\t*\n" : "\t+\t*\n");
                     }
                 }
-                if (text.size() > (8u << 20)) flush(text);
             }
-        }
-        for (uint64_t seq = 0; seq < potential && !translated; seq++) {
+        });
+        return out.cursor;
+    }
+    out.phase(potential, uint64_t(1) << 16, threads, [&](uint64_t lo, uint64_t hi, std::string &text) {
+        for (uint64_t seq = lo; seq < hi; seq++) {
             if (!real(seq)) continue;
-            const uint64_t node_id = (2 * seq + first) / 2;
-            text += "S\t" + std::to_string(node_id) + "\t" + h.sequences_labels.str(seq) + "\n";
-            if (text.size() > (8u << 20)) flush(text);
+            text += "S\t"; append_number(text, (2 * seq + first) / 2); text.push_back('\t');
+            text.append(reinterpret_cast<const char *>(h.sequences_labels.bytes.data()) + h.sequences_labels.offsets[seq], h.sequences_labels.len(seq));
+            text.push_back('\n');
         }
-        for (uint64_t seq = 0; seq < potential && !translated; seq++) {
+    });
+    out.phase(potential, uint64_t(1) << 16, threads, [&](uint64_t lo, uint64_t hi, std::string &text) {
+        std::vector<std::pair<uint64_t, uint64_t>> edges;
+        for (uint64_t seq = lo; seq < hi; seq++) {
             if (!real(seq)) continue;
             const uint64_t node_id = (2 * seq + first) / 2;
             for (int rev = 0; rev < 2; rev++) {
@@ -757,50 +833,75 @@ void host_graph_lines(const HostIndex &h, bool translated, Emit emit) {
                     const bool succ_rev = (e.first & 1) != 0;
                     const bool canonical = rev ? (succ > node_id || (succ == node_id && !succ_rev)) : (succ >= node_id);
                     if (!canonical) continue;
-                    text += "L\t" + std::to_string(node_id) + (rev ? "\t-\t" : "\t+\t") + std::to_string(succ) + (succ_rev ? "\t-\t*\n" : "\t+\t*\n");
+                    text += "L\t"; append_number(text, node_id); text += rev ? "\t-\t" : "\t+\t"; append_number(text, succ); text += succ_rev ? "\t-\t*\n" : "\t+\t*\n";
                 }
             }
-            if (text.size() > (8u << 20)) flush(text);
         }
-        flush(text);
-    }
+    });
+    return out.cursor;
 }
 
-// The writer's side of a whole-file write: one thread that first puts out the graph lines (which precede the paths in the file), then
-// takes finished batches of path lines -- device text -- and moves them to the file through two pinned buffers: the copy of piece i + 1
-// runs under the fwrite of piece i, and the main thread formats the next batch into the other device text buffer meanwhile.
+// The writer's side of a whole-file write: one thread that first puts out the graph lines (which precede the paths in the file; see
+// host_graph_lines), then takes finished batches of path lines -- device text -- and moves them to the file in pieces of 32 MiB: the
+// piece travels into one of four pinned buffers (the copy of the next piece runs under whatever happens to this one) and a small pool of
+// threads writes the buffers at their positions.  The main thread formats the next batch into the other device text buffer meanwhile.
 struct GfaWriter {
-    static constexpr size_t PIECE = size_t(64) << 20;
+    static constexpr size_t PIECE = size_t(32) << 20;
+    int WRITERS = 3, BUFFERS = 5;            // GBWT_HIP_GFA_WRITERS (1 .. 16); two more pinned buffers than writing threads
     struct Job { const char *text; uint64_t bytes; int slot; };
+    struct Piece { int buffer; uint64_t bytes, at; };
     std::mutex m;
     std::condition_variable cv;
     std::deque<Job> jobs;
-    bool closing = false, slot_busy[2] = {false, false};
+    std::deque<Piece> pieces;              // pinned buffers that hold a piece on its way to the file
+    std::vector<char> buffer_busy;
+    bool closing = false, no_more_pieces = false, slot_busy[2] = {false, false};
     gbwt_hip_status status = GBWT_HIP_OK;
     std::string message;
     std::thread worker;
-    FILE *file;
-    int device;
+    PositionalFile *file = nullptr;
+    const HostIndex *host = nullptr;
+    bool translated = false;
+    int device = 0;
 
     void fail_with(gbwt_hip_status st, const std::string &msg) {
         std::lock_guard<std::mutex> lock(m);
         if (status == GBWT_HIP_OK) { status = st; message = msg; }
         cv.notify_all();
     }
-    bool put(const char *data, size_t bytes) {
-        if (bytes != 0 && std::fwrite(data, 1, bytes, file) != bytes) { fail_with(GBWT_HIP_IO_ERROR, "short write"); return false; }
-        return true;
-    }
-    template <class Graph>
-    void run(Graph graph_lines) {
-        void *pinned[2] = {nullptr, nullptr};
+    void run() {
+        if (const char *v = std::getenv("GBWT_HIP_GFA_WRITERS")) WRITERS = std::min(16, std::max(1, std::atoi(v)));
+        BUFFERS = WRITERS + 2;
+        std::vector<void *> pinned(BUFFERS, nullptr);
+        buffer_busy.assign(BUFFERS, 0);
         hipStream_t stream = nullptr;
-        hipEvent_t landed[2] = {nullptr, nullptr};
+        const bool trace = std::getenv("GBWT_HIP_TRACE_GFA") != nullptr;       // phases of a whole-file write on stderr
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        uint64_t path_bytes = 0;
+        std::vector<std::thread> pool;
         try {
-            graph_lines([this](const char *data, size_t bytes) { (void)put(data, bytes); });
+            uint64_t cursor = host_graph_lines(*host, translated, *file);
+            if (file->failed) throw std::runtime_error("short write");
+            if (trace) std::fprintf(stderr, "[gfa] H/S/L lines: %llu bytes generated and written in %.1f ms\n", static_cast<unsigned long long>(cursor), since());
             HIP_CHECK(hipSetDevice(device));
             HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-            for (int i = 0; i < 2; i++) { HIP_CHECK(hipHostMalloc(&pinned[i], PIECE, hipHostMallocDefault)); HIP_CHECK(hipEventCreate(&landed[i])); }
+            for (int i = 0; i < BUFFERS; i++) HIP_CHECK(hipHostMalloc(&pinned[i], PIECE, hipHostMallocDefault));
+            for (int t = 0; t < WRITERS; t++)
+                pool.emplace_back([this, &pinned]() {
+                    for (;;) {
+                        Piece p;
+                        {
+                            std::unique_lock<std::mutex> lock(m);
+                            cv.wait(lock, [&] { return !pieces.empty() || no_more_pieces; });
+                            if (pieces.empty()) return;
+                            p = pieces.front(); pieces.pop_front();
+                        }
+                        if (!file->write_at(static_cast<const char *>(pinned[p.buffer]), p.bytes, p.at)) fail_with(GBWT_HIP_IO_ERROR, "short write");
+                        { std::lock_guard<std::mutex> lock(m); buffer_busy[p.buffer] = 0; }
+                        cv.notify_all();
+                    }
+                });
             for (;;) {
                 Job job;
                 {
@@ -809,31 +910,39 @@ struct GfaWriter {
                     if (status != GBWT_HIP_OK || jobs.empty()) break;
                     job = jobs.front(); jobs.pop_front();
                 }
-                const uint64_t pieces = (job.bytes + PIECE - 1) / PIECE;
-                auto fetch = [&](uint64_t i) {
-                    const uint64_t at = i * PIECE, len = std::min<uint64_t>(PIECE, job.bytes - at);
-                    HIP_CHECK(hipMemcpyAsync(pinned[i % 2], job.text + at, len, hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipEventRecord(landed[i % 2], stream));
-                };
-                if (pieces) fetch(0);
-                for (uint64_t i = 0; i < pieces; i++) {
-                    HIP_CHECK(hipEventSynchronize(landed[i % 2]));
-                    if (i + 1 < pieces) fetch(i + 1);
-                    else {   // the device text of this batch has left: the formatter may have the slot back
-                        std::lock_guard<std::mutex> lock(m);
-                        slot_busy[job.slot] = false;
-                        cv.notify_all();
+                path_bytes += job.bytes;
+                for (uint64_t done = 0; done < job.bytes; done += PIECE) {
+                    int b = -1;
+                    {
+                        std::unique_lock<std::mutex> lock(m);
+                        cv.wait(lock, [&] { for (int i = 0; i < BUFFERS; i++) if (!buffer_busy[i]) return true; return status != GBWT_HIP_OK; });
+                        if (status != GBWT_HIP_OK) break;
+                        for (int i = 0; i < BUFFERS; i++) if (!buffer_busy[i]) { b = i; break; }
+                        buffer_busy[b] = 1;
                     }
-                    if (!put(static_cast<const char *>(pinned[i % 2]), std::min<uint64_t>(PIECE, job.bytes - i * PIECE))) break;
+                    const uint64_t len = std::min<uint64_t>(PIECE, job.bytes - done);
+                    HIP_CHECK(hipMemcpyAsync(pinned[b], job.text + done, len, hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    { std::lock_guard<std::mutex> lock(m); pieces.push_back(Piece{b, len, cursor + done}); }
+                    cv.notify_all();
                 }
-                if (pieces == 0) { std::lock_guard<std::mutex> lock(m); slot_busy[job.slot] = false; cv.notify_all(); }
+                cursor += job.bytes;
+                {   // the device text of this batch has left: the formatter may have the slot back
+                    std::lock_guard<std::mutex> lock(m);
+                    slot_busy[job.slot] = false;
+                }
+                cv.notify_all();
             }
         } catch (const HipError &e) {
             fail_with(GBWT_HIP_DEVICE_ERROR, std::string(e.what) + ": " + hipGetErrorString(e.err));
         } catch (const std::exception &e) {
-            fail_with(GBWT_HIP_DEVICE_ERROR, std::string("GFA writer: ") + e.what());
+            fail_with(GBWT_HIP_IO_ERROR, std::string("GFA writer: ") + e.what());
         }
-        for (int i = 0; i < 2; i++) { if (pinned[i]) (void)hipHostFree(pinned[i]); if (landed[i]) (void)hipEventDestroy(landed[i]); }
+        { std::lock_guard<std::mutex> lock(m); no_more_pieces = true; }
+        cv.notify_all();
+        for (auto &t : pool) t.join();
+        if (trace) std::fprintf(stderr, "[gfa] path lines: %llu bytes; writer threads done at %.1f ms\n", static_cast<unsigned long long>(path_bytes), since());
+        for (int i = 0; i < BUFFERS; i++) if (pinned[i]) (void)hipHostFree(pinned[i]);
         if (stream) (void)hipStreamDestroy(stream);
         std::lock_guard<std::mutex> lock(m);
         closing = true; slot_busy[0] = slot_busy[1] = false;
@@ -848,12 +957,12 @@ struct GfaWriter {
         return true;
     }
     void submit(const char *text, uint64_t bytes, int slot) {
-        std::lock_guard<std::mutex> lock(m);
-        jobs.push_back(Job{text, bytes, slot});
+        { std::lock_guard<std::mutex> lock(m); jobs.push_back(Job{text, bytes, slot}); }
         cv.notify_all();
     }
     gbwt_hip_status finish() {
-        { std::lock_guard<std::mutex> lock(m); closing = true; cv.notify_all(); }
+        { std::lock_guard<std::mutex> lock(m); closing = true; }
+        cv.notify_all();
         if (worker.joinable()) worker.join();
         return status;
     }
@@ -915,16 +1024,12 @@ gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_works
         require_gfa_capable(ix);
         const HostIndex &h = ix->host;
         const bool translated = h.has_translation && !h.segment_starts.empty();
-        std::unique_ptr<FILE, int (*)(FILE *)> f(std::fopen(path, "wb"), std::fclose);
-        if (!f) return fail(GBWT_HIP_IO_ERROR, std::string("cannot create ") + path);
-        std::vector<char> file_buffer(size_t(8) << 20);
-        (void)std::setvbuf(f.get(), file_buffer.data(), _IOFBF, file_buffer.size());
+        PositionalFile file;
+        file.fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (file.fd < 0) return fail(GBWT_HIP_IO_ERROR, std::string("cannot create ") + path);
         GfaWriter writer;
-        writer.file = f.get();
-        writer.device = ix->device;
-        writer.worker = std::thread([&writer, &h, translated]() {
-            writer.run([&h, translated](auto emit) { host_graph_lines(h, translated, emit); });
-        });
+        writer.file = &file; writer.host = &h; writer.translated = translated; writer.device = ix->device;
+        writer.worker = std::thread([&writer]() { writer.run(); });
         // write_gfa_impl's match on the path mode (src/bin/gbunzip.rs:212-222), ascending path id (-t 1 order):
         //   default: paths of the generic sample as P-lines, then the others as W-lines (write_paths / write_walks, 343-417)
         //   pan-sn : every path as a P-line with its PanSN name (write_pan_sn, 371-393)
@@ -972,7 +1077,7 @@ gbwt_hip_status gbwt_hip_write_gfa_mode(const gbwt_hip_index *ix, gbwt_hip_works
         ws->lines_cached = false;                            // (both text buffers have been reused)
         if (st == GBWT_HIP_OK && wst != GBWT_HIP_OK) return fail(wst, writer.message);
         if (st != GBWT_HIP_OK) return wst != GBWT_HIP_OK ? fail(wst, writer.message) : st;
-        if (std::fflush(f.get()) != 0) return fail(GBWT_HIP_IO_ERROR, "short write");
+        if (file.failed) return fail(GBWT_HIP_IO_ERROR, "short write");
         return GBWT_HIP_OK;
     } catch (const InvalidData &e) {
         return fail(GBWT_HIP_BAD_ARGUMENT, e.what());
