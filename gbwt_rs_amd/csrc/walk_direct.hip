@@ -516,6 +516,17 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         // (forward nodes are walked in ascending id order in a graph whose ids are sorted topologically, as vg's are); where the guess
         // is wrong, or the rows really have gone different ways, the attempt fails after four steps, the gather loop takes over as
         // before, and the wave stops trying for a while.
+        if (!together && a.uniform_loop && a.catch_up && catch_pause == 0) {
+            // ... and only a wave whose rows are NEAR each other: lanes on records thousands apart are rows of different graph components (a
+            // batch of ragged walks over hundreds of components: config 4's shape), which no number of single steps brings together --
+            // such a wave keeps to the gather loop for a long while (round 4: 2.08 -> 1.9 ms on that batch with catch-up switched off)
+            uint32_t lo_rec = rec != 0 ? rec : 0xFFFFFFFFu, hi_rec = rec;
+            for (int d = 32; d > 0; d >>= 1) {
+                lo_rec = min(lo_rec, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo_rec), d)));
+                hi_rec = max(hi_rec, static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi_rec), d)));
+            }
+            if (hi_rec - lo_rec > 64u) catch_pause = 256;
+        }
         if (!together && a.uniform_loop && a.catch_up && catch_pause == 0 && __ballot(sink.wr - drained > ring_mask + 1 - 8) == 0) {   // (its single steps stage up to eight nodes)
             const uint64_t walking = __ballot(rec != 0);
             for (uint32_t tries = 0; tries < 4 && !together; tries++) {
