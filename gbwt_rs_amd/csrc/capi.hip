@@ -349,7 +349,8 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
                     ix.table_positions = total_positions;
                     if (6 * total_positions * sizeof(uint4) <= budget && !(deep && std::atoi(deep) == 0)) {
                         ix.wtables_deep.reserve(total_positions * 4 * sizeof(uint4));
-                        launch_fill_wtables_deep(d, ix.wtables_deep.as<uint4>(), nullptr);
+                        const char *compact = std::getenv("GBWT_HIP_COMPACT_TABLES");      // 0: seven-step entries only (round 3)
+                        launch_fill_wtables_deep(d, ix.wtables_deep.as<uint4>(), !(compact && std::atoi(compact) == 0), nullptr);
                         HIP_CHECK(hipDeviceSynchronize());
                         HIP_CHECK(hipGetLastError());
                         d.wtables_deep = ix.wtables_deep.as<uint4>();

@@ -82,6 +82,9 @@ constexpr uint32_t LEAF_CHAIN = 1u << 30;            // two-step descriptor, lea
 constexpr uint32_t CHAIN_MAX = 6;                    // at most this many nodes between the first node of a step and its landing node
 constexpr uint32_t WT_TABLE = 1u << 30;              // walk table entry: the landing record is a table record, word 3 = its table base
 constexpr uint32_t WT_DEEP_STEPS = 7;                // deep walk table entry: this many table steps in 64 bytes
+constexpr uint32_t WT_COMPACT_STEPS = 12;            // ... or this many, where all of them emit two nodes whose ids lie within 16-bit deltas of each other (k_fill_wtables_deep)
+constexpr uint32_t WT_COMPACT = 1u << 30;            // deep walk table entry, word 1: the compact form
+constexpr uint32_t WT_COMPACT_TABLE = 1u << 29;      // compact form, word 1: the last landing record is a table record (word 15 = its table base)
 constexpr uint32_t BLOCK_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANK_BLOCK_SHIFT = 6;   // 64 offsets per rank block
 constexpr uint32_t DATA_PAD = 128;  // lane 63 of a cooperative chunk reads up to 71 bytes past the chunk start

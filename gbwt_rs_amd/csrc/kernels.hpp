@@ -33,7 +33,7 @@ void launch_fill_tables(const DeviceIndex &ix, uint4 *d_desc_raw, const uint64_t
                         uint2 *d_edges, hipStream_t stream);
 // walk tables: the LF tables with the step through a unary successor and the landing record's base folded in (after fill_tables)
 void launch_fill_wtables(const DeviceIndex &ix, uint4 *d_wtables, hipStream_t stream);
-void launch_fill_wtables_deep(const DeviceIndex &ix, uint4 *d_deep, hipStream_t stream);   // ix.wtables set; 4 uint4 per table position
+void launch_fill_wtables_deep(const DeviceIndex &ix, uint4 *d_deep, bool compact, hipStream_t stream);   // ix.wtables set; 4 uint4 per table position; compact: twelve-step entries where they fit (device_index.hpp: WT_COMPACT)
 // two-step walk (device_index.hpp): composed descriptors, two-step rank blocks, look-ahead targets
 void launch_link_desc2(const DeviceIndex &ix, uint4 *d_desc2, uint32_t gather_limit, uint32_t chain_max, uint32_t *d_chained, hipStream_t stream);   // chain_max: bits 0-7 = most nodes a chained step adds, bit 8 = the index is bidirectional; *d_chained = the most nodes one iteration can stage where a step was chained (zeroed by the caller)   // gather_limit: Record::len below which the packed blocks can count
 void launch_fill_two_step_blocks(const DeviceIndex &ix, uint4 *d_cblocks /* or null */, uint4 *d_gblocks /* or null */, hipStream_t stream);   // one of the two layouts, or both in one pass

@@ -978,6 +978,7 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "1000", "GBWT_HIP_PATHS_PER_WAVE": "13"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_WALK_TABLES": "0"},   # outdegree > 2: plain table steps, one at a time
                 {"GBWT_HIP_SAMPLE_INTERVAL": "48", "GBWT_HIP_DEEP_TABLES": "0"},   # ... walk-table steps, one per load instead of seven
+                {"GBWT_HIP_SAMPLE_INTERVAL": "96", "GBWT_HIP_COMPACT_TABLES": "0"},   # ... seven per load everywhere (no twelve-step compact entries)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_SERIAL_SAMPLES": "1", "GBWT_HIP_TWO_PASS_OPEN": "1"},  # every sequence walked at open: lengths, then samples
                 {"GBWT_HIP_SAMPLE_INTERVAL": "40", "GBWT_HIP_SERIAL_SAMPLES": "1"},   # ... both in one walk (samples every 40 nodes of each sequence)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CHECKPOINT_CAP": "5"},   # checkpoint sampling with hops of at most 5 + 3 nodes: many rounds of orphans
