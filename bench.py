@@ -151,11 +151,12 @@ def lookup_traffic(workload_key, kernel=None):
     return None, "no PMC profile of this build / workload under profiles/"
 
 
-def config_roofline(obj, key, definition):
-    """The roofline object of a secondary workload: algorithmic bytes / kernel time against the HBM peak, and the measured traffic."""
+def config_roofline(obj, key, definition, kernel=None):
+    """The roofline object of a secondary workload: algorithmic bytes / kernel time against the HBM peak, and the measured traffic
+    (of `kernel` alone where the profile holds several and the object is about one of them)."""
     seconds = obj["kernel_ms"] * 1e-3
     achieved = obj["algorithmic_bytes"] / seconds / 1e9
-    traffic, source = lookup_traffic(key)
+    traffic, source = lookup_traffic(key, kernel)
     obj["roofline"] = {"bound": "hbm", "definition": definition, "kernel": obj["kernel"], "kernel_ms": obj["kernel_ms"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                        "traffic_frac": None if traffic is None else traffic / seconds / 1e9 / HBM_PEAK_GBS, "traffic_source": source}
@@ -405,7 +406,7 @@ def main():
             if not args.no_search:
                 extras["search"] = config_roofline(K.search(device=local_rank), "search",
                                                    "bytes a query must move in this layout: its nodes in, its state out, and per step one 64-byte record descriptor + "
-                                                   "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)")
+                                                   "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)", kernel="k_search")
             if not args.no_config4:
                 extras["config4"] = config_roofline(K.config4(device=local_rank), "config4",
                                                     "bytes moved by walk + format: node ids written by the walk, read by the sizing pass and by the formatter, "
