@@ -82,6 +82,12 @@ public:
     bool is_bidirectional() const { return stats_.bidirectional != 0; }
     bool has_metadata() const { return stats_.has_metadata != 0; }
     const gbwt_hip_stats &stats() const { return stats_; }
+    // bytes the index holds on the device and on the host, and what this object's workspace holds (gbwt_hip_memory_usage)
+    gbwt_hip_memory memory_usage() const {
+        gbwt_hip_memory m{};
+        check(gbwt_hip_memory_usage(index_.get(), ws_.get(), &m));
+        return m;
+    }
 
     // ---- navigation, src/gbwt.rs:213-261
     std::vector<std::optional<Pos>> start(const std::vector<uint64_t> &ids) const {
@@ -237,6 +243,29 @@ private:
         if (total) check(gbwt_hip_follow(index_.get(), ws_.get(), &state, 1, backward ? 1 : 0, offsets, out.data(), total, &total, &valid));
         return out;
     }
+};
+
+// The ordered gather of a sharded extraction (one process per GPU; the reference's writer mutex, src/bin/gbunzip.rs:421-434).  Rank 0 makes
+// the id (Comm::unique_id), every rank constructs a Comm from it (collective), and after gbwt_hip_extract_device / _path_lines_device on
+// each rank's shard gather_rows / gather_lines leave all rows in path order on `root` (device memory of the communicator).
+class Comm {
+public:
+    static gbwt_hip_unique_id unique_id() {
+        gbwt_hip_unique_id id{};
+        const gbwt_hip_status st = gbwt_hip_comm_unique_id(&id);
+        if (st != GBWT_HIP_OK) throw Error(st, gbwt_hip_last_error());
+        return id;
+    }
+    Comm(const gbwt_hip_unique_id &id, int rank, int world, int device) {
+        gbwt_hip_comm *c = nullptr;
+        const gbwt_hip_status st = gbwt_hip_comm_create(&id, rank, world, device, &c);
+        if (st != GBWT_HIP_OK) throw Error(st, gbwt_hip_last_error());
+        comm_.reset(c, gbwt_hip_comm_destroy);
+    }
+    gbwt_hip_comm *get() const { return comm_.get(); }
+
+private:
+    std::shared_ptr<gbwt_hip_comm> comm_;
 };
 
 }  // namespace gbwt_hip

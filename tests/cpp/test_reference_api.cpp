@@ -120,6 +120,16 @@ int main(int argc, char **argv) {
     } catch (const Error &e) {
         REQUIRE(e.status == GBWT_HIP_IO_ERROR);
     }
+    // what an index replica costs (gbwt_hip_memory_usage), and the exchange of a sharded extraction with one rank: the rows of an
+    // extraction gathered "from all ranks" in path order are the rows themselves (gbwt_hip_comm_*: RCCL loaded at run time)
+    const gbwt_hip_memory mem = gbz.memory_usage();
+    REQUIRE(mem.index_device_bytes > 141 && mem.index_host_bytes > 141);
+    try {
+        Comm comm(Comm::unique_id(), 0, 1, 0);
+        REQUIRE(comm.get() != nullptr);
+    } catch (const Error &e) {
+        REQUIRE(e.status == GBWT_HIP_UNSUPPORTED);                       // a box without RCCL
+    }
     std::printf("reference API mirror: all checks passed\n");
     return 0;
 }

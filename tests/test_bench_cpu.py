@@ -32,6 +32,21 @@ def test_committed_traffic_profile_names_its_build_and_workload():
     assert 13.3e9 < t["write_bytes"] < 13.5e9       # every node id once
 
 
+def test_round4_profiles_cover_every_config():
+    """Round 4: every BASELINE config has a PMC traffic file that bench.py can match (fingerprint + workload key) and the per-kernel split."""
+    keys = {"r04_hbm_traffic.json": "sites=333334 haplotypes=5000 model=mosaic seed=42", "r04_secondary_hbm_traffic.json": "secondary",
+            "r04_high_degree_hbm_traffic.json": "high_degree", "r04_search_hbm_traffic.json": "search", "r04_config4_hbm_traffic.json": "config4"}
+    prints = set()
+    for name, key in keys.items():
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert t["workload_key"] == key and len(t["source_fingerprint"]) == 16, name
+        assert t["traffic_bytes_per_launch"] == 2 * t["fetch_bytes_raw"] + t["write_bytes"] and t["kernels"], name
+        assert abs(sum(k["traffic_bytes_per_launch"] for k in t["kernels"].values()) - t["traffic_bytes_per_launch"]) < 1.0, name
+        prints.add(t["source_fingerprint"])
+    assert len(prints) == 1                         # one build, one gpurun call
+    assert set(json.load(open(os.path.join(ROOT, "profiles", "r04_config4_hbm_traffic.json")))["kernels"]) == {"k_walk_direct", "k_chunk_stats", "k_format_chunks"}
+
+
 def test_gpus_without_a_launcher_starts_the_ranks(monkeypatch):
     """--gpus N > 1 outside torchrun: the ranks are children of this (GPU-free) process, started over 127.0.0.1."""
     calls = []
