@@ -632,36 +632,40 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 while (__ballot(in_table) != 0) {
                     if (deep && __ballot(in_table && sink.wr - lds_peek(my_drained) > ring_mask + 1 - table_slack) != 0) { __builtin_amdgcn_s_sleep(2); continue; }
                     // (compact entries, device_index.hpp: twelve steps = 24 nodes as 16-bit deltas.  They are staged in two halves of twelve
-                    // with a look at the ring in between, so that the ring needs no more free slots than a seven-step entry asks for.)
+                    // with a look at the ring in between, so that the ring needs no more free slots than a seven-step entry asks for; the second
+                    // half of the entry is fetched -- from the line the first half came with -- when it is needed: all sixteen words live across
+                    // the first half and the wait cost the kernel its fourth wave per SIMD, 135 VGPRs, and the headline 9 %.)
                     bool compact = false;
-                    uint4 c0, c1, c2, c3;
+                    const uint4 *entry = nullptr;
+                    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
                     if (in_table && deep) {
-                        const uint4 *e = ix.wtables_deep + 4 * (static_cast<uint64_t>(tb) + offset);
-                        c0 = e[0]; c1 = e[1]; c2 = e[2]; c3 = e[3];
+                        entry = ix.wtables_deep + 4 * (static_cast<uint64_t>(tb) + offset);
+                        c0 = entry[0]; c1 = entry[1];
                         compact = (c0.y & WT_COMPACT) != 0;
                     }
                     if (__ballot(compact) != 0) {
                         uint32_t node = c0.x;
-                        const auto pair = [&](uint32_t word) {
-                            node += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(word & 0xFFFFu))); sink.push(node, compact);
-                            node += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(word >> 16))); sink.push(node, compact);
-                        };
+                        const auto step16 = [&](uint32_t half) { node += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(half & 0xFFFFu))); sink.push(node, compact); };
+                        const auto pair = [&](uint32_t word) { step16(word); step16(word >> 16); };
                         sink.push(node, compact);
                         pair(c0.z); pair(c0.w); pair(c1.x); pair(c1.y); pair(c1.z);
-                        node += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(c1.w & 0xFFFFu))); sink.push(node, compact);      // node 11
+                        step16(c1.w);                                                                       // node 11
+                        const uint32_t carry = c1.w >> 16, flags = c0.y;
                         lds_poke(my_mail + 3, sink.wr);
                         while (__ballot(compact && sink.wr - lds_peek(my_drained) > ring_mask + 1 - table_slack) != 0) __builtin_amdgcn_s_sleep(2);
-                        node += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(c1.w >> 16))); sink.push(node, compact);          // node 12
+                        uint4 c2 = make_uint4(0, 0, 0, 0), c3 = c2;
+                        if (compact) { c2 = entry[2]; c3 = entry[3]; }
+                        step16(carry);                                                                      // node 12
                         pair(c2.x); pair(c2.y); pair(c2.z); pair(c2.w); pair(c3.x);
-                        node += static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(c3.y & 0xFFFFu))); sink.push(node, compact);      // node 23
+                        step16(c3.y);                                                                       // node 23
                         if (compact) {
                             rec = node - ix.alphabet_offset; offset = c3.z;
-                            if (c0.y & WT_COMPACT_TABLE) tb = c3.w; else { bb = c3.w; in_table = false; }
+                            if (flags & WT_COMPACT_TABLE) tb = c3.w; else { bb = c3.w; in_table = false; }
                             if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; in_table = false; }
                         }
                     }
                     if (in_table && deep && !compact) {
-                        const uint4 q0 = c0, q1 = c1, q2 = c2, q3 = c3;
+                        const uint4 q0 = c0, q1 = c1, q2 = entry[2], q3 = entry[3];
                         const uint32_t ao = ix.alphabet_offset;
                         sink.push(q0.x, q0.x != 0); sink.push((q0.y & REC_MASK) + ao, (q0.y & LEAF_EMIT2) != 0);
                         sink.push(q0.z, q0.z != 0); sink.push((q0.w & REC_MASK) + ao, (q0.w & LEAF_EMIT2) != 0);

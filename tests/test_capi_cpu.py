@@ -200,6 +200,20 @@ def test_loader_under_sanitizers(tmp_path):
     assert "accepted" in out.stdout
 
 
+def test_walk_kernel_keeps_four_waves_per_simd():
+    """k_walk_direct is sized for four waves per SIMD = eight workgroups per CU: 128 VGPRs at most and nothing spilled.
+    Round 4 lost a tenth of the headline for a few commits to a table decoder that kept sixteen more registers alive (135 VGPRs, three
+    waves per SIMD) without any test noticing; hipcc's resource remarks need no GPU."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull,
+                          os.path.join(_lib.CSRC, "walk_direct.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stderr.splitlines()
+    at = next(i for i, l in enumerate(lines) if "Function Name" in l and "k_walk_direct" in l)
+    block = "\n".join(lines[at:at + 14])
+    field = lambda name: int(re.search(name + r": (\d+)", block).group(1))
+    assert field("    VGPRs") <= 128 and field("VGPRs Spill") == 0 and field(r"Occupancy \[waves/SIMD\]") >= 4, block
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product path fails loudly instead of computing on the host."""
     if G.device_count() > 0:
