@@ -415,11 +415,15 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             lds_poke(lds_ptr(&row_state[lane].y), static_cast<uint32_t>(at >> 32));
             lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0x7FFFFFF0u)) | (target.skip ? 0x80000000u : 0u));
             // order = the rows sorted by (address phase within a piece, row): rank by counting, once per workgroup
+            // (by ballots over the 16 / 32 possible phases: the loop over the 64 rows' LDS entries this replaces was a quarter of what a
+            // workgroup spends outside its walk -- short segments, i.e. small batches and the per-rank shards of a multi-GPU run, pay that
+            // per 300 nodes; tools/shard_probe.py)
             const uint32_t phase = (static_cast<uint32_t>(at) >> 2) & (piece - 1);
+            const uint64_t lanes_below = (uint64_t(1) << lane) - 1;
             uint32_t rank = 0;
-            for (uint32_t other = 0; other < WAVE; other++) {
-                const uint32_t theirs = (lds_peek(lds_ptr(&row_state[other].x)) >> 2) & (piece - 1);
-                rank += (theirs < phase || (theirs == phase && other < lane)) ? 1u : 0u;
+            for (uint32_t v = 0; v < piece; v++) {
+                const uint64_t same = __ballot(phase == v);
+                rank += v < phase ? static_cast<uint32_t>(__popcll(same)) : (v == phase ? static_cast<uint32_t>(__popcll(same & lanes_below)) : 0u);
             }
             if (a.debug & 32u) rank = lane;                          // measurement switch: groups of consecutive rows
             lds_poke(lds_ptr(row_order) + rank, lane);
