@@ -114,15 +114,24 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     w.cap = interval;     // A/B on the headline (profiles/r03_sampling_ab.txt): cap = interval 4.31 ms per pass, 1.5 x 4.38, 2 x 4.46; the serial samples 4.34
     w.packed = ix.packed_blocks ? 1u : 0u;
     if (const char *v = std::getenv("GBWT_HIP_CHECKPOINT_CAP")) w.cap = static_cast<uint32_t>(std::max(1, std::atoi(v)));
-    DeviceBuffer counts, cp_first, scan_tmp, summaries, misc;
-    counts.reserve(nr * sizeof(uint64_t)); cp_first.reserve((nr + 1) * sizeof(uint64_t));
+    // two allocations for all temporaries (seven of each, and seven frees, were a millisecond of the open): what is sized by the records
+    // and sequences, then what is sized by the checkpoint positions
+    struct Carver {
+        DeviceBuffer arena; size_t at = 0;
+        static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
+        void *take(size_t bytes) { void *p = static_cast<char *>(arena.ptr) + at; at += padded(bytes); return p; }
+    } small, large;
+    const size_t tb = scan_temp_bytes(nr), sb = scan_temp_bytes(S), scan_bytes = std::max<size_t>(std::max(tb, sb), 16);
+    small.arena.reserve(Carver::padded(nr * sizeof(uint64_t)) + Carver::padded((nr + 1) * sizeof(uint64_t)) + Carver::padded(scan_bytes) + Carver::padded(2 * sizeof(uint64_t)) +
+                        Carver::padded(S * sizeof(uint64_t)));
+    uint64_t *counts = static_cast<uint64_t *>(small.take(nr * sizeof(uint64_t))), *cp_first = static_cast<uint64_t *>(small.take((nr + 1) * sizeof(uint64_t)));
+    void *scan_tmp = small.take(scan_bytes);
+    uint64_t *misc = static_cast<uint64_t *>(small.take(2 * sizeof(uint64_t))), *per_sequence = static_cast<uint64_t *>(small.take(S * sizeof(uint64_t)));
     trace.mark("  (before the checkpoint passes)");
-    launch_checkpoint_counts(d, w.threshold, counts.as<uint64_t>(), nullptr);
-    const size_t tb = scan_temp_bytes(nr);
-    scan_tmp.reserve(std::max<size_t>(tb, 16));
-    launch_scan(counts.as<uint64_t>(), cp_first.as<uint64_t>(), nr, scan_tmp.ptr, tb, nullptr);
+    launch_checkpoint_counts(d, w.threshold, counts, nullptr);
+    launch_scan(counts, cp_first, nr, scan_tmp, tb, nullptr);
     uint64_t positions = 0;
-    HIP_CHECK(hipMemcpy(&positions, cp_first.as<uint64_t>() + nr, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&positions, cp_first + nr, sizeof(uint64_t), hipMemcpyDeviceToHost));
     trace.mark("    checkpoint counts + scan");
     // every orphan stands for a finished walk of at least `cap` nodes, and no two walkers share a BWT position
     // (every node of a sequence is one BWT position: at most max_walk / cap hops end at the cap.  A quarter more for the hops of up to cap + 3
@@ -130,38 +139,40 @@ bool checkpoint_samples(gbwt_hip_index &ix, uint32_t interval, uint32_t *d_flags
     const uint64_t orphan_capacity = d.max_walk / w.cap + d.max_walk / w.cap / 4 + S + 1024;
     const uint64_t n_summaries = S + positions + orphan_capacity;
     if (n_summaries >= 0xFFFFFFF0ull) return false;
-    summaries.reserve(n_summaries * sizeof(uint4));
+    const size_t span_slots = S + n_summaries / 16 + 2;                     // one splitter per sixteen summaries, behind the sequence starts (open_walks.hip: span_slot)
+    large.arena.reserve(Carver::padded(n_summaries * sizeof(uint4)) + Carver::padded(span_slots * sizeof(uint4)));
+    uint4 *summaries = static_cast<uint4 *>(large.take(n_summaries * sizeof(uint4))), *spans = static_cast<uint4 *>(large.take(span_slots * sizeof(uint4)));
     trace.mark("    summaries allocated");
-    misc.reserve(2 * sizeof(uint64_t));
-    HIP_CHECK(hipMemset(misc.ptr, 0, 2 * sizeof(uint64_t)));
-    w.cp_first = cp_first.as<uint64_t>(); w.summaries = summaries.as<uint4>();
-    w.orphan_count = misc.as<uint64_t>(); w.orphan_capacity = orphan_capacity; w.positions = positions;
-    w.flags = reinterpret_cast<uint32_t *>(misc.as<uint64_t>() + 1);
+    HIP_CHECK(hipMemset(misc, 0, 2 * sizeof(uint64_t)));
+    w.cp_first = cp_first; w.summaries = summaries;
+    w.orphan_count = misc; w.orphan_capacity = orphan_capacity; w.positions = positions;
+    w.flags = reinterpret_cast<uint32_t *>(misc + 1);
     trace.mark("  checkpoint counts + scan + allocations");
     launch_checkpoint_walk(d, w, nullptr);
     trace.mark("  k_checkpoint_walk");
     uint64_t state[2] = {0, 0};
-    HIP_CHECK(hipMemcpy(state, misc.ptr, sizeof(state), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(state, misc, sizeof(state), hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
     if ((state[1] & 4u) || state[0] > orphan_capacity) return false;   // more orphans than a consistent index can have (walks in circles)
     ix.times.checkpoint_rounds = 1; ix.times.checkpoint_walkers = S + positions; ix.times.checkpoint_orphans = state[0];
     // the chase: count, scan, write
     ix.seq_len.reserve(S * sizeof(uint32_t));
     ix.sample_base.reserve((S + 1) * sizeof(uint64_t));
-    DeviceBuffer per_sequence;
-    per_sequence.reserve(S * sizeof(uint64_t));
-    launch_chase(d, summaries.as<uint4>(), n_summaries, ix.seq_len.as<uint32_t>(), per_sequence.as<uint64_t>(), nullptr, nullptr, d_flags, nullptr);
-    const size_t sb = scan_temp_bytes(S);
-    scan_tmp.reserve(std::max<size_t>(sb, 16));
-    launch_scan(per_sequence.as<uint64_t>(), ix.sample_base.as<uint64_t>(), S, scan_tmp.ptr, sb, nullptr);
+    const uint64_t used = S + positions + state[0];                         // (the orphan slots nobody took hold nothing)
+    launch_chase_counts(d, summaries, used, spans, ix.seq_len.as<uint32_t>(), per_sequence, d_flags, nullptr);
+    launch_scan(per_sequence, ix.sample_base.as<uint64_t>(), S, scan_tmp, sb, nullptr);
     std::vector<uint64_t> base(S + 1);
     HIP_CHECK(hipMemcpy(base.data(), ix.sample_base.ptr, base.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     uint32_t overflow = 0;
     HIP_CHECK(hipMemcpy(&overflow, d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost));
     trace.mark("  chase: counts + scan");
+    if (overflow & 8u) {                                                    // lists that run into each other: no list ranking, the serial walk takes over
+        HIP_CHECK(hipMemset(d_flags, 0, sizeof(uint32_t)));
+        return false;
+    }
     if (overflow) return true;                                              // the caller reports it; no samples
     ix.samples.reserve(std::max<uint64_t>(base[S], 1) * sizeof(uint4));
-    launch_chase(d, summaries.as<uint4>(), n_summaries, nullptr, nullptr, ix.sample_base.as<uint64_t>(), ix.samples.as<uint4>(), d_flags, nullptr);
+    launch_chase_samples(d, summaries, used, spans, ix.sample_base.as<uint64_t>(), ix.samples.as<uint4>(), nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipGetLastError());
     trace.mark("  chase: samples");
@@ -404,7 +415,19 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         // at 331 G LF-steps/s with 128-node segments and at 407 G with 512; C5 at 339 and 357)
         if (d.wtables_deep != nullptr && 3 * ix.table_positions >= h.size)   // (a star site is a table record and a unary one: half of the positions)
             while (interval < 512 && (interval < 128 || (all_nodes >> 17) > interval)) interval *= 2;
+        // FINE SAMPLES, STRIDED WALKERS (round 4).  The numbers above are what a batch the size of the whole index wants: about 2 300 nodes per
+        // walker on the headline, 34 000 workgroups of half a millisecond each.  A batch of an eighth of the paths -- one rank of eight --
+        // then has 4 200 workgroups for 2 048 places, and a kernel that is two workgroup lifetimes long whatever it does (1.09 ms for an
+        // eighth of 4.2 ms of work: profiles/r04_shard_probe.txt).  So the largest indexes keep a sample every 512 nodes, and an
+        // extraction starts a walker at every `stride`-th of them, by the size of the batch (gbwt_hip_extract_device): strides of 4 or 5
+        // for the headline batch (the segments it always had), 2 for an eighth of it (0.89 ms).  16 bytes per sample: 371 MB instead of 69.
+        ix.sample_coarse = 1;
         if (const char *v = std::getenv("GBWT_HIP_SAMPLE_INTERVAL")) interval = static_cast<uint32_t>(std::max(0, std::atoi(v)));
+        else if (interval >= 1024 && d.chained == 0) {
+            const char *c = std::getenv("GBWT_HIP_SAMPLE_COARSE");
+            const uint32_t coarse = c ? static_cast<uint32_t>(std::max(1, std::atoi(c))) : interval / 512;
+            ix.sample_coarse = coarse; interval = std::max(64u, interval / coarse);
+        }
         const bool sampled = interval >= 8;
         // Without samples an extraction fills every row from both ends, which needs the proof that sequence 2k + 1 is
         // sequence 2k reversed (fingerprints); with samples nothing does, and the counting walk is twice as fast
@@ -800,7 +823,18 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
             const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && ix->max_samples > 0 && knobs.segments != 0;   // (the walker order sorts 32-bit row numbers)
             // the samples lie where the sequences pass checkpoint records, so the number of segments of a row comes from its samples, not from its length
-            a.segments = segmented ? ix->max_samples : 0u;
+            // a walker per `stride` samples of a row (fine samples, above): about 2.9 million walkers for the biggest batches, no segments
+            // shorter than two samples unless the batch is so small that it needs every walker it can get
+            uint32_t stride = static_cast<uint32_t>(std::max(1, knobs.sample_stride));
+            if (knobs.sample_stride < 0 && segmented && ix->sample_coarse > 1) {
+                uint64_t fine = 0;
+                if (ids_valid) for (uint64_t k = 0; k < n; k++) fine += ix->sample_counts[seq_ids[k]];
+                else fine = total / std::max<uint32_t>(ix->dev.sample_interval, 1);
+                const uint64_t want = (fine + 1450000) / 2900000;
+                stride = static_cast<uint32_t>(std::min<uint64_t>(2 * ix->sample_coarse, std::max<uint64_t>(want, fine >= 524288 ? 2 : 1)));
+            }
+            DeviceIndex strided = ix->dev; strided.sample_stride = stride;
+            a.segments = segmented ? (ix->max_samples + stride - 1) / stride : 0u;
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
             // every row of the batch with the same number of samples (the forward sequences of haplotypes over one reference frame: the
             // headline's shape): walker w = segment * n + row, no order to compute
@@ -811,7 +845,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             }
             const bool same_segments = segmented && ids_valid && common != 0;
             if (same_segments) {
-                a.segments = common;
+                a.segments = (common + stride - 1) / stride;
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
             } else if (segmented && knobs.walker_order != 0 && n <= 0x7FFFFFFFull) {
@@ -821,7 +855,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
                 // components, sorted by row length until round 4, had every wave on 64 different records (201 G LF-steps/s in the gather
                 // loop; profiles/r04_walk_experiments.txt).
                 ws->order_counts.reserve(n * sizeof(uint64_t)); ws->order_level.reserve((n + 1) * sizeof(uint64_t));
-                launch_walker_counts(ix->dev, ws->seq_ids.as<uint64_t>(), n, ws->order_counts.as<uint64_t>(), s);
+                launch_walker_counts(strided, ws->seq_ids.as<uint64_t>(), n, ws->order_counts.as<uint64_t>(), s);
                 launch_scan(ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
                 HIP_CHECK(hipMemcpyAsync(&walkers, ws->order_level.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
@@ -830,7 +864,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
                 ws->order_keys.reserve(2 * std::max<uint64_t>(walkers, 1) * sizeof(uint32_t)); ws->order_rows.reserve(2 * std::max<uint64_t>(walkers, 1) * sizeof(uint32_t));
                 ws->order_temp.reserve(std::max<size_t>(ob, 16));
                 const uint32_t *sorted = nullptr;
-                if (walkers) launch_walker_list(ix->dev, ws->seq_ids.as<uint64_t>(), n, ws->order_level.as<uint64_t>(), walkers, ws->order_keys.as<uint32_t>(),
+                if (walkers) launch_walker_list(strided, ws->seq_ids.as<uint64_t>(), n, ws->order_level.as<uint64_t>(), walkers, ws->order_keys.as<uint32_t>(),
                                                 ws->order_rows.as<uint32_t>(), ws->order_temp.ptr, ob, &sorted, s);
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
                 a.walker_list = walkers ? sorted : nullptr; a.row_first = ws->order_level.as<uint64_t>();
@@ -842,7 +876,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
                 ws->order_counts.reserve(a.segments * sizeof(uint64_t)); ws->order_level.reserve((a.segments + 1ull) * sizeof(uint64_t));
                 ws->order_temp.reserve(std::max<size_t>(std::max(ob, sb), 16));
                 const uint32_t *sorted_rows = nullptr;
-                launch_walker_order(ix->dev, ws->seq_ids.as<uint64_t>(), n, a.segments, ws->order_keys.as<uint32_t>(), ws->order_rows.as<uint32_t>(),
+                launch_walker_order(strided, ws->seq_ids.as<uint64_t>(), n, a.segments, ws->order_keys.as<uint32_t>(), ws->order_rows.as<uint32_t>(),
                                     ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), ws->order_temp.ptr, ob, &sorted_rows, s);
                 launch_scan(ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), a.segments, ws->order_temp.ptr, sb, s);
                 HIP_CHECK(hipMemcpyAsync(&walkers, ws->order_level.as<uint64_t>() + a.segments, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -868,7 +902,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.headroom = static_cast<uint32_t>(knobs.headroom);
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
             a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;
-            const DeviceIndex dev = a.packed_blocks ? ix->dev : with_cblocks(ix);
+            DeviceIndex dev = a.packed_blocks ? ix->dev : with_cblocks(ix);
+            dev.sample_stride = stride;
             a.row_piece = knobs.row_piece >= 0 ? static_cast<uint32_t>(knobs.row_piece) : 32u;
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
             // GBWT_HIP_HEADROOM: the walkers wait while more than ring - headroom nodes are pending, the cooperative helper moves whole pieces only:

@@ -237,6 +237,7 @@ struct gbwt_hip_index {
     std::atomic<const uint4 *> lazy_cblocks{nullptr};
     bool packed_blocks = true;        // gblocks was built (false: the index is too large for 32-bit half-block indices, or GBWT_HIP_GATHER_LIMIT=0)
     uint32_t max_samples = 0;         // the largest number of samples of a sequence
+    uint32_t sample_coarse = 1;       // the samples are this many times finer than a batch of the whole index wants: extractions stride over them (capi.hip)
     std::vector<uint32_t> sample_counts;   // samples of every sequence (host copy: an extraction looks whether its rows all have the same number)
     uint32_t uniform_samples = 0;     // every sequence has this many samples (0: they differ): the walkers of an extraction are then w = segment * n + row
     bool starts_uploaded = false;         // ... and the record starts
@@ -254,6 +255,7 @@ struct ExtractKnobs {
     int direct = 1, segments = 1, both_ends = 1;             // GBWT_HIP_DIRECT / _SEGMENTS / _BOTH_ENDS (0 switches the feature off)
     int align_segments = 0;                                   // GBWT_HIP_ALIGN_SEGMENTS: 1 = the boundary between two walkers of a row is a line boundary of the row's memory (round 4: measured, 2.4 % slower on the headline: not the default)
     int all4 = 1;                                             // GBWT_HIP_ALL4: 0 = the uniform loop counts every node it stages (rounds 1-3)
+    int sample_stride = -1;                                   // GBWT_HIP_SAMPLE_STRIDE: a walker per this many samples of a row; -1 = by the size of the batch (gbwt_hip_extract_device)
     int walker_order = 0;                                     // GBWT_HIP_WALKER_ORDER: 1 = ragged batches in the order of the walkers' start records (round 4: measured, not the default), 0 = by number of segments
     int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
@@ -269,6 +271,7 @@ struct ExtractKnobs {
         k.xcd_map = num("GBWT_HIP_XCD_MAP", -1); k.uniform_loop = num("GBWT_HIP_UNIFORM_LOOP", -1); k.packed_blocks = num("GBWT_HIP_PACKED_BLOCKS", -1);
         k.catch_up = num("GBWT_HIP_CATCH_UP", -1);
         k.walker_order = num("GBWT_HIP_WALKER_ORDER", 0);
+        k.sample_stride = num("GBWT_HIP_SAMPLE_STRIDE", -1);
         k.align_segments = num("GBWT_HIP_ALIGN_SEGMENTS", 0);
         k.all4 = num("GBWT_HIP_ALL4", 1);
         k.headroom = std::min(32, std::max(0, num("GBWT_HIP_HEADROOM", 0)));

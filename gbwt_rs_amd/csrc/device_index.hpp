@@ -106,6 +106,7 @@ struct DeviceIndex {
     const uint4 *samples;      // sequence samples {record, offset, block base, nodes emitted so far}, or null
     const uint64_t *sample_base;   // n_sequences + 1: first sample of every sequence
     uint32_t sample_interval;  // a sample about every this many nodes
+    uint32_t sample_stride;    // an extraction starts a walker at every sample_stride-th sample of a sequence (0 = 1 = at every one; set per request: gbwt_hip_extract_device)
     const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
     const uint4 *gblocks;      // 2 * n_blocks entries: the same, one 16-byte entry per 32 offsets with packed counts (gather loop)
     uint64_t data_len;

@@ -109,8 +109,8 @@ void launch_record_samples(const DeviceIndex &ix, const uint64_t *d_sample_base,
 // Records whose hashed index is below `threshold` are checkpoints; one walker per position of every checkpoint record and one per
 // sequence start walks to the next checkpoint (at most `cap` nodes per hop: there it takes a summary slot for the position it has reached -- an
 // orphan -- and walks on) and stores
-// a summary {landing record, offset, nodes walked, summary index of the landing position}; launch_chase follows the summaries of
-// every sequence: with d_samples == nullptr it counts (d_seq_len, d_counts), otherwise it writes the samples at d_sample_base.
+// a summary {landing record, offset, nodes walked, summary index of the landing position}; launch_chase_counts follows the summaries of
+// every sequence (by splitters: d_spans, n_sequences + n_summaries / 16 + 1 entries) and counts (d_seq_len, d_counts), launch_chase_samples writes the samples at d_sample_base.
 struct CheckpointWalk {
     const uint64_t *cp_first;      // [n_records + 1] exclusive scan of launch_checkpoint_counts
     uint4 *summaries;              // [n_sequences + positions + orphan_capacity]
@@ -122,8 +122,10 @@ struct CheckpointWalk {
 };
 void launch_checkpoint_counts(const DeviceIndex &ix, uint32_t threshold, uint64_t *d_counts, hipStream_t stream);
 void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, hipStream_t stream);
-void launch_chase(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, uint32_t *d_seq_len, uint64_t *d_counts, const uint64_t *d_sample_base,
-                  uint4 *d_samples, uint32_t *d_overflow, hipStream_t stream);
+void launch_chase_counts(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, uint4 *d_spans, uint32_t *d_seq_len, uint64_t *d_counts,
+                         uint32_t *d_overflow, hipStream_t stream);
+void launch_chase_samples(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, const uint4 *d_spans, const uint64_t *d_sample_base,
+                          uint4 *d_samples, hipStream_t stream);
 // walker order of a segmented extraction: per-row segment counts -> rows sorted by count (descending, stable) and
 // level[j] = number of walkers in segments < j.  d_keys / d_rows: 2 x n scratch each (double buffers of the sort).
 size_t walker_order_temp_bytes(uint64_t n);

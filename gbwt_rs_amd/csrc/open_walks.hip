@@ -328,36 +328,99 @@ __global__ void __launch_bounds__(256) k_checkpoint_walk(DeviceIndex ix, Checkpo
     }
 }
 
-// One lane per sequence: the chain of summaries from the sequence start.  samples == nullptr: count the samples and the length;
-// otherwise write them: sample 0 = the position after the start node (as the walker of segment 0 expects it), then one per hop.
-__global__ void __launch_bounds__(64) k_chase(DeviceIndex ix, const uint4 *summaries, uint64_t n_summaries, uint32_t *seq_len, uint64_t *counts,
-                                              const uint64_t *sample_base, uint4 *samples, uint32_t *overflow) {
+// THE CHASE (round 4: by splitters).  The summaries of one sequence form a linked list, and the samples of the sequence are its
+// elements in list order with the running sum of the nodes: list ranking.  One lane per sequence following its list took a
+// microsecond per hop (a dependent 16-byte load from hundreds of megabytes), twice -- once to count, once to write: 4.4 ms of the
+// headline's open with a sample every 512 nodes (2 320 hops per sequence).  Now one summary of sixteen (by a hash of its index) and
+// every sequence start is a SPLITTER:
+//   k_chase_spans     : every splitter walks to the next splitter: {next splitter, samples on the way, nodes on the way} -- a million
+//                       and a half short walks at once;
+//   k_chase_splitters : one lane per sequence follows the splitters only (a sixteenth of the hops), leaves each of them its
+//                       {sequence, first sample number, nodes before it}, and the sequence its length and sample count;
+//   k_chase_samples   : (after the scan of the counts) every splitter walks its span again and writes the samples: sample 0 of a
+//                       sequence = the position after the start node (as the walker of segment 0 expects it), then one per hop.
+constexpr uint32_t SPAN_END = 0xFFFFFFFFu, SPAN_UNVISITED = 0xFFFFFFFFu, SPAN_LIMIT = 4096;   // (4096 hops without a splitter: (15/16)^4096 -- a cycle of a corrupt index)
+// exactly one of every sixteen consecutive summary indices, which one by a hash of the others' common bits: a splitter has the compact
+// index p / 16 (behind the sequence starts), and which summaries are splitters has nothing to do with how records number their positions
+__device__ __forceinline__ bool chase_splitter(uint64_t p, uint64_t n_sequences) {
+    return p < n_sequences || (static_cast<uint32_t>(p) & 15u) == ((static_cast<uint32_t>(p >> 4) * CP_HASH) >> 28);
+}
+__device__ __forceinline__ uint64_t span_slot(uint64_t p, uint64_t n_sequences) { return p < n_sequences ? p : n_sequences + (p >> 4); }
+// ... and the other way round: the splitter of slot t, or n_summaries where the slot has none (lanes are started per SLOT: one per summary
+// had a sixteenth of every wave at work, 360 000 waves of 32 us each: 1.0 and 1.4 ms for the two walks over the spans)
+__device__ __forceinline__ uint64_t slot_splitter(uint64_t t, uint64_t n_sequences, uint64_t n_summaries) {
+    if (t < n_sequences) return t;
+    const uint64_t g = t - n_sequences, p = 16 * g + ((static_cast<uint32_t>(g) * CP_HASH) >> 28);
+    return (p < n_sequences || p >= n_summaries) ? n_summaries : p;
+}
+
+__global__ void __launch_bounds__(256) k_chase_spans(const uint4 *summaries, uint64_t n_summaries, uint64_t n_sequences, uint4 *spans, uint32_t *overflow) {
+    const uint64_t p = slot_splitter(blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x, n_sequences, n_summaries);
+    if (p >= n_summaries) return;
+    uint64_t q = p, nodes = 0;
+    uint32_t hops = 0, next = SPAN_END;
+    for (;;) {
+        const uint4 s = summaries[q];
+        nodes += s.z;
+        if (s.x == 0) break;                                        // the sequence ends inside this hop
+        q = s.w;
+        if (q >= n_summaries) { atomicOr(overflow, 2u); break; }
+        if (++hops > SPAN_LIMIT) { atomicOr(overflow, 8u); break; }  // (a list that meets no splitter: the caller walks every sequence instead)
+        if (chase_splitter(q, n_sequences)) { next = static_cast<uint32_t>(q); break; }
+    }
+    if (nodes > 0xFFFFFFF0ull) { atomicOr(overflow, 1u); nodes = 0; }
+    spans[span_slot(p, n_sequences)] = make_uint4(next, hops, static_cast<uint32_t>(nodes), SPAN_UNVISITED);
+}
+
+__global__ void __launch_bounds__(64) k_chase_splitters(DeviceIndex ix, uint4 *spans, uint64_t n_summaries, uint32_t *seq_len, uint64_t *counts, uint32_t *overflow) {
     const uint64_t id = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (id >= ix.n_sequences) return;
     uint64_t n = 0, wr = 0;
-    uint4 *out = samples ? samples + sample_base[id] : nullptr;
-    const uint64_t room = samples ? sample_base[id + 1] - sample_base[id] : 0;
     if (id < ix.n_endmarker && ix.endmarker[id].x != 0) {
         const uint2 e = ix.endmarker[id];
         uint32_t rec = 0, bb = BLOCK_NONE;
-        if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
-        wr = 1;
-        if (out && n < room) out[n] = make_uint4(rec, e.y, bb, 1u);
-        n++;
-        uint64_t p = id, hops = 0;
-        while (rec != 0) {
-            if (p >= n_summaries || ++hops > ix.max_walk) { if (overflow) atomicOr(overflow, 2u); break; }
-            const uint4 s = summaries[p];
-            wr += s.z;
-            if (wr > 0xFFFFFFF0ull) { if (overflow) atomicOr(overflow, 1u); break; }
-            rec = s.x;
-            if (rec == 0) break;
-            if (out && n < room) out[n] = make_uint4(rec, s.y, ix.block_base[rec], static_cast<uint32_t>(wr));
-            n++;
-            p = s.w;
+        n = 1; wr = 1;
+        if (arrive(ix, e.x, e.y, rec, bb)) {
+            uint64_t p = id, hops = 0;
+            for (;;) {
+                if (p >= n_summaries || ++hops > ix.max_walk) { atomicOr(overflow, 2u); break; }
+                const uint64_t slot = span_slot(p, ix.n_sequences);
+                const uint4 sp = spans[slot];
+                if (sp.w != SPAN_UNVISITED) { atomicOr(overflow, 8u); break; }       // two sequences through one position (LF is injective in a GBWT; a mutated one is what the reference makes of it): the caller walks every sequence instead
+                spans[slot] = make_uint4(sp.x, static_cast<uint32_t>(n), static_cast<uint32_t>(wr), static_cast<uint32_t>(id));
+                n += sp.y; wr += sp.z;
+                if (wr > 0xFFFFFFF0ull || n > 0xFFFFFFF0ull) { atomicOr(overflow, 1u); break; }
+                if (sp.x == SPAN_END) break;
+                p = sp.x;
+            }
         }
     }
-    if (!samples) { seq_len[id] = static_cast<uint32_t>(wr); counts[id] = n; }
+    seq_len[id] = static_cast<uint32_t>(wr); counts[id] = n;
+}
+
+__global__ void __launch_bounds__(256) k_chase_samples(DeviceIndex ix, const uint4 *summaries, uint64_t n_summaries, const uint4 *spans, const uint64_t *sample_base, uint4 *samples) {
+    const uint64_t p = slot_splitter(blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x, ix.n_sequences, n_summaries);
+    if (p >= n_summaries) return;
+    const uint4 sp = spans[span_slot(p, ix.n_sequences)];
+    if (p < ix.n_sequences && p < ix.n_endmarker && ix.endmarker[p].x != 0) {       // sample 0 of sequence p
+        const uint2 e = ix.endmarker[p];
+        uint32_t rec = 0, bb = BLOCK_NONE;
+        if (!arrive(ix, e.x, e.y, rec, bb)) { rec = 0; bb = BLOCK_NONE; }
+        if (sample_base[p + 1] > sample_base[p]) samples[sample_base[p]] = make_uint4(rec, e.y, bb, 1u);
+    }
+    if (sp.w == SPAN_UNVISITED) return;                              // on no sequence's list
+    uint4 *out = samples + sample_base[sp.w];
+    const uint64_t room = sample_base[sp.w + 1] - sample_base[sp.w];
+    uint64_t q = p, n = sp.y, wr = sp.z;
+    for (uint32_t hops = 0; hops <= SPAN_LIMIT; hops++) {
+        const uint4 s = summaries[q];
+        wr += s.z;
+        if (s.x == 0) break;
+        if (n < room) out[n] = make_uint4(s.x, s.y, ix.block_base[s.x], static_cast<uint32_t>(wr));
+        n++;
+        q = s.w;
+        if (q >= n_summaries || chase_splitter(q, ix.n_sequences)) break;
+    }
 }
 
 }  // namespace
@@ -411,11 +474,17 @@ void launch_checkpoint_walk(const DeviceIndex &ix, const CheckpointWalk &w, hipS
     hipLaunchKernelGGL(k_checkpoint_walk, dim3(grid_for(count, 256)), dim3(256), 0, stream, ix, c);
 }
 
-void launch_chase(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, uint32_t *d_seq_len, uint64_t *d_counts, const uint64_t *d_sample_base,
-                  uint4 *d_samples, uint32_t *d_overflow, hipStream_t stream) {
+void launch_chase_counts(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, uint4 *d_spans, uint32_t *d_seq_len, uint64_t *d_counts,
+                         uint32_t *d_overflow, hipStream_t stream) {
     if (ix.n_sequences == 0) return;
-    hipLaunchKernelGGL(k_chase, dim3(grid_for(ix.n_sequences, 64)), dim3(64), 0, stream, ix, d_summaries, n_summaries, d_seq_len, d_counts, d_sample_base,
-                       d_samples, d_overflow);
+    hipLaunchKernelGGL(k_chase_spans, dim3(grid_for(ix.n_sequences + n_summaries / 16 + 1, 256)), dim3(256), 0, stream, d_summaries, n_summaries, ix.n_sequences, d_spans, d_overflow);
+    hipLaunchKernelGGL(k_chase_splitters, dim3(grid_for(ix.n_sequences, 64)), dim3(64), 0, stream, ix, d_spans, n_summaries, d_seq_len, d_counts, d_overflow);
+}
+
+void launch_chase_samples(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, const uint4 *d_spans, const uint64_t *d_sample_base,
+                          uint4 *d_samples, hipStream_t stream) {
+    if (ix.n_sequences == 0) return;
+    hipLaunchKernelGGL(k_chase_samples, dim3(grid_for(ix.n_sequences + n_summaries / 16 + 1, 256)), dim3(256), 0, stream, ix, d_summaries, n_summaries, d_spans, d_sample_base, d_samples);
 }
 
 }  // namespace gbwt_hip

@@ -990,6 +990,10 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "0"},   # ... with the lane-per-row writer (64-byte boundaries)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16", "GBWT_HIP_WALKER_ORDER": "1"},   # ... and walkers in the order of their start records
                 {"GBWT_HIP_SAMPLE_INTERVAL": "2048", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_SAMPLE_STRIDE": "2"},   # strided walkers (round 4): a walker per 2 / 3 / 5 samples of a row, in every walker order
+                {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3", "GBWT_HIP_WALKER_ORDER": "1"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_SAMPLE_STRIDE": "5", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_SAMPLE_STRIDE": "1000"},   # ... more than any row has: one walker per row
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
 
@@ -1038,7 +1042,8 @@ def test_segmented_extraction(monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "50", "GBWT_HIP_XCD_MAP": "0"},
-                                 {"GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1", "GBWT_HIP_ALIGN_SEGMENTS": "1"}],
+                                 {"GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_SAMPLE_STRIDE": "3"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "2", "GBWT_HIP_WALKER_ORDER": "1"}],
                          ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
 def test_walker_order_with_ragged_rows(monkeypatch, env):
     """A few long haplotypes and thousands of short walks (a fragmented assembly): the walkers of a segmented extraction

@@ -1,0 +1,3 @@
+R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/r04_ad; mkdir -p $O
+timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "segmented or ragged or corrupt or sampl or checkpoint" > $O/tests.log 2>&1; tail -3 $O/tests.log
+GBWT_HIP_TRACE_OPEN=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-config4 --no-search 2>&1 | grep -v amdgpu | grep "checkpoint\|chase\|open_ms\|temporaries" | cut -c1-700

@@ -8,7 +8,7 @@ import gbwt_rs_amd as G
 from gbwt_rs_amd import synth as S
 s = S.Synth.chain(sites=333334, haplotypes=5000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=42)
 dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True)
-print("interval", os.environ.get("GBWT_HIP_SAMPLE_INTERVAL", "default"), "samples", dev.open_times()["samples"], flush=True)
+print("interval", os.environ.get("GBWT_HIP_SAMPLE_INTERVAL", "default"), "open", {k: round(v, 2) if isinstance(v, float) else v for k, v in dev.open_times().items()}, flush=True)
 base = None
 for n in (1, 2, 4, 8):
     ids = 2 * np.arange(0, s.paths, n, dtype=np.uint64)
