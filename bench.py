@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE index (seed 42) replicated on every rank, path p walked by rank p mod N, whole CSR gathered on rank 0 "
                          "(SURVEY 8e; default); weak = every rank its own contig (seed 42 + rank)")
+    ap.add_argument("--shard", choices=["parts", "paths"], default="parts",
+                    help="N > 1, strong scaling: parts = every rank walks EVERY path over its N-th of the way (rows cut at sequence samples: gbwt_hip_extract_part_device; "
+                         "default since round 4), paths = path p walked whole by rank p mod N (rounds 1-3)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_unsampled and the other BASELINE configs (secondary = insertion chain, high_degree = config 5, search = config 3, config4)")
     ap.add_argument("--no-search", action="store_true", help="skip the config 3 search object (its 1.1 M-site index takes half a minute to generate)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config 4 object")
@@ -168,11 +171,11 @@ def shard_paths(n_paths, rank, world):
     return np.arange(rank, n_paths, world, dtype=np.uint64)
 
 
-def timed_passes(index, ids, passes):
+def timed_passes(index, ids, passes, part=0, parts=1):
     """`passes` extractions of `ids`: (walk-kernel ms, everything-on-the-stream ms) per pass from the workspace's HIP events."""
     walk, total, out = [], [], None
     for _ in range(passes):
-        out = index.extract_device(ids)
+        out = index.extract_part_device(ids, part, parts) if parts > 1 else index.extract_device(ids)
         w, t = index.last_kernel_ms()
         walk.append(w)
         total.append(t)
@@ -244,32 +247,56 @@ def main():
     open_ms = (time.perf_counter() - t0) * 1e3
     open_times = index.open_times()
     n_paths = index.paths()
-    my_paths = shard_paths(n_paths, rank, world) if strong else np.arange(n_paths, dtype=np.uint64)
+    # N > 1, strong scaling: every rank walks EVERY path over ITS N-th of the way (--shard parts; rows are cut where their walkers start
+    # anyway, at sequence samples) -- a rank then reads an N-th of the index and keeps whole waves on every record; --shard paths is the
+    # scheme of rounds 1-3, path p whole on rank p mod N (an eighth of the batch 0.88 ms there, 0.53-0.60 ms as parts: profiles/r04_shard_probe.txt)
+    by_parts = strong and world > 1 and args.shard == "parts"
+    parts = world if by_parts else 1
+    my_paths = np.arange(n_paths, dtype=np.uint64) if (by_parts or not strong) else shard_paths(n_paths, rank, world)
     ids = 2 * my_paths
+    extract = (lambda: index.extract_part_device(ids, rank, parts)) if by_parts else (lambda: index.extract_device(ids))
     t0 = time.perf_counter()
-    out = index.extract_device(ids)
+    out = extract()
     first_pass_ms = (time.perf_counter() - t0) * 1e3
     first_walk_ms = index.last_kernel_ms()[0]
     path_len = (index.len() - index.sequences()) // 2 // n_paths if n_paths else 0   # every path of this generator visits every site
-    expected_steps = len(my_paths) * path_len
+    expected_steps = len(my_paths) * path_len                 # (by parts: of all ranks together, checked below)
     steps_done = int(out.total)
 
     # ---- steady state: the index resident, the same batch again and again
     for _ in range(args.warmup):
-        index.extract_device(ids)
+        extract()
     barrier()
     t0 = time.perf_counter()
-    out, walk_ms, total_ms = timed_passes(index, ids, args.steps)
+    out, walk_ms, total_ms = timed_passes(index, ids, args.steps, rank, parts)
     barrier()
     elapsed = time.perf_counter() - t0
-    assert int(out.total) == steps_done == expected_steps, (int(out.total), steps_done, expected_steps)
+    assert int(out.total) == steps_done and (by_parts or steps_done == expected_steps), (int(out.total), steps_done, expected_steps)
 
     # untimed: full-size check of the last extraction against the generator's ground truth
     sums = index.path_sums(len(ids))
     truth = np.array([s.path_checksum(int(p)) for p in my_paths], dtype=np.uint64)
-    assert np.array_equal(sums, truth), "extracted paths differ from the generator's ground truth"
-    for k in (0, len(ids) // 2, len(ids) - 1):
-        assert np.array_equal(index.copy_path(k), s.path(int(my_paths[k])))
+    part_from = None
+    if by_parts:
+        # a row's stretches add up to the row: the per-row sums of all ranks together are the generator's, and this rank's stretch of a row
+        # is the row from where the ranks before it stopped
+        off_mine = index.last_offsets(len(ids))
+        lens = torch.from_numpy(np.diff(off_mine).astype(np.int64)).to(comm_device)
+        all_lens = [torch.zeros_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens)
+        part_from = sum((x.cpu().numpy() for x in all_lens[:rank]), np.zeros(len(ids), dtype=np.int64))
+        row_len = sum(x.cpu().numpy() for x in all_lens)
+        assert np.all(row_len == path_len), "the stretches of a row do not add up to its length"
+        t_sums = torch.from_numpy(sums.astype(np.int64)).to(comm_device)      # (sums mod 2^64: int64 wraps the same way)
+        dist.all_reduce(t_sums, op=dist.ReduceOp.SUM)
+        assert np.array_equal(t_sums.cpu().numpy().astype(np.uint64), truth), "extracted paths differ from the generator's ground truth"
+        for k in (0, len(ids) // 2, len(ids) - 1):
+            lo = int(part_from[k])
+            assert np.array_equal(index.copy_path(k), s.path(int(my_paths[k]))[lo:lo + int(lens[k])]), f"stretch {rank} of row {k}"
+    else:
+        assert np.array_equal(sums, truth), "extracted paths differ from the generator's ground truth"
+        for k in (0, len(ids) // 2, len(ids) - 1):
+            assert np.array_equal(index.copy_path(k), s.path(int(my_paths[k])))
 
     gather_info = None
     cold_ms = open_ms + first_pass_ms              # the one-shot flow of the slowest rank
@@ -299,10 +326,11 @@ def main():
                     if comm_device != "cuda":
                         raise RuntimeError("not an RCCL run")
                     comm = D.Comm(rank, world, local_rank)
-                    comm.gather_rows(index, root=0, interleaved=True)          # untimed: connections, buffers
+                    layout = D.GATHER_PARTS if by_parts else D.GATHER_INTERLEAVED
+                    comm.gather_rows(index, root=0, layout=layout)          # untimed: connections, buffers
                     barrier()
                     tg = time.perf_counter()
-                    got = comm.gather_rows(index, root=0, interleaved=True)
+                    got = comm.gather_rows(index, root=0, layout=layout)
                     barrier()
                     gather_ms = (time.perf_counter() - tg) * 1e3
                     gather_info = {"ms": gather_ms, "backend": backend, "via": via, "rank_stats": comm.last(),
@@ -333,7 +361,12 @@ def main():
                     if rank == 0:
                         got_n = sum(int(p.numel()) for p in val_parts)
                         assert got_n == int(all_steps), (got_n, all_steps)
-                        for r in range(world):                     # first and last row of every rank's part against the generator
+                        if by_parts:                               # the stretches of every row, joined in rank order
+                            j_off, j_nodes = D.join_row_parts(len_parts, val_parts)
+                            for p_id in (0, n_paths // 2, n_paths - 1):
+                                row = j_nodes[int(j_off[p_id]):int(j_off[p_id + 1])].cpu().numpy().astype(np.uint32)
+                                assert np.array_equal(row, s.path(p_id)), f"row {p_id} changed on the way"
+                        for r in range(world if not by_parts else 0):   # first and last row of every rank's part against the generator
                             paths_r = shard_paths(n_paths, r, world)
                             ends = torch.cumsum(len_parts[r], 0)
                             for k in (0, len(paths_r) - 1):
@@ -452,14 +485,17 @@ def main():
             "first_pass_ms": first_pass_ms,
             "config": {
                 "workload": (f"bubble-chain GBZ, {args.haplotypes} paths x {3 * args.sites} nodes ({args.sites} sites, {args.model}, seed {args.seed}), "
-                             f"all forward sequences -> device CSR; index replicated, path p walked by GPU p mod {world}") if strong else
+                             f"all forward sequences -> device CSR; index replicated, " +
+                             (f"every path walked by every GPU over its {world}-th of the way" if by_parts else f"path p walked by GPU p mod {world}")) if strong else
                             (f"bubble-chain GBZ, {args.haplotypes} paths x {3 * args.sites} nodes per GPU "
                              f"({args.sites} sites, {args.model}, seed {args.seed}+rank), all forward sequences -> device CSR"),
                 "paths_per_gpu": int(len(ids)),
                 "lf_steps_per_gpu": steps_done,
                 "index_bytes": int(index.stats.data_bytes),
                 "records": int(index.stats.records),
-                "sharding": "one index replicated on every rank, path id p -> rank p mod G, no data-path collective; whole CSR gathered on rank 0 afterwards" if strong
+                "sharding": ("one index replicated on every rank, every row cut at sequence samples into G stretches, stretch r of EVERY path on rank r "
+                             "(gbwt_hip_extract_part_device), no data-path collective; whole CSR joined on rank 0 afterwards" if by_parts else
+                             "one index replicated on every rank, path id p -> rank p mod G, no data-path collective; whole CSR gathered on rank 0 afterwards") if strong
                             else "one contig (index + path set) per rank, no data-path collective",
                 "generator_seconds": round(gen_s, 1),
             },

@@ -82,6 +82,7 @@ SIGNATURES = {
     "gbwt_hip_workspace_tune": (_int, [_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "gbwt_hip_extract": (_int, [_p, _p, _p, _u64, _p, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_extract_device": (_int, [_p, _p, _p, _u64, C.POINTER(Paths)]),
+    "gbwt_hip_extract_part_device": (_int, [_p, _p, _p, _u64, C.c_uint32, C.c_uint32, C.POINTER(Paths)]),
     "gbwt_hip_copy_result": (_int, [_p, _p, _p, _p, _u64]),
     "gbwt_hip_extract_paths": (_int, [_p, _p, _p, _u64, _int, _p, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_start": (_int, [_p, _p, _p, _u64, _p, _p]),

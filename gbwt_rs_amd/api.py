@@ -228,6 +228,29 @@ class GBWT:
         check(self._L.gbwt_hip_extract_device(self._h, self._ws, _ptr(ids), ids.size, C.byref(out)))
         return out
 
+    def extract_part_device(self, ids, part, parts):
+        """Stretch `part` of `parts` of every row (gbwt_hip_extract_part_device): the rows are cut at sequence samples, the stretches of a
+        row back to back are the row.  What one rank of `parts` extracts (dist.Comm.gather_rows(..., layout=GATHER_PARTS) joins them)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = Paths()
+        check(self._L.gbwt_hip_extract_part_device(self._h, self._ws, _ptr(ids), ids.size, part, parts, C.byref(out)))
+        return out
+
+    def part_csr(self, ids, part, parts):
+        """extract_part_device + copy: (offsets[u64, n + 1], nodes[u32]) of the stretches."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = self.extract_part_device(ids, part, parts)
+        offsets = np.zeros(ids.size + 1, dtype=np.uint64)
+        nodes = np.empty(max(1, out.total), dtype=np.uint32)
+        check(self._L.gbwt_hip_copy_result(self._h, self._ws, _ptr(offsets), _ptr(nodes) if out.total else None, nodes.size))
+        return offsets, nodes[: out.total]
+
+    def last_offsets(self, n):
+        """The row offsets (u64[n + 1]) of the last extract_device() / extract_part_device() of n rows."""
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        check(self._L.gbwt_hip_copy_result(self._h, self._ws, _ptr(offsets), None, 0))
+        return offsets
+
     def path_sums(self, n):
         """Per-path sums of node ids of the last extract_device() (device-side reduction)."""
         out = np.zeros(n, dtype=np.uint64)

@@ -770,9 +770,15 @@ void *gbwt_hip_workspace_stream(gbwt_hip_workspace *ws) { return ws ? static_cas
 
 gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                         gbwt_hip_paths *out) {
+    return gbwt_hip_extract_part_device(ix, ws, seq_ids, n, 0, 1, out);
+}
+
+gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
+                                             uint32_t part, uint32_t parts, gbwt_hip_paths *out) {
     GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !seq_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null seq_ids");
+    if (parts == 0 || part >= parts) return fail(GBWT_HIP_BAD_ARGUMENT, "part must be < parts");
     // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256).  "Not found" is a value here as well: such an id
     // gets an empty row (the kernels test the id), the rest of the batch is extracted; callers tell None from an empty
     // sequence by id < sequences.
@@ -798,13 +804,39 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             // Lengths known: offsets first, then every lane writes into its row; in a bidirectional index two walkers per
             // sequence, one from each end.
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
-            launch_gather_lengths(ix->dev.seq_len, ix->dev.n_sequences, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
+            bool ids_valid = true;
+            for (uint64_t k = 0; k < n && ids_valid; k++) ids_valid = seq_ids[k] < ix->host.sequences;
+            // ONE PART OF EVERY ROW (gbwt_hip_extract_part_device; round 4): rows are cut where their walkers start anyway, at sequence samples.
+            // An index without samples (GBWT_HIP_SAMPLE_INTERVAL=0, GBWT_HIP_SEGMENTS=0) cannot cut: the last part is the whole row there.
+            const bool can_cut = ix->dev.samples != nullptr && ix->max_samples > 0 && knobs.segments != 0 && n <= 0x7FFFFFFFull;
+            if (parts > 1 && !can_cut && part + 1 < parts) {
+                HIP_CHECK(hipMemsetAsync(ws->offsets.ptr, 0, (n + 1) * sizeof(uint64_t), s));
+                ws->nodes.reserve(sizeof(uint32_t));
+                HIP_CHECK(hipEventRecord(ws->ev[0], s)); HIP_CHECK(hipEventRecord(ws->ev[1], s)); HIP_CHECK(hipEventRecord(ws->ev[2], s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                ws->timed = true; ws->last_n = n; ws->last_total = 0;
+                out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = 0; out->n = n;
+                return GBWT_HIP_OK;
+            }
+            const bool parted = parts > 1 && can_cut;
+            // a walker per `stride` samples of a row (fine samples, gbwt_hip_open): about 2.9 million walkers for the biggest batches, no segments
+            // shorter than two samples unless the batch is so small that it needs every walker it can get
+            uint32_t stride = static_cast<uint32_t>(std::max(1, knobs.sample_stride));
+            if (knobs.sample_stride < 0 && can_cut && ix->sample_coarse > 1) {
+                uint64_t fine = 0;
+                for (uint64_t k = 0; k < n; k++) if (seq_ids[k] < ix->host.sequences) fine += ix->sample_counts[seq_ids[k]];
+                if (parted) fine /= parts;
+                const uint64_t want = (fine + 1450000) / 2900000;
+                stride = static_cast<uint32_t>(std::min<uint64_t>(2 * ix->sample_coarse, std::max<uint64_t>(want, fine >= 524288 ? 2 : 1)));
+            }
+            DeviceIndex strided = ix->dev; strided.sample_stride = stride;
+            if (parted) { strided.sample_part = part; strided.sample_parts = parts; }
+            if (parted) launch_part_lengths(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
+            else launch_gather_lengths(ix->dev.seq_len, ix->dev.n_sequences, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
             launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
             uint64_t total = 0;
             uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
-            bool ids_valid = true;
-            for (uint64_t k = 0; k < n && ids_valid; k++) ids_valid = seq_ids[k] < ix->host.sequences;
-            const bool all_valid = ids_valid && ix->uniform_len != 0;
+            const bool all_valid = ids_valid && ix->uniform_len != 0 && !parted;
             if (all_valid) {
                 // every row has the same, known length: total and extremes without a round trip to the device (the offsets are
                 // still scanned there, behind which the walk is simply enqueued)
@@ -823,18 +855,8 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
             const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && ix->max_samples > 0 && knobs.segments != 0;   // (the walker order sorts 32-bit row numbers)
             // the samples lie where the sequences pass checkpoint records, so the number of segments of a row comes from its samples, not from its length
-            // a walker per `stride` samples of a row (fine samples, above): about 2.9 million walkers for the biggest batches, no segments
-            // shorter than two samples unless the batch is so small that it needs every walker it can get
-            uint32_t stride = static_cast<uint32_t>(std::max(1, knobs.sample_stride));
-            if (knobs.sample_stride < 0 && segmented && ix->sample_coarse > 1) {
-                uint64_t fine = 0;
-                if (ids_valid) for (uint64_t k = 0; k < n; k++) fine += ix->sample_counts[seq_ids[k]];
-                else fine = total / std::max<uint32_t>(ix->dev.sample_interval, 1);
-                const uint64_t want = (fine + 1450000) / 2900000;
-                stride = static_cast<uint32_t>(std::min<uint64_t>(2 * ix->sample_coarse, std::max<uint64_t>(want, fine >= 524288 ? 2 : 1)));
-            }
-            DeviceIndex strided = ix->dev; strided.sample_stride = stride;
             a.segments = segmented ? (ix->max_samples + stride - 1) / stride : 0u;
+            if (parted) a.segments = a.segments / parts + 1;          // (no row has more segments in one part)
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
             // every row of the batch with the same number of samples (the forward sequences of haplotypes over one reference frame: the
             // headline's shape): walker w = segment * n + row, no order to compute
@@ -846,6 +868,7 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             const bool same_segments = segmented && ids_valid && common != 0;
             if (same_segments) {
                 a.segments = (common + stride - 1) / stride;
+                if (parted) a.segments = static_cast<uint32_t>(uint64_t(a.segments) * (part + 1) / parts - uint64_t(a.segments) * part / parts);   // (device_index.hpp: row_segments)
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
             } else if (segmented && knobs.walker_order != 0 && n <= 0x7FFFFFFFull) {
@@ -897,13 +920,13 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.xcd_map = knobs.xcd_map >= 0 ? (knobs.xcd_map ? 1u : 0u) : (segmented ? 1u : 0u);
             a.uniform_loop = knobs.uniform_loop >= 0 ? (knobs.uniform_loop ? 1u : 0u) : 1u;
             a.catch_up = knobs.catch_up >= 0 ? (knobs.catch_up ? 1u : 0u) : 1u;
-            a.align_segments = (segmented && knobs.align_segments != 0) ? 1u : 0u;
+            a.align_segments = (segmented && knobs.align_segments != 0 && !parted) ? 1u : 0u;   // (a part ends where the next rank's begins, not at the next line)
             a.all4 = knobs.all4 != 0 ? 1u : 0u;
             a.headroom = static_cast<uint32_t>(knobs.headroom);
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)
             a.packed_blocks = (ix->packed_blocks && knobs.packed_blocks != 0) ? 1u : 0u;
             DeviceIndex dev = a.packed_blocks ? ix->dev : with_cblocks(ix);
-            dev.sample_stride = stride;
+            dev.sample_stride = stride; dev.sample_part = strided.sample_part; dev.sample_parts = strided.sample_parts;
             a.row_piece = knobs.row_piece >= 0 ? static_cast<uint32_t>(knobs.row_piece) : 32u;
             if (a.ring_slots < 2 * a.row_piece) a.ring_slots = 2 * a.row_piece;   // a walker stops staging 8 slots before its ring is full: a ring of one piece would never hold one
             // GBWT_HIP_HEADROOM: the walkers wait while more than ring - headroom nodes are pending, the cooperative helper moves whole pieces only:
@@ -912,13 +935,13 @@ gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *ix, gbwt_hip_works
             a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
             a.both_ends = (ix->orientation_pairs && knobs.both_ends != 0) ? 1u : 0u;
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
-            launch_walk(dev, a, s);
+            if (!parted || (total != 0 && walkers != 0)) launch_walk(dev, a, s);   // (a part of nothing but empty stretches: no walkers)
             HIP_CHECK(hipEventRecord(ws->ev[1], s));
             HIP_CHECK(hipEventRecord(ws->ev[2], s));
             HIP_CHECK(hipStreamSynchronize(s));
             HIP_CHECK(hipGetLastError());
             ws->timed = true; ws->last_n = n; ws->last_total = total;
-            ws->extract_key.assign(seq_ids, seq_ids + n); ws->extract_cached = true;
+            if (!parted) { ws->extract_key.assign(seq_ids, seq_ids + n); ws->extract_cached = true; }   // (gbwt_hip_extract's fill call asks for whole rows)
             out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = total; out->n = n;
             return GBWT_HIP_OK;
         }

@@ -118,13 +118,20 @@ __global__ void __launch_bounds__(256) k_scatter_rows(const uint8_t *parts, cons
     }
 }
 
+// parts of rows (GBWT_HIP_GATHER_PARTS): the interleaved placement has made world "rows" of every row, one per rank, back to back:
+// the row offsets are every world-th of theirs
+__global__ void __launch_bounds__(256) k_every_nth_offset(const uint64_t *offsets, uint32_t world, uint64_t rows, uint64_t *row_offsets) {
+    const uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (g <= rows) row_offsets[g] = offsets[g * world];
+}
+
 }  // namespace
 
 struct gbwt_hip_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer counts, part_len, part_start, parts, all_len, offsets, out, scan_temp, meta, staged;
+    DeviceBuffer counts, part_len, part_start, parts, all_len, offsets, row_offsets, out, scan_temp, meta, staged;
     gbwt_hip_comm_stats last{};
     ~gbwt_hip_comm() {
         if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
@@ -141,11 +148,16 @@ gbwt_hip_status status_of(const RcclError &e) {
 
 // The gather itself.  `lengths`: this rank's row lengths (u64, device, n rows), `payload`: its rows back to back (device, units of
 // `unit` bytes).  On the root: *out_offsets (total_rows + 1, in units) and *out_payload, device memory of the communicator.
-gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, const void *d_payload, uint64_t units, uint32_t unit, int root, int interleaved,
+gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, const void *d_payload, uint64_t units, uint32_t unit, int root, int layout,
                        bool payload_is_mapped, const uint64_t **out_offsets, const void **out_payload, uint64_t *out_rows, uint64_t *out_units) {
     const Rccl &R = rccl();
     if (!R.why.empty()) return fail(GBWT_HIP_UNSUPPORTED, R.why);
     if (root < 0 || root >= c->world) return fail(GBWT_HIP_BAD_ARGUMENT, "root out of range");
+    if (layout < 0 || layout > GBWT_HIP_GATHER_PARTS) return fail(GBWT_HIP_BAD_ARGUMENT, "unknown gather layout");
+    // Parts of rows (every rank holds ITS stretch of every row: gbwt_hip_extract_part_device with part = rank) are placed like interleaved
+    // rows -- "row" k * world + r = the part of row k that rank r holds, and these back to back ARE row k --, then the offsets are thinned.
+    const bool parts_of_rows = layout == GBWT_HIP_GATHER_PARTS;
+    const int interleaved = layout != GBWT_HIP_GATHER_BLOCKS;
     try {
         HIP_CHECK(hipSetDevice(c->device));
         hipStream_t s = c->stream;
@@ -186,8 +198,9 @@ gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, 
         if (interleaved) {
             if (total_rows > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "more than 2^31 rows in one gather");
             for (int r = 0; r < world; r++)
-                if (all[2 * r] != total_rows / world + (static_cast<uint64_t>(r) < total_rows % world ? 1 : 0))
-                    return fail(GBWT_HIP_BAD_ARGUMENT, "interleaved gather: the ranks' row counts are not those of path p -> rank p mod world");
+                if (all[2 * r] != total_rows / world + (static_cast<uint64_t>(r) < total_rows % world ? 1 : 0) || (parts_of_rows && all[2 * r] != all[0]))
+                    return fail(GBWT_HIP_BAD_ARGUMENT, parts_of_rows ? "gather of row parts: the ranks do not hold the same number of rows"
+                                                                     : "interleaved gather: the ranks' row counts are not those of path p -> rank p mod world");
         }
         if (rank != root) {
             // 2. send lengths and payload
@@ -257,13 +270,22 @@ gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, 
             hipLaunchKernelGGL(k_scatter_rows, dim3(static_cast<unsigned>(total_rows), slices), dim3(256), 0, s, d_parts, d_byte_first, d_part_start, d_start_first,
                                static_cast<uint32_t>(world), total_rows, c->offsets.as<uint64_t>(), unit, c->out.as<uint8_t>(), slices);
         }
+        const uint64_t *d_offsets = c->offsets.as<uint64_t>();
+        uint64_t rows_out = total_rows;
+        if (parts_of_rows) {
+            rows_out = total_rows / world;
+            c->row_offsets.reserve((rows_out + 1) * sizeof(uint64_t));
+            hipLaunchKernelGGL(k_every_nth_offset, dim3(static_cast<unsigned>((rows_out + 256) / 256)), dim3(256), 0, s, c->offsets.as<uint64_t>(), static_cast<uint32_t>(world), rows_out,
+                               c->row_offsets.as<uint64_t>());
+            d_offsets = c->row_offsets.as<uint64_t>();
+        }
         HIP_CHECK(hipStreamSynchronize(s));
         HIP_CHECK(hipGetLastError());
         c->last.bytes = 8 * total_rows + total_units * unit;
         c->last.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (out_offsets) *out_offsets = c->offsets.as<uint64_t>();
+        if (out_offsets) *out_offsets = d_offsets;
         if (out_payload) *out_payload = c->out.ptr;
-        if (out_rows) *out_rows = total_rows;
+        if (out_rows) *out_rows = rows_out;
         if (out_units) *out_units = total_units;
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
@@ -360,6 +382,7 @@ gbwt_hip_status gbwt_hip_gather_lines(gbwt_hip_comm *comm, const gbwt_hip_index 
     GBWT_HIP_GUARD_BEGIN
     if (!comm || !ix || !ws || ws->index != ix || !ws->lines_cached || ws->lines_slot != 0)
         return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident GFA lines on this workspace (gbwt_hip_path_lines_device first)");
+    if (interleaved == GBWT_HIP_GATHER_PARTS) return fail(GBWT_HIP_BAD_ARGUMENT, "GFA lines are not cut into parts: shard them by path");
     if (out) *out = gbwt_hip_lines{nullptr, nullptr, 0, 0};
     if (comm->device != ix->device) return fail(GBWT_HIP_BAD_ARGUMENT, "communicator and index are on different devices");
     const uint64_t n = ws->lines_key.size();

@@ -107,6 +107,7 @@ struct DeviceIndex {
     const uint64_t *sample_base;   // n_sequences + 1: first sample of every sequence
     uint32_t sample_interval;  // a sample about every this many nodes
     uint32_t sample_stride;    // an extraction starts a walker at every sample_stride-th sample of a sequence (0 = 1 = at every one; set per request: gbwt_hip_extract_device)
+    uint32_t sample_part, sample_parts;   // sample_parts > 1: the extraction fills part sample_part of sample_parts of every row only (gbwt_hip_extract_part_device; row_segments below)
     const uint4 *cblocks;      // 2 * n_blocks entries (two-step rank blocks, same indexing as blocks)
     const uint4 *gblocks;      // 2 * n_blocks entries: the same, one 16-byte entry per 32 offsets with packed counts (gather loop)
     uint64_t data_len;
@@ -119,6 +120,24 @@ struct DeviceIndex {
     uint32_t first_node;       // alphabet_offset + 1
     uint32_t chained;          // 0: no two-step descriptor has a chained step (E_CHAIN / LEAF_CHAIN); else the most nodes an iteration of the walk can stage (5 .. 16; 4 without chains)
 };
+
+// The segments of the row of sequence `id` in one extraction: the samples base .. of the sequence, `count` segments at the request's stride
+// (segment j = from sample j * stride to sample (j + 1) * stride or the end), of which this extraction fills lo .. hi - 1: all of them, or
+// the sample_part-th of sample_parts equal shares (a rank of a multi-GPU extraction: every rank walks every path over ITS stretch of it).
+struct RowSegments { uint64_t base, stride, count, lo, hi; };
+__device__ inline RowSegments row_segments(const DeviceIndex &ix, uint64_t id) {
+    RowSegments r;
+    r.stride = ix.sample_stride ? ix.sample_stride : 1u;
+    r.base = ix.sample_base[id];
+    r.count = (ix.sample_base[id + 1] - r.base + r.stride - 1) / r.stride;
+    r.lo = 0; r.hi = r.count;
+    if (ix.sample_parts > 1) { r.lo = r.count * ix.sample_part / ix.sample_parts; r.hi = r.count * (ix.sample_part + 1) / ix.sample_parts; }
+    return r;
+}
+// nodes of the row in front of segment j (j = count: the whole row; sample 0 is the state AFTER the start node, segment 0 starts with that node)
+__device__ inline uint64_t segment_position(const DeviceIndex &ix, const RowSegments &r, uint64_t id, uint64_t j) {
+    return j == 0 ? 0u : (j < r.count ? ix.samples[r.base + j * r.stride].w : ix.seq_len[id]);
+}
 
 // A chained step emits its first node x, the nodes between x and the node L of its landing record on the progression x + 2, x + 4, ...
 // (x - 2, ... for reverse nodes), then L: a run of unary records with consecutive ids in one orientation, as a GFA segment chopped into

@@ -129,6 +129,8 @@ void launch_chase_samples(const DeviceIndex &ix, const uint4 *d_summaries, uint6
 // walker order of a segmented extraction: per-row segment counts -> rows sorted by count (descending, stable) and
 // level[j] = number of walkers in segments < j.  d_keys / d_rows: 2 x n scratch each (double buffers of the sort).
 size_t walker_order_temp_bytes(uint64_t n);
+// nodes of every row inside the part of it that the request fills (ix.sample_part of ix.sample_parts, at ix.sample_stride); d_max_len as launch_gather_lengths
+void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
 void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
                          uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream);
 // the record-ordered walker list: counts[k] = segments of row k (launch_scan turns them into row_first); then keys = start record of every

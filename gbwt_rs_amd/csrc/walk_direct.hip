@@ -73,15 +73,18 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     else k = a.sorted_rows[w - a.level[lo]];
     const uint64_t id = a.seq_ids[k];
     if (id >= ix.n_sequences) return s;                      // GBWT::sequence: no such sequence -> an empty row
-    // (segment j of a row = from sample j * stride of its sequence to sample (j + 1) * stride: big batches skip samples, small ones use them all)
-    const uint64_t stride = ix.sample_stride ? ix.sample_stride : 1u;
-    const uint64_t base = ix.sample_base[id], samples = ix.sample_base[id + 1] - base, count = (samples + stride - 1) / stride;
-    const uint64_t len = a.out_offsets[k + 1] - a.out_offsets[k];
-    if (j >= count) return s;                                 // this row has fewer segments: nothing to do
+    // (segment j of a row = from sample j * stride of its sequence to sample (j + 1) * stride: big batches skip samples, small ones use them all;
+    // an extraction of one part of every row numbers its walkers over the segments lo .. hi - 1 of each row and writes the part as a row of its own)
+    const RowSegments rs = row_segments(ix, id);
+    const uint64_t base = rs.base, stride = rs.stride, count = rs.count;
+    j += rs.lo;
+    const bool parted = ix.sample_parts > 1;
+    const uint64_t len = parted ? ix.seq_len[id] : a.out_offsets[k + 1] - a.out_offsets[k];
+    if (j >= rs.hi) return s;                                 // this row has fewer segments: nothing to do
     const uint4 here = ix.samples[base + j * stride];
     const uint64_t from = j == 0 ? 0 : here.w;                // segment 0 starts with the start node (sample 0 is the state after it)
     const uint64_t to = j + 1 < count ? ix.samples[base + (j + 1) * stride].w : len;
-    t.row = a.out_nodes + a.out_offsets[k] + from;
+    t.row = a.out_nodes + a.out_offsets[k] + (from - (parted ? segment_position(ix, rs, id, rs.lo) : 0u));
     t.len = to > from ? to - from : 0;
     // LINE-ALIGNED SEGMENTS (round 4).  Samples lie where sequences pass checkpoint records, rows start wherever the rows before them
     // end: a segment begins and ends anywhere in a 128-byte line of the row's memory, and both ends used to go out as partial lines --
@@ -718,12 +721,33 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
 }  // namespace
 
 // keys[k] = number of segments of row k = samples of its sequence (0 for an empty sequence), rows[k] = k
-__global__ void __launch_bounds__(256) k_segment_counts(const uint64_t *sample_base, uint64_t stride, uint64_t n_sequences, const uint64_t *ids, uint64_t n, uint32_t *keys, uint32_t *rows) {
+__global__ void __launch_bounds__(256) k_segment_counts(DeviceIndex ix, const uint64_t *ids, uint64_t n, uint32_t *keys, uint32_t *rows) {
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (k >= n) return;
     const uint64_t id = ids[k];
-    keys[k] = id < n_sequences ? static_cast<uint32_t>((sample_base[id + 1] - sample_base[id] + stride - 1) / stride) : 0u;
+    uint32_t segments = 0;
+    if (id < ix.n_sequences) { const RowSegments rs = row_segments(ix, id); segments = static_cast<uint32_t>(rs.hi - rs.lo); }
+    keys[k] = segments;
     rows[k] = static_cast<uint32_t>(k);
+}
+
+// lengths[k] = nodes of row k that lie in the part of it this extraction fills (DeviceIndex::sample_part); max_len as k_gather_lengths has it
+__global__ void __launch_bounds__(256) k_part_lengths(DeviceIndex ix, const uint64_t *ids, uint64_t n, uint64_t *lengths, uint32_t *max_len) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t id = ids[k];
+    uint32_t len = 0;
+    if (id < ix.n_sequences) {
+        const RowSegments rs = row_segments(ix, id);
+        len = static_cast<uint32_t>(segment_position(ix, rs, id, rs.hi) - segment_position(ix, rs, id, rs.lo));
+    }
+    lengths[k] = len;
+    atomicMax(max_len, len);
+    atomicMax(max_len + 1, ~len);
+}
+
+void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_part_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix, d_ids, n, d_lengths, d_max_len);
 }
 
 // counts[j] = rows with more than j segments = the first position of the descending keys that is <= j
@@ -739,15 +763,17 @@ __global__ void __launch_bounds__(256) k_level_counts(const uint32_t *sorted_key
 }
 
 // counts[k] = segments of row k = samples of its sequence
-__global__ void __launch_bounds__(256) k_walker_counts(const uint64_t *sample_base, uint64_t stride, uint64_t n_sequences, const uint64_t *ids, uint64_t n, uint64_t *counts) {
+__global__ void __launch_bounds__(256) k_walker_counts(DeviceIndex ix, const uint64_t *ids, uint64_t n, uint64_t *counts) {
     const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (k >= n) return;
     const uint64_t id = ids[k];
-    counts[k] = id < n_sequences ? (sample_base[id + 1] - sample_base[id] + stride - 1) / stride : 0u;
+    uint64_t segments = 0;
+    if (id < ix.n_sequences) { const RowSegments rs = row_segments(ix, id); segments = rs.hi - rs.lo; }
+    counts[k] = segments;
 }
 
 // keys[t] = the record the t-th (row, segment) pair starts on, vals[t] = t
-__global__ void __launch_bounds__(256) k_walker_keys(const uint4 *samples, const uint64_t *sample_base, uint64_t stride, const uint64_t *ids, uint64_t n, const uint64_t *row_first,
+__global__ void __launch_bounds__(256) k_walker_keys(DeviceIndex ix, const uint64_t *ids, uint64_t n, const uint64_t *row_first,
                                                       uint64_t walkers, uint32_t *keys, uint32_t *vals) {
     const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     if (t >= walkers) return;
@@ -756,12 +782,13 @@ __global__ void __launch_bounds__(256) k_walker_keys(const uint4 *samples, const
         const uint64_t mid = (first + last) / 2;
         if (row_first[mid] <= t) first = mid; else last = mid;
     }
-    keys[t] = samples[sample_base[ids[first]] + (t - row_first[first]) * stride].x;
+    const RowSegments rs = row_segments(ix, ids[first]);          // (rows of ids >= n_sequences have no walkers)
+    keys[t] = ix.samples[rs.base + (rs.lo + t - row_first[first]) * rs.stride].x;
     vals[t] = static_cast<uint32_t>(t);
 }
 
 void launch_walker_counts(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_counts, hipStream_t stream) {
-    hipLaunchKernelGGL(k_walker_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, ix.sample_stride ? ix.sample_stride : 1u, ix.n_sequences, d_ids, n, d_counts);
+    hipLaunchKernelGGL(k_walker_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix, d_ids, n, d_counts);
 }
 
 size_t walker_list_temp_bytes(uint64_t walkers) {
@@ -773,7 +800,7 @@ size_t walker_list_temp_bytes(uint64_t walkers) {
 
 void launch_walker_list(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, const uint64_t *d_row_first, uint64_t walkers, uint32_t *d_keys, uint32_t *d_vals,
                         void *d_temp, size_t temp_bytes, const uint32_t **d_sorted, hipStream_t stream) {
-    hipLaunchKernelGGL(k_walker_keys, dim3(grid_for(walkers, 256)), dim3(256), 0, stream, ix.samples, ix.sample_base, ix.sample_stride ? ix.sample_stride : 1u, d_ids, n, d_row_first, walkers, d_keys, d_vals);
+    hipLaunchKernelGGL(k_walker_keys, dim3(grid_for(walkers, 256)), dim3(256), 0, stream, ix, d_ids, n, d_row_first, walkers, d_keys, d_vals);
     int bits = 1;
     while (bits < 32 && (ix.n_records >> bits) != 0) bits++;       // record indices have this many bits
     hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + walkers), vals(d_vals, d_vals + walkers);
@@ -790,7 +817,7 @@ size_t walker_order_temp_bytes(uint64_t n) {
 
 void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
                          uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream) {
-    hipLaunchKernelGGL(k_segment_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix.sample_base, ix.sample_stride ? ix.sample_stride : 1u, ix.n_sequences, d_ids, n, d_keys, d_rows);
+    hipLaunchKernelGGL(k_segment_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix, d_ids, n, d_keys, d_rows);
     hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + n), rows(d_rows, d_rows + n);
     (void)hipcub::DeviceRadixSort::SortPairsDescending(d_temp, temp_bytes, keys, rows, static_cast<int>(n), 0, 32, stream);   // radix sort: stable
     hipLaunchKernelGGL(k_level_counts, dim3(grid_for(segments, 256)), dim3(256), 0, stream, keys.Current(), n, segments, d_level_counts);

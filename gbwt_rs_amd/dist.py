@@ -62,11 +62,12 @@ class Comm:
         except Exception:
             pass
 
-    def gather_rows(self, gbwt, root=0, interleaved=False):
+    def gather_rows(self, gbwt, root=0, interleaved=False, layout=None):
         """The rows of the last gbwt.extract_device() of every rank, in path order on `root`: a Paths struct (device memory of the
-        communicator, valid until its next gather) there, None elsewhere."""
+        communicator, valid until its next gather) there, None elsewhere.  layout: GATHER_BLOCKS / GATHER_INTERLEAVED (= interleaved) /
+        GATHER_PARTS (every rank holds its stretch of every row: gbwt.extract_part_device(ids, rank, world))."""
         out = _lib.Paths()
-        _lib.check(self._L.gbwt_hip_gather_rows(self._c, gbwt._h, gbwt._ws, root, int(interleaved), C.byref(out)))
+        _lib.check(self._L.gbwt_hip_gather_rows(self._c, gbwt._h, gbwt._ws, root, int(interleaved) if layout is None else int(layout), C.byref(out)))
         return out if self.rank == root else None
 
     def gather_lines(self, gbz, root=0, interleaved=False):
@@ -79,6 +80,9 @@ class Comm:
         st = _lib.CommStats()
         _lib.check(self._L.gbwt_hip_comm_last(self._c, C.byref(st)))
         return {"ms": st.ms, "bytes": st.bytes, "staged_send": bool(st.staged_send)}
+
+
+GATHER_BLOCKS, GATHER_INTERLEAVED, GATHER_PARTS = 0, 1, 2     # include/gbwt_hip.h
 
 
 def shard_bounds(n, rank, world):
@@ -137,6 +141,24 @@ def gather_parts(lengths, values, dst=0, group=None):
     dist.all_gather_into_tensor(all_counts, counts, group=group)
     all_counts = all_counts.cpu().tolist()      # the one host synchronisation: the receive buffers are sized from it
     return _exchange(lengths, values, all_counts[0::2], all_counts[1::2], dst, group)
+
+
+def join_row_parts(len_parts, val_parts):
+    """Every rank holds ITS stretch of every row (api.GBWT.extract_part_device(ids, rank, world)): (offsets int64[n + 1], values) of the
+    whole rows -- row k = its stretches in rank order.  The torch form of gbwt_hip_gather_rows(..., GBWT_HIP_GATHER_PARTS, ...)."""
+    n = int(len_parts[0].numel())
+    assert all(int(p.numel()) == n for p in len_parts), "the ranks do not hold the same rows"
+    lens = torch.stack([p.to(torch.int64) for p in len_parts])              # [world, n]
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=lens.device)
+    torch.cumsum(lens.sum(0), 0, out=offsets[1:])
+    values = torch.empty(int(offsets[-1]), dtype=val_parts[0].dtype, device=val_parts[0].device)
+    before = torch.zeros(n, dtype=torch.int64, device=lens.device)          # nodes of row k held by the ranks before r
+    for r, part in enumerate(val_parts):
+        src_first = torch.cumsum(lens[r], 0) - lens[r]
+        shift = torch.repeat_interleave(offsets[:-1] + before - src_first, lens[r])
+        values[(torch.arange(int(part.numel()), device=shift.device) + shift).to(values.device)] = part
+        before += lens[r]
+    return offsets, values
 
 
 def rows_in_path_order(len_parts):

@@ -167,6 +167,18 @@ typedef struct { const uint64_t *d_offsets; const uint32_t *d_nodes; uint64_t to
 gbwt_hip_status gbwt_hip_extract_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws,
                                         const uint64_t *seq_ids, uint64_t n, gbwt_hip_paths *out);
 
+/* One part of every row (round 4; SURVEY 8e's partition, cut the other way): the rows of gbwt_hip_extract_device are cut where their
+ * walkers start anyway -- at the sequence samples the index made at open -- into `parts` stretches of (nearly) equal numbers of samples, and
+ * this call walks and returns stretch `part` of every row only: row k of the result is nodes [from_k, to_k) of GBWT::sequence(seq_ids[k]),
+ * and the stretches part = 0 .. parts - 1 of a row, back to back, are the row (rows with fewer samples than parts leave some stretches
+ * empty; an index opened without samples gives the whole row as the LAST part).  This is how N GPUs share one batch: every rank walks
+ * EVERY path over ITS N-th of the way -- it reads an N-th of the index and keeps whole waves on every record -- instead of every N-th
+ * path over the whole way (measured on one GPU, an eighth of the headline batch: 0.53-0.60 ms per pass against 0.88 ms;
+ * profiles/r04_shard_probe.txt); gbwt_hip_gather_rows(..., GBWT_HIP_GATHER_PARTS, ...) puts the rows together.  parts = 1 is
+ * gbwt_hip_extract_device. */
+gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
+                                             uint32_t part, uint32_t parts, gbwt_hip_paths *out);
+
 /* Copies the last device-resident extraction of `ws` to host buffers: out_offsets[n + 1] and/or out_nodes[total]
  * (either may be NULL; capacity < total -> GBWT_HIP_CAPACITY).  With gbwt_hip_extract_device this is "extract once,
  * size the buffer from gbwt_hip_paths.total, copy". */
@@ -269,11 +281,14 @@ gbwt_hip_status gbwt_hip_comm_unique_id(gbwt_hip_unique_id *out);
 gbwt_hip_status gbwt_hip_comm_create(const gbwt_hip_unique_id *id, int rank, int world, int device, gbwt_hip_comm **out);
 void gbwt_hip_comm_destroy(gbwt_hip_comm *comm);
 /* gbwt_hip_gather_rows: the rows of the last gbwt_hip_extract_device on `ws` of EVERY rank (collective), gathered on `root` in path
- * order: with interleaved != 0 row k of rank r is global row k * world + r (the ranks' row counts must be those of p -> rank p mod
- * world), otherwise the rows of rank 0, then of rank 1, ...  On the root *out describes the result -- device memory of the
- * communicator, valid until its next gather: d_offsets[rows + 1], d_nodes[total] --, elsewhere it is zeroed.
+ * order.  `interleaved` is the layout of the shards: GBWT_HIP_GATHER_BLOCKS = the rows of rank 0, then of rank 1, ...;
+ * GBWT_HIP_GATHER_INTERLEAVED = row k of rank r is global row k * world + r (the ranks' row counts must be those of p -> rank p mod
+ * world); GBWT_HIP_GATHER_PARTS = every rank holds its part of every row (gbwt_hip_extract_part_device with part = rank, parts = world,
+ * the same ids everywhere): row k of the result is the parts of row k in rank order.  On the root *out describes the result -- device
+ * memory of the communicator, valid until its next gather: d_offsets[rows + 1], d_nodes[total] --, elsewhere it is zeroed.
  * gbwt_hip_gather_lines: the same for the GFA lines of the last gbwt_hip_path_lines_device on `ws` (d_text, d_line_offsets): the final
  * GFA concatenation of north_star. */
+enum { GBWT_HIP_GATHER_BLOCKS = 0, GBWT_HIP_GATHER_INTERLEAVED = 1, GBWT_HIP_GATHER_PARTS = 2 };
 gbwt_hip_status gbwt_hip_gather_rows(gbwt_hip_comm *comm, const gbwt_hip_index *index, gbwt_hip_workspace *ws, int root, int interleaved,
                                      gbwt_hip_paths *out);
 gbwt_hip_status gbwt_hip_gather_lines(gbwt_hip_comm *comm, const gbwt_hip_index *index, gbwt_hip_workspace *ws, int root, int interleaved,

@@ -50,6 +50,37 @@ def test_shard_and_gather_world2(tmp_path, interleaved):
     assert (tmp_path / "ok").exists()
 
 
+def _parts_worker(rank, world, port, out_dir):
+    """Parts of rows (bench.py --shard parts, gbwt_hip_extract_part_device): every rank holds ITS stretch of every row -- cut here at
+    rank-dependent points of the oracle's rows, empty stretches and empty rows included --, gather_parts moves them and join_row_parts on
+    rank 0 must give back the rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle = O.OracleGBWT.load(os.path.join(O.GOLDEN, "with-empty.gbwt"))
+        ids = np.arange(oracle.sequences(), dtype=np.uint64)
+        full_off, full_nodes = oracle.extract(ids)
+        lens = np.diff(full_off).astype(np.int64)
+        cut = lambda r: np.minimum(lens, (lens * r + (r * 3) % world) // world)      # cuts that differ from row to row; cut(0) = 0, cut(world) = len
+        lo, hi = cut(rank), (lens if rank + 1 == world else cut(rank + 1))
+        mine = np.concatenate([full_nodes[int(full_off[k] + lo[k]):int(full_off[k] + hi[k])] for k in range(len(ids))] + [np.zeros(0, dtype=full_nodes.dtype)])
+        len_parts, val_parts = D.gather_parts(torch.from_numpy(hi - lo), torch.from_numpy(mine.astype(np.int64)), dst=0)
+        if rank == 0:
+            j_off, j_val = D.join_row_parts(len_parts, val_parts)
+            assert np.array_equal(j_off.numpy(), full_off.astype(np.int64)) and np.array_equal(j_val.numpy(), full_nodes.astype(np.int64))
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_parts_of_rows_joined_on_rank0(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_parts_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 def _lines_worker(rank, world, port, interleaved, out_dir):
     """The final GFA concatenation: every rank formats the W-lines of its shard of the paths (oracle here, the device
     formatter on a GPU box) and rank 0 must end up with the bytes of one pass over all paths, in path order."""

@@ -92,6 +92,17 @@ for interleaved in (True, False):
         off, text = D.lines_tensors(got, device)
         alone = gbz.path_lines(everything, 1)
         assert bytes(text.cpu().numpy().tobytes()) == alone and int(off[-1]) == len(alone) and off.numel() == n_paths + 1, interleaved
+# every rank its stretch of EVERY row (gbwt_hip_extract_part_device), joined on rank 0 (GBWT_HIP_GATHER_PARTS)
+for attempt in range(ATTEMPTS):
+    out = gbz.extract_part_device(2 * everything, rank, world)
+got = comm.gather_rows(gbz, root=0, layout=D.GATHER_PARTS)
+if rank == 0:
+    off, nodes = D.paths_tensors(got, device)
+    off, nodes = off.cpu().numpy(), nodes.cpu().numpy().astype(np.uint32)
+    w_off, w_nodes = gbz.sequences_csr(2 * everything)
+    assert int(got.n) == n_paths and np.array_equal(off, w_off.astype(np.int64)) and np.array_equal(nodes, w_nodes), "parts of rows"
+else:
+    assert got is None
 dist.barrier()
 comm.close()
 dist.destroy_process_group()

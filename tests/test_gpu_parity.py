@@ -1072,6 +1072,57 @@ def test_walker_order_with_ragged_rows(monkeypatch, env):
             assert np.array_equal(nodes[offsets[k]:offsets[k + 1]], np.array(exp, dtype=np.uint32)), (i, env)
 
 
+PART_ENVS = [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3"},
+             {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16"},
+             {"GBWT_HIP_SAMPLE_INTERVAL": "0"}, {"GBWT_HIP_SEGMENTS": "0"}]
+
+
+@pytest.mark.parametrize("env", PART_ENVS, ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
+def test_parts_of_rows(monkeypatch, env):
+    """gbwt_hip_extract_part_device: every row cut at sequence samples into `parts` stretches, one stretch of EVERY row per call (what one rank
+    of a multi-GPU extraction walks).  The stretches of a row, in order, are the row: against the oracle, for 1, 2, 3, 8 and more parts than
+    any row has samples, with rows of every length (empty ones, rows of one sample), duplicates, ids without a sequence, reverse sequences,
+    lock-step and ragged batches, every walker order, and indexes without samples (the last part is the whole row there)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = random.Random(43)
+    lengths = [0, 1, 2, 7, 9, 16, 31, 33, 64, 65, 129, 255, 700, 1001, 4097]
+    paths = [[2 * rng.randint(1, 40) + rng.randint(0, 1) for _ in range(ln)] for ln in lengths]
+    ragged = S.Synth.from_paths(paths, bidirectional=True)
+    cases = [(ragged, list(range(ragged.sequences)) + [5, 5, 28, ragged.sequences + 3, 1]),
+             (S.Synth.chain(sites=900, haplotypes=200, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.02, seed=23), None),
+             (S.Synth.chain(sites=300, haplotypes=130, alleles=5, model=S.IID, zipf=0.5, seed=24), None),
+             (S.Synth.from_paths(_skipping_haplotypes(400, 150, 25), bidirectional=True), None)]
+    for c, ids in cases:
+        dev = open_synth(c)
+        batches = [np.array(ids, dtype=np.uint64)] if ids is not None else [np.arange(0, c.sequences, 2, dtype=np.uint64), np.arange(c.sequences - 1, -1, -1, dtype=np.uint64)]
+        for batch in batches:
+            w_off, w_nodes = dev.sequences_csr(batch)
+            if ids is None:
+                o_off, o_nodes = oracle_of(c).extract(batch, threads=4)
+                assert np.array_equal(w_off, o_off) and np.array_equal(w_nodes, o_nodes), env
+            for parts in (1, 2, 3, 8, 5000):
+                pieces = [dev.part_csr(batch, r, parts) for r in range(parts if parts < 100 else 0)] or \
+                         [dev.part_csr(batch, r, parts) for r in (0, 1, 2499, 2500, 4998, 4999)]
+                if parts >= 100:
+                    # too many to join: every stretch is a piece of its row, where the stretches before it say (here: only that nothing is lost at the ends)
+                    assert all(int(off[-1]) <= int(w_off[-1]) for off, _ in pieces), (env, parts)
+                    total = sum(int(dev.extract_part_device(batch, r, parts).total) for r in range(parts))
+                    assert total == int(w_off[-1]), (env, parts)
+                    continue
+                at = np.zeros(len(batch), dtype=np.uint64)
+                for r, (off, nodes) in enumerate(pieces):
+                    assert len(off) == len(batch) + 1, (env, parts)
+                    for k in range(len(batch)):
+                        ln = int(off[k + 1] - off[k])
+                        lo = int(w_off[k] + at[k])
+                        assert lo + ln <= int(w_off[k + 1]) and np.array_equal(nodes[int(off[k]):int(off[k + 1])], w_nodes[lo:lo + ln]), (env, parts, r, k)
+                        at[k] += ln
+                assert np.array_equal(at, np.diff(w_off)), (env, parts)
+    with pytest.raises(Exception):
+        dev.extract_part_device(batch, 3, 3)
+
+
 def _layered_paths(layers, haplotypes, seed):
     """Paths over a layered graph with layers 1 .. 6 nodes wide, some layers skipped by some haplotypes: outdegrees from 1
     to 12, table records followed directly by table records, by unary records and by outdegree-2 records."""
