@@ -113,6 +113,17 @@ public:
         if (total) check(gbwt_hip_extract(index_.get(), ws_.get(), ids.data(), ids.size(), r.offsets.data(), r.nodes.data(), total, &total));
         return r;
     }
+    // Stretch `part` of `parts` of every row (gbwt_hip_extract_part_device): what one of `parts` GPUs walks of a batch they share; the
+    // stretches of a row, in order, are sequences(ids).row(k).  Not in the reference: its parallel axis is the path (src/bin/gbunzip.rs:421-434).
+    Rows sequences_part(const std::vector<uint64_t> &ids, uint32_t part, uint32_t parts) const {
+        Rows r;
+        gbwt_hip_paths p{};
+        check(gbwt_hip_extract_part_device(index_.get(), ws_.get(), ids.data(), ids.size(), part, parts, &p));
+        r.offsets.assign(ids.size() + 1, 0);
+        r.nodes.resize(p.total);
+        check(gbwt_hip_copy_result(index_.get(), ws_.get(), r.offsets.data(), p.total ? r.nodes.data() : nullptr, p.total));
+        return r;
+    }
     std::optional<std::vector<uint32_t>> sequence(uint64_t id) const {
         if (id >= sequences()) return std::nullopt;
         return sequences(std::vector<uint64_t>{id}).row(0);

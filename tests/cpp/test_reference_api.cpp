@@ -66,6 +66,19 @@ int main(int argc, char **argv) {
     }
     REQUIRE(!index.sequence(index.sequences()));
     REQUIRE(!index.start(index.sequences()));
+    // the stretches of every row that 1, 2 and 3 GPUs sharing the batch would walk, back to back, are the rows
+    {
+        std::vector<uint64_t> all(index.sequences());
+        for (uint64_t id = 0; id < all.size(); id++) all[id] = id;
+        for (uint32_t parts = 1; parts <= 3; parts++) {
+            std::vector<std::vector<uint32_t>> joined(all.size());
+            for (uint32_t part = 0; part < parts; part++) {
+                const gbwt_hip::Rows rows = index.sequences_part(all, part, parts);
+                for (size_t k = 0; k < all.size(); k++) { const auto piece = rows.row(k); joined[k].insert(joined[k].end(), piece.begin(), piece.end()); }
+            }
+            REQUIRE(joined == truth);
+        }
+    }
     // doc-test src/gbwt.rs:70-83
     auto state = index.find(24);
     REQUIRE(state);

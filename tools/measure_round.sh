@@ -33,3 +33,10 @@ if [ "${2:-}" != "quick" ]; then
 fi
 find $O -name "*kernel_trace.csv" -size +20M -delete
 find $O -name "*counter_collection.csv" -size +20M -delete
+# the bench line again, now that the PMC files of THIS build exist (bench.py quotes traffic only from a profile with its own fingerprint)
+if [ "${2:-}" != "quick" ]; then
+  mkdir -p $R/profiles
+  cp $O/hbm_traffic.json $R/profiles/${T}_hbm_traffic.json
+  for C in secondary high_degree search config4; do cp $O/${C}_hbm_traffic.json $R/profiles/${T}_${C}_hbm_traffic.json; done
+  timeout 1200 python bench.py > $O/bench_with_traffic.json 2> $O/bench_with_traffic.err; cut -c1-600 $O/bench_with_traffic.json
+fi
