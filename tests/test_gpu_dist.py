@@ -113,6 +113,78 @@ if rank == 0:
 '''
 
 
+CHILD_LOOPBACK = r'''
+import os, sys, threading
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import gbwt_rs_amd as G
+from gbwt_rs_amd import dist as D, synth as S
+device = torch.device("cuda", 0)
+path = os.path.join(TMP, "loopback.gbz")
+S.Synth.genome(contigs=5, fragments=3, haplotypes=22, sites=SITES, seed=11).save(path, as_gbz=True)
+alone = G.GBZ.load(path, device=0)
+n_paths = alone.stats.paths
+everything = np.arange(n_paths, dtype=np.uint64)
+w_off, w_nodes = alone.sequences_csr(2 * everything)
+w_lines = alone.path_lines(everything, 1)
+failures = []
+
+def rank_main(rank, world, box, ready):
+    try:
+        def broadcast(raw):
+            if raw is not None:
+                box.append(raw); ready.set()
+            ready.wait()
+            return box[0]
+        gbz = G.GBZ.load(path, device=0)
+        comm = D.Comm(rank, world, 0, broadcast=broadcast)
+        for root in (0, world - 1):
+            for layout in (D.GATHER_BLOCKS, D.GATHER_INTERLEAVED, D.GATHER_PARTS):
+                if layout == D.GATHER_PARTS:
+                    out = gbz.extract_part_device(2 * everything, rank, world)
+                else:
+                    mine = D.shard_ids(everything, rank, world, interleaved=layout == D.GATHER_INTERLEAVED)
+                    out = gbz.extract_device(2 * mine)
+                got = comm.gather_rows(gbz, root=root, layout=layout)
+                if rank == root:
+                    off, nodes = D.paths_tensors(got, device)
+                    assert int(got.n) == n_paths and int(got.total) == len(w_nodes), (layout, int(got.n), int(got.total))
+                    assert np.array_equal(off.cpu().numpy(), w_off.astype(np.int64)) and np.array_equal(nodes.cpu().numpy().astype(np.uint32), w_nodes), ("rows", world, root, layout)
+                else:
+                    assert got is None
+                if layout != D.GATHER_PARTS:
+                    gbz.path_lines_device(mine, 1)
+                    got = comm.gather_lines(gbz, root=root, interleaved=layout == D.GATHER_INTERLEAVED)
+                    if rank == root:
+                        off, text = D.lines_tensors(got, device)
+                        assert bytes(text.cpu().numpy().tobytes()) == w_lines and off.numel() == n_paths + 1, ("lines", world, root, layout)
+        comm.close()
+    except BaseException as e:
+        import traceback
+        failures.append((rank, world, traceback.format_exc()))
+        ready.set()
+
+for world in WORLDS:
+    box, ready = [], threading.Event()
+    threads = [threading.Thread(target=rank_main, args=(r, world, box, ready)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(600)
+    assert not any(t.is_alive() for t in threads), "a rank hangs"
+    assert not failures, failures[0][2]
+print("LOOPBACK_OK", WORLDS, n_paths, len(w_nodes), flush=True)
+'''
+
+
+def test_capi_gather_between_loopback_ranks(tmp_path):
+    """Everything of comm.hip except RCCL itself, for world sizes 2, 3 and 8 on ONE GPU: the ranks are threads of one process
+    (GBWT_HIP_COMM_LOOPBACK=1: the all-gather and the point-to-point group served by device-to-device copies with RCCL's matching rules),
+    each with its own index handle, workspace and communicator.  Blocks of rows, interleaved rows and stretches of every row
+    (gbwt_hip_extract_part_device) gathered on the first and on the last rank, GFA lines too; against one handle extracting alone."""
+    script = f"ROOT = {ROOT!r}; SITES = 400; TMP = {str(tmp_path)!r}; WORLDS = (2, 3, 8)\n" + CHILD_LOOPBACK
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=1500, env=dict(os.environ, GBWT_HIP_COMM_LOOPBACK="1"))
+    assert out.returncode == 0 and "LOOPBACK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
 def run_capi_ranks(world, sites, attempts, tmp, timeout, extra_env=None):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
