@@ -48,7 +48,7 @@ class Memory(C.Structure):
 
 
 class UniqueId(C.Structure):
-    _fields_ = [("bytes", C.c_char * 128)]
+    _fields_ = [("bytes", C.c_ubyte * 128)]       # binary: NOT c_char (a c_char array reads as a C string and stops at the first NUL)
 
 
 class CommStats(C.Structure):

@@ -75,6 +75,10 @@ std::map<std::string, std::shared_ptr<World>> registry;
 thread_local int group_depth = 0;
 thread_local std::vector<Op> group_ops;
 
+// every wait of the transport ends: a rank that never comes (it failed, or was given another id) is an error after two minutes, not a hang
+template <class Pred>
+bool wait_for(World &w, std::unique_lock<std::mutex> &lock, Pred pred) { return w.cv.wait_for(lock, std::chrono::seconds(120), pred); }
+
 size_t type_bytes(ncclDataType_t t) { return t == ncclUint64 || t == ncclInt64 || t == ncclFloat64 ? 8 : (t == ncclUint32 || t == ncclInt32 || t == ncclFloat32 ? 4 : 1); }
 
 ncclResult_t GetUniqueId(ncclUniqueId *id) {
@@ -95,8 +99,9 @@ ncclResult_t CommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int rank)
     if (w->world != world || rank < 0 || rank >= world) return ncclInvalidArgument;
     std::unique_lock<std::mutex> lock(w->m);
     w->joined++;
+    if (std::getenv("GBWT_HIP_COMM_TRACE")) std::fprintf(stderr, "[loopback] rank %d of %d joined (%d so far) world %p\n", rank, world, w->joined, static_cast<void *>(w.get()));
     w->cv.notify_all();
-    w->cv.wait(lock, [&]() { return w->joined >= world; });
+    if (!wait_for(*w, lock, [&]() { return w->joined >= world; })) return ncclInternalError;
     *out = reinterpret_cast<ncclComm_t>(new Handle{w, rank});
     return ncclSuccess;
 }
@@ -113,7 +118,7 @@ ncclResult_t AllGather(const void *send, void *recv, size_t count, ncclDataType_
         w.gather_src[h->rank] = send;
         w.arrived++;
         w.cv.notify_all();
-        w.cv.wait(lock, [&]() { return w.arrived >= w.world; });
+        if (!wait_for(w, lock, [&]() { return w.arrived >= w.world; })) return ncclInternalError;
     }
     for (int r = 0; r < w.world; r++)
         if (hipMemcpyAsync(static_cast<char *>(recv) + r * bytes, w.gather_src[r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
@@ -121,7 +126,7 @@ ncclResult_t AllGather(const void *send, void *recv, size_t count, ncclDataType_
     std::unique_lock<std::mutex> lock(w.m);
     const uint64_t round = w.round;
     if (++w.copied == w.world) { w.arrived = 0; w.copied = 0; w.round++; w.cv.notify_all(); }
-    else w.cv.wait(lock, [&]() { return w.round != round; });                            // nobody's buffer changes while somebody still reads it
+    else if (!wait_for(w, lock, [&]() { return w.round != round; })) return ncclInternalError;   // nobody's buffer changes while somebody still reads it
     return ncclSuccess;
 }
 
@@ -145,7 +150,7 @@ ncclResult_t run(std::vector<Op> &ops) {
         {
             std::unique_lock<std::mutex> lock(w.m);
             std::deque<Post *> &box = w.mail[{op.peer, op.h->rank}];
-            w.cv.wait(lock, [&]() { return !box.empty(); });
+            if (!wait_for(w, lock, [&]() { return !box.empty(); })) { result = ncclInternalError; continue; }
             p = box.front();
             box.pop_front();
         }
@@ -160,8 +165,8 @@ ncclResult_t run(std::vector<Op> &ops) {
         World &w = *ops[i].h->w;
         Post *p = posted[k++];
         std::unique_lock<std::mutex> lock(w.m);
-        w.cv.wait(lock, [&]() { return p->taken; });
-        delete p;
+        if (wait_for(w, lock, [&]() { return p->taken; })) delete p;
+        else result = ncclInternalError;                                                     // (the post stays in its box: leaked, not dangling)
     }
     ops.clear();
     return result;
@@ -177,7 +182,10 @@ ncclResult_t Recv(void *dst, size_t count, ncclDataType_t type, int peer, ncclCo
     group_ops.push_back(Op{false, nullptr, dst, count * type_bytes(type), peer, reinterpret_cast<Handle *>(comm), stream});
     return group_depth == 0 ? run(group_ops) : ncclSuccess;
 }
-const char *GetErrorString(ncclResult_t e) { return e == ncclInvalidArgument ? "loopback: invalid argument (sizes of a send and its receive differ?)" : "loopback: HIP error"; }
+const char *GetErrorString(ncclResult_t e) {
+    return e == ncclInvalidArgument ? "loopback: invalid argument (sizes of a send and its receive differ?)"
+         : e == ncclInternalError ? "loopback: a rank did not arrive within two minutes (did every rank get the same unique id?)" : "loopback: HIP error";
+}
 
 }  // namespace loopback
 
@@ -473,8 +481,11 @@ gbwt_hip_status gbwt_hip_comm_create(const gbwt_hip_unique_id *id, int rank, int
     std::unique_ptr<gbwt_hip_comm> c(new gbwt_hip_comm);
     c->rank = rank; c->world = world; c->device = device;
     try {
+        const bool trace = std::getenv("GBWT_HIP_COMM_TRACE") != nullptr;
+        if (trace) std::fprintf(stderr, "[comm] rank %d of %d: create\n", rank, world);
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        if (trace) std::fprintf(stderr, "[comm] rank %d of %d: stream made\n", rank, world);
         ncclUniqueId nid;
         std::memcpy(nid.internal, id->bytes, sizeof(nid.internal));
         RCCL_CHECK(R.CommInitRank(&c->comm, world, nid, rank));

@@ -28,6 +28,19 @@ import torch.distributed as dist
 from . import _lib
 
 
+def pack_unique_id(uid):
+    """All 128 bytes of a gbwt_hip_unique_id (an ncclUniqueId: binary, NULs anywhere), for whatever channel carries it to the other ranks."""
+    return C.string_at(C.byref(uid), C.sizeof(uid))
+
+
+def unpack_unique_id(raw):
+    if len(raw) != C.sizeof(_lib.UniqueId):
+        raise ValueError(f"unique id of {len(raw)} bytes, expected {C.sizeof(_lib.UniqueId)}")
+    uid = _lib.UniqueId()
+    C.memmove(C.byref(uid), raw, C.sizeof(uid))
+    return uid
+
+
 class Comm:
     """gbwt_hip_comm: one communicator per process, created collectively by the `world` ranks.  The 128-byte unique id is made by
     rank 0 and reaches the others through `broadcast` -- by default torch.distributed's broadcast_object_list over the default group
@@ -39,14 +52,14 @@ class Comm:
         if rank == 0:
             _lib.check(self._L.gbwt_hip_comm_unique_id(C.byref(uid)))
         if world > 1:
-            raw = bytes(uid.bytes) if rank == 0 else None
+            raw = pack_unique_id(uid) if rank == 0 else None
             if broadcast is None:
                 box = [raw]
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]
             else:
                 raw = broadcast(raw)
-            C.memmove(C.byref(uid), raw, 128)
+            uid = unpack_unique_id(raw)
         self._c = C.c_void_p()
         self.rank, self.world, self.device = rank, world, device
         _lib.check(self._L.gbwt_hip_comm_create(C.byref(uid), rank, world, device, C.byref(self._c)))

@@ -163,3 +163,15 @@ def test_shard_bounds_cover_everything():
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     ids = np.arange(10)
     assert sorted(np.concatenate([D.shard_ids(ids, r, 3, interleaved=True) for r in range(3)]).tolist()) == list(range(10))
+
+
+def test_unique_id_travels_whole():
+    """The 128 bytes of a communicator id are binary (an ncclUniqueId): a NUL in the middle must not cut it short on the way to the other
+    ranks (round 4: the id was read through a c_char field, i.e. as a C string, and every rank but the first joined a world of its own)."""
+    import ctypes as C
+    from gbwt_rs_amd import _lib
+    raw = bytes([7, 0, 0, 9] + [(3 * k) % 256 for k in range(124)])
+    uid = D.unpack_unique_id(raw)
+    assert C.sizeof(uid) == 128 and D.pack_unique_id(uid) == raw and bytes(uid.bytes) == raw
+    with pytest.raises(ValueError):
+        D.unpack_unique_id(raw[:40])

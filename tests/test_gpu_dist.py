@@ -114,7 +114,8 @@ if rank == 0:
 
 
 CHILD_LOOPBACK = r'''
-import os, sys, threading
+import os, sys, threading, faulthandler
+faulthandler.dump_traceback_later(90, exit=True)     # a rank that waits for ever: every thread's stack on stderr, and out
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import gbwt_rs_amd as G
@@ -162,14 +163,19 @@ def rank_main(rank, world, box, ready):
     except BaseException as e:
         import traceback
         failures.append((rank, world, traceback.format_exc()))
+        print("RANK FAILED", rank, world, traceback.format_exc(), file=sys.stderr, flush=True)
         ready.set()
+        os._exit(3)                                   # the other ranks wait for this one inside a collective: nothing to join
 
 for world in WORLDS:
     box, ready = [], threading.Event()
-    threads = [threading.Thread(target=rank_main, args=(r, world, box, ready)) for r in range(world)]
+    threads = [threading.Thread(target=rank_main, args=(r, world, box, ready), daemon=True) for r in range(world)]
     for t in threads: t.start()
-    for t in threads: t.join(600)
-    assert not any(t.is_alive() for t in threads), "a rank hangs"
+    for t in threads: t.join(60)
+    if any(t.is_alive() for t in threads):
+        faulthandler.dump_traceback(all_threads=True)
+        print("A RANK HANGS", world, file=sys.stderr, flush=True)
+        os._exit(4)
     assert not failures, failures[0][2]
 print("LOOPBACK_OK", WORLDS, n_paths, len(w_nodes), flush=True)
 '''
@@ -181,8 +187,10 @@ def test_capi_gather_between_loopback_ranks(tmp_path):
     each with its own index handle, workspace and communicator.  Blocks of rows, interleaved rows and stretches of every row
     (gbwt_hip_extract_part_device) gathered on the first and on the last rank, GFA lines too; against one handle extracting alone."""
     script = f"ROOT = {ROOT!r}; SITES = 400; TMP = {str(tmp_path)!r}; WORLDS = (2, 3, 8)\n" + CHILD_LOOPBACK
-    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=1500, env=dict(os.environ, GBWT_HIP_COMM_LOOPBACK="1"))
-    assert out.returncode == 0 and "LOOPBACK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, GBWT_HIP_COMM_LOOPBACK="1"))
+    if out.returncode != 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # every thread's stack, where a gpurun call can take it home
+        open(os.path.join(ROOT, "gpurun_out", "loopback_failure.txt"), "w").write(out.stdout + "\n" + out.stderr)
+    assert out.returncode == 0 and "LOOPBACK_OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
 
 
 def run_capi_ranks(world, sites, attempts, tmp, timeout, extra_env=None):
