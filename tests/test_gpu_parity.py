@@ -724,6 +724,23 @@ def test_headline_full_size():
     dev.extract_device(rev)
     for k, h in enumerate((1234, 0, 4999)):
         assert np.array_equal(dev.copy_path(k), (s.path(h) ^ 1)[::-1])
+    # the same batch as eight GPUs (and three) share it: stretch r of EVERY path (gbwt_hip_extract_part_device).  The stretches of a row
+    # follow each other without gap or overlap, their checksums add up to the row's, and a few rows are put together and compared whole
+    for parts in (8, 3):
+        at, sums, steps = np.zeros(s.paths, dtype=np.uint64), np.zeros(s.paths, dtype=np.uint64), 0
+        pieces = {h: [] for h in (0, 1234, 4999)}
+        for r in range(parts):
+            out = dev.extract_part_device(ids, r, parts)
+            steps += int(out.total)
+            lens = np.diff(dev.last_offsets(s.paths))
+            assert lens.min() > 0 and lens.max() < 2 * (2 * s.sites // parts), (parts, r, int(lens.min()), int(lens.max()))   # (every rank gets its share of every row)
+            sums += dev.path_sums(s.paths)                                   # (uint64: wraps like the generator's)
+            for h in pieces:
+                pieces[h].append(dev.copy_path(h))
+            at += lens
+        assert steps == 5000 * 2 * 333334 and np.all(at == 2 * s.sites) and np.array_equal(sums, truth), parts
+        for h, got in pieces.items():
+            assert np.array_equal(np.concatenate(got), s.path(h)), (parts, h)
     # The 13.3 GB of rows start as one hipMalloc and are rebuilt from spread 2 GiB chunks (virtual-memory API) when the workspace
     # serves its third request of that size; every byte must come back when the workspace goes -- one hipMemUnmap per mapped chunk,
     # hipMemAddressFree, hipMemRelease (capi_internal.hpp: DeviceBuffer::release) -- and when it regrows.
