@@ -803,7 +803,6 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
         if (n && ix->dev.seq_len && ws->walk_mode == WALK_TWO_STEP && knobs.direct != 0) {
             // Lengths known: offsets first, then every lane writes into its row; in a bidirectional index two walkers per
             // sequence, one from each end.
-            HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             bool ids_valid = true;
             for (uint64_t k = 0; k < n && ids_valid; k++) ids_valid = seq_ids[k] < ix->host.sequences;
             // ONE PART OF EVERY ROW (gbwt_hip_extract_part_device; round 4): rows are cut where their walkers start anyway, at sequence samples.
@@ -831,17 +830,39 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             }
             DeviceIndex strided = ix->dev; strided.sample_stride = stride;
             if (parted) { strided.sample_part = part; strided.sample_parts = parts; }
-            if (parted) launch_part_lengths(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
-            else launch_gather_lengths(ix->dev.seq_len, ix->dev.n_sequences, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
-            launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+            // lengths, offsets and extremes: one launch for the batch sizes there are, else a memset and three
+            if (!launch_row_offsets(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), ws->counters.as<uint32_t>(), s)) {
+                HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
+                if (parted) launch_part_lengths(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
+                else launch_gather_lengths(ix->dev.seq_len, ix->dev.n_sequences, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
+                launch_scan(ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
+            }
             uint64_t total = 0;
             uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
             const bool all_valid = ids_valid && ix->uniform_len != 0 && !parted;
+            // every row of the batch with the same number of samples (the forward sequences of haplotypes over one reference frame: the
+            // headline's shape): walker w = segment * n + row, no order to compute -- and nothing the host has to ask the device for
+            uint32_t common = ix->uniform_samples;
+            if (can_cut && ids_valid && common == 0 && n != 0) {
+                common = ix->sample_counts[seq_ids[0]];
+                for (uint64_t k = 1; k < n && common != 0; k++) if (ix->sample_counts[seq_ids[k]] != common) common = 0;
+            }
+            // ROWS SIZED AFTER THE LAUNCH (round 4): a request that knows its walkers without the device (above) and finds rows in its
+            // workspace does not wait for the total of its row lengths either -- 20 us of a round trip in front of a walk of 0.6 ms: the walk
+            // is launched into the rows that are there with their size as `capacity`, every workgroup looks at offsets[n] first, and
+            // if the rows were too small (the first request of its size) the host makes them and launches again.  One host wait per request.
+            const uint64_t capacity = ws->nodes.bytes / sizeof(uint32_t);
+            const bool defer = knobs.defer_total != 0 && !all_valid && can_cut && ids_valid && common != 0 && capacity != 0;
             if (all_valid) {
                 // every row has the same, known length: total and extremes without a round trip to the device (the offsets are
                 // still scanned there, behind which the walk is simply enqueued)
                 total = n * static_cast<uint64_t>(ix->uniform_len);
                 extremes[0] = ix->uniform_len; extremes[1] = ~ix->uniform_len;
+            } else if (defer) {
+                if (!ws->pinned_words) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ws->pinned_words), 4 * sizeof(uint64_t)));
+                HIP_CHECK(hipMemcpyAsync(ws->pinned_words, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                total = capacity;                                  // (stands in until the wait at the end)
+                extremes[0] = 1; extremes[1] = ~1u;                // (a row may have nodes: the walk is a segmented one)
             } else {
                 HIP_CHECK(hipMemcpyAsync(&total, ws->offsets.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipMemcpyAsync(extremes, ws->counters.ptr, sizeof(extremes), hipMemcpyDeviceToHost, s));
@@ -858,13 +879,6 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             a.segments = segmented ? (ix->max_samples + stride - 1) / stride : 0u;
             if (parted) a.segments = a.segments / parts + 1;          // (no row has more segments in one part)
             uint64_t walkers = ix->orientation_pairs ? 2 * n : n;
-            // every row of the batch with the same number of samples (the forward sequences of haplotypes over one reference frame: the
-            // headline's shape): walker w = segment * n + row, no order to compute
-            uint32_t common = ix->uniform_samples;
-            if (segmented && ids_valid && common == 0 && n != 0) {
-                common = ix->sample_counts[seq_ids[0]];
-                for (uint64_t k = 1; k < n && common != 0; k++) if (ix->sample_counts[seq_ids[k]] != common) common = 0;
-            }
             const bool same_segments = segmented && ids_valid && common != 0;
             if (same_segments) {
                 a.segments = (common + stride - 1) / stride;
@@ -934,12 +948,26 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             if (a.headroom > a.ring_slots - std::max(a.row_piece, 1u)) a.headroom = a.ring_slots - std::max(a.row_piece, 1u);
             a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
             a.both_ends = (ix->orientation_pairs && knobs.both_ends != 0) ? 1u : 0u;
+            a.capacity = defer ? capacity : 0;
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             if (!parted || (total != 0 && walkers != 0)) launch_walk(dev, a, s);   // (a part of nothing but empty stretches: no walkers)
             HIP_CHECK(hipEventRecord(ws->ev[1], s));
             HIP_CHECK(hipEventRecord(ws->ev[2], s));
             HIP_CHECK(hipStreamSynchronize(s));
             HIP_CHECK(hipGetLastError());
+            if (defer) {
+                total = ws->pinned_words[0];
+                if (total > capacity) {                              // the rows were too small and nobody walked: make them, walk
+                    ws->nodes.reserve(total * sizeof(uint32_t));
+                    a.out_nodes = ws->nodes.as<uint32_t>(); a.capacity = 0;
+                    HIP_CHECK(hipEventRecord(ws->ev[0], s));
+                    if (walkers != 0) launch_walk(dev, a, s);
+                    HIP_CHECK(hipEventRecord(ws->ev[1], s));
+                    HIP_CHECK(hipEventRecord(ws->ev[2], s));
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    HIP_CHECK(hipGetLastError());
+                }
+            }
             ws->timed = true; ws->last_n = n; ws->last_total = total;
             if (!parted) { ws->extract_key.assign(seq_ids, seq_ids + n); ws->extract_cached = true; }   // (gbwt_hip_extract's fill call asks for whole rows)
             out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = total; out->n = n;

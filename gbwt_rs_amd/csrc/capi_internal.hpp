@@ -256,6 +256,7 @@ struct ExtractKnobs {
     int align_segments = 0;                                   // GBWT_HIP_ALIGN_SEGMENTS: 1 = the boundary between two walkers of a row is a line boundary of the row's memory (round 4: measured, 2.4 % slower on the headline: not the default)
     int all4 = 1;                                             // GBWT_HIP_ALL4: 0 = the uniform loop counts every node it stages (rounds 1-3)
     int sample_stride = -1;                                   // GBWT_HIP_SAMPLE_STRIDE: a walker per this many samples of a row; -1 = by the size of the batch (gbwt_hip_extract_device)
+    int defer_total = 1;                                      // GBWT_HIP_DEFER_TOTAL: 0 = every request waits for the total of its row lengths before it launches the walk (rounds 1-3)
     int walker_order = 0;                                     // GBWT_HIP_WALKER_ORDER: 1 = ragged batches in the order of the walkers' start records (round 4: measured, not the default), 0 = by number of segments
     int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
@@ -272,6 +273,7 @@ struct ExtractKnobs {
         k.catch_up = num("GBWT_HIP_CATCH_UP", -1);
         k.walker_order = num("GBWT_HIP_WALKER_ORDER", 0);
         k.sample_stride = num("GBWT_HIP_SAMPLE_STRIDE", -1);
+        k.defer_total = num("GBWT_HIP_DEFER_TOTAL", 1);
         k.align_segments = num("GBWT_HIP_ALIGN_SEGMENTS", 0);
         k.all4 = num("GBWT_HIP_ALL4", 1);
         k.headroom = std::min(32, std::max(0, num("GBWT_HIP_HEADROOM", 0)));
@@ -287,6 +289,7 @@ struct gbwt_hip_workspace {
     const gbwt_hip_index *index = nullptr;
     ExtractKnobs knobs;
     hipStream_t stream = nullptr;
+    uint64_t *pinned_words = nullptr;         // four words of pinned host memory: the total and extremes of a request whose rows are sized after its launch (capi.hip)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t qev[2] = {nullptr, nullptr};   // around the kernel(s) of the last navigation / search call
     hipEvent_t gev[2] = {nullptr, nullptr};   // around the formatting of the last GFA lines request (behind its walk)
@@ -311,6 +314,7 @@ struct gbwt_hip_workspace {
         for (auto &e : qev) if (e) (void)hipEventDestroy(e);
         for (auto &e : gev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
+        if (pinned_words) (void)hipHostFree(pinned_words);
     }
 };
 

@@ -86,6 +86,7 @@ struct WalkArgs {
     // they belong to: the waves of a batch of ragged walks over hundreds of graph components are uniform again (launch_walker_list).
     const uint32_t *walker_list;   // [walkers], or null
     const uint64_t *row_first;     // [n + 1]
+    uint64_t capacity;         // > 0: the rows hold this many nodes and out_offsets[n] may say that more are needed: then nobody walks (gbwt_hip_extract_part_device launches again)
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
@@ -129,6 +130,10 @@ void launch_chase_samples(const DeviceIndex &ix, const uint4 *d_summaries, uint6
 // walker order of a segmented extraction: per-row segment counts -> rows sorted by count (descending, stable) and
 // level[j] = number of walkers in segments < j.  d_keys / d_rows: 2 x n scratch each (double buffers of the sort).
 size_t walker_order_temp_bytes(uint64_t n);
+// lengths (whole rows, or the part of them the request fills: ix.sample_parts), their exclusive scan (n + 1 offsets) and d_max_len = {longest,
+// ~shortest} in ONE launch of one workgroup; false (nothing launched) above ROW_OFFSETS_MAX rows
+constexpr uint64_t ROW_OFFSETS_MAX = uint64_t(1) << 18;
+bool launch_row_offsets(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint64_t *d_offsets, uint32_t *d_max_len, hipStream_t stream);
 // nodes of every row inside the part of it that the request fills (ix.sample_part of ix.sample_parts, at ix.sample_stride); d_max_len as launch_gather_lengths
 void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
 void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,

@@ -362,6 +362,12 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
 __attribute__((amdgpu_waves_per_eu(GBWT_HIP_WALK_WAVES, GBWT_HIP_WALK_WAVES)))
 #endif
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
+    // rows sized AFTER the launch (WalkArgs::capacity): the request did not wait for the total of its row lengths; where the rows it was
+    // given are too small for it -- or there is nothing to walk -- every workgroup goes home and the host launches again
+    if (a.capacity != 0) {
+        const uint64_t total = a.out_offsets[a.n];
+        if (total == 0 || total > a.capacity) return;
+    }
     extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
     __shared__ uint4 row_state[WAVE];        // per walking lane: {row address low, high, length (cooperative row writes), nodes the helper has moved to the row}
@@ -748,6 +754,50 @@ __global__ void __launch_bounds__(256) k_part_lengths(DeviceIndex ix, const uint
 
 void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_part_lengths, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix, d_ids, n, d_lengths, d_max_len);
+}
+
+// ROW OFFSETS IN ONE LAUNCH (round 4).  Lengths, their exclusive scan and the extremes of a batch were a memset and three launches (the
+// lengths, hipcub's two scan kernels): 36 us of host time per request at 9 us a launch -- a twentieth of a pass that takes 0.6 ms (one
+// rank of eight).  One workgroup does all of it for the batch sizes there are (a thread per stretch of rows, a block scan of the
+// stretch sums); launch_row_offsets says no above ROW_OFFSETS_MAX rows and the caller takes the three launches.
+constexpr uint32_t ROW_OFFSETS_THREADS = 1024;
+__global__ void __launch_bounds__(ROW_OFFSETS_THREADS) k_row_offsets(DeviceIndex ix, const uint64_t *ids, uint64_t n, uint64_t *lengths, uint64_t *offsets, uint32_t *max_len) {
+    __shared__ uint64_t sums[ROW_OFFSETS_THREADS];
+    __shared__ uint32_t longest[ROW_OFFSETS_THREADS], shortest[ROW_OFFSETS_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint64_t per = (n + ROW_OFFSETS_THREADS - 1) / ROW_OFFSETS_THREADS, first = min(n, t * per), last = min(n, first + per);
+    uint64_t sum = 0;
+    uint32_t hi = 0, lo = 0xFFFFFFFFu;
+    for (uint64_t k = first; k < last; k++) {
+        const uint64_t id = ids[k];
+        uint32_t len = 0;
+        if (id < ix.n_sequences) {
+            if (ix.sample_parts > 1) {
+                const RowSegments rs = row_segments(ix, id);
+                len = static_cast<uint32_t>(segment_position(ix, rs, id, rs.hi) - segment_position(ix, rs, id, rs.lo));
+            } else len = ix.seq_len[id];
+        }
+        lengths[k] = len;
+        sum += len; hi = max(hi, len); lo = min(lo, len);
+    }
+    sums[t] = sum; longest[t] = hi; shortest[t] = lo;
+    __syncthreads();
+    for (uint32_t d = 1; d < ROW_OFFSETS_THREADS; d *= 2) {      // inclusive scan of the stretch sums; the extremes ride along as plain reductions
+        const uint64_t add = t >= d ? sums[t - d] : 0;
+        const uint32_t h = t >= d ? longest[t - d] : 0, l = t >= d ? shortest[t - d] : 0xFFFFFFFFu;
+        __syncthreads();
+        sums[t] += add; longest[t] = max(longest[t], h); shortest[t] = min(shortest[t], l);
+        __syncthreads();
+    }
+    uint64_t at = sums[t] - sum;
+    for (uint64_t k = first; k < last; k++) { offsets[k] = at; at += lengths[k]; }
+    if (t == ROW_OFFSETS_THREADS - 1) { offsets[n] = sums[t]; max_len[0] = longest[t]; max_len[1] = ~shortest[t]; }
+}
+
+bool launch_row_offsets(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint64_t *d_offsets, uint32_t *d_max_len, hipStream_t stream) {
+    if (n == 0 || n > ROW_OFFSETS_MAX) return false;
+    hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(ROW_OFFSETS_THREADS), 0, stream, ix, d_ids, n, d_lengths, d_offsets, d_max_len);
+    return true;
 }
 
 // counts[j] = rows with more than j segments = the first position of the descending keys that is <= j

@@ -1091,7 +1091,7 @@ def test_walker_order_with_ragged_rows(monkeypatch, env):
 
 PART_ENVS = [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3"},
              {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16"},
-             {"GBWT_HIP_SAMPLE_INTERVAL": "0"}, {"GBWT_HIP_SEGMENTS": "0"}]
+             {"GBWT_HIP_SAMPLE_INTERVAL": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_DEFER_TOTAL": "0"}]
 
 
 @pytest.mark.parametrize("env", PART_ENVS, ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
@@ -1138,6 +1138,37 @@ def test_parts_of_rows(monkeypatch, env):
                 assert np.array_equal(at, np.diff(w_off)), (env, parts)
     with pytest.raises(Exception):
         dev.extract_part_device(batch, 3, 3)
+
+
+@pytest.mark.parametrize("defer", ["1", "0"])
+def test_rows_sized_after_the_launch(monkeypatch, defer):
+    """A request that knows its walkers without the device launches the walk into the rows its workspace has and looks at the total
+    afterwards (GBWT_HIP_DEFER_TOTAL, round 4): requests that grow (the rows are too small: nobody walks, the host makes them and launches
+    again), shrink, come as parts and as whole rows, in one workspace; and batches of more rows than the one-launch row offsets take."""
+    monkeypatch.setenv("GBWT_HIP_DEFER_TOTAL", defer)
+    monkeypatch.setenv("GBWT_HIP_SAMPLE_INTERVAL", "64")
+    c = S.Synth.chain(sites=700, haplotypes=300, alleles=3, model=S.MOSAIC, founders=6, switch_rate=0.01, seed=77)
+    dev, oracle = open_synth(c), oracle_of(c)
+    forward = np.arange(0, c.sequences, 2, dtype=np.uint64)
+    for ids in (forward[:3], forward[:40], forward, forward[:7], np.arange(c.sequences, dtype=np.uint64), forward[::-1].copy()):
+        o_off, o_nodes = oracle.extract(ids, threads=4)
+        for parts in (1, 4, 1, 2):
+            at = np.zeros(len(ids), dtype=np.uint64)
+            for r in range(parts):
+                off, nodes = dev.part_csr(ids, r, parts)
+                for k in range(len(ids)):
+                    ln, lo = int(off[k + 1] - off[k]), int(o_off[k] + at[k])
+                    assert np.array_equal(nodes[int(off[k]):int(off[k + 1])], o_nodes[lo:lo + ln]), (defer, parts, r, k)
+                    at[k] += ln
+            assert np.array_equal(at, np.diff(o_off)), (defer, parts)
+    many = np.tile(forward, 900)[: (1 << 18) + 77]             # more rows than k_row_offsets takes: lengths + scan the long way
+    off, nodes = dev.sequences_csr(many)
+    o_off, o_nodes = oracle.extract(forward, threads=4)
+    ln = np.diff(o_off)
+    assert np.array_equal(np.diff(off), np.tile(ln, 900)[: len(many)])
+    for k in (0, 299, 300, len(many) - 1):
+        h = k % len(forward)
+        assert np.array_equal(nodes[int(off[k]):int(off[k + 1])], o_nodes[int(o_off[h]):int(o_off[h + 1])])
 
 
 def _layered_paths(layers, haplotypes, seed):
