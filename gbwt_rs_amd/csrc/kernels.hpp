@@ -131,8 +131,8 @@ void launch_chase_samples(const DeviceIndex &ix, const uint4 *d_summaries, uint6
 // level[j] = number of walkers in segments < j.  d_keys / d_rows: 2 x n scratch each (double buffers of the sort).
 size_t walker_order_temp_bytes(uint64_t n);
 // lengths (whole rows, or the part of them the request fills: ix.sample_parts), their exclusive scan (n + 1 offsets) and d_max_len = {longest,
-// ~shortest} in ONE launch of one workgroup; false (nothing launched) above ROW_OFFSETS_MAX rows
-constexpr uint64_t ROW_OFFSETS_MAX = uint64_t(1) << 18;
+// ~shortest} in ONE launch of one workgroup; false (nothing launched) above ROW_OFFSETS_MAX rows, where the three launches are faster
+constexpr uint64_t ROW_OFFSETS_MAX = uint64_t(1) << 13;   // (one workgroup takes about 3 us per 1 024 rows: config 4's 32 000 rows were 70 us slower this way than by three launches)
 bool launch_row_offsets(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint64_t *d_offsets, uint32_t *d_max_len, hipStream_t stream);
 // nodes of every row inside the part of it that the request fills (ix.sample_part of ix.sample_parts, at ix.sample_stride); d_max_len as launch_gather_lengths
 void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);

@@ -758,8 +758,8 @@ void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t 
 
 // ROW OFFSETS IN ONE LAUNCH (round 4).  Lengths, their exclusive scan and the extremes of a batch were a memset and three launches (the
 // lengths, hipcub's two scan kernels): 36 us of host time per request at 9 us a launch -- a twentieth of a pass that takes 0.6 ms (one
-// rank of eight).  One workgroup does all of it for the batch sizes there are (a thread per stretch of rows, a block scan of the
-// stretch sums); launch_row_offsets says no above ROW_OFFSETS_MAX rows and the caller takes the three launches.
+// rank of eight).  One workgroup does all of it for batches of up to 8 192 rows (a thread per stretch of rows, a block scan of the
+// stretch sums: about 3 us per 1 024 rows); launch_row_offsets says no above ROW_OFFSETS_MAX rows and the caller takes the three launches.
 constexpr uint32_t ROW_OFFSETS_THREADS = 1024;
 __global__ void __launch_bounds__(ROW_OFFSETS_THREADS) k_row_offsets(DeviceIndex ix, const uint64_t *ids, uint64_t n, uint64_t *lengths, uint64_t *offsets, uint32_t *max_len) {
     __shared__ uint64_t sums[ROW_OFFSETS_THREADS];

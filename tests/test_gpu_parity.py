@@ -1161,12 +1161,12 @@ def test_rows_sized_after_the_launch(monkeypatch, defer):
                     assert np.array_equal(nodes[int(off[k]):int(off[k + 1])], o_nodes[lo:lo + ln]), (defer, parts, r, k)
                     at[k] += ln
             assert np.array_equal(at, np.diff(o_off)), (defer, parts)
-    many = np.tile(forward, 900)[: (1 << 18) + 77]             # more rows than k_row_offsets takes: lengths + scan the long way
+    many = np.tile(forward, 900)[: (1 << 13) + 77]             # more rows than k_row_offsets takes: lengths + scan the long way
     off, nodes = dev.sequences_csr(many)
     o_off, o_nodes = oracle.extract(forward, threads=4)
     ln = np.diff(o_off)
     assert np.array_equal(np.diff(off), np.tile(ln, 900)[: len(many)])
-    for k in (0, 299, 300, len(many) - 1):
+    for k in (0, 299, 300, 8191, 8192, len(many) - 1):
         h = k % len(forward)
         assert np.array_equal(nodes[int(off[k]):int(off[k + 1])], o_nodes[int(o_off[h]):int(o_off[h + 1])])
 
