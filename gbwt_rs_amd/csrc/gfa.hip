@@ -76,12 +76,25 @@ __global__ void __launch_bounds__(256) k_chunk_counts(const uint64_t *offsets, u
 
 struct ChunkRange { uint64_t path, begin, lo, hi; bool first, last; };
 
-__device__ __forceinline__ ChunkRange chunk_range(const uint64_t *chunk_first, uint64_t n, const uint64_t *offsets, uint64_t c) {
+__device__ __forceinline__ uint64_t chunk_path_of(const uint64_t *chunk_first, uint64_t n, uint64_t c) {
     uint64_t lo = 0, hi = n;                                        // chunk_first[lo] <= c < chunk_first[hi]
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) / 2;
         if (chunk_first[mid] <= c) lo = mid; else hi = mid;
     }
+    return lo;
+}
+
+// The path of every chunk, once per request: every workgroup (wave) of the kernels below started with this search -- fifteen dependent
+// loads for 32 000 paths -- and now starts with one load (round 4: 3 % of config 4's formatting time; with the node ids of a batch asked
+// for one batch ahead, 10 %: profiles/r04_gfa_pmc.txt).
+__global__ void __launch_bounds__(256) k_chunk_paths(const uint64_t *chunk_first, uint64_t n, uint64_t chunks_cap, uint32_t *chunk_path) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (c < chunks_cap && c < chunk_first[n]) chunk_path[c] = static_cast<uint32_t>(chunk_path_of(chunk_first, n, c));
+}
+
+__device__ __forceinline__ ChunkRange chunk_range(const uint64_t *chunk_first, const uint32_t *chunk_path, const uint64_t *offsets, uint64_t c) {
+    const uint64_t lo = chunk_path[c];
     ChunkRange r;
     r.path = lo;
     r.begin = offsets[lo];
@@ -97,14 +110,14 @@ __device__ __forceinline__ ChunkRange chunk_range(const uint64_t *chunk_first, u
 // src/bin/gbunzip.rs:532-536: sequence_len(node).unwrap_or(0)).
 // The number of chunks of a request is known on the device only (chunk_first[n]); the host launches for its upper bound
 // (total / LINE_CHUNK + n) and the chunks past the end count nothing, so that the scans over the bound are those over the chunks.
-__global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, uint64_t chunks_cap,
+__global__ void __launch_bounds__(256) k_chunk_stats(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path, uint64_t chunks_cap,
                                                       const uint32_t *label_len, uint64_t n_labels, uint32_t first_node, int p_lines, uint64_t *chunk_text,
                                                       uint64_t *chunk_seq) {
     const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     if (c >= chunks_cap) return;
     if (c >= chunk_first[n]) { if (lane == 0) { chunk_text[c] = 0; chunk_seq[c] = 0; } return; }
-    const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, c);
     uint64_t text = 0, labels = 0;
     for (uint64_t k0 = r.lo + 4 * lane; k0 < r.hi; k0 += 4 * WAVE) {   // four consecutive positions per lane: the loads and the label gathers of a round overlap
         uint32_t node[4];
@@ -162,26 +175,30 @@ __device__ __forceinline__ uint64_t line_header(const LineHeaders &hdr, uint64_t
 // (With every lane storing its own six bytes one at a time the formatter wrote 330 GB/s of text.)
 constexpr uint32_t TOKEN_MAX = 12;   // ',' + ten digits + '+' (P-lines); '>' + ten digits (W-lines)
 constexpr uint32_t PER_THREAD = 4;   // consecutive positions per thread and batch (one scan and two barriers per 1 024 positions)
-__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
                                                                    const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint64_t *seq_ids,
                                                                    LineHeaders hdr, const uint64_t *line_end, uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
     __shared__ __attribute__((aligned(16))) uint8_t stage[FORMAT_THREADS * PER_THREAD * TOKEN_MAX + 32];
     if (blockIdx.x >= chunk_first[n]) return;                           // (launched for the host's upper bound of the chunk count)
-    const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, blockIdx.x);
     const uint32_t t = threadIdx.x;
     uint8_t *line = out + line_start[r.path];
     const uint64_t header_len = line_header(hdr, seq_ids[r.path] >> 1, line_end, r.path, r.first, line, t, FORMAT_THREADS);
     uint64_t cursor = header_len + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    uint32_t ahead[PER_THREAD];                                        // the node ids of the next batch are asked for before this one is put together
+#pragma unroll
+    for (uint32_t i = 0; i < PER_THREAD; i++) { const uint64_t k = r.lo + PER_THREAD * t + i; ahead[i] = k < r.hi ? nodes[k] : 0u; }
     for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS * PER_THREAD) {
         const uint64_t k0 = base + PER_THREAD * t;
         uint32_t node[PER_THREAD], digits[PER_THREAD], len = 0;
 #pragma unroll
         for (uint32_t i = 0; i < PER_THREAD; i++) {
-            node[i] = 0; digits[i] = 0;
+            node[i] = ahead[i]; digits[i] = 0;
+            const uint64_t next = k0 + FORMAT_THREADS * PER_THREAD + i;
+            ahead[i] = next < r.hi ? nodes[next] : 0u;
             if (k0 + i < r.hi) {
-                node[i] = nodes[k0 + i];
                 digits[i] = decimal_digits(node[i] >> 1);
                 // ',' between the tokens of a P-line and '+' / '-' behind each, '>' / '<' in front of a W-line's
                 len += digits[i] + (p_lines ? (k0 + i > r.begin ? 2u : 1u) : 1u);
@@ -258,14 +275,14 @@ __device__ __forceinline__ uint32_t classify_position(const SegmentTables &t, co
 }
 
 // One wave per chunk, translation graphs: text bytes of the segment tokens, summed segment lengths, positions that fit no segment.
-__global__ void __launch_bounds__(256) k_chunk_stats_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
+__global__ void __launch_bounds__(256) k_chunk_stats_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
                                                                uint64_t chunks_cap, SegmentTables t, int p_lines, uint64_t *chunk_text, uint64_t *chunk_seq,
                                                                uint64_t *chunk_bad) {
     const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     if (c >= chunks_cap) return;
     if (c >= chunk_first[n]) { if (lane == 0) { chunk_text[c] = 0; chunk_seq[c] = 0; chunk_bad[c] = 0; } return; }
-    const ChunkRange r = chunk_range(chunk_first, n, offsets, c);
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, c);
     uint64_t text = 0, labels = 0;
     uint32_t bad = 0;
     for (uint64_t k = r.lo + lane; k < r.hi; k += WAVE) {
@@ -282,14 +299,14 @@ __global__ void __launch_bounds__(256) k_chunk_stats_segments(const uint64_t *of
 }
 
 // One workgroup per chunk, translation graphs.  Lines of flagged paths are left to the host.
-__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first,
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
                                                                             const uint64_t *text_before, SegmentTables t, int p_lines, const uint8_t *valid,
                                                                             const uint64_t *line_start, const uint64_t *seq_ids, LineHeaders hdr,
                                                                             const uint64_t *line_end, uint8_t *out) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
     if (blockIdx.x >= chunk_first[n]) return;
-    const ChunkRange r = chunk_range(chunk_first, n, offsets, blockIdx.x);
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, blockIdx.x);
     if (!valid[r.path]) return;
     const uint32_t tid = threadIdx.x;
     uint8_t *line = out + line_start[r.path];
@@ -575,24 +592,26 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         ws->gfa_a.reserve(2 * n * sizeof(uint64_t));
         ws->gfa_b.reserve((n + 1) * sizeof(uint64_t));
         ws->gfa_chunk_first.reserve(2 * (n + 1) * sizeof(uint64_t));
-        ws->gfa_chunks.reserve((3 * chunks_cap + 3 * (chunks_cap + 1)) * sizeof(uint64_t));
+        ws->gfa_chunks.reserve((3 * chunks_cap + 3 * (chunks_cap + 1)) * sizeof(uint64_t) + (chunks_cap + 1) * sizeof(uint32_t));
         ws->scan_temp.reserve(std::max<size_t>(tb, 16));
         ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
         uint64_t *d_line_len = ws->gfa_a.as<uint64_t>(), *d_line_end = d_line_len + n, *d_line_start = ws->gfa_b.as<uint64_t>();
         uint64_t *d_chunk_first = ws->gfa_chunk_first.as<uint64_t>(), *d_chunk_counts = d_chunk_first + (n + 1);
         uint64_t *d_chunk_text = ws->gfa_chunks.as<uint64_t>(), *d_chunk_seq = d_chunk_text + chunks_cap, *d_chunk_bad = d_chunk_seq + chunks_cap;
         uint64_t *d_text_before = d_chunk_bad + chunks_cap, *d_seq_before = d_text_before + (chunks_cap + 1), *d_bad_before = d_seq_before + (chunks_cap + 1);
+        uint32_t *d_chunk_path = reinterpret_cast<uint32_t *>(d_bad_before + (chunks_cap + 1));
         uint8_t *d_valid = translated ? ws->gfa_valid.as<uint8_t>() : nullptr;
         const LineHeaders hdr{ix->line_prefix[mode].as<uint8_t>(), ix->line_prefix_off[mode].as<uint64_t>(), mode == 1 ? ix->line_fragment.as<uint32_t>() : nullptr};
         hipLaunchKernelGGL(k_chunk_counts, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_counts);
         launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb, s);
+        hipLaunchKernelGGL(k_chunk_paths, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, d_chunk_first, n, chunks_cap, d_chunk_path);
         const unsigned stat_blocks = static_cast<unsigned>((chunks_cap + 3) / 4);
         if (translated) {
-            hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks_cap,
+            hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
                                segment_tables(ix), p_lines, d_chunk_text, d_chunk_seq, d_chunk_bad);
             launch_scan(d_chunk_bad, d_bad_before, chunks_cap, ws->scan_temp.ptr, tb, s);
         } else {
-            hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, chunks_cap,
+            hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
                                ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
                                static_cast<uint32_t>(h.alphabet_offset + 1), p_lines, d_chunk_text, d_chunk_seq);
         }
@@ -647,10 +666,10 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         text.reserve(std::max<uint64_t>(total, 16));
         if (translated)
             hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_text_before, segment_tables(ix), p_lines, d_valid, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
+                               d_chunk_first, d_chunk_path, d_text_before, segment_tables(ix), p_lines, d_valid, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
         else
             hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
+                               d_chunk_first, d_chunk_path, d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
         for (uint64_t k = 0; k < host_lines.size(); k++)
             if (!valid[k] && !host_lines[k].empty())
