@@ -63,7 +63,8 @@ def parse_args():
 
 def cpu_baseline(index_path, n_paths, target_seconds):
     """The oracle (a port of the reference algorithm with its per-step costs), timed on this host's cores.
-    Only this leg of bench.py touches oracle/."""
+    Only this leg of bench.py touches oracle/.  The timed walk keeps one (length, sum, order-dependent hash) per path, so the leg is also
+    a parity check of the sampled paths at full size: returns (object for the line, path ids walked, lengths, sums, hashes)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import subprocess
     import oracle_lib as O
@@ -88,11 +89,12 @@ def cpu_baseline(index_path, n_paths, target_seconds):
     want = int(max(len(ids), min(n_paths, target_seconds * rate / per_path)))
     ids = np.arange(0, 2 * want, 2, dtype=np.uint64)
     t0 = time.perf_counter()
-    steps = oracle.extract_timed(ids, threads)
+    steps, lengths, sums, hashes = oracle.extract_checksums(ids, threads)
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{want} of {n_paths} forward paths ({steps} LF-steps, {dt:.1f} s wall, {kind_note}, "
-                      f"pthread pool pulling path ids like gbunzip's rayon par_iter)"}
+    return ({"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port",
+             "sample": f"{want} of {n_paths} forward paths ({steps} LF-steps, {dt:.1f} s wall, {kind_note}, "
+                       f"pthread pool pulling path ids like gbunzip's rayon par_iter; every path's length, node sum and order-dependent hash "
+                       f"kept and compared with the GPU's)"}, ids // 2, lengths, sums, hashes)
 
 
 def algorithmic_bytes(index_path, n_paths, sample):
@@ -275,6 +277,8 @@ def main():
 
     # untimed: full-size check of the last extraction against the generator's ground truth
     sums = index.path_sums(len(ids))
+    hashes = index.path_hashes(len(ids))
+    row_lens = np.diff(index.last_offsets(len(ids)))
     truth = np.array([s.path_checksum(int(p)) for p in my_paths], dtype=np.uint64)
     part_from = None
     if by_parts:
@@ -403,7 +407,17 @@ def main():
 
     if rank == 0:
         # cpu_baseline is reported at N = 1 only (rank 0's host cores)
-        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(index_path, n_paths, args.cpu_seconds)
+        cpu, parity_checked = None, 0
+        if not (args.no_cpu_baseline or world > 1):
+            # ... and every run of the baseline is a parity run at headline size: the oracle's walk of the sampled paths against the rows of
+            # the last timed extraction (length, sum of node ids, order-dependent hash of every path: gbwt_hip_path_sums / _hashes)
+            cpu, o_paths, o_lens, o_sums, o_hashes = cpu_baseline(index_path, n_paths, args.cpu_seconds)
+            assert np.array_equal(my_paths[o_paths], o_paths), "paths are not in id order"
+            assert np.array_equal(row_lens[o_paths], o_lens), "row lengths differ from the oracle's"
+            assert np.array_equal(sums[o_paths], o_sums), "node sums of the extracted paths differ from the oracle's"
+            assert np.array_equal(hashes[o_paths], o_hashes), "order-dependent hashes of the extracted paths differ from the oracle's"
+            parity_checked = int(len(o_paths))
+            cpu["parity_checked_paths"] = parity_checked
         b_per_step, sampled_steps = algorithmic_bytes(index_path, n_paths, args.bytes_sample)
         walk_avg_ms = float(np.mean(walk_ms))
         extras = {}
@@ -473,6 +487,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",   # device arithmetic: record indices, offsets and node ids are 32-bit (the C ABI widens to u64 where the reference has usize)
             "data": "synthetic",
+            # paths of the last timed extraction whose length, node sum and order-dependent hash equal the CPU oracle's walk (the cpu_baseline leg)
+            "parity_checked_paths": parity_checked,
             # the one-shot flow (load, extract once) next to the steady state `value` is quoted on
             # LF-steps of all ranks / (open + first pass) of the slowest rank; value_cold_incl_init also counts what starting the HIP runtime cost
             "value_cold": all_steps / (cold_ms * 1e-3),

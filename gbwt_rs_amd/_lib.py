@@ -101,6 +101,7 @@ SIGNATURES = {
     "gbwt_hip_write_gfa": (_int, [_p, _p, C.c_char_p]),
     "gbwt_hip_write_gfa_mode": (_int, [_p, _p, C.c_char_p, _int]),
     "gbwt_hip_path_sums": (_int, [_p, _p, _p, _u64]),
+    "gbwt_hip_path_hashes": (_int, [_p, _p, _p, _u64]),
     "gbwt_hip_copy_path": (_int, [_p, _p, _u64, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_last_kernel_ms": (_int, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gbwt_hip_last_query_ms": (_int, [_p, C.POINTER(C.c_float)]),

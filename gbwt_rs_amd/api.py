@@ -257,6 +257,12 @@ class GBWT:
         check(self._L.gbwt_hip_path_sums(self._h, self._ws, _ptr(out), n))
         return out
 
+    def path_hashes(self, n):
+        """Per-path ORDER-dependent checksums of the last extract_device(): sum of (node + 1) * splitmix64(position), gbwt_hip.h."""
+        out = np.zeros(n, dtype=np.uint64)
+        check(self._L.gbwt_hip_path_hashes(self._h, self._ws, _ptr(out), n))
+        return out
+
     def copy_path(self, k):
         """Row k of the last extract_device() as a host array."""
         ln = C.c_uint64(0)

@@ -973,6 +973,18 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = total; out->n = n;
             return GBWT_HIP_OK;
         }
+        // The pool-output kernels (no sequence lengths, GBWT_HIP_DIRECT=0, a tuned walk mode) walk whole rows and cannot cut them: as the
+        // header says for rows that cannot be cut, the LAST part is the whole row and every earlier part is n empty rows -- never the whole
+        // row from every part (a gather of parts would then hold every row `parts` times).
+        if (parts > 1 && part + 1 < parts) {
+            HIP_CHECK(hipMemsetAsync(ws->offsets.ptr, 0, (n + 1) * sizeof(uint64_t), s));
+            ws->nodes.reserve(sizeof(uint32_t));
+            HIP_CHECK(hipEventRecord(ws->ev[0], s)); HIP_CHECK(hipEventRecord(ws->ev[1], s)); HIP_CHECK(hipEventRecord(ws->ev[2], s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            ws->timed = true; ws->last_n = n; ws->last_total = 0;
+            out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = 0; out->n = n;
+            return GBWT_HIP_OK;
+        }
         uint32_t flags = 0;
         WalkArgs a{};
         const DeviceIndex dev = ws->walk_mode == WALK_TWO_STEP ? with_cblocks(ix) : ix->dev;   // the pool-output kernel walks on the full-width two-step blocks
@@ -1151,15 +1163,14 @@ gbwt_hip_status gbwt_hip_copy_result(const gbwt_hip_index *ix, gbwt_hip_workspac
     GBWT_HIP_GUARD_END
 }
 
-gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n) {
-    GBWT_HIP_GUARD_BEGIN
+static gbwt_hip_status path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n, bool hashed) {
     if (!ix || !ws || ws->index != ix || !ws->timed) return fail(GBWT_HIP_BAD_ARGUMENT, "no device-resident extraction on this workspace");
     if (n != ws->last_n || (n && !out_sums)) return fail(GBWT_HIP_BAD_ARGUMENT, "n does not match the last extraction");
     if (n == 0) return GBWT_HIP_OK;
     try {
         HIP_CHECK(hipSetDevice(ix->device));
         ws->out_a.reserve(n * sizeof(uint64_t));
-        launch_path_sums(ws->offsets.as<uint64_t>(), ws->nodes.as<uint32_t>(), n, ws->out_a.as<uint64_t>(), ws->stream);
+        launch_path_sums(ws->offsets.as<uint64_t>(), ws->nodes.as<uint32_t>(), n, ws->out_a.as<uint64_t>(), hashed, ws->stream);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out_sums, ws->out_a.ptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
         HIP_CHECK(hipStreamSynchronize(ws->stream));
@@ -1167,6 +1178,17 @@ gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace 
     } catch (const HipError &e) {
         return status_of(e);
     }
+}
+
+gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n) {
+    GBWT_HIP_GUARD_BEGIN
+    return path_sums(ix, ws, out_sums, n, false);
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_path_hashes(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, uint64_t *out_hashes, uint64_t n) {
+    GBWT_HIP_GUARD_BEGIN
+    return path_sums(ix, ws, out_hashes, n, true);
     GBWT_HIP_GUARD_END
 }
 

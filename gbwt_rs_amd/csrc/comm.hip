@@ -19,11 +19,13 @@
 
 #include <atomic>
 #include <chrono>
+#ifdef GBWT_HIP_TEST_TRANSPORT
 #include <condition_variable>
-#include <cstdio>
-#include <cstring>
 #include <deque>
 #include <map>
+#endif
+#include <cstdio>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -49,156 +51,22 @@ struct Rccl {
     std::string why;
 };
 
-// ---- loopback transport (GBWT_HIP_COMM_LOOPBACK=1): test infrastructure --------------------------------------------------------------
-// The ranks are THREADS of one process that share one GPU, and the nine RCCL entry points above are served by the functions below:
-// an all-gather and point-to-point groups with RCCL's matching rules (sends and receives of a pair of ranks pair up in order), moved
-// by device-to-device copies.  No box of rounds 1-4 had a second GPU, and RCCL refuses two ranks on one device: this is how everything
-// in this file EXCEPT RCCL itself -- the counts, the buffers, the three placements on the root for world sizes above one -- runs under
-// `pytest -m gpu` (tests/test_gpu_dist.py).  Operations complete before the call returns (RCCL's complete on the stream).
-namespace loopback {
-
-struct Post { const void *src; size_t bytes; bool taken; };
-struct World {
-    int world = 0, joined = 0;
-    std::mutex m;
-    std::condition_variable cv;
-    std::vector<const void *> gather_src;
-    int arrived = 0, copied = 0;
-    uint64_t round = 0;
-    std::map<std::pair<int, int>, std::deque<Post *>> mail;       // (from, to): sends waiting for their receive, in order
-};
-struct Handle { std::shared_ptr<World> w; int rank; };
-struct Op { bool send; const void *src; void *dst; size_t bytes; int peer; Handle *h; hipStream_t stream; };
-
-std::mutex registry_mutex;
-std::map<std::string, std::shared_ptr<World>> registry;
-thread_local int group_depth = 0;
-thread_local std::vector<Op> group_ops;
-
-// every wait of the transport ends: a rank that never comes (it failed, or was given another id) is an error after two minutes, not a hang
-template <class Pred>
-bool wait_for(World &w, std::unique_lock<std::mutex> &lock, Pred pred) { return w.cv.wait_for(lock, std::chrono::seconds(120), pred); }
-
-size_t type_bytes(ncclDataType_t t) { return t == ncclUint64 || t == ncclInt64 || t == ncclFloat64 ? 8 : (t == ncclUint32 || t == ncclInt32 || t == ncclFloat32 ? 4 : 1); }
-
-ncclResult_t GetUniqueId(ncclUniqueId *id) {
-    static std::atomic<uint64_t> next{1};
-    std::memset(id->internal, 0, sizeof(id->internal));
-    std::snprintf(id->internal, sizeof(id->internal), "gbwt_hip loopback %llu %p", static_cast<unsigned long long>(next++), static_cast<void *>(&next));
-    return ncclSuccess;
-}
-
-ncclResult_t CommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int rank) {
-    std::shared_ptr<World> w;
-    {
-        std::lock_guard<std::mutex> lock(registry_mutex);
-        std::shared_ptr<World> &slot = registry[std::string(id.internal, sizeof(id.internal))];
-        if (!slot) { slot = std::make_shared<World>(); slot->world = world; slot->gather_src.assign(world, nullptr); }
-        w = slot;
-    }
-    if (w->world != world || rank < 0 || rank >= world) return ncclInvalidArgument;
-    std::unique_lock<std::mutex> lock(w->m);
-    w->joined++;
-    if (std::getenv("GBWT_HIP_COMM_TRACE")) std::fprintf(stderr, "[loopback] rank %d of %d joined (%d so far) world %p\n", rank, world, w->joined, static_cast<void *>(w.get()));
-    w->cv.notify_all();
-    if (!wait_for(*w, lock, [&]() { return w->joined >= world; })) return ncclInternalError;
-    *out = reinterpret_cast<ncclComm_t>(new Handle{w, rank});
-    return ncclSuccess;
-}
-
-ncclResult_t CommDestroy(ncclComm_t comm) { delete reinterpret_cast<Handle *>(comm); return ncclSuccess; }
-
-ncclResult_t AllGather(const void *send, void *recv, size_t count, ncclDataType_t type, ncclComm_t comm, hipStream_t stream) {
-    Handle *h = reinterpret_cast<Handle *>(comm);
-    World &w = *h->w;
-    const size_t bytes = count * type_bytes(type);
-    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;        // what this rank contributes is written
-    {
-        std::unique_lock<std::mutex> lock(w.m);
-        w.gather_src[h->rank] = send;
-        w.arrived++;
-        w.cv.notify_all();
-        if (!wait_for(w, lock, [&]() { return w.arrived >= w.world; })) return ncclInternalError;
-    }
-    for (int r = 0; r < w.world; r++)
-        if (hipMemcpyAsync(static_cast<char *>(recv) + r * bytes, w.gather_src[r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
-    std::unique_lock<std::mutex> lock(w.m);
-    const uint64_t round = w.round;
-    if (++w.copied == w.world) { w.arrived = 0; w.copied = 0; w.round++; w.cv.notify_all(); }
-    else if (!wait_for(w, lock, [&]() { return w.round != round; })) return ncclInternalError;   // nobody's buffer changes while somebody still reads it
-    return ncclSuccess;
-}
-
-ncclResult_t run(std::vector<Op> &ops) {
-    std::vector<Post *> posted;
-    for (const Op &op : ops) if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
-    for (const Op &op : ops) {
-        if (!op.send) continue;
-        World &w = *op.h->w;
-        Post *p = new Post{op.src, op.bytes, false};
-        posted.push_back(p);
-        std::lock_guard<std::mutex> lock(w.m);
-        w.mail[{op.h->rank, op.peer}].push_back(p);
-        w.cv.notify_all();
-    }
-    ncclResult_t result = ncclSuccess;
-    for (const Op &op : ops) {
-        if (op.send) continue;
-        World &w = *op.h->w;
-        Post *p = nullptr;
-        {
-            std::unique_lock<std::mutex> lock(w.m);
-            std::deque<Post *> &box = w.mail[{op.peer, op.h->rank}];
-            if (!wait_for(w, lock, [&]() { return !box.empty(); })) { result = ncclInternalError; continue; }
-            p = box.front();
-            box.pop_front();
-        }
-        if (p->bytes != op.bytes) result = ncclInvalidArgument;                              // RCCL: a send and its receive have one size
-        else if (hipMemcpyAsync(op.dst, p->src, op.bytes, hipMemcpyDeviceToDevice, op.stream) != hipSuccess || hipStreamSynchronize(op.stream) != hipSuccess) result = ncclUnhandledCudaError;
-        std::lock_guard<std::mutex> lock(w.m);
-        p->taken = true;
-        w.cv.notify_all();
-    }
-    for (size_t i = 0, k = 0; i < ops.size(); i++) {
-        if (!ops[i].send) continue;
-        World &w = *ops[i].h->w;
-        Post *p = posted[k++];
-        std::unique_lock<std::mutex> lock(w.m);
-        if (wait_for(w, lock, [&]() { return p->taken; })) delete p;
-        else result = ncclInternalError;                                                     // (the post stays in its box: leaked, not dangling)
-    }
-    ops.clear();
-    return result;
-}
-
-ncclResult_t GroupStart() { group_depth++; return ncclSuccess; }
-ncclResult_t GroupEnd() { return --group_depth == 0 ? run(group_ops) : ncclSuccess; }
-ncclResult_t Send(const void *src, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
-    group_ops.push_back(Op{true, src, nullptr, count * type_bytes(type), peer, reinterpret_cast<Handle *>(comm), stream});
-    return group_depth == 0 ? run(group_ops) : ncclSuccess;
-}
-ncclResult_t Recv(void *dst, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
-    group_ops.push_back(Op{false, nullptr, dst, count * type_bytes(type), peer, reinterpret_cast<Handle *>(comm), stream});
-    return group_depth == 0 ? run(group_ops) : ncclSuccess;
-}
-const char *GetErrorString(ncclResult_t e) {
-    return e == ncclInvalidArgument ? "loopback: invalid argument (sizes of a send and its receive differ?)"
-         : e == ncclInternalError ? "loopback: a rank did not arrive within two minutes (did every rank get the same unique id?)" : "loopback: HIP error";
-}
-
-}  // namespace loopback
+#ifdef GBWT_HIP_TEST_TRANSPORT
+#include "comm_loopback.hpp"   // the test build only (libgbwt_hip_testtransport.so): ranks = threads of one process on one GPU
+#endif
 
 const Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, []() {
+#ifdef GBWT_HIP_TEST_TRANSPORT
         if (const char *v = std::getenv("GBWT_HIP_COMM_LOOPBACK"); v && std::atoi(v) != 0) {
             r.GetUniqueId = loopback::GetUniqueId; r.CommInitRank = loopback::CommInitRank; r.CommDestroy = loopback::CommDestroy;
             r.GroupStart = loopback::GroupStart; r.GroupEnd = loopback::GroupEnd; r.Send = loopback::Send; r.Recv = loopback::Recv;
             r.AllGather = loopback::AllGather; r.GetErrorString = loopback::GetErrorString;
             return;
         }
+#endif
         const char *names[] = {"librccl.so.1", "librccl.so"};
         for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // the copy the process already has (torch's)
         for (const char *n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -236,6 +104,8 @@ __global__ void __launch_bounds__(256) k_interleave_lengths(const uint64_t *part
     all_len[g] = part_len[part_first[r] + k];
 }
 
+constexpr uint64_t SCATTER_GRID = 32768;   // workgroups (x slices) of k_scatter_rows: enough to fill the chip; more rows than that take turns
+
 // Row g of the result <- row k of the part of rank r, as bytes.  One workgroup per (row, slice).  The destination is written in whole
 // dwords (the bytes in front of its first and behind its last dword one by one); the source may start at any byte (GFA lines), so a
 // dword is put together from the two aligned dwords it straddles (v_alignbyte_b32).  Every part is followed by 16 bytes of slack, so
@@ -243,12 +113,12 @@ __global__ void __launch_bounds__(256) k_interleave_lengths(const uint64_t *part
 __global__ void __launch_bounds__(256) k_scatter_rows(const uint8_t *parts, const uint64_t *part_byte_first, const uint64_t *part_row_start /* per part: exclusive scan of its lengths (rows + 1 entries), concatenated */,
                                                        const uint64_t *part_first /* first entry of every part in part_row_start */, uint32_t world, uint64_t total_rows,
                                                        const uint64_t *out_offsets, uint32_t unit, uint8_t *out, uint32_t slices) {
-    const uint64_t g = blockIdx.x;
-    if (g >= total_rows) return;
+  // (a grid-stride loop over the rows: gridDim.x * blockDim.x must stay below 2^32, i.e. 2^24 workgroups of 256, far below the 2^31 rows a gather takes)
+  for (uint64_t g = blockIdx.x; g < total_rows; g += gridDim.x) {
     const uint32_t r = static_cast<uint32_t>(g % world), t = threadIdx.x;
     const uint64_t k = g / world;
     const uint64_t bytes = (out_offsets[g + 1] - out_offsets[g]) * unit;
-    if (bytes == 0) return;
+    if (bytes == 0) continue;
     const uint8_t *src = parts + part_byte_first[r] + part_row_start[part_first[r] + k] * unit;
     uint8_t *dst = out + out_offsets[g] * unit;
     const uintptr_t d0 = reinterpret_cast<uintptr_t>(dst), d1 = d0 + bytes;
@@ -267,6 +137,7 @@ __global__ void __launch_bounds__(256) k_scatter_rows(const uint8_t *parts, cons
     } else {
         for (uint64_t i = w_lo + t; i < w_hi; i += 256) __builtin_nontemporal_store(__builtin_amdgcn_alignbyte(sa[i + 1], sa[i], shift), da + i);
     }
+  }
 }
 
 // parts of rows (GBWT_HIP_GATHER_PARTS): the interleaved placement has made world "rows" of every row, one per rank, back to back:
@@ -335,7 +206,11 @@ gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, 
             send_from = c->staged.ptr;
             c->last.staged_send = 1;
         }
-        const bool self_send = std::getenv("GBWT_HIP_COMM_SELF_SEND") != nullptr;     // tests on one GPU: the root's own part travels through RCCL too
+#ifdef GBWT_HIP_TEST_TRANSPORT
+        const bool self_send = std::getenv("GBWT_HIP_COMM_SELF_SEND") != nullptr;     // tests on one GPU (the test build only): the root's own part travels through RCCL too
+#else
+        constexpr bool self_send = false;
+#endif
         uint64_t total_rows = 0, total_units = 0;
         std::vector<uint64_t> row_first(world + 1, 0), byte_first(world + 1, 0);
         for (int r = 0; r < world; r++) {
@@ -346,8 +221,10 @@ gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, 
         for (int r = 0; r < world; r++) total_units += all[2 * r + 1];
         // interleaved shards are those of path p -> rank p mod world: the first (rows mod world) ranks hold one row more.  Every rank sees
         // the same counts and takes the same way out, so nobody is left waiting in the exchange.
+        // the scans over the rows take an int count (hipcub) whatever the layout: checked here, where every rank sees the same counts and
+        // takes the same way out -- before the point-to-point group, not as a device error behind it
+        if (total_rows > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "more than 2^31 - 1 rows in one gather");
         if (interleaved) {
-            if (total_rows > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "more than 2^31 rows in one gather");
             for (int r = 0; r < world; r++)
                 if (all[2 * r] != total_rows / world + (static_cast<uint64_t>(r) < total_rows % world ? 1 : 0) || (parts_of_rows && all[2 * r] != all[0]))
                     return fail(GBWT_HIP_BAD_ARGUMENT, parts_of_rows ? "gather of row parts: the ranks do not hold the same number of rows"
@@ -418,7 +295,7 @@ gbwt_hip_status gather(gbwt_hip_comm *c, const uint64_t *d_lengths, uint64_t n, 
                                static_cast<uint32_t>(world), total_rows, c->all_len.as<uint64_t>());
             launch_scan(c->all_len.as<uint64_t>(), c->offsets.as<uint64_t>(), total_rows, c->scan_temp.ptr, tb, s);
             const uint32_t slices = static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(1, 4096 / total_rows)));   // few long rows: several workgroups per row
-            hipLaunchKernelGGL(k_scatter_rows, dim3(static_cast<unsigned>(total_rows), slices), dim3(256), 0, s, d_parts, d_byte_first, d_part_start, d_start_first,
+            hipLaunchKernelGGL(k_scatter_rows, dim3(static_cast<unsigned>(std::min<uint64_t>(total_rows, SCATTER_GRID)), slices), dim3(256), 0, s, d_parts, d_byte_first, d_part_start, d_start_first,
                                static_cast<uint32_t>(world), total_rows, c->offsets.as<uint64_t>(), unit, c->out.as<uint8_t>(), slices);
         }
         const uint64_t *d_offsets = c->offsets.as<uint64_t>();

@@ -147,7 +147,7 @@ void launch_walker_list(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 
 // per-path sum of node ids over CSR rows (checking hook)
-void launch_path_sums(const uint64_t *d_offsets, const uint32_t *d_nodes, uint64_t n, uint64_t *d_sums, hipStream_t stream);
+void launch_path_sums(const uint64_t *d_offsets, const uint32_t *d_nodes, uint64_t n, uint64_t *d_sums, bool hashed, hipStream_t stream);
 
 // ---- navigation / search ----------------------------------------------------------------------
 void launch_start(const DeviceIndex &ix, const uint64_t *ids, uint64_t n, gbwt_hip_pos *out, uint8_t *valid, hipStream_t s);

@@ -265,12 +265,23 @@ __global__ void __launch_bounds__(256) k_compact(WalkArgs a, const uint64_t *off
 }
 
 // One wave per CSR row: sum of the node ids (checking hook for device-resident results).
+// splitmix64 of the position: the weight of the node at position i of its row in gbwt_hip_path_hashes (include/gbwt_hip.h)
+__device__ __forceinline__ uint64_t position_weight(uint64_t i) {
+    uint64_t z = i + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// hashed: sum of (node + 1) * splitmix64(position) -- depends on the ORDER of the nodes, which a plain sum does not
+template <bool HASHED>
 __global__ void __launch_bounds__(256) k_path_sums(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, uint64_t *sums) {
     const uint64_t path = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     if (path >= n) return;
     uint64_t acc = 0;
-    for (uint64_t k = offsets[path] + lane; k < offsets[path + 1]; k += WAVE) acc += nodes[k];
+    const uint64_t first = offsets[path];
+    for (uint64_t k = first + lane; k < offsets[path + 1]; k += WAVE) acc += HASHED ? (static_cast<uint64_t>(nodes[k]) + 1) * position_weight(k - first) : nodes[k];
     for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, WAVE);
     if (lane == 0) sums[path] = acc;
 }
@@ -305,8 +316,10 @@ void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d
     hipLaunchKernelGGL(k_compact, dim3(grid_for(args.n, 256 / WAVE)), dim3(256), 0, stream, args, d_offsets, d_nodes);
 }
 
-void launch_path_sums(const uint64_t *d_offsets, const uint32_t *d_nodes, uint64_t n, uint64_t *d_sums, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_path_sums, dim3(grid_for(n, 256 / WAVE)), dim3(256), 0, stream, d_offsets, d_nodes, n, d_sums);
+void launch_path_sums(const uint64_t *d_offsets, const uint32_t *d_nodes, uint64_t n, uint64_t *d_sums, bool hashed, hipStream_t stream) {
+    if (n == 0) return;
+    if (hashed) hipLaunchKernelGGL(k_path_sums<true>, dim3(grid_for(n, 256 / WAVE)), dim3(256), 0, stream, d_offsets, d_nodes, n, d_sums);
+    else hipLaunchKernelGGL(k_path_sums<false>, dim3(grid_for(n, 256 / WAVE)), dim3(256), 0, stream, d_offsets, d_nodes, n, d_sums);
 }
 
 }  // namespace gbwt_hip

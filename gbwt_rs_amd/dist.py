@@ -48,18 +48,29 @@ class Comm:
 
     def __init__(self, rank, world, device, broadcast=None):
         self._L = _lib.lib()
+        self._c = None
         uid = _lib.UniqueId()
+        # A failure of rank 0 (RCCL not loadable -> GBWT_HIP_UNSUPPORTED, the documented fallback case) must be COLLECTIVE: the other
+        # ranks are waiting in the broadcast, so rank 0 broadcasts either the id or an error marker, and every rank raises on the marker.
+        failure = None
         if rank == 0:
-            _lib.check(self._L.gbwt_hip_comm_unique_id(C.byref(uid)))
+            status = self._L.gbwt_hip_comm_unique_id(C.byref(uid))
+            if status != _lib.OK:
+                failure = (status, self._L.gbwt_hip_last_error().decode(errors="replace"))
         if world > 1:
-            raw = pack_unique_id(uid) if rank == 0 else None
+            raw = (pack_unique_id(uid) if failure is None else (b"!", failure)) if rank == 0 else None
             if broadcast is None:
                 box = [raw]
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]
             else:
                 raw = broadcast(raw)
-            uid = unpack_unique_id(raw)
+            if isinstance(raw, tuple):
+                failure = raw[1]
+            else:
+                uid = unpack_unique_id(raw)
+        if failure is not None:
+            raise _lib.GbwtHipError(*failure)
         self._c = C.c_void_p()
         self.rank, self.world, self.device = rank, world, device
         _lib.check(self._L.gbwt_hip_comm_create(C.byref(uid), rank, world, device, C.byref(self._c)))

@@ -303,6 +303,11 @@ gbwt_hip_status gbwt_hip_comm_last(const gbwt_hip_comm *comm, gbwt_hip_comm_stat
  * Per-path sums of the node ids of the last gbwt_hip_extract_device call on `ws` (a wave-per-path
  * reduction on the device), copied to out_sums[n]: a cheap full-size checksum of the extraction. */
 gbwt_hip_status gbwt_hip_path_sums(const gbwt_hip_index *index, gbwt_hip_workspace *ws, uint64_t *out_sums, uint64_t n);
+/* The same with a checksum that depends on the ORDER of the nodes: out_hashes[k] = sum over the positions i of row k of
+ * (node_i + 1) * splitmix64(i)  (mod 2^64; splitmix64(i): z = i + 0x9E3779B97F4A7C15, z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9,
+ * z = (z ^ z >> 27) * 0x94D049BB133111EB, z ^ z >> 31).  What bench.py compares with the CPU oracle's walk of the same paths
+ * (SequenceIter, src/gbwt.rs:557-568) at full size, where copying 13 GB of rows out to compare them would dominate the run. */
+gbwt_hip_status gbwt_hip_path_hashes(const gbwt_hip_index *index, gbwt_hip_workspace *ws, uint64_t *out_hashes, uint64_t n);
 /* Copies row k of the last device-resident extraction to host: out_nodes[min(len, capacity)], *len = row length. */
 gbwt_hip_status gbwt_hip_copy_path(const gbwt_hip_index *index, gbwt_hip_workspace *ws, uint64_t k, uint32_t *out_nodes,
                                    uint64_t capacity, uint64_t *len);

@@ -686,9 +686,18 @@ int go_gbwt_extend_backward(const go_gbwt *g, const go_bdstate *state, uint64_t 
 typedef struct {
     const go_gbwt *g; const uint64_t *seq_ids; uint64_t n;
     uint64_t *lengths; const uint64_t *offsets; uint32_t *nodes;
+    uint64_t *sums, *hashes;      /* per sequence: sum of its node ids, and the order-dependent hash of include/gbwt_hip.h */
     uint64_t next; uint64_t steps;
     pthread_mutex_t lock;
 } extract_job;
+
+/* the weight of position i in a path hash (include/gbwt_hip.h: gbwt_hip_path_hashes): splitmix64(i) */
+static inline uint64_t position_weight(uint64_t i) {
+    uint64_t z = i + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 
 static void *extract_worker(void *arg) {
     extract_job *job = (extract_job *)arg;
@@ -696,7 +705,7 @@ static void *extract_worker(void *arg) {
     for (;;) {
         uint64_t k = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
         if (k >= job->n) break;
-        uint64_t id = job->seq_ids[k], n = 0;
+        uint64_t id = job->seq_ids[k], n = 0, sum = 0, hash = 0;
         if (id < job->g->sequences) {
             go_pos pos;
             int have = go_gbwt_start(job->g, id, &pos);
@@ -705,15 +714,27 @@ static void *extract_worker(void *arg) {
                 go_pos next;
                 int have_next = go_gbwt_forward(job->g, pos, &next);
                 if (dst) dst[n] = (uint32_t)pos.node;
+                if (job->sums) { sum += pos.node; hash += (pos.node + 1) * position_weight(n); }
                 n++;
                 pos = next; have = have_next;
             }
         }
         if (job->lengths) job->lengths[k] = n;
+        if (job->sums) { job->sums[k] = sum; job->hashes[k] = hash; }
         local_steps += n;
     }
     __atomic_fetch_add(&job->steps, local_steps, __ATOMIC_RELAXED);
     return NULL;
+}
+
+static uint64_t run_extract(extract_job *job, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads == 1) { extract_worker(job); return job->steps; }
+    pthread_t *tids = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) pthread_create(&tids[t], NULL, extract_worker, job);
+    for (int t = 0; t < threads; t++) pthread_join(tids[t], NULL);
+    free(tids);
+    return job->steps;
 }
 
 uint64_t go_gbwt_extract_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t n, int threads,
@@ -721,13 +742,15 @@ uint64_t go_gbwt_extract_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t 
     extract_job job;
     memset(&job, 0, sizeof(job));
     job.g = g; job.seq_ids = seq_ids; job.n = n; job.lengths = lengths; job.offsets = offsets; job.nodes = nodes;
-    if (threads < 1) threads = 1;
-    if (threads == 1) { extract_worker(&job); return job.steps; }
-    pthread_t *tids = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
-    for (int t = 0; t < threads; t++) pthread_create(&tids[t], NULL, extract_worker, &job);
-    for (int t = 0; t < threads; t++) pthread_join(tids[t], NULL);
-    free(tids);
-    return job.steps;
+    return run_extract(&job, threads);
+}
+
+uint64_t go_gbwt_extract_sums_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t n, int threads,
+                                 uint64_t *lengths, uint64_t *sums, uint64_t *hashes) {
+    extract_job job;
+    memset(&job, 0, sizeof(job));
+    job.g = g; job.seq_ids = seq_ids; job.n = n; job.lengths = lengths; job.sums = sums; job.hashes = hashes;
+    return run_extract(&job, threads);
 }
 
 /* Batched search (src/bin/benchmark.rs:155-169 shape) ------------------------------------------------- */

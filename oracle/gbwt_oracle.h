@@ -130,6 +130,11 @@ int go_gbwt_extend_backward(const go_gbwt *g, const go_bdstate *state, uint64_t 
  * Returns total LF steps (nodes emitted).  With nodes == NULL only lengths[] is filled. */
 uint64_t go_gbwt_extract_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t n, int threads,
                             uint64_t *lengths, const uint64_t *offsets, uint32_t *nodes);
+/* The same walk without the rows: per sequence its length, the sum of its node ids and the order-dependent checksum that
+ * gbwt_hip_path_hashes (include/gbwt_hip.h) computes on the device, sum of (node + 1) * splitmix64(position).  This is what bench.py's
+ * cpu_baseline leg times, so that every bench run is also a parity check of the sampled paths at full size. */
+uint64_t go_gbwt_extract_sums_mt(const go_gbwt *g, const uint64_t *seq_ids, uint64_t n, int threads,
+                                 uint64_t *lengths, uint64_t *sums, uint64_t *hashes);
 /* Batched search with a worker pool, the loop of src/bin/benchmark.rs:155-169: for query q (row q of the n x len
  * matrix) find(q[0]) then extend by q[1..]; out[q] / valid[q] describe the final state.  With bidirectional != 0 the
  * query starts with bd_find(q[first]) and alternates extend_forward (q[first+1], ...) / extend_backward (q[first-1], ...)

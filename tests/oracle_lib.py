@@ -131,6 +131,7 @@ def lib():
         "go_gbwt_extend_forward": (C.c_int, [p, C.POINTER(BdState), u64, C.POINTER(BdState)]),
         "go_gbwt_extend_backward": (C.c_int, [p, C.POINTER(BdState), u64, C.POINTER(BdState)]),
         "go_gbwt_extract_mt": (u64, [p, p, u64, C.c_int, p, p, p]),
+        "go_gbwt_extract_sums_mt": (u64, [p, p, u64, C.c_int, p, p, p]),
         "go_gbwt_search_mt": (u64, [p, p, u64, u64, C.c_int, p, p]),
         "go_gbwt_bd_search_mt": (u64, [p, p, u64, u64, u64, C.c_int, p, p]),
         "go_gbwt_extract_bytes": (u64, [p, p, u64, C.POINTER(u64)]),
@@ -469,6 +470,15 @@ class OracleGBWT:
         """Counting-only run (what the cpu_baseline leg times): returns total LF steps."""
         ids = np.ascontiguousarray(seq_ids, dtype=np.uint64)
         return self.L.go_gbwt_extract_mt(self.h, ids.ctypes.data, len(ids), threads, None, None, None)
+
+    def extract_checksums(self, seq_ids, threads):
+        """The same walk keeping one (length, sum of node ids, order-dependent hash) per sequence instead of the rows: what bench.py's
+        cpu_baseline times AND compares with gbwt_hip_path_sums / gbwt_hip_path_hashes.  Returns (steps, lengths, sums, hashes)."""
+        ids = np.ascontiguousarray(seq_ids, dtype=np.uint64)
+        n = len(ids)
+        lengths, sums, hashes = (np.zeros(max(1, n), dtype=np.uint64) for _ in range(3))
+        steps = self.L.go_gbwt_extract_sums_mt(self.h, ids.ctypes.data, n, threads, lengths.ctypes.data, sums.ctypes.data, hashes.ctypes.data)
+        return steps, lengths[:n], sums[:n], hashes[:n]
 
     def search_batch(self, queries, threads=1):
         """find + extend over every row (src/bin/benchmark.rs:155-169); returns (states[n,3] u64, valid[n] bool)."""

@@ -248,3 +248,15 @@ def test_cpp_mirror_compiles_and_reports_no_device(tmp_path):
     import gbwt_rs_amd as G
     if G.device_count() == 0:
         assert "GBWT_HIP_NO_DEVICE" in out.stdout
+
+
+def test_product_library_holds_no_test_transport():
+    """The loopback transport (ranks as threads of one process) and the self-send switch are test infrastructure: compiled only into
+    libgbwt_hip_testtransport.so (-DGBWT_HIP_TEST_TRANSPORT), never into the product library -- a stray environment variable cannot
+    replace RCCL with same-device copies."""
+    csrc = _lib.CSRC
+    product = open(os.path.join(csrc, "libgbwt_hip.so"), "rb").read()
+    for needle in (b"GBWT_HIP_COMM_LOOPBACK", b"GBWT_HIP_COMM_SELF_SEND", b"loopback"):
+        assert needle not in product, needle
+    test_build = open(os.path.join(csrc, "libgbwt_hip_testtransport.so"), "rb").read()
+    assert b"GBWT_HIP_COMM_LOOPBACK" in test_build and b"GBWT_HIP_COMM_SELF_SEND" in test_build

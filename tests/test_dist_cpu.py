@@ -175,3 +175,42 @@ def test_unique_id_travels_whole():
     assert C.sizeof(uid) == 128 and D.pack_unique_id(uid) == raw and bytes(uid.bytes) == raw
     with pytest.raises(ValueError):
         D.unpack_unique_id(raw[:40])
+
+
+def test_comm_failure_of_rank0_is_collective(monkeypatch):
+    """Rank 0 cannot make a communicator id (RCCL not loadable: GBWT_HIP_UNSUPPORTED, the documented fallback case): EVERY rank must
+    raise -- rank 0 broadcasts an error marker instead of leaving alone while the peers sit in the broadcast."""
+    import threading
+    from gbwt_rs_amd import _lib
+
+    real = _lib.lib()
+
+    class NoRccl:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def gbwt_hip_comm_unique_id(self, out):
+            return _lib.UNSUPPORTED
+
+    monkeypatch.setattr(_lib, "lib", lambda: NoRccl())
+    world, box, ready, raised = 3, [], threading.Event(), []
+
+    def broadcast(raw):
+        if raw is not None:
+            box.append(raw)
+            ready.set()
+        assert ready.wait(30)
+        return box[0]
+
+    def rank_main(rank):
+        try:
+            D.Comm(rank, world, 0, broadcast=broadcast)
+        except _lib.GbwtHipError as e:
+            raised.append((rank, e.status))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert sorted(raised) == [(r, _lib.UNSUPPORTED) for r in range(world)]

@@ -11,6 +11,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the TEST build of the library (csrc/Makefile): the product objects + comm.hip compiled with -DGBWT_HIP_TEST_TRANSPORT, i.e. with the
+# loopback transport (ranks = threads of one process on one GPU) and the self-send switch.  libgbwt_hip.so itself holds neither.
+TEST_LIB = os.path.join(ROOT, "gbwt_rs_amd", "csrc", "libgbwt_hip_testtransport.so")
 
 CHILD = r'''
 import os, sys
@@ -183,11 +186,11 @@ print("LOOPBACK_OK", WORLDS, n_paths, len(w_nodes), flush=True)
 
 def test_capi_gather_between_loopback_ranks(tmp_path):
     """Everything of comm.hip except RCCL itself, for world sizes 2, 3 and 8 on ONE GPU: the ranks are threads of one process
-    (GBWT_HIP_COMM_LOOPBACK=1: the all-gather and the point-to-point group served by device-to-device copies with RCCL's matching rules),
+    (libgbwt_hip_testtransport.so with GBWT_HIP_COMM_LOOPBACK=1: the all-gather and the point-to-point group served by device-to-device copies with RCCL's matching rules),
     each with its own index handle, workspace and communicator.  Blocks of rows, interleaved rows and stretches of every row
     (gbwt_hip_extract_part_device) gathered on the first and on the last rank, GFA lines too; against one handle extracting alone."""
     script = f"ROOT = {ROOT!r}; SITES = 400; TMP = {str(tmp_path)!r}; WORLDS = (2, 3, 8)\n" + CHILD_LOOPBACK
-    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, GBWT_HIP_COMM_LOOPBACK="1"))
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, GBWT_HIP_COMM_LOOPBACK="1", GBWT_HIP_LIB=TEST_LIB))
     if out.returncode != 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # every thread's stack, where a gpurun call can take it home
         open(os.path.join(ROOT, "gpurun_out", "loopback_failure.txt"), "w").write(out.stdout + "\n" + out.stderr)
     assert out.returncode == 0 and "LOOPBACK_OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
@@ -209,7 +212,7 @@ def test_capi_comm_on_one_gpu(tmp_path, self_send):
     """gbwt_hip_comm_* with world size 1 on the one GPU of a box: RCCL loaded by the library, a communicator, the all-gather of the
     counts, the placement kernels (interleaved and contiguous, node ids and ragged GFA lines at every byte alignment) -- and, with
     GBWT_HIP_COMM_SELF_SEND, the root's own part through ncclSend / ncclRecv in one group.  The peers are what is missing."""
-    out = run_capi_ranks(1, 300, 1, tmp_path, 600, {"GBWT_HIP_COMM_SELF_SEND": "1"} if self_send else None)
+    out = run_capi_ranks(1, 300, 1, tmp_path, 600, {"GBWT_HIP_COMM_SELF_SEND": "1", "GBWT_HIP_LIB": TEST_LIB} if self_send else None)
     assert out.returncode == 0 and "CAPI_RANKS_OK" in out.stdout, out.stderr[-3000:]
 
 

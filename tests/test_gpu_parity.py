@@ -183,6 +183,11 @@ def test_fixture_extract(name, with_empty):
     assert list(m_nodes) == truth[0] + kat.reverse_path(truth[1])
     if with_empty:
         assert dev.sequence(8) == [] and dev.sequence(9) == []
+    # the per-row checksums of the device-resident rows (gbwt_hip_path_sums / gbwt_hip_path_hashes) against the oracle's walk of the same ids
+    dev.extract_device(mixed)
+    steps, o_lens, o_sums, o_hashes = O.OracleGBWT.load(os.path.join(GOLDEN, name)).extract_checksums(mixed, 2)
+    assert steps == len(m_nodes) and np.array_equal(np.diff(dev.last_offsets(len(mixed))), o_lens)
+    assert np.array_equal(dev.path_sums(len(mixed)), o_sums) and np.array_equal(dev.path_hashes(len(mixed)), o_hashes)
 
 
 def test_size_then_fill_computes_once():
@@ -705,10 +710,10 @@ def test_headline_scale_properties():
 
 
 def test_headline_full_size():
-    """BASELINE's headline index at its full size (5 000 paths x 1 000 002 nodes, 3.33 G LF-steps per pass), checked through
-    what does not need the oracle: every extracted path against the generator's ground truth (per-path checksums reduced
-    on the device, full rows for a few), uniform lengths, total = (size - sequences) / 2, reverse sequences = flipped
-    reversals, and the same answers from a second pass (the extraction is idempotent)."""
+    """BASELINE's headline index at its full size (5 000 paths x 1 000 002 nodes, 3.33 G LF-steps per pass): every extracted path
+    against the generator's ground truth (per-path checksums reduced on the device, full rows for a few), a seeded sample of 64 paths
+    against the ORACLE's walk (whole rows + length / sum / order-dependent hash), uniform lengths, total = (size - sequences) / 2,
+    reverse sequences = flipped reversals, and the same answers from a second pass (the extraction is idempotent)."""
     s = S.Synth.chain(sites=333334, haplotypes=5000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=42)
     dev = open_synth(s)
     ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
@@ -720,10 +725,24 @@ def test_headline_full_size():
     for h in (0, 1234, 4999):
         row = dev.copy_path(h)
         assert len(row) == 2 * s.sites and np.array_equal(row, s.path(h))
+    # ... and against the ORACLE at this size: a seeded sample of 64 paths walked by the CPU restatement of SequenceIter
+    # (src/gbwt.rs:557-568) -- whole rows, and the length / node sum / order-dependent hash of every sampled path as bench.py's
+    # cpu_baseline leg compares them (gbwt_hip_path_sums, gbwt_hip_path_hashes)
+    oracle = oracle_of(s)
+    sample = np.sort(np.random.default_rng(64).choice(s.paths, size=64, replace=False)).astype(np.uint64)
+    o_off, o_nodes = oracle.extract(2 * sample, threads=min(os.cpu_count() or 1, 64))
+    o_steps, o_lens, o_sums, o_hashes = oracle.extract_checksums(2 * sample, threads=min(os.cpu_count() or 1, 64))
+    assert o_steps == int(o_off[-1]) == 64 * 2 * s.sites
+    lens, sums, hashes = np.diff(dev.last_offsets(s.paths)), dev.path_sums(s.paths), dev.path_hashes(s.paths)
+    assert np.array_equal(lens[sample], o_lens) and np.array_equal(sums[sample], o_sums) and np.array_equal(hashes[sample], o_hashes)
+    for k, h in enumerate(sample):
+        assert np.array_equal(dev.copy_path(int(h)), o_nodes[int(o_off[k]):int(o_off[k + 1])]), f"path {h} differs from the oracle's walk"
     rev = np.array([2 * 1234 + 1, 1, 2 * 4999 + 1], dtype=np.uint64)
     dev.extract_device(rev)
     for k, h in enumerate((1234, 0, 4999)):
         assert np.array_equal(dev.copy_path(k), (s.path(h) ^ 1)[::-1])
+    o_off, o_nodes = oracle.extract(rev, threads=3)
+    assert np.array_equal(dev.path_hashes(3), oracle.extract_checksums(rev, 3)[3]) and np.array_equal(dev.copy_path(2), o_nodes[int(o_off[2]):])
     # the same batch as eight GPUs (and three) share it: stretch r of EVERY path (gbwt_hip_extract_part_device).  The stretches of a row
     # follow each other without gap or overlap, their checksums add up to the row's, and a few rows are put together and compared whole
     for parts in (8, 3):
@@ -1091,7 +1110,9 @@ def test_walker_order_with_ragged_rows(monkeypatch, env):
 
 PART_ENVS = [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3"},
              {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16"},
-             {"GBWT_HIP_SAMPLE_INTERVAL": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_DEFER_TOTAL": "0"}]
+             {"GBWT_HIP_SAMPLE_INTERVAL": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_DEFER_TOTAL": "0"},
+             # the pool-output fallbacks cannot cut rows: the whole row is the LAST part, every earlier part is empty (never the row from every part)
+             {"GBWT_HIP_DIRECT": "0"}, {"GBWT_HIP_WALK_MODE": "1"}, {"GBWT_HIP_SEQ_LEN": "0"}]
 
 
 @pytest.mark.parametrize("env", PART_ENVS, ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")

@@ -1,6 +1,7 @@
 """Oracle GBWT navigation/search on the reference fixtures; mirrors src/gbwt/tests.rs:44-462."""
 import os
 
+import numpy as np
 import pytest
 
 import kat
@@ -253,3 +254,30 @@ def test_batched_search_matches_single_calls():
             assert bool(v) == (exp is not None)
             if exp:
                 assert (tuple(int(x) for x in r[:3]), tuple(int(x) for x in r[3:])) == exp
+
+
+def _splitmix64(i):
+    m = (1 << 64) - 1
+    z = (i + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def test_extract_checksums_follow_the_header_definition():
+    """go_gbwt_extract_sums_mt (what bench.py's cpu_baseline leg times and compares with the GPU): per sequence its length, the sum of its
+    node ids and the order-dependent hash of include/gbwt_hip.h (gbwt_hip_path_hashes), sum of (node + 1) * splitmix64(position) -- checked
+    here against the known paths of the fixtures (src/gbwt/tests.rs:44-49) with the definition written out in Python."""
+    for name in ("example.gbwt", "with-empty.gbwt"):
+        oracle = O.OracleGBWT.load(os.path.join(O.GOLDEN, name))
+        ids = np.arange(oracle.sequences() + 2, dtype=np.uint64)          # two ids without a sequence: empty rows
+        for threads in (1, 3):
+            steps, lengths, sums, hashes = oracle.extract_checksums(ids, threads)
+            off, nodes = oracle.extract(ids, threads)
+            assert steps == int(off[-1])
+            for k in range(len(ids)):
+                row = [int(v) for v in nodes[int(off[k]):int(off[k + 1])]]
+                assert int(lengths[k]) == len(row) and int(sums[k]) == sum(row)
+                assert int(hashes[k]) == sum((v + 1) * _splitmix64(i) for i, v in enumerate(row)) % (1 << 64)
+    # the hash tells two orders of the same nodes apart, the sum does not
+    assert (23 * _splitmix64(0) + 25 * _splitmix64(1)) % (1 << 64) != (25 * _splitmix64(0) + 23 * _splitmix64(1)) % (1 << 64)
