@@ -97,6 +97,59 @@ def cpu_baseline(index_path, n_paths, target_seconds):
                        f"kept and compared with the GPU's)"}, ids // 2, lengths, sums, hashes)
 
 
+def _oracle_of_synth(s):
+    """(cpu_baseline legs only) The CPU oracle over a generated index held in memory."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    bwt = O.OracleBWT.from_parts(bytes(s.data()), s.starts())
+    return O.OracleGBWT.from_bwt(bwt, s.sequences, s.size, s.alphabet_offset, s.alphabet_size, s.bidirectional)
+
+
+def cpu_leg_extraction(seconds):
+    """cpu_baseline leg of an extraction config (tools/configs.py calls it with the generated index and the length / sum / hash of every row
+    of its last GPU extraction of all forward sequences): the oracle walks a bounded sample of the same paths, timed, and must agree."""
+    def leg(s, lens, sums, hashes):
+        threads = min(os.cpu_count() or 1, 64)
+        oracle = _oracle_of_synth(s)
+        n_paths = len(lens)
+        ids = np.arange(0, 2 * min(threads, n_paths), 2, dtype=np.uint64)
+        t0 = time.perf_counter()
+        steps = oracle.extract_timed(ids, threads)
+        rate, per_path = steps / (time.perf_counter() - t0), steps / len(ids)
+        want = int(max(len(ids), min(n_paths, seconds * rate / max(per_path, 1))))
+        ids = np.arange(0, 2 * want, 2, dtype=np.uint64)
+        t0 = time.perf_counter()
+        steps, o_lens, o_sums, o_hashes = oracle.extract_checksums(ids, threads)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(lens[:want], o_lens) and np.array_equal(sums[:want], o_sums) and np.array_equal(hashes[:want], o_hashes), \
+            "the extracted paths differ from the oracle's walk"
+        return {"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port", "parity_checked_paths": want,
+                "sample": f"{want} of {n_paths} forward paths ({steps} LF-steps, {dt:.1f} s wall), lengths / sums / hashes equal to the GPU's"}
+    return leg
+
+
+def cpu_leg_search(seconds):
+    """cpu_baseline leg of config 3: the oracle's find + extend loop (src/bin/benchmark.rs:155-169) over a bounded sample of the same queries
+    on min(cores, 64) threads, in the reference's own units (src/internal.rs:58-65: time per query, time per node); final states compared."""
+    def leg(s, queries, states, ok):
+        threads = min(os.cpu_count() or 1, 64)
+        oracle = _oracle_of_synth(s)
+        n, length = queries.shape
+        t0 = time.perf_counter()
+        oracle.search_batch(queries[:2048 * threads // 8 + 256], threads)
+        rate = (2048 * threads // 8 + 256) / (time.perf_counter() - t0)
+        want = int(max(1024, min(n, seconds * rate)))
+        t0 = time.perf_counter()
+        o_st, o_ok = oracle.search_batch(queries[:want], threads)
+        dt = time.perf_counter() - t0
+        got = np.stack([states["node"], states["start"], states["end"]], axis=1)[:want]
+        assert np.array_equal(ok[:want], o_ok) and np.array_equal(got[o_ok], o_st[o_ok]), "final states differ from the oracle's"
+        return {"value": want / dt, "unit": "queries/s", "us_per_query": dt * 1e6 / want, "ns_per_node": dt * 1e9 / (want * length), "cores": threads,
+                "kind": "port", "parity_checked_queries": want,
+                "sample": f"the first {want} of {n} queries, find + {length - 1} x extend ({dt:.1f} s wall), every final state equal to the GPU's"}
+    return leg
+
+
 def algorithmic_bytes(index_path, n_paths, sample):
     """Exact algorithmic bytes W = sum(H + P + 4) over a sample of paths (untimed oracle pass)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -448,10 +501,13 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import configs as K
             emitted = "emitted bytes: the u32 node id every LF-step writes (4 B per step) / kernel time; index reads show up in `traffic`"
+            # every config with its own bounded CPU leg (5 s of oracle each, compared with what the GPU returned) unless --no-cpu-baseline
+            leg_x = None if args.no_cpu_baseline else cpu_leg_extraction(5.0)
+            leg_s = None if args.no_cpu_baseline else cpu_leg_search(5.0)
             extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank), "secondary", emitted)
-            extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank), "high_degree", emitted)
+            extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank, cpu_leg=leg_x), "high_degree", emitted)
             if not args.no_search:
-                extras["search"] = config_roofline(K.search(device=local_rank), "search",
+                extras["search"] = config_roofline(K.search(device=local_rank, cpu_leg=leg_s), "search",
                                                    "bytes a query must move in this layout: its nodes in, its state out, and per step one 64-byte record descriptor + "
                                                    "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)", kernel="k_search")
             if not args.no_config4:

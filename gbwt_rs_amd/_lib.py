@@ -6,6 +6,7 @@ raises, and on a box without a HIP device every compute call returns GBWT_HIP_NO
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -59,6 +60,10 @@ class Paths(C.Structure):
     _fields_ = [("d_offsets", C.c_void_p), ("d_nodes", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
 
 
+class States(C.Structure):
+    _fields_ = [("d_states", C.c_void_p), ("d_valid", C.c_void_p), ("n", C.c_uint64)]
+
+
 class Lines(C.Structure):
     _fields_ = [("d_text", C.c_void_p), ("d_line_offsets", C.c_void_p), ("total", C.c_uint64), ("n", C.c_uint64)]
 
@@ -96,6 +101,8 @@ SIGNATURES = {
     "gbwt_hip_extend_backward": (_int, [_p, _p, _p, _p, _u64, _p, _p]),
     "gbwt_hip_search": (_int, [_p, _p, _p, _u64, _u64, _p, _p]),
     "gbwt_hip_bd_search": (_int, [_p, _p, _p, _u64, _u64, _u64, _p, _p]),
+    "gbwt_hip_search_device": (_int, [_p, _p, _p, _u64, _u64, C.POINTER(States)]),
+    "gbwt_hip_bd_search_device": (_int, [_p, _p, _p, _u64, _u64, _u64, C.POINTER(States)]),
     "gbwt_hip_path_lines": (_int, [_p, _p, _p, _u64, _int, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_path_lines_device": (_int, [_p, _p, _p, _u64, _int, C.POINTER(Lines)]),
     "gbwt_hip_write_gfa": (_int, [_p, _p, C.c_char_p]),
@@ -124,6 +131,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `make -C {CSRC}` (or __graft_entry__.build()); "
                               "gbwt_rs_amd has no CPU fallback")
+        # A process that uses torch AND this library must load torch FIRST: torch brings its own copy of the HIP runtime, and when
+        # libgbwt_hip.so (linked against /opt/rocm's) has started the device before torch is imported, torch's runtime finds "No HIP
+        # GPUs" (measured on the GPU box, round 5: a late `import torch` + .cuda() after the first extraction).  The other order works:
+        # this library then binds to the runtime that is already in the process.  So the Python mirror imports torch here, before the
+        # library is loaded, when torch is installed (dist.py needs it anyway); GBWT_HIP_NO_TORCH_PRELOAD=1 skips that.
+        if "torch" not in sys.modules and not os.environ.get("GBWT_HIP_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

@@ -71,9 +71,10 @@ def _ptr(a):
 class GBWT:
     """A GBWT index resident in HBM.  Mirrors gbwt::GBWT (src/gbwt.rs:95-385) for the hot path."""
 
-    def __init__(self, handle, owner=None):
+    def __init__(self, handle, owner=None, device=0):
         self._L = _lib.lib()
         self._h = handle
+        self._device = device
         self._owner = owner                 # a view of another object's index (another_workspace): that object closes it
         self._ws = C.c_void_p()
         check(self._L.gbwt_hip_workspace_create(self._h, C.byref(self._ws)))
@@ -86,7 +87,7 @@ class GBWT:
         """serialize::load_from::<GBWT | GBZ>(path) (src/gbwt.rs:402-438, src/gbz.rs:674-717)."""
         h = C.c_void_p()
         check(_lib.lib().gbwt_hip_open_file(os.fsencode(path), device, C.byref(h)))
-        return cls(h)
+        return cls(h, device=device)
 
     @classmethod
     def from_records(cls, data, starts, alphabet_offset, alphabet_size, sequences, size, bidirectional=True, device=0):
@@ -96,7 +97,7 @@ class GBWT:
         h = C.c_void_p()
         check(_lib.lib().gbwt_hip_open_records(_ptr(d), d.size, _ptr(s), s.size, alphabet_offset, alphabet_size,
                                                sequences, size, int(bidirectional), device, C.byref(h)))
-        return cls(h)
+        return cls(h, device=device)
 
     def close(self):
         if getattr(self, "_ws", None):
@@ -118,7 +119,7 @@ class GBWT:
         """The same index through a workspace of its own: what a second host thread uses (a handle is immutable after open and safe
         for concurrent read-only calls as long as every thread has its own workspace; the reference shares &GBZ across rayon
         workers, src/bin/gbunzip.rs:421-434).  The view keeps this object alive and never closes the index."""
-        return type(self)(self._h, owner=self)
+        return type(self)(self._h, owner=self, device=self._device)
 
     def new_workspace(self):
         """A fresh workspace: the GBWT_HIP_* extraction knobs are read when a workspace is created, not per call."""
@@ -349,6 +350,27 @@ class GBWT:
         check(self._L.gbwt_hip_search(self._h, self._ws, _ptr(q), q.shape[0], q.shape[1], _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 
+    def search_device(self, d_queries, n, length):
+        """gbwt_hip_search_device: `d_queries` = device pointer (int) to an n x length u64 matrix in HBM; the final states stay in the
+        workspace: a _lib.States struct (d_states, d_valid, n).  states_to_host() copies them out."""
+        out = _lib.States()
+        check(self._L.gbwt_hip_search_device(self._h, self._ws, C.c_void_p(int(d_queries)), n, length, C.byref(out)))
+        return out
+
+    def states_to_host(self, states, bidirectional=False):
+        """(states, valid) of a search_device() / bd_search_device() result as host arrays (through torch views of the workspace's memory)."""
+        import torch
+        from . import dist as D
+        dtype = BD_DTYPE if bidirectional else STATE_DTYPE
+        device = torch.device("cuda", self._device)
+        raw = D.device_view(states.d_states, states.n * dtype.itemsize, torch.uint8, device).cpu().numpy()
+        valid = D.device_view(states.d_valid, states.n, torch.uint8, device).cpu().numpy()
+        return raw.view(dtype).copy(), valid.astype(bool)
+
+    def bd_search_device(self, d_queries, n, length, first):
+        out = _lib.States()
+        check(self._L.gbwt_hip_bd_search_device(self._h, self._ws, C.c_void_p(int(d_queries)), n, length, first, C.byref(out)))
+        return out
 
     def bd_search(self, queries, first):
         """bd_find(q[first]) then alternating extend_forward / extend_backward over every row of the query matrix."""

@@ -551,33 +551,126 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
     return GBWT_HIP_OK;
 }
 
-// Staging helper for the one-lane-per-query entry points.
+// Staging helper for the one-lane-per-query entry points.  A query is a ROW: a_row bytes of `in_a` (+ b_row bytes of `in_b`) in,
+// out_row bytes of `out` + one byte of `valid` out; launch(d_a, d_b, d_out, d_valid, rows, stream) runs the kernel over `rows` rows.
+//
+// Small batches: copy in, one launch, copy out, on the workspace stream.  Large ones (round 5; src/bin/benchmark.rs:161-164 times the
+// whole call, not the kernel): the rows are cut into chunks that travel through the workspace's copy lanes -- the threads, pinned buffers
+// and streams of copy_to_host -- so that one chunk's upload, another's kernel and a third's download share the time, and the host side
+// of the copies (pageable -> pinned, pinned -> pageable) runs on several cores.  A million 10-node queries: 2.95 ms per call with plain
+// hipMemcpyAsync from / to the caller's pageable memory around a 0.49 ms kernel.  The results of all chunks end up in out_a / out_valid
+// like those of a single launch.
 template <class Launch>
-gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *in_a, size_t a_bytes,
-                          const void *in_b, size_t b_bytes, void *out, size_t out_bytes, uint8_t *valid, uint64_t n,
-                          Launch launch) {
+gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *in_a, size_t a_row, const void *in_b, size_t b_row,
+                          void *out, size_t out_row, uint8_t *valid, uint64_t n, Launch launch) {
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n == 0) return GBWT_HIP_OK;
     if (!in_a || !out || !valid) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
     ws->follow_cached = false;   // the staging buffers are shared with gbwt_hip_follow
     try {
         HIP_CHECK(hipSetDevice(ix->device));
-        ws->in_a.reserve(a_bytes);
-        ws->out_a.reserve(out_bytes);
+        ws->in_a.reserve(n * a_row);
+        ws->out_a.reserve(n * out_row);
         ws->out_valid.reserve(n);
-        HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, a_bytes, hipMemcpyHostToDevice, ws->stream));
-        if (in_b) {
-            ws->in_b.reserve(b_bytes);
-            HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, b_bytes, hipMemcpyHostToDevice, ws->stream));
+        if (in_b) ws->in_b.reserve(n * b_row);
+        for (auto &e : ws->qev) if (!e) HIP_CHECK(hipEventCreate(&e));
+        const size_t in_row = a_row + (in_b ? b_row : 0), back_row = out_row + 1;
+        const unsigned threads = ws->knobs.copy_threads;
+        const size_t PIECE = std::min<size_t>(HostCopier::CHUNK, std::max<size_t>(4096, ws->knobs.query_piece));   // bytes of a chunk in either direction
+        const size_t widest = std::max(in_row, back_row);
+        const uint64_t rows_per_chunk = std::max<uint64_t>(1, PIECE / widest);                  // (rows wider than a piece take the plain way below)
+        const uint64_t chunks = widest <= PIECE ? (n + rows_per_chunk - 1) / rows_per_chunk : 0;
+        std::unique_lock<std::mutex> lanes_lock(ws->copier.busy, std::defer_lock);
+        if (chunks >= 4 && threads >= 2 && ws->knobs.query_pipeline == 1 && (lanes_lock.lock(), ws->copier.ensure(ix->device, threads))) {
+            hipStream_t s = ws->stream;
+            HIP_CHECK(hipEventRecord(ws->qev[0], s));
+            std::atomic<uint64_t> next{0};
+            std::atomic<int> failed{0};
+            const unsigned lanes = static_cast<unsigned>(std::min<uint64_t>(threads, chunks));
+            auto work = [&](unsigned t) {
+                HostCopier::Lane &l = ws->copier.lanes[t];
+                if (hipSetDevice(ix->device) != hipSuccess || hipStreamWaitEvent(l.stream, ws->qev[0], 0) != hipSuccess) { failed = 1; return; }
+                char *pin_in = static_cast<char *>(l.pinned[0]), *pin_out = static_cast<char *>(l.pinned[1]);
+                for (uint64_t c = next++; c < chunks && !failed; c = next++) {
+                    const uint64_t lo = c * rows_per_chunk, rows = std::min(rows_per_chunk, n - lo);
+                    std::memcpy(pin_in, static_cast<const char *>(in_a) + lo * a_row, rows * a_row);
+                    if (in_b) std::memcpy(pin_in + rows * a_row, static_cast<const char *>(in_b) + lo * b_row, rows * b_row);
+                    char *d_a = ws->in_a.as<char>() + lo * a_row, *d_b = in_b ? ws->in_b.as<char>() + lo * b_row : nullptr;
+                    char *d_out = ws->out_a.as<char>() + lo * out_row;
+                    uint8_t *d_valid = ws->out_valid.as<uint8_t>() + lo;
+                    bool ok = hipMemcpyAsync(d_a, pin_in, rows * a_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
+                    if (ok && in_b) ok = hipMemcpyAsync(d_b, pin_in + rows * a_row, rows * b_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
+                    if (ok) { launch(d_a, d_b, d_out, d_valid, rows, l.stream); ok = hipGetLastError() == hipSuccess; }
+                    ok = ok && hipMemcpyAsync(pin_out, d_out, rows * out_row, hipMemcpyDeviceToHost, l.stream) == hipSuccess &&
+                         hipMemcpyAsync(pin_out + rows * out_row, d_valid, rows, hipMemcpyDeviceToHost, l.stream) == hipSuccess &&
+                         hipStreamSynchronize(l.stream) == hipSuccess;
+                    if (!ok) { failed = 1; break; }
+                    std::memcpy(static_cast<char *>(out) + lo * out_row, pin_out, rows * out_row);
+                    std::memcpy(valid + lo, pin_out + rows * out_row, rows);
+                }
+                if (hipEventRecord(l.landed[0], l.stream) != hipSuccess) failed = 1;
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < lanes; t++) pool.emplace_back(work, t);
+            work(0);
+            for (auto &t : pool) t.join();
+            if (failed) { (void)hipGetLastError(); return fail(GBWT_HIP_DEVICE_ERROR, "a chunk of the query pipeline failed"); }
+            for (unsigned t = 0; t < lanes; t++) HIP_CHECK(hipStreamWaitEvent(s, ws->copier.lanes[t].landed[0], 0));
+            HIP_CHECK(hipEventRecord(ws->qev[1], s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            ws->query_timed = true;
+            return GBWT_HIP_OK;
         }
+        if (lanes_lock.owns_lock()) lanes_lock.unlock();
+        hipStream_t s = ws->stream;
+        // mode 2: ONE launch, the copies around it through the lanes (several threads, pinned pieces); mode 3: only the copy back
+        const bool lanes_in = ws->knobs.query_pipeline == 2, lanes_out = ws->knobs.query_pipeline == 2 || ws->knobs.query_pipeline == 3;
+        const size_t piece = std::min<size_t>(HostCopier::CHUNK, std::max<size_t>(4096, ws->knobs.query_piece));
+        if (lanes_in) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            copy_to_device(ws, ws->in_a.ptr, in_a, n * a_row, piece);
+            if (in_b) copy_to_device(ws, ws->in_b.ptr, in_b, n * b_row, piece);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, n * a_row, hipMemcpyHostToDevice, s));
+            if (in_b) HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, n * b_row, hipMemcpyHostToDevice, s));
+        }
+        HIP_CHECK(hipEventRecord(ws->qev[0], s));
+        launch(ws->in_a.as<char>(), in_b ? ws->in_b.as<char>() : nullptr, ws->out_a.as<char>(), ws->out_valid.as<uint8_t>(), n, s);
+        HIP_CHECK(hipEventRecord(ws->qev[1], s));
+        ws->query_timed = true;
+        HIP_CHECK(hipGetLastError());
+        if (lanes_out) {
+            HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            copy_to_host(ws, out, ws->out_a.ptr, n * out_row, piece);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(out, ws->out_a.ptr, n * out_row, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
+}
+
+// Device-resident form: the rows of `d_in` are in HBM already (the caller's buffer, read on the workspace stream), the results stay
+// in the workspace.
+template <class Launch>
+gbwt_hip_status run_query_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *d_in, size_t out_row, uint64_t n, Launch launch) {
+    if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (n && !d_in) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
+    ws->follow_cached = false;
+    try {
+        HIP_CHECK(hipSetDevice(ix->device));
+        ws->out_a.reserve(std::max<uint64_t>(n, 1) * out_row);
+        ws->out_valid.reserve(std::max<uint64_t>(n, 1));
         for (auto &e : ws->qev) if (!e) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventRecord(ws->qev[0], ws->stream));
-        launch();
+        if (n) launch(ws->out_a.as<char>(), ws->out_valid.as<uint8_t>(), ws->stream);
         HIP_CHECK(hipEventRecord(ws->qev[1], ws->stream));
         ws->query_timed = true;
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(out, ws->out_a.ptr, out_bytes, hipMemcpyDeviceToHost, ws->stream));
-        HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, ws->stream));
         HIP_CHECK(hipStreamSynchronize(ws->stream));
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
@@ -1069,8 +1162,8 @@ bool HostCopier::ensure(int device, unsigned threads) {
     return true;
 }
 
-void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes) {
-    constexpr size_t CHUNK = HostCopier::CHUNK;
+void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece) {
+    const size_t CHUNK = std::min(std::max<size_t>(piece, 4096), HostCopier::CHUNK);
     const int device = ws->index->device;
     const unsigned threads = ws->knobs.copy_threads;
     if (bytes < 4 * CHUNK || threads < 2) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return; }
@@ -1101,11 +1194,47 @@ void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t byt
         }
         (void)hipStreamSynchronize(l.stream);
     };
+    const unsigned used = static_cast<unsigned>(std::min<size_t>(threads, chunks));
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work, t);
+    for (unsigned t = 1; t < used; t++) pool.emplace_back(work, t);
     work(0);
     for (auto &t : pool) t.join();
     if (failed) { (void)hipGetLastError(); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }   // whatever went wrong: the plain way, which reports it
+}
+
+// The other direction (round 5: the queries of a large search batch): every thread copies its pieces of the caller's pageable memory into
+// its pinned buffers and sends them on; returns when everything has landed.
+void copy_to_device(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece) {
+    const size_t CHUNK = std::min(std::max<size_t>(piece, 4096), HostCopier::CHUNK);
+    const int device = ws->index->device;
+    const unsigned threads = ws->knobs.copy_threads;
+    if (bytes < 4 * CHUNK || threads < 2) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
+    std::lock_guard<std::mutex> guard(ws->copier.busy);
+    if (!ws->copier.ensure(device, threads)) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
+    const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&](unsigned t) {
+        HostCopier::Lane &l = ws->copier.lanes[t];
+        if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
+        bool used_buffer[2] = {false, false};
+        int b = 0;
+        for (size_t c = next++; c < chunks && !failed; c = next++, b ^= 1) {
+            const size_t at = c * CHUNK, len = std::min(CHUNK, bytes - at);
+            if (used_buffer[b] && hipEventSynchronize(l.landed[b]) != hipSuccess) { failed = 1; break; }      // the copy out of this buffer two pieces ago
+            std::memcpy(l.pinned[b], static_cast<const char *>(src) + at, len);
+            if (hipMemcpyAsync(static_cast<char *>(dst) + at, l.pinned[b], len, hipMemcpyHostToDevice, l.stream) != hipSuccess ||
+                hipEventRecord(l.landed[b], l.stream) != hipSuccess) { failed = 1; break; }
+            used_buffer[b] = true;
+        }
+        if (hipStreamSynchronize(l.stream) != hipSuccess) failed = 1;
+    };
+    const unsigned used = static_cast<unsigned>(std::min<size_t>(threads, chunks));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < used; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &t : pool) t.join();
+    if (failed) { (void)hipGetLastError(); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
 }
 
 }  // namespace gbwt_hip
@@ -1234,8 +1363,8 @@ gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kern
 gbwt_hip_status gbwt_hip_start(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n,
                                gbwt_hip_pos *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
-    return run_query(ix, ws, seq_ids, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
-        launch_start(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, seq_ids, sizeof(uint64_t), nullptr, 0, out, sizeof(gbwt_hip_pos), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_start(ix->dev, static_cast<const uint64_t *>(a), rows, static_cast<gbwt_hip_pos *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1243,8 +1372,8 @@ gbwt_hip_status gbwt_hip_start(const gbwt_hip_index *ix, gbwt_hip_workspace *ws,
 gbwt_hip_status gbwt_hip_forward(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const gbwt_hip_pos *in, uint64_t n,
                                  gbwt_hip_pos *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
-    return run_query(ix, ws, in, n * sizeof(gbwt_hip_pos), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
-        launch_forward(ix->dev, ws->in_a.as<gbwt_hip_pos>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, in, sizeof(gbwt_hip_pos), nullptr, 0, out, sizeof(gbwt_hip_pos), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_forward(ix->dev, static_cast<const gbwt_hip_pos *>(a), rows, static_cast<gbwt_hip_pos *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1253,8 +1382,8 @@ gbwt_hip_status gbwt_hip_backward(const gbwt_hip_index *ix, gbwt_hip_workspace *
                                   gbwt_hip_pos *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Following sequences backward requires a bidirectional GBWT");
-    return run_query(ix, ws, in, n * sizeof(gbwt_hip_pos), nullptr, 0, out, n * sizeof(gbwt_hip_pos), valid, n, [&] {
-        launch_backward(ix->dev, ws->in_a.as<gbwt_hip_pos>(), n, ws->out_a.as<gbwt_hip_pos>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, in, sizeof(gbwt_hip_pos), nullptr, 0, out, sizeof(gbwt_hip_pos), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_backward(ix->dev, static_cast<const gbwt_hip_pos *>(a), rows, static_cast<gbwt_hip_pos *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1262,8 +1391,8 @@ gbwt_hip_status gbwt_hip_backward(const gbwt_hip_index *ix, gbwt_hip_workspace *
 gbwt_hip_status gbwt_hip_find(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *nodes, uint64_t n,
                               gbwt_hip_state *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
-    return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {
-        launch_find(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, nodes, sizeof(uint64_t), nullptr, 0, out, sizeof(gbwt_hip_state), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_find(ix->dev, static_cast<const uint64_t *>(a), rows, static_cast<gbwt_hip_state *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1272,9 +1401,8 @@ gbwt_hip_status gbwt_hip_extend(const gbwt_hip_index *ix, gbwt_hip_workspace *ws
                                 const uint64_t *nodes, uint64_t n, gbwt_hip_state *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
     if (n && !nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null nodes");
-    return run_query(ix, ws, states, n * sizeof(gbwt_hip_state), nodes, n * sizeof(uint64_t), out, n * sizeof(gbwt_hip_state), valid, n, [&] {
-        launch_extend(ix->dev, ws->in_a.as<gbwt_hip_state>(), ws->in_b.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_state>(),
-                      ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, states, sizeof(gbwt_hip_state), nodes, sizeof(uint64_t), out, sizeof(gbwt_hip_state), valid, n, [&](const void *a, const void *b, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_extend(ix->dev, static_cast<const gbwt_hip_state *>(a), static_cast<const uint64_t *>(b), rows, static_cast<gbwt_hip_state *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1284,8 +1412,8 @@ gbwt_hip_status gbwt_hip_bd_find(const gbwt_hip_index *ix, gbwt_hip_workspace *w
     GBWT_HIP_GUARD_BEGIN
     // the reference asserts here (src/gbwt.rs:312)
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
-    return run_query(ix, ws, nodes, n * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
-        launch_bd_find(ix->dev, ws->in_a.as<uint64_t>(), n, ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, nodes, sizeof(uint64_t), nullptr, 0, out, sizeof(gbwt_hip_bd_state), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_bd_find(ix->dev, static_cast<const uint64_t *>(a), rows, static_cast<gbwt_hip_bd_state *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1295,9 +1423,8 @@ static gbwt_hip_status bd_extend(const gbwt_hip_index *ix, gbwt_hip_workspace *w
     GBWT_HIP_GUARD_BEGIN
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
     if (n && !nodes) return fail(GBWT_HIP_BAD_ARGUMENT, "null nodes");
-    return run_query(ix, ws, states, n * sizeof(gbwt_hip_bd_state), nodes, n * sizeof(uint64_t), out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
-        launch_bd_extend(ix->dev, ws->in_a.as<gbwt_hip_bd_state>(), ws->in_b.as<uint64_t>(), n, backward,
-                         ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    return run_query(ix, ws, states, sizeof(gbwt_hip_bd_state), nodes, sizeof(uint64_t), out, sizeof(gbwt_hip_bd_state), valid, n, [&](const void *a, const void *b, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_bd_extend(ix->dev, static_cast<const gbwt_hip_bd_state *>(a), static_cast<const uint64_t *>(b), rows, backward, static_cast<gbwt_hip_bd_state *>(o), v, s);
     });
     GBWT_HIP_GUARD_END
 }
@@ -1370,9 +1497,24 @@ gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *ix, gbwt_hip_workspace *ws
 gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *queries, uint64_t n,
                                 uint64_t len, gbwt_hip_state *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
-    return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_state), valid, n, [&] {
-        launch_search(ix->dev, ws->in_a.as<uint64_t>(), n, len, ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    if (len > (uint64_t(1) << 32)) return fail(GBWT_HIP_BAD_ARGUMENT, "query length out of range");
+    return run_query(ix, ws, queries, len * sizeof(uint64_t), nullptr, 0, out, sizeof(gbwt_hip_state), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_search(ix->dev, static_cast<const uint64_t *>(a), rows, len, static_cast<gbwt_hip_state *>(o), v, s);
     });
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_search_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *d_queries, uint64_t n, uint64_t len,
+                                       gbwt_hip_states *out) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!out) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
+    *out = gbwt_hip_states{nullptr, nullptr, 0};
+    if (len > (uint64_t(1) << 32)) return fail(GBWT_HIP_BAD_ARGUMENT, "query length out of range");
+    const gbwt_hip_status st = run_query_device(ix, ws, d_queries, sizeof(gbwt_hip_state), n, [&](void *o, uint8_t *v, hipStream_t s) {
+        launch_search(ix->dev, d_queries, n, len, static_cast<gbwt_hip_state *>(o), v, s);
+    });
+    if (st == GBWT_HIP_OK) *out = gbwt_hip_states{ws->out_a.as<gbwt_hip_state>(), ws->out_valid.as<uint8_t>(), n};
+    return st;
     GBWT_HIP_GUARD_END
 }
 
@@ -1380,9 +1522,25 @@ gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *ix, gbwt_hip_workspace 
                                    uint64_t len, uint64_t first, gbwt_hip_bd_state *out, uint8_t *valid) {
     GBWT_HIP_GUARD_BEGIN
     if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
-    return run_query(ix, ws, queries, n * len * sizeof(uint64_t), nullptr, 0, out, n * sizeof(gbwt_hip_bd_state), valid, n, [&] {
-        launch_bd_search(ix->dev, ws->in_a.as<uint64_t>(), n, len, first, ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), ws->stream);
+    if (len > (uint64_t(1) << 32)) return fail(GBWT_HIP_BAD_ARGUMENT, "query length out of range");
+    return run_query(ix, ws, queries, len * sizeof(uint64_t), nullptr, 0, out, sizeof(gbwt_hip_bd_state), valid, n, [&](const void *a, const void *, void *o, uint8_t *v, uint64_t rows, hipStream_t s) {
+        launch_bd_search(ix->dev, static_cast<const uint64_t *>(a), rows, len, first, static_cast<gbwt_hip_bd_state *>(o), v, s);
     });
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_bd_search_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *d_queries, uint64_t n, uint64_t len,
+                                          uint64_t first, gbwt_hip_bd_states *out) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!out) return fail(GBWT_HIP_BAD_ARGUMENT, "null output");
+    *out = gbwt_hip_bd_states{nullptr, nullptr, 0};
+    if (ix && !ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
+    if (len > (uint64_t(1) << 32)) return fail(GBWT_HIP_BAD_ARGUMENT, "query length out of range");
+    const gbwt_hip_status st = run_query_device(ix, ws, d_queries, sizeof(gbwt_hip_bd_state), n, [&](void *o, uint8_t *v, hipStream_t s) {
+        launch_bd_search(ix->dev, d_queries, n, len, first, static_cast<gbwt_hip_bd_state *>(o), v, s);
+    });
+    if (st == GBWT_HIP_OK) *out = gbwt_hip_bd_states{ws->out_a.as<gbwt_hip_bd_state>(), ws->out_valid.as<uint8_t>(), n};
+    return st;
     GBWT_HIP_GUARD_END
 }
 

@@ -262,6 +262,8 @@ struct ExtractKnobs {
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
     uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
     unsigned copy_threads = 8;                                // GBWT_HIP_COPY_THREADS
+    int query_pipeline = 1;                                   // GBWT_HIP_QUERY_PIPELINE: 0 = large query batches in one piece over the workspace stream (rounds 1-4)
+    size_t query_piece = size_t(2) << 20;                     // GBWT_HIP_QUERY_PIECE_KIB: bytes of a piece of the copy lanes in a query call
     static ExtractKnobs from_env() {
         ExtractKnobs k;
         const auto num = [](const char *name, int unset) { const char *v = std::getenv(name); return v ? std::atoi(v) : unset; };
@@ -281,6 +283,8 @@ struct ExtractKnobs {
         k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;
         k.debug = static_cast<uint32_t>(num("GBWT_HIP_DEBUG_DRY_ROWS", 0));
         k.copy_threads = static_cast<unsigned>(std::min(64, std::max(1, num("GBWT_HIP_COPY_THREADS", 8))));
+        k.query_pipeline = num("GBWT_HIP_QUERY_PIPELINE", 1);
+        k.query_piece = static_cast<size_t>(std::max(4, num("GBWT_HIP_QUERY_PIECE_KIB", 2048))) << 10;
         return k;
     }
 };
@@ -321,5 +325,6 @@ struct gbwt_hip_workspace {
 namespace gbwt_hip {
 // Device -> pageable host memory over the workspace's copy threads (GBWT_HIP_COPY_THREADS, default 8), each with two pinned staging
 // buffers and a stream of its own (capi.hip)
-void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes);
+void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece = HostCopier::CHUNK);
+void copy_to_device(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece = HostCopier::CHUNK);
 }

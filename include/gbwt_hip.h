@@ -240,6 +240,18 @@ gbwt_hip_status gbwt_hip_search(const gbwt_hip_index *index, gbwt_hip_workspace 
 gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *queries,
                                    uint64_t n, uint64_t len, uint64_t first, gbwt_hip_bd_state *out, uint8_t *valid);
 
+/* Device-resident forms (round 5): the queries are in HBM already (`d_queries`: n x len u64, a device pointer of the caller, read on the
+ * workspace stream), the final states stay in HBM inside the workspace (valid until the next query call on it): d_states[n], d_valid[n].
+ * What a pipeline that produces its queries on the GPU calls, and what separates the kernel from PCIe: a million 10-node queries are
+ * 80 MB in and 25 MB out around a 0.5 ms kernel.  (The host forms above move large batches in chunks through the workspace's pinned copy
+ * lanes, upload / kernel / download of different chunks at the same time.) */
+typedef struct { const gbwt_hip_state *d_states; const uint8_t *d_valid; uint64_t n; } gbwt_hip_states;
+typedef struct { const gbwt_hip_bd_state *d_states; const uint8_t *d_valid; uint64_t n; } gbwt_hip_bd_states;
+gbwt_hip_status gbwt_hip_search_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *d_queries, uint64_t n, uint64_t len,
+                                       gbwt_hip_states *out);
+gbwt_hip_status gbwt_hip_bd_search_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *d_queries, uint64_t n, uint64_t len,
+                                          uint64_t first, gbwt_hip_bd_states *out);
+
 /* ---- GFA text (GBZ handles with metadata) ------------------------------------------------------------
  * gbwt_hip_path_lines: the lines gbunzip writes for the given paths, in the order given, byte for byte:
  * mode 0 = P-lines named by the contig (write_p_line / path_to_p_line, src/bin/gbunzip.rs:438-485), mode 1 = W-lines
@@ -323,7 +335,9 @@ gbwt_hip_status gbwt_hip_last_lines_ms(const gbwt_hip_workspace *ws, float *walk
 /* Free and total memory of a device in bytes (hipMemGetInfo): what the tests use to see that a workspace gives its rows back. */
 gbwt_hip_status gbwt_hip_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Kernel time (ms, HIP events on the workspace stream, host staging excluded) of the last navigation / search call
- * (start, forward, backward, find, extend, bd_*, search, bd_search) on `ws`. */
+ * (start, forward, backward, find, extend, bd_*, search, bd_search and the *_device forms) on `ws`.  For a host-pointer call large enough
+ * to be moved in chunks through the copy lanes it is the span of the whole pipeline on the device, copies included: use the *_device
+ * forms to time the kernel alone. */
 gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kernel_ms);
 
 #ifdef __cplusplus

@@ -56,6 +56,24 @@ def test_config_c3_full_size():
     assert np.array_equal((st["end"] - st["start"])[ok], (bd["forward"]["end"] - bd["forward"]["start"])[ok])
     assert np.array_equal((bd["forward"]["end"] - bd["forward"]["start"])[ok], (bd["reverse"]["end"] - bd["reverse"]["start"])[ok])
     assert np.array_equal(bd["reverse"]["node"][ok], queries[ok][:, 0] ^ np.uint64(1))
+    # the same queries through the other ways in: in one piece over the workspace stream (the host forms above moved them in chunks through
+    # the pinned copy lanes), and the device-resident forms (queries in HBM, states left in the workspace)
+    import torch
+    os.environ["GBWT_HIP_QUERY_PIPELINE"] = "0"
+    try:
+        plain = dev.another_workspace()
+    finally:
+        del os.environ["GBWT_HIP_QUERY_PIPELINE"]
+    st1, ok1 = plain.search(queries)
+    bd1, bok1 = plain.bd_search(queries, 4)
+    assert np.array_equal(ok, ok1) and np.array_equal(st, st1) and np.array_equal(bok, bok1) and np.array_equal(bd, bd1)
+    d_q = torch.from_numpy(queries.view(np.int64)).cuda()
+    st2, ok2 = plain.states_to_host(plain.search_device(d_q.data_ptr(), len(queries), 10))
+    assert np.array_equal(ok, ok2) and np.array_equal(st, st2) and plain.last_query_ms() > 0
+    bd2, bok2 = plain.states_to_host(plain.bd_search_device(d_q.data_ptr(), len(queries), 10, 4), bidirectional=True)
+    assert np.array_equal(bok, bok2) and np.array_equal(bd, bd2)
+    plain.close()
+    del d_q
     oracle = oracle_of(s)
     pick = np.sort(np.random.default_rng(8).choice(len(queries), 30000, replace=False))
     o_st, o_ok = oracle.search_batch(queries[pick], threads=16)

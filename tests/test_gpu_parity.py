@@ -887,6 +887,73 @@ def test_config_c3_search_bit_exact(model, haplotypes):
         assert np.array_equal(got[bok][:, 0], queries[bok][:, 9]) and np.array_equal(got[bok][:, 3], queries[bok][:, 0] ^ 1)
 
 
+def test_large_query_batches_travel_in_chunks(monkeypatch):
+    """Host-pointer query calls large enough for the chunk pipeline (round 5: chunks of ~2 MiB through the workspace's pinned copy lanes,
+    upload / kernel / download of different chunks at once) -- every entry point of the navigation / search group, with a row count that
+    is not a multiple of the chunk: the same answers as one piece over the workspace stream (GBWT_HIP_QUERY_PIPELINE=0), as the
+    device-resident forms, and (a seeded sample) as the oracle."""
+    import torch
+    s = S.Synth.chain(sites=2000, haplotypes=600, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=29)
+    dev, oracle = open_synth(s), oracle_of(s)
+    monkeypatch.setenv("GBWT_HIP_QUERY_PIPELINE", "0")
+    plain = dev.another_workspace()
+    monkeypatch.delenv("GBWT_HIP_QUERY_PIPELINE")
+    gen = np.random.default_rng(12)
+    n = 1300003
+    nodes = gen.integers(0, s.alphabet_size + 3, n, dtype=np.uint64)
+    a, a_ok = dev.find(nodes)
+    b, b_ok = plain.find(nodes)
+    assert np.array_equal(a, b) and np.array_equal(a_ok, b_ok) and 0.3 < a_ok.mean() < 1.0
+    for k in gen.choice(n, 300, replace=False):
+        exp = oracle.find(int(nodes[k]))
+        assert bool(a_ok[k]) == (exp is not None) and (exp is None or tuple(int(v) for v in a[k]) == exp)
+    nxt = nodes + np.where(nodes % 6 < 2, 2, 4).astype(np.uint64)                  # anchor -> an allele, allele -> the next anchor (or nothing)
+    e, e_ok = dev.extend(a, nxt)
+    f, f_ok = plain.extend(a, nxt)
+    assert np.array_equal(e, f) and np.array_equal(e_ok, f_ok) and e_ok.any()
+    for k in gen.choice(np.flatnonzero(a_ok), 300, replace=False):
+        exp = oracle.extend(tuple(int(v) for v in a[k]), int(nxt[k]))
+        assert bool(e_ok[k]) == (exp is not None) and (exp is None or tuple(int(v) for v in e[k]) == exp)
+    bd, bd_ok = dev.bd_find(nodes)
+    bd1, bd1_ok = plain.bd_find(nodes)
+    assert np.array_equal(bd, bd1) and np.array_equal(bd_ok, bd1_ok)
+    x, x_ok = dev.extend_forward(bd, nxt)
+    y, y_ok = plain.extend_forward(bd, nxt)
+    assert np.array_equal(x, y) and np.array_equal(x_ok, y_ok)
+    x, x_ok = dev.extend_backward(bd, nodes - np.uint64(2))
+    y, y_ok = plain.extend_backward(bd, nodes - np.uint64(2))
+    assert np.array_equal(x, y) and np.array_equal(x_ok, y_ok)
+    pos = np.zeros(n, dtype=G.POS_DTYPE)
+    pos["node"], pos["offset"] = nodes, gen.integers(0, 700, n)
+    p, p_ok = dev.forward(pos)
+    q, q_ok = plain.forward(pos)
+    assert np.array_equal(p, q) and np.array_equal(p_ok, q_ok) and p_ok.any() and not p_ok.all()
+    p, p_ok = dev.backward(pos)
+    q, q_ok = plain.backward(pos)
+    assert np.array_equal(p, q) and np.array_equal(p_ok, q_ok)
+    ids = gen.integers(0, s.sequences + 5, n, dtype=np.uint64)
+    p, p_ok = dev.start(ids)
+    q, q_ok = plain.start(ids)
+    assert np.array_equal(p, q) and np.array_equal(p_ok, q_ok)
+    # whole queries: chunked, in one piece, device-resident
+    queries = make_queries(s, random.Random(5), 3000, 7)
+    queries = np.ascontiguousarray(np.tile(queries, (60, 1))[:170001])
+    st, ok = dev.search(queries)
+    st1, ok1 = plain.search(queries)
+    d_q = torch.from_numpy(queries.view(np.int64)).cuda()
+    st2, ok2 = plain.states_to_host(plain.search_device(d_q.data_ptr(), len(queries), 7))
+    assert np.array_equal(st, st1) and np.array_equal(ok, ok1) and np.array_equal(st, st2) and np.array_equal(ok, ok2)
+    o_st, o_ok = oracle.search_batch(queries[:3000], threads=8)
+    assert np.array_equal(ok[:3000], o_ok) and np.array_equal(np.stack([st["node"], st["start"], st["end"]], axis=1)[:3000][o_ok], o_st[o_ok])
+    bd, bok = dev.bd_search(queries, 3)
+    bd1, bok1 = plain.bd_search(queries, 3)
+    bd2, bok2 = plain.states_to_host(plain.bd_search_device(d_q.data_ptr(), len(queries), 7, 3), bidirectional=True)
+    assert np.array_equal(bd, bd1) and np.array_equal(bok, bok1) and np.array_equal(bd, bd2) and np.array_equal(bok, bok2)
+    empty = plain.search_device(0, 0, 7)
+    assert empty.n == 0
+    plain.close()
+
+
 def test_config_c3_scale_states_against_the_oracle():
     """Config 3 at a third of its full length (400 000 sites x 5 008 haplotypes, 1.2 M nodes; the full 1.1 M-site run is tools/search_bench.py):
     a million queries go through the device, EVERY final state of a seeded sample of 30 000 of them is compared with the oracle

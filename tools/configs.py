@@ -32,7 +32,7 @@ def _timed_passes(index, ids, passes):
     return out, walk, total
 
 
-def _extraction(s, passes, warm, device):
+def _extraction(s, passes, warm, device, cpu_leg=None):
     import gbwt_rs_amd as G
     import torch
     dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, device=device)
@@ -49,6 +49,8 @@ def _extraction(s, passes, warm, device):
     res = {"value": steps * passes / elapsed, "unit": "LF-steps/s", "kernel": "k_walk_direct", "kernel_ms": float(np.mean(walk)),
            "value_kernel": steps / (float(np.mean(walk)) * 1e-3), "lf_steps": steps, "algorithmic_bytes": 4.0 * steps,
            "open_ms": dev.open_times()["total_ms"], "memory": dev.memory_usage()}
+    if cpu_leg is not None:       # bench.py's cpu_baseline leg: the oracle over a bounded sample of these paths, compared with the rows just extracted
+        res["cpu_baseline"] = cpu_leg(s, np.diff(dev.last_offsets(len(ids))), dev.path_sums(len(ids)), dev.path_hashes(len(ids)))
     dev.close()
     return res
 
@@ -64,11 +66,11 @@ def secondary(sites=333334, haplotypes=5000, model=0, seed=42, passes=5, device=
     return res
 
 
-def high_degree(haplotypes=5000, seed=42, passes=10, device=0):
+def high_degree(haplotypes=5000, seed=42, passes=10, device=0, cpu_leg=None):
     from gbwt_rs_amd import synth as S
     t0 = time.perf_counter()
     s = S.Synth.chain(sites=3000, haplotypes=haplotypes, alleles=300, model=S.IID, seed=seed)
-    res = _extraction(s, passes, 3, device)
+    res = _extraction(s, passes, 3, device, cpu_leg)
     res["workload"] = (f"BASELINE config 5: {haplotypes} haplotypes x 3 000 sites with 300 alleles each, i.i.d. Zipf(1.2) ({res['lf_steps']} LF-steps; "
                        "every site is a table record of outdegree >= 255, two-varint runs)")
     res["seconds_incl_generator"] = round(time.perf_counter() - t0, 1)
@@ -98,7 +100,7 @@ def make_benchmark_queries(dev, first, alphabet, n_queries, length, seed):
     return np.stack(rows, axis=1)[alive][:n_queries].astype(np.uint64)
 
 
-def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7, passes=5, device=0, keep=None):
+def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7, passes=5, device=0, keep=None, cpu_leg=None):
     import gbwt_rs_amd as G
     from gbwt_rs_amd import synth as S
     t0 = time.perf_counter()
@@ -110,23 +112,52 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
                        f"src/bin/benchmark.rs:124-153 does (seed {seed}); find + {length - 1} x extend per query in one launch, and bd_find + alternating "
                        "extend_forward / extend_backward",
            "queries": int(n), "unit": "queries/s"}
-    for name, kernel, fn in (("unidirectional", "k_search", lambda: dev.search(queries)), ("bidirectional", "k_bd_search", lambda: dev.bd_search(queries, length // 2))):
-        fn()
-        ks, ws = [], []
+    # the kernel alone: queries resident in HBM, states left in the workspace (gbwt_hip_search_device); the call as src/bin/benchmark.rs:161-164
+    # times it: host pointers in and out (gbwt_hip_search: chunks through the pinned copy lanes), and the same in one piece (rounds 1-4)
+    import torch
+    d_q = torch.from_numpy(queries.view(np.int64)).cuda(device)
+    os.environ["GBWT_HIP_QUERY_PIPELINE"] = "0"
+    try:
+        plain = dev.another_workspace()
+    finally:
+        del os.environ["GBWT_HIP_QUERY_PIPELINE"]
+    forms = (("unidirectional", "k_search", lambda w: w.search(queries), lambda: dev.states_to_host(dev.search_device(d_q.data_ptr(), n, length))),
+             ("bidirectional", "k_bd_search", lambda w: w.bd_search(queries, length // 2),
+              lambda: dev.states_to_host(dev.bd_search_device(d_q.data_ptr(), n, length, length // 2), bidirectional=True)))
+    for name, kernel, host_form, device_form in forms:
+        host_form(dev), host_form(plain), device_form()
+        ks, ws, ws1 = [], [], []
         for _ in range(passes):
             t1 = time.perf_counter()
-            out, ok = fn()
+            out, ok = host_form(dev)
             ws.append((time.perf_counter() - t1) * 1e3)
+            t1 = time.perf_counter()
+            out1, ok1 = host_form(plain)
+            ws1.append((time.perf_counter() - t1) * 1e3)
+            out2, ok2 = device_form()
             ks.append(dev.last_query_ms())
         assert ok.all(), "a query cut out of the index itself was not found"
+        assert np.array_equal(out, out1) and np.array_equal(out, out2) and ok1.all() and ok2.all(), "the three ways into the kernel disagree"
         fwd = out if name == "unidirectional" else out["forward"]
         assert ((fwd["end"] > fwd["start"]) & (fwd["node"] == queries[:, -1 if name == "unidirectional" else length - 1])).all()
         k = float(np.mean(ks))
         # what a query must move in this layout: its nodes in (8 B each), its state out (24 / 48 B + 1), and per step the 64-byte descriptor of
         # the record + two 16-byte rank blocks (range start and end)
         bytes_q = 8 * length + (24 if name == "unidirectional" else 48) + 1 + length * (64 + 2 * 16)
-        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.mean(ws)), "value": n / (k * 1e-3), "steps_per_s": n * length / (k * 1e-3),
+        pcie = n * (8 * length + (24 if name == "unidirectional" else 48) + 1)
+        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.median(ws)), "wall_ms_one_piece": float(np.median(ws1)), "value": n / (k * 1e-3),
+                     "value_call": n / (float(np.median(ws)) * 1e-3), "steps_per_s": n * length / (k * 1e-3), "ns_per_node_call": float(np.median(ws)) * 1e6 / (n * length),
+                     "pcie_bytes_per_call": int(pcie), "pcie_GB_per_s": pcie / (float(np.median(ws)) * 1e-3) / 1e9,
                      "algorithmic_bytes": float(bytes_q * n), "found": int(ok.sum())}
+        if name == "unidirectional":
+            final_states, final_ok = out, ok
+    plain.close()
+    del d_q
+    res["value_call"] = res["unidirectional"]["value_call"]
+    res["value_note"] = ("value = queries / kernel time with the queries resident in HBM (gbwt_hip_search_device); value_call = queries / wall time of "
+                         "gbwt_hip_search with host pointers (src/bin/benchmark.rs:161-164 times the whole call): 80 MB in and 25 MB out over PCIe")
+    if cpu_leg is not None:
+        res["cpu_baseline"] = cpu_leg(s, queries, final_states, final_ok)
     res["value"] = res["unidirectional"]["value"]
     res["kernel"], res["kernel_ms"], res["algorithmic_bytes"] = "k_search", res["unidirectional"]["kernel_ms"], res["unidirectional"]["algorithmic_bytes"]
     res["memory"] = dev.memory_usage()
