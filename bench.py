@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip value_unsampled and the other BASELINE configs (secondary = insertion chain, high_degree = config 5, search = config 3, config4)")
     ap.add_argument("--no-search", action="store_true", help="skip the config 3 search object (its 1.1 M-site index takes half a minute to generate)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config 4 object")
+    ap.add_argument("--c4-size", choices=["full", "small", "medium", "tiny"], default="full",
+                    help="config 4's stand-in (tools/c4_bench.py: SIZES): full = the size SURVEY 8(d) states (~42 000 walks over ~90 M nodes, labels of 1..1024 bp); "
+                         "small / tiny for rehearsals")
     return ap.parse_args()
 
 
@@ -158,6 +161,161 @@ def algorithmic_bytes(index_path, n_paths, sample):
     ids = np.arange(0, 2 * min(sample, n_paths), 2, dtype=np.uint64)
     total, steps = oracle.algorithmic_bytes(ids)
     return total / steps, int(steps)
+
+
+def final_gather(args, index, out, s, rank, world, local_rank, backend, comm_device, by_parts, strong, n_paths, all_steps, my_paths, barrier, dist, torch):
+    """The one exchange of the job: the extracted rows of every rank on rank 0, in path order, over RCCL point-to-point sends (one group,
+    every peer over its own xGMI link).  Strong scaling: the WHOLE CSR (13.3 GB / N per rank) through the C ABI (gbwt_hip_comm_*: RCCL
+    called by the library, rows placed by kernels on rank 0); where the library cannot make a communicator (no RCCL: GBWT_HIP_UNSUPPORTED;
+    the gloo rehearsal on a shared GPU) ALL ranks agree on the torch.distributed form.  Weak scaling: the W-lines of a bounded sample of
+    every rank's paths.  Wrong rows are an error, never a fallback."""
+    import gbwt_rs_amd as G
+    from gbwt_rs_amd import dist as D
+    device = torch.device("cuda", local_rank)
+    payload_note = "the whole CSR: node ids (u32) + row lengths of every rank's shard, gathered on rank 0 in path order"
+    if not strong:
+        sample = np.arange(min(args.gather_paths, n_paths), dtype=np.uint64)
+        lines = index.path_lines_device(sample, 1)
+        line_off, text = D.lines_tensors(lines, device)
+        mine = text.clone()
+        if comm_device == "cpu":
+            line_off, text = line_off.cpu(), text.cpu()
+        sizes = torch.tensor([float(text.numel())], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+        barrier()
+        tg = time.perf_counter()
+        g_off, g_text = D.gather_lines(line_off, text, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        info = {"ms": gather_ms, "bytes": int(sizes.item()), "payload": f"W-lines of {len(sample)} paths of every rank, formatted on the device", "backend": backend}
+        if rank == 0:
+            assert g_text.numel() == int(sizes.item()) and int(g_off[1]) == mine.numel()
+            assert torch.equal(g_text[:mine.numel()].to(mine.device), mine), "rank 0's own lines changed on the way"
+            info["GB_per_s"] = int(sizes.item()) / 1e9 / (gather_ms * 1e-3)
+        return info
+    # every rank learns whether EVERY rank has a communicator before anybody enters a collective of either kind
+    comm, why = None, None
+    try:
+        if comm_device != "cuda":
+            raise RuntimeError("not an RCCL run (BENCH_DIST_BACKEND)")
+        comm = D.Comm(rank, world, local_rank)           # (a failure of rank 0 to make the id is raised on every rank: dist.Comm)
+    except (G.GbwtHipError, RuntimeError) as e:
+        why = repr(e)[:200]
+    agreed = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=comm_device)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+    if float(agreed.item()) == 1.0:
+        layout = D.GATHER_PARTS if by_parts else D.GATHER_INTERLEAVED
+        comm.gather_rows(index, root=0, layout=layout)          # untimed: connections, buffers
+        barrier()
+        tg = time.perf_counter()
+        got = comm.gather_rows(index, root=0, layout=layout)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        info = {"ms": gather_ms, "backend": backend, "via": "gbwt_hip_comm (C ABI, RCCL)", "rank_stats": comm.last(), "payload": payload_note}
+        if rank == 0:
+            assert int(got.total) == int(all_steps) and int(got.n) == n_paths, (int(got.total), all_steps)
+            g_off, g_nodes = D.paths_tensors(got, device)
+            for p_id in list(range(min(world, n_paths))) + list(range(max(0, n_paths - world), n_paths)):   # first and last row of every rank
+                row = g_nodes[int(g_off[p_id]):int(g_off[p_id + 1])].cpu().numpy().astype(np.uint32)
+                assert np.array_equal(row, s.path(p_id)), f"row {p_id} changed on the way"
+            info["bytes"] = 4 * int(got.total) + 8 * n_paths
+            info["GB_per_s"] = info["bytes"] / 1e9 / (gather_ms * 1e-3)
+        comm.close()
+        return info
+    if comm is not None:
+        comm.close()
+    offsets, nodes = D.paths_tensors(out, device)
+    lengths = (offsets[1:] - offsets[:-1]).clone()
+    payload = nodes.clone()                                     # (rows may be mapped from spread chunks: staged for the send)
+    if comm_device == "cpu":
+        lengths, payload = lengths.cpu(), payload.cpu()
+    barrier()
+    tg = time.perf_counter()
+    len_parts, val_parts = D.gather_parts(lengths, payload, dst=0)
+    barrier()
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    info = {"ms": gather_ms, "backend": backend, "via": "torch.distributed batch_isend_irecv (no gbwt_hip_comm on some rank; this rank: " + str(why) + ")", "payload": payload_note}
+    if rank == 0:
+        got_n = sum(int(p.numel()) for p in val_parts)
+        assert got_n == int(all_steps), (got_n, all_steps)
+        if by_parts:                               # the stretches of every row, joined in rank order
+            j_off, j_nodes = D.join_row_parts(len_parts, val_parts)
+            for p_id in (0, n_paths // 2, n_paths - 1):
+                row = j_nodes[int(j_off[p_id]):int(j_off[p_id + 1])].cpu().numpy().astype(np.uint32)
+                assert np.array_equal(row, s.path(p_id)), f"row {p_id} changed on the way"
+        for r in range(world if not by_parts else 0):   # first and last row of every rank's part against the generator
+            paths_r = shard_paths(n_paths, r, world)
+            ends = torch.cumsum(len_parts[r], 0)
+            for k in (0, len(paths_r) - 1):
+                lo = int(ends[k - 1]) if k else 0
+                row = val_parts[r][lo:int(ends[k])].cpu().numpy().astype(np.uint32)
+                assert np.array_equal(row, s.path(int(paths_r[k]))), f"row {k} of rank {r} changed on the way"
+        info["bytes"] = 4 * got_n + 8 * n_paths
+        info["GB_per_s"] = info["bytes"] / 1e9 / (gather_ms * 1e-3)
+    return info
+
+
+def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch):
+    """BASELINE config 4 as it is named: full GFA extraction sharded over the N GPUs with the RCCL gather (tools/c4_bench.py: run_sharded).
+    Rank 0 generates the GBZ once (/dev/shm), every rank opens it (the index is replicated), formats the lines of its block of path ids
+    and the text is gathered on rank 0; the gathered text is compared with rank 0 formatting alone.  Collective: every rank calls it;
+    returns the object for the line on rank 0."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import c4_bench
+    import gbwt_rs_amd as G
+    from gbwt_rs_amd import dist as D
+    box = [None]
+    if rank == 0:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        box[0] = os.path.join(tempfile.mkdtemp(prefix="gbwt_bench_c4_", dir=base), "c4.gbz")
+        g = c4_bench.generate(args.c4_size, box[0])
+        gen = {"generator_seconds": round(g.generator_seconds, 1), "save_seconds": round(g.save_seconds, 1), "paths": int(g.paths)}
+        del g
+    dist.broadcast_object_list(box, src=0)
+    path = box[0]
+    try:
+        generic = np.load(path + ".generic.npy")
+        t0 = time.perf_counter()
+        gbz = G.GBZ.load(path, device=local_rank)
+        open_ms = (time.perf_counter() - t0) * 1e3
+        walks = np.setdiff1d(np.arange(gbz.paths(), dtype=np.uint64), generic)
+        steps = (gbz.len() - gbz.sequences()) // 2
+        comm, why = None, None
+        try:
+            if comm_device != "cuda":
+                raise RuntimeError("not an RCCL run (BENCH_DIST_BACKEND)")
+            comm = D.Comm(rank, world, local_rank)
+        except (G.GbwtHipError, RuntimeError) as e:
+            why = repr(e)[:200]
+        agreed = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if float(agreed.item()) != 1.0 and comm is not None:
+            comm.close()
+            comm = None
+
+        def torch_gather(off, text):                       # the torch.distributed form (gloo: CPU tensors)
+            if comm_device == "cpu":
+                off, text = off.cpu(), text.cpu()
+            return D.gather_lines(off, text, dst=0)
+
+        res, my = c4_bench.run_sharded(gbz, generic, walks, rank, world, comm, barrier, local_rank, passes=3, torch_gather=torch_gather)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, my)
+        if comm is not None:
+            comm.close()
+        gbz.close()
+        if rank != 0:
+            return None
+        slowest = max(r["loop_ms"] for r in everyone)
+        res.update({"workload": f"BASELINE config 4, {args.c4_size}: {gen['paths']} paths, {steps} LF-steps, P- and W-lines; rank r formats its block of path ids, text "
+                                f"gathered on rank 0 ({'gbwt_hip_gather_lines (C ABI, RCCL)' if comm is not None else 'torch.distributed: ' + str(why)})",
+                    "size": args.c4_size, "lf_steps": int(steps), "n_gpus": world, "open_ms_rank0": open_ms, "ranks": everyone, "ms_per_pass": slowest,
+                    "value": steps / (slowest * 1e-3), "value_incl_gather": steps / ((slowest + res["gather_ms"]) * 1e-3), "unit": "LF-steps/s", **gen})
+        return res
+    finally:
+        barrier()
+        if rank == 0:
+            c4_bench.cleanup(path)
 
 
 def launch_ranks(args):
@@ -356,6 +514,8 @@ def main():
             assert np.array_equal(index.copy_path(k), s.path(int(my_paths[k])))
 
     gather_info = None
+    other_cut = None
+    c4_sharded = None
     cold_ms = open_ms + first_pass_ms              # the one-shot flow of the slowest rank
     rank_kernel_ms = [float(np.mean(walk_ms))]
     if dist is not None:
@@ -368,93 +528,33 @@ def main():
         per_rank = torch.zeros(world, dtype=torch.float64, device=comm_device)
         dist.all_gather_into_tensor(per_rank, torch.tensor([float(np.mean(walk_ms))], dtype=torch.float64, device=comm_device))
         rank_kernel_ms = [float(x) for x in per_rank.cpu().tolist()]
-        # The one exchange of the job (outside the timed region, src/bin/gbunzip.rs:421-434: the writer's mutex): the extracted rows
-        # travel to rank 0 over RCCL point-to-point sends, one group (gbwt_rs_amd/dist.py), every peer over its own xGMI link.
-        # Strong scaling: the WHOLE CSR of the rank's shard (rows + lengths; 13.3 GB / N per rank); weak scaling (every rank a
-        # contig of its own, N x 13.3 GB in all): the W-lines of a bounded sample of paths, formatted on the device.
-        try:
-            from gbwt_rs_amd import dist as D
-            device = torch.device("cuda", local_rank)
-            if strong:
-                # through the C ABI (gbwt_hip_comm_*: RCCL called by the library, rows placed in path order by kernels on rank 0); the
-                # torch.distributed form is the fallback (and what the gloo rehearsal on one shared GPU takes), reported as such
-                via, comm = "gbwt_hip_comm (C ABI, RCCL)", None
-                try:
-                    if comm_device != "cuda":
-                        raise RuntimeError("not an RCCL run")
-                    comm = D.Comm(rank, world, local_rank)
-                    layout = D.GATHER_PARTS if by_parts else D.GATHER_INTERLEAVED
-                    comm.gather_rows(index, root=0, layout=layout)          # untimed: connections, buffers
-                    barrier()
-                    tg = time.perf_counter()
-                    got = comm.gather_rows(index, root=0, layout=layout)
-                    barrier()
-                    gather_ms = (time.perf_counter() - tg) * 1e3
-                    gather_info = {"ms": gather_ms, "backend": backend, "via": via, "rank_stats": comm.last(),
-                                   "payload": "the whole CSR: node ids (u32) + row lengths of every rank's shard, gathered on rank 0 in path order"}
-                    if rank == 0:
-                        assert int(got.total) == int(all_steps) and int(got.n) == n_paths, (int(got.total), all_steps)
-                        g_off, g_nodes = D.paths_tensors(got, device)
-                        for p_id in list(range(min(world, n_paths))) + list(range(max(0, n_paths - world), n_paths)):   # first and last row of every rank
-                            row = g_nodes[int(g_off[p_id]):int(g_off[p_id + 1])].cpu().numpy().astype(np.uint32)
-                            assert np.array_equal(row, s.path(p_id)), f"row {p_id} changed on the way"
-                        gather_info["bytes"] = 4 * int(got.total) + 8 * n_paths
-                        gather_info["GB_per_s"] = gather_info["bytes"] / 1e9 / (gather_ms * 1e-3)
-                except Exception as first:
-                    if comm is not None:
-                        comm.close()
-                    offsets, nodes = D.paths_tensors(out, device)
-                    lengths = (offsets[1:] - offsets[:-1]).clone()
-                    payload = nodes.clone()                                     # (rows may be mapped from spread chunks: staged for the send)
-                    if comm_device == "cpu":
-                        lengths, payload = lengths.cpu(), payload.cpu()
-                    barrier()
-                    tg = time.perf_counter()
-                    len_parts, val_parts = D.gather_parts(lengths, payload, dst=0)
-                    barrier()
-                    gather_ms = (time.perf_counter() - tg) * 1e3
-                    gather_info = {"ms": gather_ms, "backend": backend, "via": "torch.distributed batch_isend_irecv (fallback: " + repr(first)[:200] + ")",
-                                   "payload": "the whole CSR: node ids (u32) + row lengths of every rank's shard, gathered on rank 0"}
-                    if rank == 0:
-                        got_n = sum(int(p.numel()) for p in val_parts)
-                        assert got_n == int(all_steps), (got_n, all_steps)
-                        if by_parts:                               # the stretches of every row, joined in rank order
-                            j_off, j_nodes = D.join_row_parts(len_parts, val_parts)
-                            for p_id in (0, n_paths // 2, n_paths - 1):
-                                row = j_nodes[int(j_off[p_id]):int(j_off[p_id + 1])].cpu().numpy().astype(np.uint32)
-                                assert np.array_equal(row, s.path(p_id)), f"row {p_id} changed on the way"
-                        for r in range(world if not by_parts else 0):   # first and last row of every rank's part against the generator
-                            paths_r = shard_paths(n_paths, r, world)
-                            ends = torch.cumsum(len_parts[r], 0)
-                            for k in (0, len(paths_r) - 1):
-                                lo = int(ends[k - 1]) if k else 0
-                                row = val_parts[r][lo:int(ends[k])].cpu().numpy().astype(np.uint32)
-                                assert np.array_equal(row, s.path(int(paths_r[k]))), f"row {k} of rank {r} changed on the way"
-                        gather_info["bytes"] = 4 * got_n + 8 * n_paths
-                        gather_info["GB_per_s"] = gather_info["bytes"] / 1e9 / (gather_ms * 1e-3)
-            else:
-                sample = np.arange(min(args.gather_paths, n_paths), dtype=np.uint64)
-                lines = index.path_lines_device(sample, 1)
-                line_off, text = D.lines_tensors(lines, device)
-                mine = text.clone()
-                if comm_device == "cpu":
-                    line_off, text = line_off.cpu(), text.cpu()
-                sizes = torch.tensor([float(text.numel())], dtype=torch.float64, device=comm_device)
-                dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
-                barrier()
-                tg = time.perf_counter()
-                g_off, g_text = D.gather_lines(line_off, text, dst=0)
-                if comm_device == "cuda":
-                    torch.cuda.synchronize()
-                gather_ms = (time.perf_counter() - tg) * 1e3
-                gather_info = {"ms": gather_ms, "bytes": int(sizes.item()), "payload": f"W-lines of {len(sample)} paths of every rank, formatted on the device",
-                               "backend": backend}
-                if rank == 0:
-                    assert g_text.numel() == int(sizes.item()) and int(g_off[1]) == mine.numel()
-                    assert torch.equal(g_text[:mine.numel()].to(mine.device), mine), "rank 0's own lines changed on the way"
-                    gather_info["GB_per_s"] = int(sizes.item()) / 1e9 / (gather_ms * 1e-3)
-        except Exception as e:  # never lose the measurement to the exchange that follows it
-            gather_info = {"error": repr(e)}
+        # The one exchange of the job (outside the timed region, src/bin/gbunzip.rs:421-434: the writer's mutex)
+        gather_info = final_gather(args, index, out, s, rank, world, local_rank, backend, comm_device, by_parts, strong, n_paths, all_steps, my_paths, barrier, dist, torch)
+        if strong:
+            # ... and the SAME batch under the other cut (north_star: "the path set shards ... across the 8 GPUs" = --shard paths; the default
+            # is --shard parts, every rank its stretch of every row): the same K timed passes between the same barriers
+            o_parts = 1 if by_parts else world
+            o_paths = shard_paths(n_paths, rank, world) if by_parts else np.arange(n_paths, dtype=np.uint64)
+            o_ids = 2 * o_paths
+            o_extract = (lambda: index.extract_device(o_ids)) if by_parts else (lambda: index.extract_part_device(o_ids, rank, o_parts))
+            for _ in range(args.warmup):
+                o_extract()
+            barrier()
+            t0 = time.perf_counter()
+            o_out, o_walk, _ = timed_passes(index, o_ids, args.steps, rank, o_parts)
+            barrier()
+            o_elapsed = time.perf_counter() - t0
+            t = torch.tensor([o_elapsed, float(np.mean(o_walk))], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            o_tot = torch.tensor([float(int(o_out.total))], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(o_tot, op=dist.ReduceOp.SUM)
+            assert float(o_tot.item()) == all_steps, "the two cuts of the batch do not hold the same LF-steps"
+            other_cut = {"shard": "paths" if by_parts else "parts", "value": all_steps * args.steps / float(t[0].item()), "ms_per_step": float(t[0].item()) / args.steps * 1e3,
+                         "slowest_kernel_ms": float(t[1].item()),
+                         "sharding": ("path p walked whole by rank p mod G (SURVEY 8e; north_star's partition)" if by_parts else
+                                      "every rank walks stretch r of EVERY path (gbwt_hip_extract_part_device)")}
+        if not (args.no_extras or args.no_config4):
+            c4_sharded = config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch)
     else:
         all_steps = float(steps_done)
 
@@ -511,9 +611,11 @@ def main():
                                                    "bytes a query must move in this layout: its nodes in, its state out, and per step one 64-byte record descriptor + "
                                                    "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)", kernel="k_search")
             if not args.no_config4:
-                extras["config4"] = config_roofline(K.config4(device=local_rank), "config4",
-                                                    "bytes moved by walk + format: node ids written by the walk, read by the sizing pass and by the formatter, "
-                                                    "+ the text written / wall time of the two requests (P-lines, W-lines), host side included")
+                c4_definition = ("bytes moved by walk + format: node ids written by the walk and read by the formatter + the text written "
+                                 "/ wall time of the two requests (P-lines, W-lines), host side included")
+                extras["config4"] = config_roofline(K.config4(device=local_rank, size=args.c4_size), "config4", c4_definition)
+                if args.c4_size == "full":
+                    extras["config4_small"] = config_roofline(K.config4_small(device=local_rank), "config4_small", c4_definition)
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/measure_round.sh -> profiles/*_hbm_traffic.json).  It is quoted only when those passes ran THIS build with
         # THESE knobs on THIS workload (fingerprint of the kernel sources + GBWT_HIP_* environment); a profile of another
@@ -617,6 +719,11 @@ def main():
             },
         }
         result.update(extras)
+        if world > 1:
+            result["shard"] = args.shard if strong else None
+            result["other_cut"] = other_cut          # the same batch under the other partition, same K passes: both on every N > 1 line
+            if c4_sharded is not None:
+                result["config4"] = c4_sharded       # BASELINE config 4 as named: sharded over the N GPUs, RCCL gather of the text
         if cpu is not None:
             result["cpu_baseline"] = cpu
         if gather_info is not None:

@@ -798,7 +798,7 @@ gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hi
     out->index_device_bytes = sum({&ix.data, &ix.starts, &ix.endmarker, &ix.desc, &ix.desc_raw, &ix.block_base, &ix.blocks, &ix.desc2, &ix.gblocks, &ix.tables,
                                    &ix.wtables, &ix.wtables_deep, &ix.seq_len, &ix.samples, &ix.sample_base, &ix.label_len, &ix.seg_of, &ix.seg_start,
                                    &ix.seg_name_off, &ix.seg_names, &ix.seg_seq_len, &ix.node_real, &ix.line_prefix[0], &ix.line_prefix[1], &ix.line_prefix[2],
-                                   &ix.line_prefix_off[0], &ix.line_prefix_off[1], &ix.line_prefix_off[2], &ix.line_fragment});
+                                   &ix.line_prefix_off[0], &ix.line_prefix_off[1], &ix.line_prefix_off[2], &ix.line_fragment, &ix.lc_chunk_first, &ix.lc_text, &ix.lc_path});
     // (the full-width two-step blocks: at open, or by the first request that needs them -- the atomic says when they are there)
     if (ix.dev.cblocks != nullptr || ix.lazy_cblocks.load(std::memory_order_acquire) != nullptr) out->index_device_bytes += ix.cblocks.bytes;
     const HostIndex &h = ix.host;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -228,6 +229,16 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceBuffer line_prefix[3], line_prefix_off[3], line_fragment;
     std::vector<char> host_line_prefix[3];
     std::vector<uint64_t> host_line_prefix_off[3];
+    // LINE CACHE (round 5, gfa.hip): what the GFA line of a path is made of -- the text bytes of its node tokens, chunk by chunk, and its
+    // summed label lengths (the W-line's end coordinate) -- is a property of the index, not of the request.  The first request that formats
+    // a path leaves them here; later requests of that path size and place its line without reading its node ids (the sizing pass was a
+    // fifth of a lines request: the node ids crossed HBM three times -- written by the walk, read to size the lines, read to format them).
+    // 8 bytes per 4 096 path positions + 16 per path.  Built on first use (line_cache_once); unusable (-1) without sequence lengths and
+    // for graphs with a node-to-segment translation.
+    mutable std::once_flag line_cache_once;
+    gbwt_hip::DeviceBuffer lc_chunk_first, lc_text, lc_path;    // u64[paths + 1]: first chunk of every path; u64 per chunk: W-token bytes of the path in front of it; u64[2] per path: {W-token bytes, summed label lengths}
+    std::unique_ptr<std::atomic<uint8_t>[]> lc_ready;             // per path: its entries are there (set by the request that wrote them, after its wait)
+    std::atomic<int> lc_state{0};                                  // 0 = not looked at, 1 = usable, -1 = not for this index
     std::vector<uint32_t> host_seq_len;   // host copy of seq_len (empty when the lengths are not known): sizes byte-bounded batches of a whole-file write
     gbwt_hip::DeviceIndex dev{};
     // The full-width two-step blocks (cblocks, as large as gblocks: 1.7 GB on the headline index) are only read by the loops for records
@@ -262,7 +273,12 @@ struct ExtractKnobs {
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
     uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
     unsigned copy_threads = 8;                                // GBWT_HIP_COPY_THREADS
-    int query_pipeline = 1;                                   // GBWT_HIP_QUERY_PIPELINE: 0 = large query batches in one piece over the workspace stream (rounds 1-4)
+    int query_pipeline = 0;                                   // GBWT_HIP_QUERY_PIPELINE: 0 = query batches in one piece over the workspace stream (default); 1 = large batches in chunks through the
+                                                              // copy lanes (upload / kernel / download of different chunks at once), 2 = one launch with both copies through the lanes,
+                                                              // 3 = only the copy back through them.  Measured (profiles/r05_query_call_sweep.txt, a million 10-node queries = 105 / 129 MB over
+                                                              // PCIe per call): alone in a process the chunks win on the bidirectional form (7.2 -> 3.0 ms) and tie on the other (3.1 ms),
+                                                              // inside bench.py's process they lose on both (3.1 -> 4.1, 5.8 -> 10.6 ms): the call is bound by PCIe and by the host's
+                                                              // memcpy threads, not by the 0.5 ms kernel -- so one piece stays the default and the device-resident forms are the fast path
     size_t query_piece = size_t(2) << 20;                     // GBWT_HIP_QUERY_PIECE_KIB: bytes of a piece of the copy lanes in a query call
     static ExtractKnobs from_env() {
         ExtractKnobs k;
@@ -283,7 +299,7 @@ struct ExtractKnobs {
         k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;
         k.debug = static_cast<uint32_t>(num("GBWT_HIP_DEBUG_DRY_ROWS", 0));
         k.copy_threads = static_cast<unsigned>(std::min(64, std::max(1, num("GBWT_HIP_COPY_THREADS", 8))));
-        k.query_pipeline = num("GBWT_HIP_QUERY_PIPELINE", 1);
+        k.query_pipeline = num("GBWT_HIP_QUERY_PIPELINE", 0);
         k.query_piece = static_cast<size_t>(std::max(4, num("GBWT_HIP_QUERY_PIECE_KIB", 2048))) << 10;
         return k;
     }

@@ -154,6 +154,40 @@ __global__ void __launch_bounds__(256) k_line_sizes(const uint64_t *seq_ids, con
     if (valid) valid[p] = ok ? 1 : 0;
 }
 
+// The line cache of the index as the kernels see it (gbwt_hip_index::lc_*): per path its first chunk, per chunk the W-line token bytes of
+// the path in front of the chunk, per path {its W-line token bytes, its summed label lengths}.  A W-line token is '>' + digits, a P-line
+// token digits + '+' and a ',' in front of all but the first: the P-line text in front of chunk k is the W-line text + cache_p_extra(k).
+struct LineCache { const uint64_t *chunk_first; uint64_t *text; uint64_t *path; };
+
+__host__ __device__ __forceinline__ uint64_t cache_p_extra(uint64_t k_chunk) { return k_chunk == 0 ? 0 : k_chunk * LINE_CHUNK - 1; }
+
+// What a sizing pass has found goes into the cache (the epilogue of a request that had to size its lines): one thread per chunk.
+__global__ void __launch_bounds__(256) k_fill_line_cache(const uint64_t *offsets, const uint64_t *seq_ids, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
+                                                          uint64_t chunks_cap, const uint64_t *text_before, const uint64_t *seq_before, int p_lines, LineCache cache) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (c >= chunks_cap || c >= chunk_first[n]) return;
+    const uint64_t row = chunk_path[c], path = seq_ids[row] >> 1, a = chunk_first[row], k = c - a;
+    cache.text[cache.chunk_first[path] + k] = text_before[c] - text_before[a] - (p_lines ? cache_p_extra(k) : 0);
+    if (k == 0) {
+        const uint64_t b = chunk_first[row + 1], len = offsets[row + 1] - offsets[row];
+        cache.path[2 * path] = text_before[b] - text_before[a] - (p_lines && len != 0 ? len - 1 : 0);
+        cache.path[2 * path + 1] = seq_before[b] - seq_before[a];
+    }
+}
+
+// Line lengths and end coordinates from the cache: no node id is read.
+__global__ void __launch_bounds__(256) k_line_sizes_cached(const uint64_t *offsets, const uint64_t *seq_ids, uint64_t n, LineCache cache, LineHeaders hdr, int p_lines,
+                                                            uint64_t *line_len, uint64_t *line_end) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t path = seq_ids[p] >> 1, len = offsets[p + 1] - offsets[p];
+    const uint64_t text = cache.path[2 * path] + (p_lines && len != 0 ? len - 1 : 0), labels = cache.path[2 * path + 1];
+    uint64_t header = hdr.prefix_off[path + 1] - hdr.prefix_off[path], end = 0;
+    if (hdr.fragment) { end = hdr.fragment[path] + labels; header += decimal_digits64(end) + 1; }
+    line_end[p] = end;
+    line_len[p] = header + text + (p_lines ? 3u : 1u);
+}
+
 // The header of a line, written by the workgroup of its first chunk; every chunk needs its length.
 __device__ __forceinline__ uint64_t line_header(const LineHeaders &hdr, uint64_t path, const uint64_t *line_end, uint64_t row, bool write, uint8_t *line, uint32_t t,
                                                 uint32_t threads) {
@@ -177,7 +211,7 @@ constexpr uint32_t TOKEN_MAX = 12;   // ',' + ten digits + '+' (P-lines); '>' + 
 constexpr uint32_t PER_THREAD = 4;   // consecutive positions per thread and batch (one scan and two barriers per 1 024 positions)
 __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
                                                                    const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint64_t *seq_ids,
-                                                                   LineHeaders hdr, const uint64_t *line_end, uint8_t *out) {
+                                                                   LineHeaders hdr, const uint64_t *line_end, uint8_t *out, LineCache cache) {
     using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
     __shared__ __attribute__((aligned(16))) uint8_t stage[FORMAT_THREADS * PER_THREAD * TOKEN_MAX + 32];
@@ -185,8 +219,12 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t
     const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, blockIdx.x);
     const uint32_t t = threadIdx.x;
     uint8_t *line = out + line_start[r.path];
-    const uint64_t header_len = line_header(hdr, seq_ids[r.path] >> 1, line_end, r.path, r.first, line, t, FORMAT_THREADS);
-    uint64_t cursor = header_len + (text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    const uint64_t path = seq_ids[r.path] >> 1;
+    const uint64_t header_len = line_header(hdr, path, line_end, r.path, r.first, line, t, FORMAT_THREADS);
+    // where the chunk's tokens start inside the line: from the scan of this request's sizing pass, or from the line cache of the index
+    const uint64_t k_chunk = blockIdx.x - chunk_first[r.path];
+    uint64_t cursor = header_len + (cache.text ? cache.text[cache.chunk_first[path] + k_chunk] + (p_lines ? cache_p_extra(k_chunk) : 0)
+                                               : text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
     uint32_t ahead[PER_THREAD];                                        // the node ids of the next batch are asked for before this one is put together
 #pragma unroll
     for (uint32_t i = 0; i < PER_THREAD; i++) { const uint64_t k = r.lo + PER_THREAD * t + i; ahead[i] = k < r.hi ? nodes[k] : 0u; }
@@ -544,6 +582,38 @@ void upload_label_lengths(gbwt_hip_index &ix) {
 
 }  // namespace gbwt_hip
 
+// The line cache of a handle, made on first use (gbwt_hip_index::lc_*): usable when the sequence lengths are known (they say how many
+// chunks a path has) and the graph has no node-to-segment translation (tokens are then segment names, sized by other rules).
+static bool ensure_line_cache(const gbwt_hip_index *index) {
+    gbwt_hip_index *ix = const_cast<gbwt_hip_index *>(index);          // the lazily built part of an otherwise immutable handle
+    std::call_once(ix->line_cache_once, [ix]() {
+        const HostIndex &h = ix->host;
+        const uint64_t paths = h.path_names.size();
+        const bool translated = h.has_translation && !h.segment_starts.empty();
+        const char *off = std::getenv("GBWT_HIP_LINE_CACHE");
+        if (translated || paths == 0 || ix->host_seq_len.size() < 2 * paths || (off && std::atoi(off) == 0)) { ix->lc_state.store(-1); return; }
+        try {
+            HIP_CHECK(hipSetDevice(ix->device));
+            std::vector<uint64_t> first(paths + 1, 0);
+            for (uint64_t p = 0; p < paths; p++) {
+                const uint64_t len = ix->host_seq_len[2 * p];              // the forward sequence of path p (support::encode_path)
+                first[p + 1] = first[p] + (len == 0 ? 1 : (len + LINE_CHUNK - 1) / LINE_CHUNK);
+            }
+            ix->lc_chunk_first.reserve((paths + 1) * sizeof(uint64_t));
+            ix->lc_text.reserve(std::max<uint64_t>(first[paths], 1) * sizeof(uint64_t));
+            ix->lc_path.reserve(2 * paths * sizeof(uint64_t));
+            HIP_CHECK(hipMemcpy(ix->lc_chunk_first.ptr, first.data(), (paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+            ix->lc_ready.reset(new std::atomic<uint8_t>[paths]);
+            for (uint64_t p = 0; p < paths; p++) ix->lc_ready[p].store(0, std::memory_order_relaxed);
+            ix->lc_state.store(1, std::memory_order_release);
+        } catch (...) {
+            (void)hipGetLastError();
+            ix->lc_state.store(-1);
+        }
+    });
+    return ix->lc_state.load(std::memory_order_acquire) == 1;
+}
+
 // The lines of a batch of paths, formatted ONCE into device memory (the text buffer of `slot`: ws->gfa_text or gfa_text2; line k at
 // [line_start[k], line_start[k + 1]), offsets also on the device in ws->gfa_b).  The request is remembered in the workspace: the fill call that
 // follows a size query, and the copy-out of gbwt_hip_path_lines after gbwt_hip_path_lines_device, find the text there.
@@ -602,23 +672,35 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         uint32_t *d_chunk_path = reinterpret_cast<uint32_t *>(d_bad_before + (chunks_cap + 1));
         uint8_t *d_valid = translated ? ws->gfa_valid.as<uint8_t>() : nullptr;
         const LineHeaders hdr{ix->line_prefix[mode].as<uint8_t>(), ix->line_prefix_off[mode].as<uint64_t>(), mode == 1 ? ix->line_fragment.as<uint32_t>() : nullptr};
+        // the line cache of the index: when it holds every path of the request, nothing below reads a node id before the formatter does
+        const bool have_cache = !translated && ensure_line_cache(ix);
+        bool all_cached = have_cache;
+        for (uint64_t k = 0; k < n && all_cached; k++) all_cached = ix->lc_ready[path_ids[k]].load(std::memory_order_acquire) != 0;
+        const LineCache cache{ix->lc_chunk_first.as<uint64_t>(), ix->lc_text.as<uint64_t>(), ix->lc_path.as<uint64_t>()};
         hipLaunchKernelGGL(k_chunk_counts, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_counts);
         launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb, s);
         hipLaunchKernelGGL(k_chunk_paths, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, d_chunk_first, n, chunks_cap, d_chunk_path);
         const unsigned stat_blocks = static_cast<unsigned>((chunks_cap + 3) / 4);
-        if (translated) {
-            hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
-                               segment_tables(ix), p_lines, d_chunk_text, d_chunk_seq, d_chunk_bad);
-            launch_scan(d_chunk_bad, d_bad_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+        if (all_cached) {
+            hipLaunchKernelGGL(k_line_sizes_cached, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, d_seq_ids, n, cache, hdr, p_lines, d_line_len, d_line_end);
         } else {
-            hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
-                               ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
-                               static_cast<uint32_t>(h.alphabet_offset + 1), p_lines, d_chunk_text, d_chunk_seq);
+            if (translated) {
+                hipLaunchKernelGGL(k_chunk_stats_segments, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
+                                   segment_tables(ix), p_lines, d_chunk_text, d_chunk_seq, d_chunk_bad);
+                launch_scan(d_chunk_bad, d_bad_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+            } else {
+                hipLaunchKernelGGL(k_chunk_stats, dim3(stat_blocks), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
+                                   ix->label_len.as<uint32_t>(), static_cast<uint64_t>(h.sequences_labels.size()),
+                                   static_cast<uint32_t>(h.alphabet_offset + 1), p_lines, d_chunk_text, d_chunk_seq);
+            }
+            launch_scan(d_chunk_text, d_text_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+            launch_scan(d_chunk_seq, d_seq_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+            hipLaunchKernelGGL(k_line_sizes, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_seq_ids, d_chunk_first, n, d_text_before, d_seq_before,
+                               translated ? d_bad_before : nullptr, hdr, p_lines, d_line_len, d_line_end, d_valid);
+            if (have_cache)
+                hipLaunchKernelGGL(k_fill_line_cache, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, paths.d_offsets, d_seq_ids, n, d_chunk_first, d_chunk_path,
+                                   chunks_cap, d_text_before, d_seq_before, p_lines, cache);
         }
-        launch_scan(d_chunk_text, d_text_before, chunks_cap, ws->scan_temp.ptr, tb, s);
-        launch_scan(d_chunk_seq, d_seq_before, chunks_cap, ws->scan_temp.ptr, tb, s);
-        hipLaunchKernelGGL(k_line_sizes, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_seq_ids, d_chunk_first, n, d_text_before, d_seq_before,
-                           translated ? d_bad_before : nullptr, hdr, p_lines, d_line_len, d_line_end, d_valid);
         launch_scan(d_line_len, d_line_start, n, ws->scan_temp.ptr, tb, s);
         uint64_t total = 0;
         std::vector<uint8_t> valid;
@@ -669,13 +751,16 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
                                d_chunk_first, d_chunk_path, d_text_before, segment_tables(ix), p_lines, d_valid, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
         else
             hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_chunk_path, d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
+                               d_chunk_first, d_chunk_path, d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>(),
+                               all_cached ? cache : LineCache{nullptr, nullptr, nullptr});
         HIP_CHECK(hipGetLastError());
         for (uint64_t k = 0; k < host_lines.size(); k++)
             if (!valid[k] && !host_lines[k].empty())
                 HIP_CHECK(hipMemcpyAsync(text.as<char>() + line_start[k], host_lines[k].data(), host_lines[k].size(), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(ws->gev[1], s));
         HIP_CHECK(hipStreamSynchronize(s));   // the text is there when the call returns (and host_lines / line_start go out of scope)
+        // what the sizing pass of this request has left in the line cache is there now: later requests of these paths skip the pass
+        if (have_cache && !all_cached) for (uint64_t k = 0; k < n; k++) ix->lc_ready[path_ids[k]].store(1, std::memory_order_release);
         ws->lines_timed = true;
         ws->lines_total = total;
         ws->lines_key.assign(path_ids, path_ids + n);

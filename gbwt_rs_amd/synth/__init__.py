@@ -25,6 +25,10 @@ def lib():
         L.gbwt_synth_chain_indel.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32]
         L.gbwt_synth_chain_chopped.restype = p
         L.gbwt_synth_chain_chopped.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.gbwt_synth_chain_labeled.restype = p
+        L.gbwt_synth_chain_labeled.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.gbwt_synth_path_text_stats.restype = None
+        L.gbwt_synth_path_text_stats.argtypes = [p, u64, u64 * 3]
         L.gbwt_synth_from_paths.restype = p
         L.gbwt_synth_from_paths.argtypes = [p, p, u64, C.c_int]
         L.gbwt_synth_merge.restype = p
@@ -66,10 +70,11 @@ class Synth:
         self.bidirectional = bool(bd)
 
     @classmethod
-    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0, indel_every=1, chop=1):
+    def chain(cls, sites, haplotypes, alleles=2, model=MOSAIC, founders=32, switch_rate=2e-3, zipf=1.2, seed=42, extra=0, indel_every=1, chop=1, labels=0):
         """`extra` > 0: alleles >= 1 are insertions of `extra` more nodes at every `indel_every`-th site (paths of
-        different lengths); `chop` > 1: every node is a chain of that many nodes with consecutive ids (gbwt_synth.h)."""
-        h = lib().gbwt_synth_chain_chopped(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every, chop)
+        different lengths); `chop` > 1: every node is a chain of that many nodes with consecutive ids; `labels` = 1: node labels of
+        realistic lengths, 1 .. 1 024 bp, instead of one base each (gbwt_synth.h)."""
+        h = lib().gbwt_synth_chain_labeled(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every, chop, labels)
         if not h:
             raise ValueError("gbwt_synth_chain: parameters out of range")
         return cls(h)
@@ -97,30 +102,44 @@ class Synth:
         return merged
 
     @classmethod
-    def genome(cls, contigs=24, fragments=3, haplotypes=12, sites=60, seed=1, extra=1, generic_per_contig=1):
+    def genome(cls, contigs=24, fragments=3, haplotypes=12, sites=60, seed=1, extra=1, generic_per_contig=1, labels=0, min_walkers=0.5, threads=1,
+               wrap_contig=None):
         """Config C4's shape at any scale: `contigs` contigs, each cut into `fragments` graph components that a random
-        subset of the `haplotypes` haplotypes (sample s<h/2>, phase h%2+1) walks -- one ragged walk per (haplotype, component),
-        with the fragment field = where the walk starts on its haplotype (the running sum of the earlier fragments plus gaps) -- and
-        `generic_per_contig` reference paths (sample _gbwt_ref) in the first component of every contig."""
+        subset of the `haplotypes` haplotypes (at least `min_walkers` of them; sample s<h/2>, phase h%2+1) walks -- one ragged walk per
+        (haplotype, component), with the fragment field = where the walk starts on its haplotype (the running sum of the earlier fragments
+        plus gaps) -- and `generic_per_contig` reference paths (sample _gbwt_ref) in the first component of every contig.  `labels` = 1:
+        node labels of realistic lengths (chain()).  `wrap_contig` = c: the walks of contig c start just below 2^32, so that the end
+        coordinates of its W-lines (fragment + summed label lengths) pass 2^32 while the fragment fields still fit their 32 bits.
+        `threads`: the components are generated side by side (the result does not depend on it)."""
         import random
+        from concurrent.futures import ThreadPoolExecutor
         rng = random.Random(seed)
-        parts, names = [], []
+        jobs, names = [], []
         n_samples = (haplotypes + 1) // 2
         for c in range(contigs):
             at = [rng.randrange(0, 1000) for _ in range(haplotypes)]         # where every haplotype is on this contig
             for f in range(fragments):
                 generic = generic_per_contig if f == 0 else 0
-                walkers = sorted(rng.sample(range(haplotypes), rng.randint(max(1, haplotypes // 2), haplotypes)))
+                walkers = sorted(rng.sample(range(haplotypes), rng.randint(max(1, int(haplotypes * min_walkers)), haplotypes)))
                 n_sites = max(2, int(sites * rng.uniform(0.5, 2.0)))
-                part = cls.chain(sites=n_sites, haplotypes=generic + len(walkers), alleles=2, model=MOSAIC, founders=max(2, min(8, len(walkers))),
-                                 switch_rate=0.02, seed=rng.randrange(1 << 30), extra=extra if (c + f) % 2 else 0, indel_every=3)
-                parts.append(part)
+                jobs.append(dict(sites=n_sites, haplotypes=generic + len(walkers), alleles=2, model=MOSAIC, founders=max(2, min(8, len(walkers))),
+                                 switch_rate=0.02, seed=rng.randrange(1 << 30), extra=extra if (c + f) % 2 else 0, indel_every=3, labels=labels))
                 names += [(n_samples, c, 0, 0)] * generic
                 for h in walkers:
-                    names.append((h // 2, c, h % 2 + 1, at[h]))
+                    start = at[h]
+                    if wrap_contig == c:                                     # the last component's walks start within a thousand bases of 2^32
+                        start = (1 << 32) - 1 - (fragments - 1 - f) * 200000000 - at[h] % 1000
+                    names.append((h // 2, c, h % 2 + 1, start))
                     at[h] += 3 * n_sites + rng.randrange(0, 500)
+        if threads > 1:
+            with ThreadPoolExecutor(threads) as pool:
+                parts = list(pool.map(lambda kw: cls.chain(**kw), jobs))
+        else:
+            parts = [cls.chain(**kw) for kw in jobs]
         samples = [f"s{k}" for k in range(n_samples)] + ["_gbwt_ref"]
-        return cls.merge(parts, names, samples, [f"chr{c + 1}" for c in range(contigs)], haplotypes)
+        merged = cls.merge(parts, names, samples, [f"chr{c + 1}" for c in range(contigs)], haplotypes)
+        merged.sample_names = samples
+        return merged
 
     @classmethod
     def from_file(cls, path):
@@ -169,6 +188,12 @@ class Synth:
         out = np.zeros(max(1, n), dtype=np.uint32)
         self._L.gbwt_synth_path(self._h, path_id, out.ctypes.data, n)
         return out[:n]
+
+    def path_text_stats(self, path_id):
+        """(nodes, decimal digits of the node ids, summed label lengths) of a path: what its GFA line is made of (gbwt_synth.h)."""
+        out = (C.c_uint64 * 3)()
+        self._L.gbwt_synth_path_text_stats(self._h, path_id, out)
+        return int(out[0]), int(out[1]), int(out[2])
 
     def path_checksum(self, path_id):
         return int(self._L.gbwt_synth_path_checksum(self._h, path_id))

@@ -49,6 +49,13 @@ gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t
 gbwt_synth *gbwt_synth_chain_chopped(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                                      double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every, uint32_t chop);
 
+/* ... and with node labels of realistic lengths (label_mode 1; 0 = the 1 bp labels of the functions above): anchors 1 + Exp(40) bp, one in
+ * twelve a full 1 024 bp piece; alleles 85 % single bases, else 1 + Exp(6); inserted nodes 1 + Exp(20); all capped at 1 024, seeded -- so
+ * that the end coordinate of a W-line (fragment + summed label lengths, src/bin/gbunzip.rs:532-540) and the S-lines are those of a real
+ * graph, not of a one-base-per-node stand-in. */
+gbwt_synth *gbwt_synth_chain_labeled(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                                     double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every, uint32_t chop, uint32_t label_mode);
+
 /* Paths as CSR over GBWT-encoded nodes (2 * id + orientation, id >= 1).  bidirectional != 0 adds the
  * reverse sequence of every path (src/support.rs:310-314).  No metadata, no graph. */
 gbwt_synth *gbwt_synth_from_paths(const uint64_t *offsets, const uint64_t *nodes, uint64_t n_paths, int bidirectional);
@@ -81,6 +88,9 @@ int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz);
 /* Ground truth of chain generators: GBWT-encoded nodes of path `path_id` (forward orientation).
  * Returns the path length; writes at most `cap` nodes. */
 uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, uint64_t cap);
+/* out = {nodes of the path, decimal digits of their node ids, summed lengths of their labels}: the ground truth of the path's GFA line
+ * (one token per node; a W-line ends at fragment + out[2]). */
+void gbwt_synth_path_text_stats(const gbwt_synth *s, uint64_t path_id, uint64_t out[3]);
 /* Sum over the path of its GBWT-encoded node values (cheap full-size checksum), computed from the allele matrix. */
 uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id);
 

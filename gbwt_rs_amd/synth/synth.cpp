@@ -82,6 +82,7 @@ struct gbwt_synth {
     uint64_t extra = 0;             // alleles >= 1 are insertions: `extra` more nodes behind the allele node ...
     uint64_t indel_every = 1;       // ... at the sites s with s % indel_every == 0 (the tail ids of the other sites stay unused)
     uint64_t chop = 1;              // every logical node (anchor, allele, inserted node) is a chain of `chop` nodes with consecutive ids
+    uint32_t label_mode = 0;        // 0: 1 bp labels; 1: labels of realistic lengths, 1 .. 1024 bp (gbwt_synth.h: gbwt_synth_chain_labeled)
     std::vector<uint64_t> bits;     // alleles == 2: site-major bit rows
     uint64_t row_words = 0;
     std::vector<uint16_t> choices;  // alleles > 2: site-major
@@ -388,7 +389,7 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     Rng rng(seed ^ 0xACDCACDCull);
     SiteStats st;
     uint64_t real = 0, visits = 0;
-    ix.sequences_labels.bytes.reserve(S * W);
+    ix.sequences_labels.bytes.reserve(g.label_mode == 0 ? S * W : S * W * 40);
     ix.sequences_labels.offsets.reserve(S * W + 1);
     const uint64_t K = g.chop;
     for (uint64_t s = 0; s < S; s++) {
@@ -404,7 +405,25 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
                 const uint64_t piece = q < K ? q : (q - K) % wide;
                 exists = a < A && st.cnt[a] != 0 && piece <= g.tails_at(s, a);
             }
-            if (exists) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
+            if (exists && g.label_mode == 0) { ix.sequences_labels.bytes.push_back("ACGT"[rng.next() >> 62]); real++; }
+            else if (exists) {
+                // lengths as a chopped minigraph-cactus graph has them: the stretches between variants are tens of bases, one in twelve a
+                // full 1 024 bp piece of a long segment; most alleles are single bases, the rest short indel alleles; inserted nodes
+                // a few dozen bases
+                const double u = rng.uniform();
+                uint64_t len;
+                if (k < K) len = u < 0.08 ? 1024 : 1 + static_cast<uint64_t>(-40.0 * std::log(1.0 - rng.uniform()));
+                else if ((k - K) < K || ((k - K - K) % (K * (1 + g.extra))) < K) len = u < 0.85 ? 1 : 1 + static_cast<uint64_t>(-6.0 * std::log(1.0 - rng.uniform()));
+                else len = 1 + static_cast<uint64_t>(-20.0 * std::log(1.0 - rng.uniform()));
+                len = std::min<uint64_t>(len, 1024);
+                uint64_t word = 0;
+                for (uint64_t i = 0; i < len; i++) {
+                    if ((i & 31) == 0) word = rng.next();
+                    ix.sequences_labels.bytes.push_back("ACGT"[word & 3]);
+                    word >>= 2;
+                }
+                real++;
+            }
             ix.sequences_labels.offsets.push_back(ix.sequences_labels.bytes.size());
         }
     }
@@ -503,9 +522,14 @@ gbwt_synth *gbwt_synth_chain_indel(uint64_t sites, uint64_t haplotypes, uint32_t
 
 gbwt_synth *gbwt_synth_chain_chopped(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
                                      double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every, uint32_t chop) {
-    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64 || indel_every == 0 || chop == 0 || chop > 64) return nullptr;
+    return gbwt_synth_chain_labeled(sites, haplotypes, alleles, model, founders, switch_rate, zipf, seed, extra, indel_every, chop, 0);
+}
+
+gbwt_synth *gbwt_synth_chain_labeled(uint64_t sites, uint64_t haplotypes, uint32_t alleles, uint32_t model, uint32_t founders,
+                                     double switch_rate, double zipf, uint64_t seed, uint32_t extra, uint32_t indel_every, uint32_t chop, uint32_t label_mode) {
+    if (sites == 0 || haplotypes == 0 || alleles < 2 || alleles > 60000 || extra > 64 || indel_every == 0 || chop == 0 || chop > 64 || label_mode > 1) return nullptr;
     gbwt_synth *g = new gbwt_synth;
-    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra; g->indel_every = indel_every; g->chop = chop;
+    g->sites = sites; g->haplotypes = haplotypes; g->alleles = alleles; g->extra = extra; g->indel_every = indel_every; g->chop = chop; g->label_mode = label_mode;
     if (alleles == 2) { g->row_words = (haplotypes + 63) / 64; g->bits.assign(sites * g->row_words, 0); }
     else g->choices.assign(sites * haplotypes, 0);
     draw_alleles(*g, model, founders, switch_rate, zipf, seed);
@@ -747,6 +771,36 @@ uint64_t gbwt_synth_path(const gbwt_synth *s, uint64_t path_id, uint32_t *out, u
     uint64_t a = s->path_offsets[path_id], b = s->path_offsets[path_id + 1];
     for (uint64_t k = a; k < b && k - a < cap; k++) out[k - a] = s->path_nodes[k];
     return b - a;
+}
+
+// nodes, decimal digits of their ids and summed label lengths of a path: what its GFA line is made of
+static void add_node_stats(const gbwt_synth *s, uint64_t id, uint64_t out[3]) {
+    out[0]++;
+    uint64_t digits = 1;
+    for (uint64_t v = id; v >= 10; v /= 10) digits++;
+    out[1] += digits;
+    const gbwt_hip::Strings &l = s->index.sequences_labels;
+    if (id >= 1 && id <= l.size()) out[2] += l.offsets[id] - l.offsets[id - 1];
+}
+
+void gbwt_synth_path_text_stats(const gbwt_synth *s, uint64_t path_id, uint64_t out[3]) {
+    out[0] = out[1] = out[2] = 0;
+    uint64_t part = 0, local = 0;
+    const gbwt_synth *chain = s;
+    uint64_t shift = 0;
+    if (merged_part(s, path_id, part, local)) { chain = &s->parts[part]; shift = s->part_shift[part]; path_id = local; }
+    if (chain->sites) {
+        if (path_id >= chain->haplotypes) return;
+        for (uint64_t site = 0; site < chain->sites; site++) {
+            const uint32_t a = chain->allele(site, path_id);
+            for (uint64_t i = 0; i < chain->chop; i++) add_node_stats(s, shift + chain->anchor_first(site) + i, out);
+            add_node_stats(s, shift + chain->allele_id(site, a), out);
+            for (uint64_t e = 0; e < chain->tails_at(site, a); e++) add_node_stats(s, shift + chain->tail_id(site, a, e), out);
+        }
+        return;
+    }
+    if (path_id + 1 >= s->path_offsets.size()) return;
+    for (uint64_t k = s->path_offsets[path_id]; k < s->path_offsets[path_id + 1]; k++) add_node_stats(s, s->path_nodes[k] / 2, out);
 }
 
 uint64_t gbwt_synth_path_checksum(const gbwt_synth *s, uint64_t path_id) {

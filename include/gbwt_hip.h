@@ -243,8 +243,8 @@ gbwt_hip_status gbwt_hip_bd_search(const gbwt_hip_index *index, gbwt_hip_workspa
 /* Device-resident forms (round 5): the queries are in HBM already (`d_queries`: n x len u64, a device pointer of the caller, read on the
  * workspace stream), the final states stay in HBM inside the workspace (valid until the next query call on it): d_states[n], d_valid[n].
  * What a pipeline that produces its queries on the GPU calls, and what separates the kernel from PCIe: a million 10-node queries are
- * 80 MB in and 25 MB out around a 0.5 ms kernel.  (The host forms above move large batches in chunks through the workspace's pinned copy
- * lanes, upload / kernel / download of different chunks at the same time.) */
+ * 80 MB in and 25 MB out around a 0.5 ms kernel: a host-pointer call is bound by PCIe (3 ms), whichever way the copies are staged
+ * (GBWT_HIP_QUERY_PIPELINE, profiles/r05_query_call_sweep.txt). */
 typedef struct { const gbwt_hip_state *d_states; const uint8_t *d_valid; uint64_t n; } gbwt_hip_states;
 typedef struct { const gbwt_hip_bd_state *d_states; const uint8_t *d_valid; uint64_t n; } gbwt_hip_bd_states;
 gbwt_hip_status gbwt_hip_search_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *d_queries, uint64_t n, uint64_t len,
@@ -335,9 +335,8 @@ gbwt_hip_status gbwt_hip_last_lines_ms(const gbwt_hip_workspace *ws, float *walk
 /* Free and total memory of a device in bytes (hipMemGetInfo): what the tests use to see that a workspace gives its rows back. */
 gbwt_hip_status gbwt_hip_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Kernel time (ms, HIP events on the workspace stream, host staging excluded) of the last navigation / search call
- * (start, forward, backward, find, extend, bd_*, search, bd_search and the *_device forms) on `ws`.  For a host-pointer call large enough
- * to be moved in chunks through the copy lanes it is the span of the whole pipeline on the device, copies included: use the *_device
- * forms to time the kernel alone. */
+ * (start, forward, backward, find, extend, bd_*, search, bd_search and the *_device forms) on `ws`.  (With GBWT_HIP_QUERY_PIPELINE=1 a large
+ * host-pointer call moves in chunks through the copy lanes and this is the span of the whole pipeline on the device, copies included.) */
 gbwt_hip_status gbwt_hip_last_query_ms(const gbwt_hip_workspace *ws, float *kernel_ms);
 
 #ifdef __cplusplus

@@ -214,3 +214,60 @@ def test_comm_failure_of_rank0_is_collective(monkeypatch):
     for t in threads:
         t.join(60)
     assert sorted(raised) == [(r, _lib.UNSUPPORTED) for r in range(world)]
+
+
+def _c4_worker(rank, world, port, path, out_dir):
+    """Config 4's partition over gloo (tools/c4_bench.py: run_sharded, with the oracle as the per-rank formatter): rank r formats the W-lines
+    of ITS block of the walks and the P-lines of its block of the generic paths; rank 0 must hold the bytes of one pass over all of them."""
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gbz = O.OracleGBZ(path)
+        generic = np.load(path + ".generic.npy")
+        walks = np.setdiff1d(np.arange(gbz.gbwt().sequences() // 2, dtype=np.uint64), generic)
+        for ids, mode in ((walks, 1), (generic, 0)):
+            lo, hi = D.shard_bounds(len(ids), rank, world)
+            lines = [gbz.path_lines([int(p)], mode) for p in ids[lo:hi]]
+            text = torch.frombuffer(bytearray(b"".join(lines)), dtype=torch.uint8) if lines else torch.empty(0, dtype=torch.uint8)
+            offsets = torch.zeros(len(lines) + 1, dtype=torch.int64)
+            if lines:
+                offsets[1:] = torch.cumsum(torch.tensor([len(x) for x in lines], dtype=torch.int64), 0)
+            g_off, g_text = D.gather_lines(offsets, text, dst=0)
+            if rank == 0:
+                alone = gbz.path_lines([int(p) for p in ids], mode)
+                assert hashlib.sha256(g_text.numpy().tobytes()).hexdigest() == hashlib.sha256(alone).hexdigest(), mode
+        if rank == 0:
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config4_partition_over_gloo(tmp_path, world):
+    """BASELINE config 4's N > 1 flow at rehearsal size ("tiny": 6 contigs x 4 components, labels of 1..1024 bp, one contig whose W-line
+    ends pass 2^32): walks dealt to ranks in blocks of path ids, lines gathered on rank 0, sha256 == one rank alone.  The generator's
+    ground truth of every line (header fields, end coordinate = fragment + summed label lengths, length) is checked against the oracle
+    first -- it is what the full-size GPU test trusts."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import c4_bench
+    path = str(tmp_path / "c4_tiny.gbz")
+    g = c4_bench.generate("tiny", path, threads=2)
+    oracle = O.OracleGBZ(path)
+    generic = set(g.generic_paths())
+    past = 0
+    for p in range(g.paths):
+        if p in generic:
+            continue
+        line = oracle.path_lines([p], 1)
+        sample, contig, phase, fragment = (int(x) for x in g.path_names[p])
+        nodes, digits, bp = g.path_text_stats(p)
+        header = f"W\t{g.sample_names[sample]}\t{phase}\tchr{contig + 1}\t{fragment}\t{fragment + bp}\t".encode()
+        assert line.startswith(header) and len(line) == len(header) + digits + nodes + 1, p
+        past += fragment + bp > 1 << 32
+    assert past > 0, "no W-line of the rehearsal ends past 2^32"
+    port = _free_port()
+    mp.spawn(_c4_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").exists()

@@ -196,6 +196,62 @@ def test_capi_gather_between_loopback_ranks(tmp_path):
     assert out.returncode == 0 and "LOOPBACK_OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
 
 
+CHILD_C4_LOOPBACK = r'''
+import os, sys, threading, faulthandler, json
+faulthandler.dump_traceback_later(400, exit=True)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch
+import gbwt_rs_amd as G
+from gbwt_rs_amd import dist as D
+import c4_bench
+path = os.path.join(TMP, "c4.gbz")
+g = c4_bench.generate(SIZE, path)
+generic = np.load(path + ".generic.npy")
+walks = np.setdiff1d(np.arange(g.paths, dtype=np.uint64), generic)
+results = {}
+
+def rank_main(rank, world, box, ready, barrier):
+    try:
+        def broadcast(raw):
+            if raw is not None:
+                box.append(raw); ready.set()
+            ready.wait()
+            return box[0]
+        gbz = G.GBZ.load(path, device=0)                     # every rank its own replica of the index, as one process per GPU has
+        comm = D.Comm(rank, world, 0, broadcast=broadcast)
+        res, my = c4_bench.run_sharded(gbz, generic, walks, rank, world, comm, barrier.wait, 0, passes=2)
+        results[(world, rank)] = (res, my)
+        comm.close(); gbz.close()
+    except BaseException:
+        import traceback
+        print("RANK FAILED", rank, world, traceback.format_exc(), file=sys.stderr, flush=True)
+        os._exit(3)
+
+for world in WORLDS:
+    box, ready, barrier = [], threading.Event(), threading.Barrier(world)
+    threads = [threading.Thread(target=rank_main, args=(r, world, box, ready, barrier), daemon=True) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(300)
+    if any(t.is_alive() for t in threads):
+        faulthandler.dump_traceback(all_threads=True)
+        os._exit(4)
+    root = results[(world, 0)][0]
+    assert root["check"] and root["text_bytes"] == sum(results[(world, r)][1]["text_bytes"] for r in range(world)) - root["p_text_bytes"], root
+    assert sum(results[(world, r)][1]["walks"] for r in range(world)) == len(walks)
+print("C4_LOOPBACK_OK", WORLDS, len(walks), json.dumps(results[(WORLDS[-1], 0)][0]), flush=True)
+'''
+
+
+def test_config4_sharded_between_loopback_ranks(tmp_path):
+    """BASELINE config 4's N > 1 flow exactly as bench.py --gpus N runs it (tools/c4_bench.py: run_sharded) -- rank r walks and formats ITS
+    block of path ids, gbwt_hip_gather_lines puts W- and P-lines in path order on rank 0, every gathered byte compared on the device with
+    rank 0 formatting alone -- for world sizes 8 and 3 on ONE GPU, the ranks being threads of one process over the loopback transport of
+    the test build (each with its own index replica, workspace and communicator).  What is left for real hardware is RCCL itself."""
+    script = f"ROOT = {ROOT!r}; SIZE = 'medium'; TMP = {str(tmp_path)!r}; WORLDS = (8, 3)\n" + CHILD_C4_LOOPBACK
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900, env=dict(os.environ, GBWT_HIP_COMM_LOOPBACK="1", GBWT_HIP_LIB=TEST_LIB))
+    assert out.returncode == 0 and "C4_LOOPBACK_OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
+
+
 def run_capi_ranks(world, sites, attempts, tmp, timeout, extra_env=None):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))

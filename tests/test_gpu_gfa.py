@@ -200,9 +200,9 @@ def test_whole_file_in_many_batches(tmp_path):
         assert out.read_bytes() == exp, mode
 
 
-def test_config_c4_full_size():
-    """Config 4 at the size bench.py's `config4` object is quoted on: Synth.genome 24 contigs x 20 components, 90 haplotypes -- 32 286
-    ragged walks, 0.50 G LF-steps, 4.5 GB of GFA.  The whole file through the pipelined writer (1 GiB batches, 64 MiB pieces), checked
+def test_config_c4_small_whole_file():
+    """Config 4's stand-in of rounds 3-4 (bench.py's `config4_small`): Synth.genome 24 contigs x 20 components, 90 haplotypes -- 32 286
+    ragged walks over one-base nodes, 0.50 G LF-steps, 4.5 GB of GFA.  The whole file through the pipelined writer (1 GiB batches, 64 MiB pieces), checked
     piece by piece:
       * H-, S-, L- and P-lines: byte-identical to the oracle's gbunzip restatement in ref-only mode (src/bin/gbunzip.rs:205-332);
       * the W-lines: identical to the text of ONE device request for all walks; a seeded sample of 2 048 of them byte-identical to the
@@ -258,6 +258,116 @@ def test_config_c4_full_size():
         for f in (path, out):
             if os.path.exists(f):
                 os.remove(f)
+
+
+def test_config_c4_full_size():
+    """BASELINE config 4 at the size SURVEY 8(d) states (tools/c4_bench.py: SIZES["full"], bench.py's `config4`): 24 contigs x 20 graph
+    components walked by 90 haplotypes = ~42 000 ragged walks over ~109 M node ids with labels of 1 .. 1 024 bp, 5.7 G LF-steps, 51 GB of
+    W-lines -- the walks of the last contig start just below 2^32, so their end coordinates (fragment + summed label lengths,
+    src/bin/gbunzip.rs:532-540) need more than 32 bits.
+      * the extraction: per-path checksums of ALL forward sequences against the generator, order-dependent hashes of a seeded sample
+        against the oracle's walk;
+      * ONE device request for all W-lines: EVERY line's length and header fields (sample, phase, contig, fragment, end) against the
+        generator's ground truth (path_text_stats, itself checked against the oracle in tests/test_dist_cpu.py);
+      * a seeded sample of 192 W-lines and all P-lines byte for byte against the oracle (path_to_w_line / write_p_line,
+        src/bin/gbunzip.rs:438-550);
+      * the whole file through the pipelined writer to /dev/shm: its size, and its P/W part against the device text at 96 seeded places
+        (H/S/L lines are compared with the oracle at the small size: test_config_c4_small_whole_file -- the same host code)."""
+    import sys
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from gbwt_rs_amd import dist as D
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import c4_bench
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path, out = os.path.join(tmp, "gbwt_c4_stated.gbz"), os.path.join(tmp, "gbwt_c4_stated.gfa")
+    cores = min(os.cpu_count() or 1, 64)
+    try:
+        g = c4_bench.generate("full", path)
+        assert g.paths > 40000 and g.alphabet_size // 2 > 85000000
+        dev, oracle = G.GBZ.load(path), O.OracleGBZ(path)
+        generic = np.array(g.generic_paths(), dtype=np.uint64)
+        walks = np.setdiff1d(np.arange(g.paths, dtype=np.uint64), generic)
+        with ThreadPoolExecutor(cores) as pool:
+            truth = np.array(list(pool.map(g.path_checksum, range(g.paths))), dtype=np.uint64)
+            stats = np.array(list(pool.map(g.path_text_stats, range(g.paths))), dtype=np.int64)      # nodes, digits, bp per path
+        # the extraction
+        ids = 2 * np.arange(g.paths, dtype=np.uint64)
+        res = dev.extract_device(ids)
+        assert int(res.total) == (g.size - g.sequences) // 2 == int(stats[:, 0].sum())
+        assert np.array_equal(dev.path_sums(len(ids)), truth)
+        hashes, lens = dev.path_hashes(len(ids)), np.diff(dev.last_offsets(len(ids)))
+        assert np.array_equal(lens, stats[:, 0].astype(np.uint64))
+        pick = np.sort(np.random.default_rng(4).choice(g.paths, 256, replace=False)).astype(np.uint64)
+        o_steps, o_lens, o_sums, o_hashes = oracle.gbwt().extract_checksums(2 * pick, cores)
+        assert np.array_equal(hashes[pick], o_hashes) and np.array_equal(lens[pick], o_lens) and np.array_equal(truth[pick], o_sums)
+        # one request for all W-lines: every line's length and header against the generator
+        lines = dev.path_lines_device(walks, 1)
+        device = torch.device("cuda", 0)
+        off, text = D.lines_tensors(lines, device)
+        assert int(lines.total) > 45 << 30 and off.numel() == len(walks) + 1
+        names = np.array([g.path_names[int(p)] for p in walks], dtype=np.int64)                      # sample, contig, phase, fragment
+        headers = [f"W\t{g.sample_names[s]}\t{ph}\tchr{c + 1}\t{f}\t{f + bp}\t".encode() for (s, c, ph, f), bp in zip(names, stats[walks.astype(np.int64), 2])]
+        assert sum(f + bp > 1 << 32 for (_, _, _, f), bp in zip(names, stats[walks.astype(np.int64), 2])) >= 64, "no end coordinate past 2^32"
+        want_len = np.array([len(h) for h in headers], dtype=np.int64) + stats[walks.astype(np.int64), 1] + stats[walks.astype(np.int64), 0] + 1
+        assert np.array_equal(np.diff(off.cpu().numpy()), want_len), "line lengths differ from the generator's ground truth"
+        heads = text[(off[:-1, None] + torch.arange(96, device=device)[None, :]).clamp_(max=text.numel() - 1)].cpu().numpy()
+        for k, h in enumerate(headers):
+            assert heads[k, :len(h)].tobytes() == h, (k, int(walks[k]))
+        host_off = off.cpu().numpy()
+        assert int(text[int(host_off[-1]) - 1]) == 10 and bool((text[(off[1:] - 1)] == 10).all())           # every line ends with a newline
+        # a seeded sample of W-lines and all P-lines against the oracle, byte for byte
+        for k in np.sort(np.random.default_rng(2025).choice(len(walks), 192, replace=False)):
+            got = text[int(host_off[k]):int(host_off[k + 1])].cpu().numpy().tobytes()
+            assert got == oracle.path_lines([int(walks[k])], 1), int(walks[k])
+        assert dev.another_workspace().path_lines(generic, 0) == oracle.path_lines([int(p) for p in generic], 0)
+        # the whole file (50 batches of 1 GiB through the writer), its P/W part against the single request at seeded places
+        p_text_len = len(dev.another_workspace().path_lines(generic, 0))
+        keep = text.clone()                                                                          # (the writer uses this workspace's text buffers)
+        dev.write_gfa(out)
+        size = os.path.getsize(out)
+        head_len = size - p_text_len - int(keep.numel())
+        assert head_len > 0
+        whole = np.memmap(out, dtype=np.uint8, mode="r")
+        assert bytes(whole[:2]) == b"H\t" and whole[head_len - 1] == 10 and bytes(whole[head_len:head_len + 2]) == b"P\t"
+        w_at = head_len + p_text_len
+        assert bytes(whole[w_at:w_at + 2]) == b"W\t" and whole[-1] == 10
+        gen = np.random.default_rng(7)
+        for lo in list(gen.integers(0, keep.numel() - (1 << 20), 94)) + [0, keep.numel() - (1 << 20)]:
+            assert np.array_equal(whole[w_at + int(lo):w_at + int(lo) + (1 << 20)], keep[int(lo):int(lo) + (1 << 20)].cpu().numpy()), int(lo)
+        del whole, keep
+        dev.close()
+    finally:
+        for f in (path, path + ".generic.npy", out):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+@pytest.mark.parametrize("fill_mode", [0, 1, 2])
+def test_line_cache_serves_every_mode(tmp_path, monkeypatch, fill_mode):
+    """The line cache of the index (round 5): the first request that formats a path leaves the sizes of its line there -- token bytes
+    chunk by chunk, summed label lengths -- and later requests of that path size and place its line without a sizing pass, in ANY line
+    mode (a P-line's text is the W-line's plus separators).  Lines of paths longer than one chunk, empty paths, duplicates and subsets in
+    another order: filled by one mode, asked for in all three, against the oracle and against a handle with the cache switched off."""
+    paths = [[2 * (1 + (7 * k + j) % 50) + ((k + j) % 3 == 0) for j in range(ln)] for k, ln in enumerate([0, 1, 9000, 4096, 4097, 12289, 5, 0, 8192, 300])]
+    s = S.Synth.from_paths(paths, bidirectional=True).attach_gbz(seed=3)
+    path = str(tmp_path / "cache.gbz")
+    s.save(path, as_gbz=True)
+    oracle = O.OracleGBZ(path)
+    dev = G.GBZ.load(path)
+    monkeypatch.setenv("GBWT_HIP_LINE_CACHE", "0")
+    plain = G.GBZ.load(path)
+    monkeypatch.delenv("GBWT_HIP_LINE_CACHE")
+    everything = list(range(len(paths)))
+    first = [2, 0, 5, 9]
+    assert dev.path_lines(first, fill_mode) == oracle.path_lines(first, fill_mode)               # fills the cache for these four
+    for mode in (0, 1, 2):
+        for ids in (first, [5, 5, 2], everything, everything[::-1], [7], [3, 2]):                    # cached, mixed (sized again, the rest filled), cached
+            got = dev.path_lines(ids, mode)
+            assert got == oracle.path_lines(ids, mode) == plain.path_lines(ids, mode), (fill_mode, mode, ids)
+    out = tmp_path / "whole.gfa"
+    dev.write_gfa(str(out))
+    assert out.read_bytes() == oracle.gfa()
 
 
 def test_bare_gbwt_has_no_gfa():

@@ -890,13 +890,14 @@ def test_config_c3_search_bit_exact(model, haplotypes):
 def test_large_query_batches_travel_in_chunks(monkeypatch):
     """Host-pointer query calls large enough for the chunk pipeline (round 5: chunks of ~2 MiB through the workspace's pinned copy lanes,
     upload / kernel / download of different chunks at once) -- every entry point of the navigation / search group, with a row count that
-    is not a multiple of the chunk: the same answers as one piece over the workspace stream (GBWT_HIP_QUERY_PIPELINE=0), as the
+    is not a multiple of the chunk: (GBWT_HIP_QUERY_PIPELINE=1) the same answers as one piece over the workspace stream (the default), as the
     device-resident forms, and (a seeded sample) as the oracle."""
     import torch
     s = S.Synth.chain(sites=2000, haplotypes=600, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=29)
     dev, oracle = open_synth(s), oracle_of(s)
-    monkeypatch.setenv("GBWT_HIP_QUERY_PIPELINE", "0")
-    plain = dev.another_workspace()
+    plain = dev.another_workspace()                        # (in one piece over the workspace stream: the default)
+    monkeypatch.setenv("GBWT_HIP_QUERY_PIPELINE", "1")
+    dev.new_workspace()                                    # chunks through the copy lanes
     monkeypatch.delenv("GBWT_HIP_QUERY_PIPELINE")
     gen = np.random.default_rng(12)
     n = 1300003

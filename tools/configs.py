@@ -6,7 +6,8 @@
   high_degree  BASELINE config 5: 300 alleles per site (outdegree >= 255: two-varint runs), walked on the deep walk tables
   search       BASELINE config 3: 1.1 M sites x 5 008 haplotypes, 1 M queries of 10 nodes as src/bin/benchmark.rs:124-169 builds
                them (seeded), find + 9 x extend in one launch and the bidirectional form
-  config4      BASELINE config 4's shape on one GPU (tools/c4_bench.py)
+  config4      BASELINE config 4 on one GPU at its stated size: ~42 000 walks over ~90 M nodes with labels of 1..1024 bp (tools/c4_bench.py)
+  config4_small  the stand-in of rounds 3-4 (32 286 walks over 16 M one-base nodes), with the whole file written
 
 Every object carries {workload, value, unit, kernel, kernel_ms, algorithmic_bytes}; bench.py adds the roofline fraction and the
 measured HBM traffic of a PMC profile taken with the same sources and knobs (profiles/*_hbm_traffic.json, key = the config's name).
@@ -113,26 +114,27 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
                        "extend_forward / extend_backward",
            "queries": int(n), "unit": "queries/s"}
     # the kernel alone: queries resident in HBM, states left in the workspace (gbwt_hip_search_device); the call as src/bin/benchmark.rs:161-164
-    # times it: host pointers in and out (gbwt_hip_search: chunks through the pinned copy lanes), and the same in one piece (rounds 1-4)
+    # times it: host pointers in and out (gbwt_hip_search: one piece over the workspace stream), and the same in chunks through the pinned
+    # copy lanes (GBWT_HIP_QUERY_PIPELINE=1: measured, not the default -- profiles/r05_query_call_sweep.txt)
     import torch
     d_q = torch.from_numpy(queries.view(np.int64)).cuda(device)
-    os.environ["GBWT_HIP_QUERY_PIPELINE"] = "0"
+    os.environ["GBWT_HIP_QUERY_PIPELINE"] = "1"
     try:
-        plain = dev.another_workspace()
+        chunked = dev.another_workspace()
     finally:
         del os.environ["GBWT_HIP_QUERY_PIPELINE"]
     forms = (("unidirectional", "k_search", lambda w: w.search(queries), lambda: dev.states_to_host(dev.search_device(d_q.data_ptr(), n, length))),
              ("bidirectional", "k_bd_search", lambda w: w.bd_search(queries, length // 2),
               lambda: dev.states_to_host(dev.bd_search_device(d_q.data_ptr(), n, length, length // 2), bidirectional=True)))
     for name, kernel, host_form, device_form in forms:
-        host_form(dev), host_form(plain), device_form()
+        host_form(dev), host_form(chunked), device_form()
         ks, ws, ws1 = [], [], []
         for _ in range(passes):
             t1 = time.perf_counter()
             out, ok = host_form(dev)
             ws.append((time.perf_counter() - t1) * 1e3)
             t1 = time.perf_counter()
-            out1, ok1 = host_form(plain)
+            out1, ok1 = host_form(chunked)
             ws1.append((time.perf_counter() - t1) * 1e3)
             out2, ok2 = device_form()
             ks.append(dev.last_query_ms())
@@ -145,13 +147,13 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
         # the record + two 16-byte rank blocks (range start and end)
         bytes_q = 8 * length + (24 if name == "unidirectional" else 48) + 1 + length * (64 + 2 * 16)
         pcie = n * (8 * length + (24 if name == "unidirectional" else 48) + 1)
-        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.median(ws)), "wall_ms_one_piece": float(np.median(ws1)), "value": n / (k * 1e-3),
+        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.median(ws)), "wall_ms_chunked": float(np.median(ws1)), "value": n / (k * 1e-3),
                      "value_call": n / (float(np.median(ws)) * 1e-3), "steps_per_s": n * length / (k * 1e-3), "ns_per_node_call": float(np.median(ws)) * 1e6 / (n * length),
                      "pcie_bytes_per_call": int(pcie), "pcie_GB_per_s": pcie / (float(np.median(ws)) * 1e-3) / 1e9,
                      "algorithmic_bytes": float(bytes_q * n), "found": int(ok.sum())}
         if name == "unidirectional":
             final_states, final_ok = out, ok
-    plain.close()
+    chunked.close()
     del d_q
     res["value_call"] = res["unidirectional"]["value_call"]
     res["value_note"] = ("value = queries / kernel time with the queries resident in HBM (gbwt_hip_search_device); value_call = queries / wall time of "
@@ -169,11 +171,13 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
     return res
 
 
-def config4(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0):
+def config4(passes=3, out="", device=0, size="full"):
+    """BASELINE config 4 on one GPU at the size SURVEY 8(d) states (tools/c4_bench.py: SIZES["full"]); size="small" is the stand-in of rounds
+    3-4 (bench.py's `config4_small`, with the whole file written to /dev/shm)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import c4_bench
     try:
-        res = c4_bench.run(passes=passes, out=out, device=device)
+        res = c4_bench.run(size=size, passes=passes, out=out, device=device)
     finally:
         if out and os.path.exists(out):
             os.remove(out)
@@ -183,8 +187,12 @@ def config4(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0):
     return res
 
 
+def config4_small(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0):
+    return config4(passes, out, device, size="small")
+
+
 if __name__ == "__main__":
     import json
     name = sys.argv[1]
-    fn = {"secondary": secondary, "high_degree": high_degree, "search": search, "config4": config4}[name]
+    fn = {"secondary": secondary, "high_degree": high_degree, "search": search, "config4": config4, "config4_small": config4_small}[name]
     print(json.dumps(fn()), flush=True)
