@@ -974,7 +974,7 @@ struct GfaWriter {
         cv.notify_all();
     }
     void run() {
-        if (const char *v = std::getenv("GBWT_HIP_GFA_WRITERS")) WRITERS = std::min(16, std::max(1, std::atoi(v)));
+        if (const char *v = std::getenv("GBWT_HIP_GFA_WRITERS")) WRITERS = std::min(64, std::max(1, std::atoi(v)));
         BUFFERS = WRITERS + 2;
         std::vector<void *> pinned(BUFFERS, nullptr);
         buffer_busy.assign(BUFFERS, 0);

@@ -222,7 +222,7 @@ def run_sharded(gbz, generic, walks, rank, world, comm, barrier, device, passes=
             assert sha_w == hashlib.sha256(a_txt[:head].cpu().numpy().tobytes()).hexdigest()
             alone.close()
         res = {"text_bytes": total_text, "gather_ms": gather_ms, "gather_GB_per_s": total_text / gather_ms / 1e6,
-               "check": None if not check else "gathered W-lines == rank 0 formatting all walks alone: every byte compared on the device, line offsets equal, "
+               "check": None if not check else "gathered W-lines == rank 0 formatting all walks alone: every byte compared on the device" + (", line offsets equal, " if comm is not None else ", ") +
                                                f"sha256 of the first {min(total_text, 64 << 20)} bytes {sha_w}"}
     p_off, p_txt, p_gather_ms, _ = gather(my_generic, 0)
     if rank == 0 and check:

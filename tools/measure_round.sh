@@ -2,7 +2,7 @@
 # of the bench, and the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of the headline kernel and of every other config.
 # usage: measure_round.sh TAG [quick]
 set -x
-R=$GRAFT_REPO_ROOT; T=${1:-r04}; O=$R/gpurun_out/$T; mkdir -p $O
+R=$GRAFT_REPO_ROOT; T=${1:-r05}; O=$R/gpurun_out/$T; mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err
@@ -15,10 +15,10 @@ cd $R
 python3 tools/hbm_traffic.py $O/fetch $O/write k_walk_direct "headline C5k (333334 sites x 5000 haplotypes, mosaic, seed 42)" 13333360000 > $O/hbm_traffic.json; head -30 $O/hbm_traffic.json
 find $O/stats -name "*kernel_stats.csv" -exec head -12 {} \; | cut -c1-200
 if [ "${2:-}" != "quick" ]; then
-  for C in secondary high_degree search config4; do
+  for C in secondary high_degree search config4 config4_small; do
     case $C in
       search) K=k_search,k_bd_search; P=max;;
-      config4) K=k_walk_direct,k_chunk_stats,k_format_chunks; P=max;;
+      config4|config4_small) K=k_walk_direct,k_chunk_stats,k_format_chunks; P=max;;
       *) K=k_walk_direct; P=last;;
     esac
     cd /tmp
@@ -37,6 +37,6 @@ find $O -name "*counter_collection.csv" -size +20M -delete
 if [ "${2:-}" != "quick" ]; then
   mkdir -p $R/profiles
   cp $O/hbm_traffic.json $R/profiles/${T}_hbm_traffic.json
-  for C in secondary high_degree search config4; do cp $O/${C}_hbm_traffic.json $R/profiles/${T}_${C}_hbm_traffic.json; done
+  for C in secondary high_degree search config4 config4_small; do cp $O/${C}_hbm_traffic.json $R/profiles/${T}_${C}_hbm_traffic.json; done
   timeout 1200 python bench.py > $O/bench_with_traffic.json 2> $O/bench_with_traffic.err; cut -c1-600 $O/bench_with_traffic.json
 fi
