@@ -153,6 +153,43 @@ def cpu_leg_search(seconds):
     return leg
 
 
+def cpu_leg_lines(seconds):
+    """cpu_baseline leg of config 4: the oracle's path_to_w_line (src/bin/gbunzip.rs:495-550: walk + format) over a bounded sample of the walks
+    on min(cores, 64) threads pulling path ids like gbunzip's rayon pool; every line compared byte for byte with the device's text."""
+    def leg(gbz_path, gbz, walks):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from gbwt_rs_amd import dist as D
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        threads = min(os.cpu_count() or 1, 64)
+        t0 = time.perf_counter()
+        oracle = O.OracleGBZ(gbz_path)
+        load_s = time.perf_counter() - t0
+        pick = np.sort(np.random.default_rng(11).choice(len(walks), min(len(walks), 4 * threads), replace=False))
+        with ThreadPoolExecutor(threads) as pool:
+            t0 = time.perf_counter()
+            lines = list(pool.map(lambda k: oracle.path_lines([int(walks[k])], 1), pick[:threads]))
+            rate = sum(len(x) for x in lines) / (time.perf_counter() - t0)                      # text bytes per second, all threads
+            want = int(max(threads, min(len(pick), seconds * rate / max(1, np.mean([len(x) for x in lines])))))
+            pick = pick[:want]
+            t0 = time.perf_counter()
+            lines = list(pool.map(lambda k: oracle.path_lines([int(walks[k])], 1), pick))
+            dt = time.perf_counter() - t0
+        device = torch.device("cuda", gbz._device)
+        got = gbz.path_lines_device(walks, 1)
+        off, text = D.lines_tensors(got, device)
+        off = off.cpu().numpy()
+        nodes = 0
+        for k, line in zip(pick, lines):
+            assert text[int(off[k]):int(off[k + 1])].cpu().numpy().tobytes() == line, f"W-line of walk {int(walks[k])} differs from the oracle's"
+            nodes += line.count(b">") + line.count(b"<")
+        return {"value": nodes / dt, "unit": "LF-steps/s", "text_GB_per_s": sum(len(x) for x in lines) / dt / 1e9, "cores": threads, "kind": "port",
+                "parity_checked_lines": int(len(pick)), "oracle_load_seconds": round(load_s, 1),
+                "sample": f"{len(pick)} of {len(walks)} W-lines ({nodes} LF-steps, {dt:.1f} s wall): walk + format per path as gbunzip's workers do, every line equal to the device's"}
+    return leg
+
+
 def algorithmic_bytes(index_path, n_paths, sample):
     """Exact algorithmic bytes W = sum(H + P + 4) over a sample of paths (untimed oracle pass)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -604,7 +641,8 @@ def main():
             # every config with its own bounded CPU leg (5 s of oracle each, compared with what the GPU returned) unless --no-cpu-baseline
             leg_x = None if args.no_cpu_baseline else cpu_leg_extraction(5.0)
             leg_s = None if args.no_cpu_baseline else cpu_leg_search(5.0)
-            extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank), "secondary", emitted)
+            leg_l = None if args.no_cpu_baseline else cpu_leg_lines(5.0)
+            extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank, cpu_leg=leg_x), "secondary", emitted)
             extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank, cpu_leg=leg_x), "high_degree", emitted)
             if not args.no_search:
                 extras["search"] = config_roofline(K.search(device=local_rank, cpu_leg=leg_s), "search",
@@ -613,7 +651,7 @@ def main():
             if not args.no_config4:
                 c4_definition = ("bytes moved by walk + format: node ids written by the walk and read by the formatter + the text written "
                                  "/ wall time of the two requests (P-lines, W-lines), host side included")
-                extras["config4"] = config_roofline(K.config4(device=local_rank, size=args.c4_size), "config4", c4_definition)
+                extras["config4"] = config_roofline(K.config4(device=local_rank, size=args.c4_size, cpu_leg=leg_l), "config4", c4_definition)
                 if args.c4_size == "full":
                     extras["config4_small"] = config_roofline(K.config4_small(device=local_rank), "config4_small", c4_definition)
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command

@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("GBWT_HIP_LIB") or os.path.join(CSRC, "libgbwt_hip.so")   # GBWT_HIP_LIB: A/B runs of two builds (tools/)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "gbwt_hip.h")
 
+OPEN_EXTRACT, OPEN_SEARCH, OPEN_GFA, OPEN_ALL = 1, 2, 4, 7     # gbwt_hip_open_*_flags
 OK, INVALID_DATA, IO_ERROR, BAD_ARGUMENT, NO_DEVICE, DEVICE_ERROR, CAPACITY, UNSUPPORTED = range(8)
 STATUS_NAMES = ["OK", "INVALID_DATA", "IO_ERROR", "BAD_ARGUMENT", "NO_DEVICE", "DEVICE_ERROR", "CAPACITY", "UNSUPPORTED"]
 
@@ -76,6 +77,8 @@ SIGNATURES = {
     "gbwt_hip_open_file": (_int, [C.c_char_p, _int, C.POINTER(_p)]),
     "gbwt_hip_parse_file": (_int, [C.c_char_p, C.POINTER(Stats)]),
     "gbwt_hip_open_records": (_int, [_p, _u64, _p, _u64, _u64, _u64, _u64, _u64, _int, _int, C.POINTER(_p)]),
+    "gbwt_hip_open_file_flags": (_int, [C.c_char_p, _int, C.c_uint32, C.POINTER(_p)]),
+    "gbwt_hip_open_records_flags": (_int, [_p, _u64, _p, _u64, _u64, _u64, _u64, _u64, _int, _int, C.c_uint32, C.POINTER(_p)]),
     "gbwt_hip_close": (None, [_p]),
     "gbwt_hip_get_stats": (_int, [_p, C.POINTER(Stats)]),
     "gbwt_hip_get_open_times": (_int, [_p, C.POINTER(OpenTimes)]),

@@ -83,20 +83,21 @@ class GBWT:
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
-    def load(cls, path, device=0):
-        """serialize::load_from::<GBWT | GBZ>(path) (src/gbwt.rs:402-438, src/gbz.rs:674-717)."""
+    def load(cls, path, device=0, flags=_lib.OPEN_ALL):
+        """serialize::load_from::<GBWT | GBZ>(path) (src/gbwt.rs:402-438, src/gbz.rs:674-717).  flags: what the handle is for
+        (_lib.OPEN_EXTRACT | OPEN_SEARCH | OPEN_GFA, gbwt_hip_open_file_flags): only those structures are built in HBM."""
         h = C.c_void_p()
-        check(_lib.lib().gbwt_hip_open_file(os.fsencode(path), device, C.byref(h)))
+        check(_lib.lib().gbwt_hip_open_file_flags(os.fsencode(path), device, flags, C.byref(h)))
         return cls(h, device=device)
 
     @classmethod
-    def from_records(cls, data, starts, alphabet_offset, alphabet_size, sequences, size, bidirectional=True, device=0):
+    def from_records(cls, data, starts, alphabet_offset, alphabet_size, sequences, size, bidirectional=True, device=0, flags=_lib.OPEN_ALL):
         """From the raw record stream of a bwt::BWT (compressed_record, src/bwt.rs:134-143) + header fields."""
         d = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         s = np.ascontiguousarray(starts, dtype=np.uint64)
         h = C.c_void_p()
-        check(_lib.lib().gbwt_hip_open_records(_ptr(d), d.size, _ptr(s), s.size, alphabet_offset, alphabet_size,
-                                               sequences, size, int(bidirectional), device, C.byref(h)))
+        check(_lib.lib().gbwt_hip_open_records_flags(_ptr(d), d.size, _ptr(s), s.size, alphabet_offset, alphabet_size,
+                                                     sequences, size, int(bidirectional), device, flags, C.byref(h)))
         return cls(h, device=device)
 
     def close(self):

@@ -233,7 +233,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
     uint64_t *d_stats = tmp.as<uint64_t>();
     {
         const uint64_t nr = std::max<uint64_t>(n_records, 1);
-        ix.desc.reserve(nr * 4 * sizeof(uint4));
+        if (ix.caps & GBWT_HIP_OPEN_EXTRACT) ix.desc.reserve(nr * 4 * sizeof(uint4));
         ix.desc_raw.reserve(nr * 4 * sizeof(uint4));
         ix.block_base.reserve(nr * sizeof(uint32_t));
         DeviceBuffer counts, scan_tmp;
@@ -265,8 +265,18 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         trace.mark("block scan + allocation");
         if (n_blocks > 1) launch_fill_blocks(d, counts.as<uint32_t>(), ix.block_base.as<uint32_t>(), ix.blocks.as<uint4>(), nullptr);
         trace.mark("k_fill_blocks");
-        launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
-        {
+        const bool for_extract = (ix.caps & GBWT_HIP_OPEN_EXTRACT) != 0;
+        uint64_t generic_count = n_records;
+        if (!for_extract) {
+            // a handle opened for SEARCH only: no walk descriptors, no two-step blocks (the statistics the passes below would have left are read here)
+            uint64_t early_stats[6] = {0, 0, 0, 0, 0, 0};
+            HIP_CHECK(hipMemcpy(early_stats, d_stats, sizeof(early_stats), hipMemcpyDeviceToHost));
+            generic_count = early_stats[4];
+            d.desc = nullptr; d.desc2 = nullptr; d.gblocks = nullptr; d.cblocks = nullptr;
+            ix.packed_blocks = false;
+        }
+        if (for_extract) launch_link_desc(d, ix.desc.as<uint4>(), nullptr);
+        if (for_extract) {
             uint32_t hops = 15;   // LF steps between a walk and its look-ahead target (7 until the packed blocks and the spread rows: fresh processes,
                                   // 7 / 11 / 15 / 23 hops = 4.40-4.44 / 4.30-4.33 / 4.27-4.28 / 4.29-4.30 ms; profiles/r02_walk_bounds.txt #26)
             if (const char *v = std::getenv("GBWT_HIP_LOOKAHEAD_HOPS")) hops = static_cast<uint32_t>(std::max(0, std::atoi(v)));
@@ -304,6 +314,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
                                        static_cast<unsigned long long>(early_stats[5] >> 32), static_cast<unsigned long long>(n_records), d.chained);
             const uint64_t longest = early_stats[0];
             generic_records = early_stats[4];
+            generic_count = generic_records;
             const bool full_width_now = gather_limit == 0 || longest >= gather_limit;
             if (full_width_now) {
                 ix.cblocks.reserve(n_blocks * 2 * sizeof(uint4));
@@ -318,6 +329,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         d.tables = nullptr;
         d.wtables = nullptr;
         d.wtables_deep = nullptr;
+        if (!for_extract) generic_records = generic_count;
         if (n_records > 0 && generic_records > 0) {
             DeviceBuffer positions, sigmas, table_base, edge_base, edges;
             positions.reserve(n_records * sizeof(uint64_t)); sigmas.reserve(n_records * sizeof(uint64_t));
@@ -349,7 +361,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
                 HIP_CHECK(hipGetLastError());
                 // walk tables next to them while both fit (GBWT_HIP_WALK_TABLES=0: walks take one plain table step at a time)
                 const char *wt = std::getenv("GBWT_HIP_WALK_TABLES");
-                if (2 * total_positions * sizeof(uint4) <= budget && n_records <= 0x7FFFFFFFull && !(wt && std::atoi(wt) == 0)) {
+                if (for_extract && 2 * total_positions * sizeof(uint4) <= budget && n_records <= 0x7FFFFFFFull && !(wt && std::atoi(wt) == 0)) {
                     ix.wtables.reserve(total_positions * sizeof(uint4));
                     launch_fill_wtables(d, ix.wtables.as<uint4>(), nullptr);
                     HIP_CHECK(hipDeviceSynchronize());
@@ -396,7 +408,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
     // pool of chained blocks and walk every sequence from one end).
     d.seq_len = nullptr;
     const char *want_len = std::getenv("GBWT_HIP_SEQ_LEN");
-    if (h.sequences > 0 && !(want_len && std::atoi(want_len) == 0)) {
+    if ((ix.caps & GBWT_HIP_OPEN_EXTRACT) != 0 && h.sequences > 0 && !(want_len && std::atoi(want_len) == 0)) {
         const auto t_samples = std::chrono::steady_clock::now();
         ix.seq_len.reserve(h.sequences * sizeof(uint32_t));
         // 16 bytes per sample.  Large indexes: about every 2 048 nodes (1 024 .. 4 096 measure within 3 % of each other on the
@@ -530,7 +542,7 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
             try {
                 HIP_CHECK(hipSetDevice(raw->device));
                 raw->host.finish();
-                upload_label_lengths(*raw);
+                if (raw->caps & GBWT_HIP_OPEN_GFA) upload_label_lengths(*raw);
             } catch (...) { tail_failure = std::current_exception(); }
         });
         try { upload(*ix, &endmarker); } catch (...) { tail.join(); throw; }
@@ -540,7 +552,7 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
     } else {
         upload(*ix, nullptr);
         ix->host.finish();                // the loader's background work, if any: needed from here on
-        upload_label_lengths(*ix);
+        if (ix->caps & GBWT_HIP_OPEN_GFA) upload_label_lengths(*ix);
     }
     const auto t_done = std::chrono::steady_clock::now();
     const auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
@@ -564,6 +576,7 @@ template <class Launch>
 gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *in_a, size_t a_row, const void *in_b, size_t b_row,
                           void *out, size_t out_row, uint8_t *valid, uint64_t n, Launch launch) {
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (!(ix->caps & GBWT_HIP_OPEN_SEARCH)) return fail(GBWT_HIP_BAD_ARGUMENT, "the handle was not opened for navigation / search (GBWT_HIP_OPEN_SEARCH)");
     if (n == 0) return GBWT_HIP_OK;
     if (!in_a || !out || !valid) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
     ws->follow_cached = false;   // the staging buffers are shared with gbwt_hip_follow
@@ -659,6 +672,7 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
 template <class Launch>
 gbwt_hip_status run_query_device(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *d_in, size_t out_row, uint64_t n, Launch launch) {
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
+    if (!(ix->caps & GBWT_HIP_OPEN_SEARCH)) return fail(GBWT_HIP_BAD_ARGUMENT, "the handle was not opened for navigation / search (GBWT_HIP_OPEN_SEARCH)");
     if (n && !d_in) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
     ws->follow_cached = false;
     try {
@@ -701,13 +715,19 @@ gbwt_hip_status gbwt_hip_parse_file(const char *path, gbwt_hip_stats *out) {
     GBWT_HIP_GUARD_END
 }
 
-gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index **out) {
+static uint32_t normalised_caps(uint32_t flags) { return (flags & GBWT_HIP_OPEN_GFA) ? (flags | GBWT_HIP_OPEN_EXTRACT) : flags; }   // the lines are formatted from extracted rows
+
+gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index **out) { return gbwt_hip_open_file_flags(path, device, GBWT_HIP_OPEN_ALL, out); }
+
+gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t flags, gbwt_hip_index **out) {
     GBWT_HIP_GUARD_BEGIN
     if (!path || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    if (flags == 0 || (flags & ~uint32_t(GBWT_HIP_OPEN_ALL)) != 0) return fail(GBWT_HIP_BAD_ARGUMENT, "flags: a non-empty set of GBWT_HIP_OPEN_EXTRACT | _SEARCH | _GFA");
     *out = nullptr;
     const auto t_open = std::chrono::steady_clock::now();
     std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
+    ix->caps = normalised_caps(flags);
     // The record bytes start for the device as soon as the loader knows where they are, next to its decoding of the record starts
     // (9 ms of staged copy next to 6.7 ms of Elias-Fano decode on the headline index, one after the other until round 3).
     struct EarlyCopy {
@@ -750,12 +770,20 @@ gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index 
 gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
                                       uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,
                                       int bidirectional, int device, gbwt_hip_index **out) {
+    return gbwt_hip_open_records_flags(data, data_len, starts, n_records, alphabet_offset, alphabet_size, n_sequences, size, bidirectional, device, GBWT_HIP_OPEN_ALL, out);
+}
+
+gbwt_hip_status gbwt_hip_open_records_flags(const uint8_t *data, uint64_t data_len, const uint64_t *starts, uint64_t n_records,
+                                            uint64_t alphabet_offset, uint64_t alphabet_size, uint64_t n_sequences, uint64_t size,
+                                            int bidirectional, int device, uint32_t flags, gbwt_hip_index **out) {
     GBWT_HIP_GUARD_BEGIN
     if (!out || (data_len && !data) || (n_records && !starts)) return fail(GBWT_HIP_BAD_ARGUMENT, "null argument");
+    if (flags == 0 || (flags & ~uint32_t(GBWT_HIP_OPEN_ALL)) != 0) return fail(GBWT_HIP_BAD_ARGUMENT, "flags: a non-empty set of GBWT_HIP_OPEN_EXTRACT | _SEARCH | _GFA");
     *out = nullptr;
     const auto t_open = std::chrono::steady_clock::now();
     std::unique_ptr<gbwt_hip_index> ix(new gbwt_hip_index);
     ix->device = device;
+    ix->caps = normalised_caps(flags);
     ix->host = index_from_records(data, data_len, starts, n_records, alphabet_offset, alphabet_size, n_sequences, size,
                                   bidirectional != 0);
     return open_common(std::move(ix), out, t_open);
@@ -872,6 +900,7 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
     if (!ix || !ws || ws->index != ix || !out) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (n && !seq_ids) return fail(GBWT_HIP_BAD_ARGUMENT, "null seq_ids");
     if (parts == 0 || part >= parts) return fail(GBWT_HIP_BAD_ARGUMENT, "part must be < parts");
+    if (!(ix->caps & GBWT_HIP_OPEN_EXTRACT)) return fail(GBWT_HIP_BAD_ARGUMENT, "the handle was not opened for extraction (GBWT_HIP_OPEN_EXTRACT)");
     // GBWT::sequence: id >= sequences -> no iterator (src/gbwt.rs:254-256).  "Not found" is a value here as well: such an id
     // gets an empty row (the kernels test the id), the rest of the batch is extracted; callers tell None from an empty
     // sequence by id < sequences.
@@ -1448,6 +1477,7 @@ gbwt_hip_status gbwt_hip_follow(const gbwt_hip_index *ix, gbwt_hip_workspace *ws
     GBWT_HIP_GUARD_BEGIN
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (!ix->host.bidirectional) return fail(GBWT_HIP_BAD_ARGUMENT, "Bidirectional search requires a bidirectional GBWT");
+    if (!(ix->caps & GBWT_HIP_OPEN_SEARCH)) return fail(GBWT_HIP_BAD_ARGUMENT, "the handle was not opened for navigation / search (GBWT_HIP_OPEN_SEARCH)");
     if (!total || !out_offsets || (n && (!states || !valid))) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
     *total = 0;
     out_offsets[0] = 0;

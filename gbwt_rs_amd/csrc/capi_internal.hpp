@@ -212,6 +212,7 @@ struct HostCopier {
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
+    uint32_t caps = GBWT_HIP_OPEN_ALL;   // what the handle was opened for (gbwt_hip_open_*_flags): which arrays exist, which entry points answer
     uint64_t table_positions = 0;     // BWT positions in records with LF tables (outdegree > 2)
     gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks, gblocks, tables, wtables, wtables_deep, seq_len, samples, sample_base;
     gbwt_hip::DeviceBuffer label_len;   // GBZ only: label length per potential node (0 for nodes that do not exist)

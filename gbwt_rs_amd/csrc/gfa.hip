@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const
 }
 
 void require_gfa_capable(const gbwt_hip_index *ix) {
+    if (!(ix->caps & GBWT_HIP_OPEN_GFA)) throw InvalidData("the handle was not opened for GFA lines (GBWT_HIP_OPEN_GFA)");
     if (!ix->host.is_gbz) throw InvalidData("GFA lines need a GBZ (graph + metadata), this handle holds a bare GBWT");
     if (!ix->host.has_metadata) throw InvalidData("GFA lines need path metadata");
 }
@@ -974,7 +975,7 @@ struct GfaWriter {
         cv.notify_all();
     }
     void run() {
-        if (const char *v = std::getenv("GBWT_HIP_GFA_WRITERS")) WRITERS = std::min(64, std::max(1, std::atoi(v)));
+        if (const char *v = std::getenv("GBWT_HIP_GFA_WRITERS")) WRITERS = std::min(16, std::max(1, std::atoi(v)));
         BUFFERS = WRITERS + 2;
         std::vector<void *> pinned(BUFFERS, nullptr);
         buffer_busy.assign(BUFFERS, 0);

@@ -104,6 +104,22 @@ gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, co
                                       uint64_t n_records, uint64_t alphabet_offset, uint64_t alphabet_size,
                                       uint64_t n_sequences, uint64_t size, int bidirectional, int device,
                                       gbwt_hip_index **out);
+/* The same with a statement of what the handle is FOR (round 5): an index is replicated per GPU and most of what a handle holds in HBM
+ * is built for one group of entry points only, so a caller that names its group pays for that group:
+ *   GBWT_HIP_OPEN_EXTRACT  gbwt_hip_extract*, path sums / hashes / copies: walk descriptors (64 + 128 B per record), rank blocks and packed
+ *                          two-step half-blocks (16 + 32 B per 64 positions of an outdegree-2 record), walk tables, sequence lengths + samples
+ *   GBWT_HIP_OPEN_SEARCH   start / forward / backward / find / extend / bd_* / follow / search: raw descriptors (64 B per record), rank
+ *                          blocks (16 B per 64 positions), LF tables of the records with outdegree > 2 (16 B per position)
+ *   GBWT_HIP_OPEN_GFA      gbwt_hip_path_lines*, gbwt_hip_write_gfa* (implies EXTRACT): label lengths, translation and line header tables
+ * Record bytes, record starts and the endmarker are always there.  An entry point outside the handle's groups returns
+ * GBWT_HIP_BAD_ARGUMENT.  gbwt_hip_open_file / gbwt_hip_open_records = GBWT_HIP_OPEN_ALL.  Config 3's index (1.1 M sites x 5 008
+ * haplotypes): 11.4 GB opened for everything, 3.5 GB for SEARCH; gbwt_hip_memory_usage reports what a handle holds. */
+enum { GBWT_HIP_OPEN_EXTRACT = 1, GBWT_HIP_OPEN_SEARCH = 2, GBWT_HIP_OPEN_GFA = 4, GBWT_HIP_OPEN_ALL = 7 };
+gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t flags, gbwt_hip_index **out);
+gbwt_hip_status gbwt_hip_open_records_flags(const uint8_t *data, uint64_t data_len, const uint64_t *starts,
+                                            uint64_t n_records, uint64_t alphabet_offset, uint64_t alphabet_size,
+                                            uint64_t n_sequences, uint64_t size, int bidirectional, int device, uint32_t flags,
+                                            gbwt_hip_index **out);
 void gbwt_hip_close(gbwt_hip_index *index);
 gbwt_hip_status gbwt_hip_get_stats(const gbwt_hip_index *index, gbwt_hip_stats *out);
 

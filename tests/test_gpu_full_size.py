@@ -74,6 +74,15 @@ def test_config_c3_full_size():
     assert np.array_equal(bok, bok2) and np.array_equal(bd, bd2)
     plain.close()
     del d_q
+    # the same index opened for SEARCH only (gbwt_hip_open_records_flags): the same answers from a third of the memory
+    everything = dev.memory_usage()["index_device_bytes"]
+    lean = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, flags=G.OPEN_SEARCH)
+    lean_bytes = lean.memory_usage()["index_device_bytes"]
+    assert lean_bytes <= 4 << 30 and lean_bytes < 0.4 * everything, (lean_bytes, everything)
+    st3, ok3 = lean.search(queries)
+    bd3, bok3 = lean.bd_search(queries, 4)
+    assert np.array_equal(st, st3) and np.array_equal(ok, ok3) and np.array_equal(bd, bd3) and np.array_equal(bok, bok3)
+    lean.close()
     oracle = oracle_of(s)
     pick = np.sort(np.random.default_rng(8).choice(len(queries), 30000, replace=False))
     o_st, o_ok = oracle.search_batch(queries[pick], threads=16)

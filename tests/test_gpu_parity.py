@@ -955,6 +955,63 @@ def test_large_query_batches_travel_in_chunks(monkeypatch):
     plain.close()
 
 
+def test_open_flags_build_what_they_name(tmp_path):
+    """gbwt_hip_open_*_flags (round 5): a handle opened for SEARCH answers the navigation / search group bit for bit like a handle opened
+    for everything, holds a fraction of its memory (no walk descriptors, two-step blocks, samples) and refuses extraction and GFA lines with
+    GBWT_HIP_BAD_ARGUMENT; a handle opened for EXTRACT extracts like the full one and refuses searches and lines; GFA implies EXTRACT."""
+    s = S.Synth.chain(sites=3000, haplotypes=800, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=31)
+    path = str(tmp_path / "flags.gbz")
+    s.save(path, as_gbz=True)
+    full = G.GBZ.load(path)
+    search = G.GBZ.load(path, flags=G.OPEN_SEARCH)
+    extract = G.GBZ.load(path, flags=G.OPEN_EXTRACT)
+    lines = G.GBZ.load(path, flags=G.OPEN_GFA)
+    recs = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, flags=G.OPEN_SEARCH)
+    mem = {k: h.memory_usage()["index_device_bytes"] for k, h in (("full", full), ("search", search), ("extract", extract), ("lines", lines))}
+    assert mem["search"] < 0.5 * mem["full"] and mem["extract"] < mem["full"] and mem["extract"] <= mem["lines"] <= mem["full"], mem
+    queries = make_queries(s, random.Random(9), 4000, 8)
+    a, a_ok = full.search(queries)
+    for h in (search, recs):
+        b, b_ok = h.search(queries)
+        assert np.array_equal(a, b) and np.array_equal(a_ok, b_ok)
+        bd, bd_ok = h.bd_search(queries, 3)
+        fbd, fbd_ok = full.bd_search(queries, 3)
+        assert np.array_equal(bd, fbd) and np.array_equal(bd_ok, fbd_ok)
+        pos, ok = h.start(np.arange(s.sequences))
+        fpos, fok = full.start(np.arange(s.sequences))
+        assert np.array_equal(pos, fpos) and np.array_equal(ok, fok)
+        nxt, nok = h.forward(pos)
+        fnxt, fnok = full.forward(fpos)
+        assert np.array_equal(nxt, fnxt) and np.array_equal(nok, fnok)
+        back, bok = h.backward(nxt)
+        fback, fbok = full.backward(fnxt)
+        assert np.array_equal(back, fback) and np.array_equal(bok, fbok)
+        with pytest.raises(G.GbwtHipError) as e:
+            h.sequences_csr(np.arange(4))
+        assert e.value.status == _lib_status("BAD_ARGUMENT")
+    ids = np.arange(s.sequences, dtype=np.uint64)
+    f_off, f_nodes = full.sequences_csr(ids)
+    for h in (extract, lines):
+        off, nodes = h.sequences_csr(ids)
+        assert np.array_equal(off, f_off) and np.array_equal(nodes, f_nodes)
+        with pytest.raises(G.GbwtHipError) as e:
+            h.find([4])
+        assert e.value.status == _lib_status("BAD_ARGUMENT")
+    assert lines.path_lines([0, 5, 7], 1) == full.path_lines([0, 5, 7], 1)
+    for h in (search, extract):
+        with pytest.raises(G.GbwtHipError):
+            h.path_lines([0], 1)
+    with pytest.raises(G.GbwtHipError):
+        G.GBZ.load(path, flags=0)
+    with pytest.raises(G.GbwtHipError):
+        G.GBZ.load(path, flags=8)
+
+
+def _lib_status(name):
+    from gbwt_rs_amd import _lib
+    return _lib.STATUS_NAMES.index(name)
+
+
 def test_config_c3_scale_states_against_the_oracle():
     """Config 3 at a third of its full length (400 000 sites x 5 008 haplotypes, 1.2 M nodes; the full 1.1 M-site run is tools/search_bench.py):
     a million queries go through the device, EVERY final state of a seeded sample of 30 000 of them is compared with the oracle

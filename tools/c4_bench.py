@@ -62,7 +62,7 @@ def generate(size, path, threads=None):
     return g
 
 
-def run(size="small", passes=5, out="", device=0, keep=None):
+def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
     import gbwt_rs_amd as G
     tmpdir = tempfile.mkdtemp(prefix="gbwt_c4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     path = os.path.join(tmpdir, "c4.gbz")
@@ -116,6 +116,8 @@ def run(size="small", passes=5, out="", device=0, keep=None):
                           "note": "bytes_moved = node ids written once by the walk (4 B/step) and read once by the formatter + the text written (the sizes of the "
                                   "lines come from the index's line cache, filled by the first request of a path: first_request_ms); frac = that / wall time / 8 TB/s"}
     res["memory"] = gbz.memory_usage()
+    if cpu_leg is not None:       # bench.py's cpu_baseline leg: the oracle formats a bounded sample of these W-lines, compared byte for byte with the device's
+        res["cpu_baseline"] = cpu_leg(path, gbz, walks)
     if out:
         t0 = time.perf_counter()
         gbz.write_gfa(out)

@@ -56,11 +56,11 @@ def _extraction(s, passes, warm, device, cpu_leg=None):
     return res
 
 
-def secondary(sites=333334, haplotypes=5000, model=0, seed=42, passes=5, device=0):
+def secondary(sites=333334, haplotypes=5000, model=0, seed=42, passes=5, device=0, cpu_leg=None):
     from gbwt_rs_amd import synth as S
     t0 = time.perf_counter()
     s = S.Synth.chain(sites=sites, haplotypes=haplotypes, alleles=2, model=model, founders=32, switch_rate=2e-3, seed=seed, extra=1)
-    res = _extraction(s, passes, 3, device)
+    res = _extraction(s, passes, 3, device, cpu_leg)
     res["workload"] = (f"the headline's bubble chain with a one-node insertion as allele 1 of every site ({res['lf_steps']} LF-steps; rows of a batch "
                        "leave lock step after the first site: every wave is mixed)")
     res["seconds_incl_generator"] = round(time.perf_counter() - t0, 1)
@@ -171,13 +171,13 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
     return res
 
 
-def config4(passes=3, out="", device=0, size="full"):
+def config4(passes=3, out="", device=0, size="full", cpu_leg=None):
     """BASELINE config 4 on one GPU at the size SURVEY 8(d) states (tools/c4_bench.py: SIZES["full"]); size="small" is the stand-in of rounds
     3-4 (bench.py's `config4_small`, with the whole file written to /dev/shm)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import c4_bench
     try:
-        res = c4_bench.run(size=size, passes=passes, out=out, device=device)
+        res = c4_bench.run(size=size, passes=passes, out=out, device=device, cpu_leg=cpu_leg)
     finally:
         if out and os.path.exists(out):
             os.remove(out)
@@ -187,8 +187,8 @@ def config4(passes=3, out="", device=0, size="full"):
     return res
 
 
-def config4_small(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0):
-    return config4(passes, out, device, size="small")
+def config4_small(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0, cpu_leg=None):
+    return config4(passes, out, device, size="small", cpu_leg=cpu_leg)
 
 
 if __name__ == "__main__":
