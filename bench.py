@@ -166,7 +166,7 @@ def cpu_leg_lines(seconds):
         t0 = time.perf_counter()
         oracle = O.OracleGBZ(gbz_path)
         load_s = time.perf_counter() - t0
-        pick = np.sort(np.random.default_rng(11).choice(len(walks), min(len(walks), 4 * threads), replace=False))
+        pick = np.random.default_rng(11).choice(len(walks), min(len(walks), 64 * threads), replace=False)
         with ThreadPoolExecutor(threads) as pool:
             t0 = time.perf_counter()
             lines = list(pool.map(lambda k: oracle.path_lines([int(walks[k])], 1), pick[:threads]))
@@ -335,7 +335,13 @@ def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier
                 off, text = off.cpu(), text.cpu()
             return D.gather_lines(off, text, dst=0)
 
-        res, my = c4_bench.run_sharded(gbz, generic, walks, rank, world, comm, barrier, local_rank, passes=3, torch_gather=torch_gather)
+        def allgather(value):
+            got = [None] * world
+            dist.all_gather_object(got, value)
+            return got
+
+        res, my = c4_bench.run_sharded(gbz, generic, walks, rank, world, comm, barrier, local_rank, passes=3, torch_gather=torch_gather,
+                                       file_path=path + ".lines.gfa", allgather=allgather)
         everyone = [None] * world
         dist.all_gather_object(everyone, my)
         if comm is not None:
@@ -352,6 +358,8 @@ def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier
     finally:
         barrier()
         if rank == 0:
+            if os.path.exists(path + ".lines.gfa"):
+                os.remove(path + ".lines.gfa")
             c4_bench.cleanup(path)
 
 
@@ -399,8 +407,10 @@ def lookup_traffic(workload_key, kernel=None):
         entry = tj if kernel is None else tj.get("kernels", {}).get(kernel)
         if entry is None:
             continue
+        factor = tj.get("fetch_factor", 2.0)
         return entry["traffic_bytes_per_launch"], (f"profiles/{os.path.basename(tpath)} (same kernel sources and knobs, fingerprint {fingerprint}): "
-                                                   "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes")
+                                                   f"{factor:g} x FETCH_SIZE ({'gfx950 correction for wide coalesced loads' if factor == 2.0 else 'scattered 64-byte requests: counted exactly, profiles/r05_fetch_calibration.txt'}) "
+                                                   "+ WRITE_SIZE, separate --pmc passes")
     return None, "no PMC profile of this build / workload under profiles/"
 
 
@@ -653,7 +663,7 @@ def main():
                                  "/ wall time of the two requests (P-lines, W-lines), host side included")
                 extras["config4"] = config_roofline(K.config4(device=local_rank, size=args.c4_size, cpu_leg=leg_l), "config4", c4_definition)
                 if args.c4_size == "full":
-                    extras["config4_small"] = config_roofline(K.config4_small(device=local_rank), "config4_small", c4_definition)
+                    extras["config4_small"] = config_roofline(K.config4_small(device=local_rank, cpu_leg=leg_l), "config4_small", c4_definition)
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/measure_round.sh -> profiles/*_hbm_traffic.json).  It is quoted only when those passes ran THIS build with
         # THESE knobs on THIS workload (fingerprint of the kernel sources + GBWT_HIP_* environment); a profile of another

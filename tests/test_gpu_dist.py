@@ -209,6 +209,7 @@ g = c4_bench.generate(SIZE, path)
 generic = np.load(path + ".generic.npy")
 walks = np.setdiff1d(np.arange(g.paths, dtype=np.uint64), generic)
 results = {}
+shared = [None] * 8
 
 def rank_main(rank, world, box, ready, barrier):
     try:
@@ -219,7 +220,13 @@ def rank_main(rank, world, box, ready, barrier):
             return box[0]
         gbz = G.GBZ.load(path, device=0)                     # every rank its own replica of the index, as one process per GPU has
         comm = D.Comm(rank, world, 0, broadcast=broadcast)
-        res, my = c4_bench.run_sharded(gbz, generic, walks, rank, world, comm, barrier.wait, 0, passes=2)
+        def allgather(value):                                # (between threads: a shared list, two barriers)
+            shared[rank] = value
+            barrier.wait()
+            got = list(shared[:world])
+            barrier.wait()
+            return got
+        res, my = c4_bench.run_sharded(gbz, generic, walks, rank, world, comm, barrier.wait, 0, passes=2, file_path=path + f".{world}.gfa", allgather=allgather)
         results[(world, rank)] = (res, my)
         comm.close(); gbz.close()
     except BaseException:
@@ -236,6 +243,7 @@ for world in WORLDS:
         faulthandler.dump_traceback(all_threads=True)
         os._exit(4)
     root = results[(world, 0)][0]
+    assert root["sharded_file"]["bytes"] == root["text_bytes"] + root["p_text_bytes"]
     assert root["check"] and root["text_bytes"] == sum(results[(world, r)][1]["text_bytes"] for r in range(world)) - root["p_text_bytes"], root
     assert sum(results[(world, r)][1]["walks"] for r in range(world)) == len(walks)
 print("C4_LOOPBACK_OK", WORLDS, len(walks), json.dumps(results[(WORLDS[-1], 0)][0]), flush=True)

@@ -150,7 +150,22 @@ def device_bytes_equal(a, b, piece=1 << 28):
     return all(bool(torch.equal(a[lo:lo + piece], b[lo:lo + piece])) for lo in range(0, a.numel(), piece))
 
 
-def run_sharded(gbz, generic, walks, rank, world, comm, barrier, device, passes=3, check=True, torch_gather=None):
+def write_at(fd, data, at, threads=8, piece=32 << 20):
+    """`data` (a numpy uint8 array) into the open file at byte `at`, by a few threads with positional writes."""
+    from concurrent.futures import ThreadPoolExecutor
+    view = memoryview(data)
+
+    def one(lo):
+        done = 0
+        chunk = view[lo:lo + piece]
+        while done < len(chunk):
+            done += os.pwrite(fd, chunk[done:], at + lo + done)
+
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(one, range(0, len(data), piece)))
+
+
+def run_sharded(gbz, generic, walks, rank, world, comm, barrier, device, passes=3, check=True, torch_gather=None, file_path=None, allgather=None):
     """The N-rank flow of config 4 on an index that every rank has opened (`gbz`: this rank's handle / workspace).  Collective: every rank
     calls it.  `comm`: a gbwt_rs_amd.dist.Comm (RCCL behind the C ABI, or the loopback ranks of the test build); None = gather through
     `torch_gather` (lengths, text) -> (offsets, text) on rank 0 (the torch.distributed form: what the gloo rehearsal takes).
@@ -226,6 +241,50 @@ def run_sharded(gbz, generic, walks, rank, world, comm, barrier, device, passes=
         res = {"text_bytes": total_text, "gather_ms": gather_ms, "gather_GB_per_s": total_text / gather_ms / 1e6,
                "check": None if not check else "gathered W-lines == rank 0 formatting all walks alone: every byte compared on the device" + (", line offsets equal, " if comm is not None else ", ") +
                                                f"sha256 of the first {min(total_text, 64 << 20)} bytes {sha_w}"}
+    # ---- the other way to the file: nobody gathers text -- every rank copies ITS lines to the host and writes them at
+    # their place in the one file (the offsets come from an all-gather of the ranks' byte counts: 8 bytes per rank instead of 51 GB to
+    # rank 0 and one writer there).  `allgather(value) -> [value of rank 0, ...]`.
+    if file_path is not None and allgather is not None:
+        side = gbz.another_workspace()                        # the few P-lines: a workspace of their own, the W-lines stay in the main one
+        lines = gbz.path_lines_device(mine, 1)
+        p_bytes = allgather(int(side.path_lines_device(my_generic, 0).total) if len(my_generic) else 0)
+        w_bytes = allgather(int(lines.total))
+        p_total = sum(p_bytes)
+        if rank == 0:
+            with open(file_path, "wb") as f:
+                f.truncate(p_total + sum(w_bytes))
+        barrier()
+        t0 = time.perf_counter()
+        fd = os.open(file_path, os.O_WRONLY)
+        try:
+            if len(my_generic):
+                write_at(fd, side.path_lines_array(my_generic, 0), sum(p_bytes[:rank]))
+            text = gbz.path_lines_array(mine, 1)              # (the request of a moment ago: copied out of the workspace, not formatted again)
+            write_at(fd, text, p_total + sum(w_bytes[:rank]))
+        finally:
+            os.close(fd)
+        barrier()
+        file_s = time.perf_counter() - t0
+        side.close()
+        my["file_seconds"] = file_s
+        if rank == 0:
+            size = os.path.getsize(file_path)
+            assert size == p_total + sum(w_bytes), (size, p_total, sum(w_bytes))
+            res["sharded_file"] = {"bytes": size, "seconds": file_s, "GB_per_s": size / file_s / 1e9,
+                                   "note": "every rank writes its own P- and W-lines at their offsets in ONE file (offsets from an all-gather of byte counts): no text "
+                                           "travels between GPUs; compare with gather_ms + one writer on rank 0"}
+            if check:                                         # the file against rank 0 formatting alone, at seeded places (and whole when it is small)
+                alone = gbz.another_workspace()
+                a_txt = D.lines_tensors(alone.path_lines_device(walks, 1), dev)[1]
+                whole = np.memmap(file_path, dtype=np.uint8, mode="r")
+                gen = np.random.default_rng(3)
+                window = min(1 << 20, int(a_txt.numel()))
+                for lo in [0, int(a_txt.numel()) - window] + [int(x) for x in gen.integers(0, max(1, int(a_txt.numel()) - window), 62)]:
+                    assert np.array_equal(whole[p_total + lo:p_total + lo + window], a_txt[lo:lo + window].cpu().numpy()), ("sharded file differs at", lo)
+                assert bytes(whole[:p_total]) == alone.path_lines(generic, 0), "P-lines of the sharded file differ"
+                del whole
+                alone.close()
+        barrier()
     p_off, p_txt, p_gather_ms, _ = gather(my_generic, 0)
     if rank == 0 and check:
         alone = gbz.another_workspace()

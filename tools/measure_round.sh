@@ -16,8 +16,9 @@ python3 tools/hbm_traffic.py $O/fetch $O/write k_walk_direct "headline C5k (3333
 find $O/stats -name "*kernel_stats.csv" -exec head -12 {} \; | cut -c1-200
 if [ "${2:-}" != "quick" ]; then
   for C in secondary high_degree search config4 config4_small; do
+    F=""
     case $C in
-      search) K=k_search,k_bd_search; P=max;;
+      search) K=k_search,k_bd_search; P=max; F="--fetch-factor 1";;
       config4|config4_small) K=k_walk_direct,k_chunk_stats,k_format_chunks; P=max;;
       *) K=k_walk_direct; P=last;;
     esac
@@ -27,7 +28,7 @@ if [ "${2:-}" != "quick" ]; then
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${C}_write -- python3 $R/tools/configs.py $C > $O/${C}_write.log 2>&1
     cd $R
     A=$(python3 -c "import json,sys; print(json.loads(open('$O/${C}.json').read().strip().splitlines()[-1])['algorithmic_bytes'])")
-    python3 tools/hbm_traffic.py $O/${C}_fetch $O/${C}_write $K "$C (tools/configs.py)" $A --key $C --pick $P > $O/${C}_hbm_traffic.json; head -12 $O/${C}_hbm_traffic.json
+    python3 tools/hbm_traffic.py $O/${C}_fetch $O/${C}_write $K "$C (tools/configs.py)" $A --key $C --pick $P $F > $O/${C}_hbm_traffic.json; head -12 $O/${C}_hbm_traffic.json
     find $O/${C}_stats -name "*kernel_stats.csv" -exec head -8 {} \; | cut -c1-200
   done
 fi
