@@ -313,7 +313,7 @@ def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier
     try:
         generic = np.load(path + ".generic.npy")
         t0 = time.perf_counter()
-        gbz = G.GBZ.load(path, device=local_rank)
+        gbz = G.GBZ.load(path, device=local_rank, flags=G.OPEN_GFA)     # GFA extraction only: no search structures on any of the N replicas
         open_ms = (time.perf_counter() - t0) * 1e3
         walks = np.setdiff1d(np.arange(gbz.paths(), dtype=np.uint64), generic)
         steps = (gbz.len() - gbz.sequences()) // 2

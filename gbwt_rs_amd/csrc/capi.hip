@@ -45,6 +45,7 @@ void fill_stats(gbwt_hip_index &ix) {
 const uint4 *ensure_cblocks(const gbwt_hip_index *index) {
     gbwt_hip_index *ix = const_cast<gbwt_hip_index *>(index);     // the lazily built part of an otherwise immutable handle
     if (ix->dev.cblocks != nullptr) return ix->dev.cblocks;        // built at open
+    if (ix->lean_extract) throw Unsupported("this handle was opened for extraction only and has given its raw descriptors back: the full-width blocks cannot be built (open with GBWT_HIP_OPEN_ALL)");
     std::call_once(ix->cblocks_once, [ix]() {
         HIP_CHECK(hipSetDevice(ix->device));
         ix->cblocks.reserve(std::max<uint64_t>(ix->dev.n_blocks, 1) * 2 * sizeof(uint4));
@@ -293,6 +294,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
             // steps through runs of unary records with consecutive ids (k_link_desc2: CHAINS); GBWT_HIP_CHAINS=0: none, k: at most k more nodes per step
             uint32_t chain_max = CHAIN_MAX;
             if (const char *v = std::getenv("GBWT_HIP_CHAINS")) chain_max = static_cast<uint32_t>(std::min<long>(CHAIN_MAX, std::max<long>(0, std::atol(v))));
+            HIP_CHECK(hipMemsetAsync(d_stats + 6, 0, sizeof(uint64_t), nullptr));      // (word 2 behind the chain statistics: slow records)
             launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, chain_max | (h.bidirectional ? 0x100u : 0u), reinterpret_cast<uint32_t *>(d_stats + 5), nullptr);
             ix.gblocks.reserve((gather_limit ? n_blocks : 1) * 2 * sizeof(uint4));   // no record takes the packed path: only the zero block
             HIP_CHECK(hipMemsetAsync(ix.gblocks.ptr, 0, 2 * sizeof(uint4), nullptr));
@@ -306,7 +308,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
             // headroom every walker then keeps free: below one record in a thousand the descriptors are linked again without chains
             // (0.1 ms), unless GBWT_HIP_CHAINS asked for them
             if (d.chained != 0 && std::getenv("GBWT_HIP_CHAINS") == nullptr && (early_stats[5] >> 32) * 1000 < n_records) {
-                HIP_CHECK(hipMemset(d_stats + 5, 0, sizeof(uint64_t)));
+                HIP_CHECK(hipMemset(d_stats + 5, 0, 2 * sizeof(uint64_t)));
                 launch_link_desc2(d, ix.desc2.as<uint4>(), gather_limit, h.bidirectional ? 0x100u : 0u, reinterpret_cast<uint32_t *>(d_stats + 5), nullptr);
                 d.chained = 0;
             }
@@ -390,6 +392,7 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
     HIP_CHECK(hipGetLastError());
     ix.stats.max_record_len = hs[0];
     ix.stats.max_outdegree = hs[1];
+    if (ix.caps & GBWT_HIP_OPEN_EXTRACT) ix.slow_records = hs[6] & 0xFFFFFFFFull;
     if (hs[2] != 0) throw InvalidData("BWT: record without a readable outdegree");
     if (hs[0] >= (uint64_t(1) << 32)) throw Unsupported("a record with 2^32 or more positions is not supported (u32 offsets on device)");
     d.max_walk = hs[3];
@@ -553,6 +556,21 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
         upload(*ix, nullptr);
         ix->host.finish();                // the loader's background work, if any: needed from here on
         if (ix->caps & GBWT_HIP_OPEN_GFA) upload_label_lengths(*ix);
+    }
+    // A handle that was NOT opened for search and whose walks never leave the descriptors and rank blocks (no record takes the generic
+    // decoder, lengths and samples are there, the full-width blocks are built or not needed) gives its raw descriptors back: 64 bytes per
+    // record -- 14 of config 4's 65 GB.  What still needs them -- the pool-output walk modes, blocks built on first need -- is refused
+    // on such a handle with GBWT_HIP_UNSUPPORTED (gbwt_hip_extract_part_device, ensure_cblocks).
+    {
+        gbwt_hip_index &x = *ix;
+        const char *keep = std::getenv("GBWT_HIP_KEEP_RAW");
+        if (!(x.caps & GBWT_HIP_OPEN_SEARCH) && x.slow_records == 0 && x.dev.seq_len != nullptr && x.dev.samples != nullptr && x.max_samples > 0 &&
+            x.dev.tables == nullptr && (x.dev.cblocks != nullptr || x.packed_blocks) && !(keep && std::atoi(keep) != 0)) {
+            HIP_CHECK(hipDeviceSynchronize());
+            x.desc_raw.release();
+            x.dev.desc_raw = nullptr;
+            x.lean_extract = true;
+        }
     }
     const auto t_done = std::chrono::steady_clock::now();
     const auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
@@ -1095,6 +1113,17 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = total; out->n = n;
             return GBWT_HIP_OK;
         }
+        if (n == 0) {                                        // nothing asked for: an empty CSR, whatever the handle holds
+            HIP_CHECK(hipMemsetAsync(ws->offsets.ptr, 0, sizeof(uint64_t), s));
+            ws->nodes.reserve(sizeof(uint32_t));
+            HIP_CHECK(hipEventRecord(ws->ev[0], s)); HIP_CHECK(hipEventRecord(ws->ev[1], s)); HIP_CHECK(hipEventRecord(ws->ev[2], s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            ws->timed = true; ws->last_n = 0; ws->last_total = 0;
+            ws->extract_key.clear(); ws->extract_cached = true;
+            out->d_offsets = ws->offsets.as<uint64_t>(); out->d_nodes = ws->nodes.as<uint32_t>(); out->total = 0; out->n = 0;
+            return GBWT_HIP_OK;
+        }
+        if (ix->lean_extract) return fail(GBWT_HIP_UNSUPPORTED, "this handle was opened for extraction only and has given its raw descriptors back: the pool-output walk modes need GBWT_HIP_OPEN_ALL");
         // The pool-output kernels (no sequence lengths, GBWT_HIP_DIRECT=0, a tuned walk mode) walk whole rows and cannot cut them: as the
         // header says for rows that cannot be cut, the LAST part is the whole row and every earlier part is n empty rows -- never the whole
         // row from every part (a gather of parts would then hold every row `parts` times).

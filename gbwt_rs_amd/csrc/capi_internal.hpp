@@ -212,6 +212,8 @@ struct HostCopier {
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
+    bool lean_extract = false;           // opened without SEARCH and no record needs the generic decoder: desc_raw was given back after the open (capi.hip: open_common)
+    uint64_t slow_records = ~uint64_t(0); // non-empty records whose walk descriptor says "generic decoder" (k_link_desc2's count; ~0 = not counted)
     uint32_t caps = GBWT_HIP_OPEN_ALL;   // what the handle was opened for (gbwt_hip_open_*_flags): which arrays exist, which entry points answer
     uint64_t table_positions = 0;     // BWT positions in records with LF tables (outdegree > 2)
     gbwt_hip::DeviceBuffer data, starts, endmarker, desc, desc_raw, block_base, blocks, desc2, cblocks, gblocks, tables, wtables, wtables_deep, seq_len, samples, sample_base;

@@ -503,6 +503,7 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
         all4 = all4 && cls_w != 0;
         for (uint32_t b = 0; b < cls_w && all4; b++) all4 = leaf[2 * a + b].x != 0 && (leaf[2 * a + b].z & LEAF_EMIT2) != 0;
     }
+    if (slow && VB.y != 0 && chained != nullptr) atomicAdd(chained + 2, 1u);        // non-empty records that take the generic decoder (class 0, edges that failed a check)
     uint4 *o = out + 8 * v;
     o[0] = make_uint4(n1[0], base[0], wword[0] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[0] | (any_chain ? E_ANYCHAIN : 0u) | (all4 ? E_ALL4 : 0u));
     o[1] = make_uint4(n1[1], base[1], wword[1] | (slow ? DESC2_SLOW : 0u), (packed ? GATHER_OK : 0u) | chain[1]);

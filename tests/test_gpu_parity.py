@@ -997,6 +997,18 @@ def test_open_flags_build_what_they_name(tmp_path):
         with pytest.raises(G.GbwtHipError) as e:
             h.find([4])
         assert e.value.status == _lib_status("BAD_ARGUMENT")
+    # ... and a handle without SEARCH whose walks never need the generic decoder has given its raw descriptors back (64 bytes per record);
+    # what would read them -- the pool-output walk modes -- is refused, not answered wrongly
+    records = int(full.stats.records)
+    assert mem["extract"] <= mem["full"] - 64 * records, (mem, records)
+    extract.tune(walk_mode=1)
+    with pytest.raises(G.GbwtHipError) as e:
+        extract.sequences_csr(ids[:8])
+    assert e.value.status == _lib_status("UNSUPPORTED")
+    extract.tune(walk_mode=0)
+    off, nodes = extract.sequences_csr(ids[:8])
+    assert np.array_equal(nodes, f_nodes[:int(f_off[8])])
+    assert extract.sequences_csr(np.zeros(0, dtype=np.uint64))[0].tolist() == [0]
     assert lines.path_lines([0, 5, 7], 1) == full.path_lines([0, 5, 7], 1)
     for h in (search, extract):
         with pytest.raises(G.GbwtHipError):

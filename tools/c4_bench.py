@@ -69,7 +69,7 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
     g = generate(size, path)
     generic = np.load(path + ".generic.npy")
     t0 = time.perf_counter()
-    gbz = G.GBZ.load(path, device=device)
+    gbz = G.GBZ.load(path, device=device, flags=G.OPEN_GFA)     # GFA extraction only: no search structures (gbwt_hip_open_file_flags)
     open_ms = (time.perf_counter() - t0) * 1e3
     walks = np.setdiff1d(np.arange(g.paths, dtype=np.uint64), generic)
     steps = (gbz.len() - gbz.sequences()) // 2
