@@ -370,6 +370,39 @@ def test_line_cache_serves_every_mode(tmp_path, monkeypatch, fill_mode):
     assert out.read_bytes() == oracle.gfa()
 
 
+def test_line_cache_filled_by_concurrent_requests(tmp_path):
+    """Several host threads, each with a workspace of its own, format overlapping sets of paths of ONE handle at the same time, in different
+    line modes, while the handle's line cache is still empty: whichever request fills an entry first, every text equals the oracle's."""
+    import threading
+    s = S.Synth.chain(sites=2500, haplotypes=160, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.01, seed=19, extra=1, indel_every=5)
+    path = str(tmp_path / "threads.gbz")
+    s.save(path, as_gbz=True)
+    oracle = O.OracleGBZ(path)
+    dev = G.GBZ.load(path, flags=G.OPEN_GFA)
+    everything = list(range(s.paths))
+    jobs = [(everything, 1), (everything[::-1], 0), (everything[::2], 2), (everything[40:120], 1), ([3, 3, 77], 0), (everything, 2)]
+    want = [oracle.path_lines(ids, mode) for ids, mode in jobs]
+    failures = []
+
+    def work(k):
+        try:
+            view = dev.another_workspace()
+            for _ in range(3):
+                ids, mode = jobs[k]
+                if view.path_lines(ids, mode) != want[k]:
+                    failures.append(k)
+            view.close()
+        except Exception as e:      # noqa: BLE001
+            failures.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
+
+
 def test_bare_gbwt_has_no_gfa():
     dev = G.GBZ.load(os.path.join(O.GOLDEN, "example.gbwt"))
     with pytest.raises(G.GbwtHipError):

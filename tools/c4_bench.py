@@ -75,21 +75,6 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
     steps = (gbz.len() - gbz.sequences()) // 2
     res = {"workload": describe(size, g, generic, walks, steps), "size": size, "paths": int(g.paths), "lf_steps": int(steps), "open_ms": open_ms,
            "gbz_bytes": os.path.getsize(path), "generator_seconds": round(g.generator_seconds, 1), "save_seconds": round(g.save_seconds, 1)}
-    # walk only: all forward sequences of the walks -> device CSR (the ragged batch: walker order computed per request)
-    ids = 2 * walks
-    for _ in range(2):
-        o = gbz.extract_device(ids)
-    wk, tot, wall = [], [], []
-    for _ in range(passes):
-        t0 = time.perf_counter()
-        o = gbz.extract_device(ids)
-        wall.append((time.perf_counter() - t0) * 1e3)
-        w, t = gbz.last_kernel_ms()
-        wk.append(w)
-        tot.append(t)
-    walk_steps = int(o.total)
-    res["walk"] = {"kernel": "k_walk_direct", "kernel_ms": float(np.mean(wk)), "stream_ms": float(np.mean(tot)), "wall_ms": float(np.mean(wall)),
-                   "lf_steps": walk_steps, "value_kernel": walk_steps / (np.mean(wk) * 1e-3), "value": walk_steps / (np.mean(wall) * 1e-3)}
     # walk + format, text left in HBM: ONE request for the P-lines, ONE for the W-lines
     def lines_pass():
         t0 = time.perf_counter()
@@ -115,6 +100,23 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
                           "frac": moved / wall_ms / 1e6 / 8000.0, "first_request_ms": first[0],
                           "note": "bytes_moved = node ids written once by the walk (4 B/step) and read once by the formatter + the text written (the sizes of the "
                                   "lines come from the index's line cache, filled by the first request of a path: first_request_ms); frac = that / wall time / 8 TB/s"}
+    # walk only: all forward sequences of the walks -> device CSR (the ragged batch: walker order computed per request).  Behind the lines
+    # passes: its third request rebuilds the rows from spread chunks (GBWT_HIP_VMM), and memory a process gives back is paid for by its NEXT
+    # large allocation (profiles/r05_alloc_microbench.txt: hipMalloc of 16 GiB 0.2 ms, 2.5 s right after a hipFree of 48 GiB) -- medians
+    ids = 2 * walks
+    for _ in range(2):
+        o = gbz.extract_device(ids)
+    wk, tot, wall = [], [], []
+    for _ in range(max(passes, 3)):
+        t0 = time.perf_counter()
+        o = gbz.extract_device(ids)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        w, t = gbz.last_kernel_ms()
+        wk.append(w)
+        tot.append(t)
+    walk_steps = int(o.total)
+    res["walk"] = {"kernel": "k_walk_direct", "kernel_ms": float(np.median(wk)), "stream_ms": float(np.median(tot)), "wall_ms": float(np.median(wall)),
+                   "lf_steps": walk_steps, "value_kernel": walk_steps / (np.median(wk) * 1e-3), "value": walk_steps / (np.median(wall) * 1e-3)}
     res["memory"] = gbz.memory_usage()
     if cpu_leg is not None:       # bench.py's cpu_baseline leg: the oracle formats a bounded sample of these W-lines, compared byte for byte with the device's
         res["cpu_baseline"] = cpu_leg(path, gbz, walks)
