@@ -465,10 +465,12 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
+        import datetime
+        patience = datetime.timedelta(minutes=5)        # (rank 0 generates config 4's GBZ for half a minute while the others wait for its path)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=patience)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=patience)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: gbwt_rs_amd has no CPU fallback")
 
@@ -576,7 +578,12 @@ def main():
         dist.all_gather_into_tensor(per_rank, torch.tensor([float(np.mean(walk_ms))], dtype=torch.float64, device=comm_device))
         rank_kernel_ms = [float(x) for x in per_rank.cpu().tolist()]
         # The one exchange of the job (outside the timed region, src/bin/gbunzip.rs:421-434: the writer's mutex)
-        gather_info = final_gather(args, index, out, s, rank, world, local_rank, backend, comm_device, by_parts, strong, n_paths, all_steps, my_paths, barrier, dist, torch)
+        try:
+            gather_info = final_gather(args, index, out, s, rank, world, local_rank, backend, comm_device, by_parts, strong, n_paths, all_steps, my_paths, barrier, dist, torch)
+        except AssertionError:
+            raise                                  # wrong rows are an error of the run, not of the transport
+        except Exception as e:  # noqa: BLE001    (a transport that fails -- RCCL, the process group -- must not take the measurement with it)
+            gather_info = {"error": repr(e)[:500], "rank": rank}
         if strong:
             # ... and the SAME batch under the other cut (north_star: "the path set shards ... across the 8 GPUs" = --shard paths; the default
             # is --shard parts, every rank its stretch of every row): the same K timed passes between the same barriers
@@ -601,7 +608,12 @@ def main():
                          "sharding": ("path p walked whole by rank p mod G (SURVEY 8e; north_star's partition)" if by_parts else
                                       "every rank walks stretch r of EVERY path (gbwt_hip_extract_part_device)")}
         if not (args.no_extras or args.no_config4):
-            c4_sharded = config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch)
+            # (the headline's numbers above must not be lost to this object: whatever a rank throws in here ends up in the object, and a rank
+            # that waits for one that threw is released by the process group's timeout)
+            try:
+                c4_sharded = config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch)
+            except Exception as e:  # noqa: BLE001
+                c4_sharded = {"error": repr(e)[:500], "rank": rank}
     else:
         all_steps = float(steps_done)
 
@@ -778,8 +790,11 @@ def main():
             result["config"]["final_gather"] = gather_info
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001  (a rank that failed above: the line is out, nothing left to agree on)
+            pass
     try:
         os.remove(index_path)
         os.rmdir(tmpdir)
