@@ -47,6 +47,29 @@ def test_round4_profiles_cover_every_config():
     assert set(json.load(open(os.path.join(ROOT, "profiles", "r04_config4_hbm_traffic.json")))["kernels"]) == {"k_walk_direct", "k_chunk_stats", "k_format_chunks"}
 
 
+def test_round5_profiles_cover_every_config():
+    """Round 5: every BASELINE config (config 4 at its stated size AND as the small stand-in) has a PMC traffic file of ONE build; the search
+    profile takes FETCH_SIZE as it is (scattered 64-byte requests are counted exactly: profiles/r05_fetch_calibration.txt), the others x 2."""
+    keys = {"r05_hbm_traffic.json": "sites=333334 haplotypes=5000 model=mosaic seed=42", "r05_secondary_hbm_traffic.json": "secondary",
+            "r05_high_degree_hbm_traffic.json": "high_degree", "r05_search_hbm_traffic.json": "search", "r05_config4_hbm_traffic.json": "config4",
+            "r05_config4_small_hbm_traffic.json": "config4_small"}
+    prints = set()
+    for name, key in keys.items():
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        factor = t.get("fetch_factor", 2.0)
+        assert t["workload_key"] == key and len(t["source_fingerprint"]) == 16, name
+        assert factor == (1.0 if key == "search" else 2.0), name
+        assert t["traffic_bytes_per_launch"] == factor * t["fetch_bytes_raw"] + t["write_bytes"] and t["kernels"], name
+        prints.add(t["source_fingerprint"])
+    assert len(prints) == 1
+    c4 = json.load(open(os.path.join(ROOT, "profiles", "r05_config4_hbm_traffic.json")))
+    assert set(c4["kernels"]) == {"k_walk_direct", "k_format_chunks"} and 50e9 < c4["kernels"]["k_format_chunks"]["write_bytes"] < 53e9   # 51 GB of lines
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    assert line["parity_checked_paths"] > 1000 and line["config4"]["size"] == "full" and line["config4"]["lf_steps"] > 5e9
+    for k in ("secondary", "high_degree", "search", "config4", "config4_small"):
+        assert line[k]["cpu_baseline"]["kind"] == "port", k
+
+
 def test_gpus_without_a_launcher_starts_the_ranks(monkeypatch):
     """--gpus N > 1 outside torchrun: the ranks are children of this (GPU-free) process, started over 127.0.0.1."""
     calls = []
