@@ -53,18 +53,19 @@ struct Rows {
 class GBWT {
 public:
     // serialize::load_from::<GBWT | GBZ>(path)
-    explicit GBWT(const std::string &path, int device = 0) {
+    // `flags`: what the handle is for (GBWT_HIP_OPEN_EXTRACT | _SEARCH | _GFA): only those structures are built in HBM
+    explicit GBWT(const std::string &path, int device = 0, uint32_t flags = GBWT_HIP_OPEN_ALL) {
         gbwt_hip_index *h = nullptr;
-        check(gbwt_hip_open_file(path.c_str(), device, &h));
+        check(gbwt_hip_open_file_flags(path.c_str(), device, flags, &h));
         index_.reset(h, gbwt_hip_close);
         init();
     }
     // an index that is already in memory: raw record stream + record starts + header fields (gbwt_hip_open_records)
     GBWT(const uint8_t *data, uint64_t data_len, const std::vector<uint64_t> &starts, uint64_t alphabet_offset, uint64_t alphabet_size,
-         uint64_t sequences, uint64_t size, bool bidirectional, int device = 0) {
+         uint64_t sequences, uint64_t size, bool bidirectional, int device = 0, uint32_t flags = GBWT_HIP_OPEN_ALL) {
         gbwt_hip_index *h = nullptr;
-        check(gbwt_hip_open_records(data, data_len, starts.data(), starts.size(), alphabet_offset, alphabet_size, sequences, size,
-                                    bidirectional ? 1 : 0, device, &h));
+        check(gbwt_hip_open_records_flags(data, data_len, starts.data(), starts.size(), alphabet_offset, alphabet_size, sequences, size,
+                                          bidirectional ? 1 : 0, device, flags, &h));
         index_.reset(h, gbwt_hip_close);
         init();
     }
@@ -209,7 +210,7 @@ protected:
 
 class GBZ : public GBWT {
 public:
-    explicit GBZ(const std::string &path, int device = 0) : GBWT(path, device) {}
+    explicit GBZ(const std::string &path, int device = 0, uint32_t flags = GBWT_HIP_OPEN_ALL) : GBWT(path, device, flags) {}
 
     uint64_t paths() const { return sequences() / 2; }   // GBZ::paths, src/gbz.rs:446-452
     // GBZ::path(path_id, orientation).collect(): (node id, orientation) pairs, or nullopt (src/gbz.rs:461-466)
