@@ -952,6 +952,13 @@ def test_large_query_batches_travel_in_chunks(monkeypatch):
     assert np.array_equal(bd, bd1) and np.array_equal(bok, bok1) and np.array_equal(bd, bd2) and np.array_equal(bok, bok2)
     empty = plain.search_device(0, 0, 7)
     assert empty.n == 0
+    # queries of no nodes at all: find(q[0]) has nothing to find -- "not found" for every row, through every way in (src/bin/benchmark.rs builds none)
+    z2, z2_ok = plain.states_to_host(plain.search_device(d_q.data_ptr(), 5, 0))
+    assert not z2_ok.any() and not z2["node"].any() and not z2["end"].any()
+    with pytest.raises(G.GbwtHipError):
+        plain.search(np.zeros((5, 0), dtype=np.uint64))   # (the host form has no buffer to read: a null pointer is an error, not a query)
+    with pytest.raises(G.GbwtHipError):
+        plain.search_device(0, 5, 7)                      # rows but no pointer
     plain.close()
 
 
