@@ -570,6 +570,14 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
             x.desc_raw.release();
             x.dev.desc_raw = nullptr;
             x.lean_extract = true;
+            // ... and with them the one-step walk descriptors and the plain rank blocks (64 B per record + 16 B per 64 positions): all that read
+            // them after the open were the catch-up steps of k_walk_direct, which on such a handle step on the two-step descriptors and the
+            // packed half-blocks instead (WalkArgs::catch_up == 2), and the walk modes that are refused here anyway
+            const char *keep_steps = std::getenv("GBWT_HIP_KEEP_ONE_STEP");
+            if (x.packed_blocks && x.dev.gblocks != nullptr && !(keep_steps && std::atoi(keep_steps) != 0)) {
+                x.desc.release(); x.blocks.release();
+                x.dev.desc = nullptr; x.dev.blocks = nullptr;
+            }
         }
     }
     const auto t_done = std::chrono::steady_clock::now();
@@ -1073,7 +1081,10 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             a.out_nodes = ws->nodes.as<uint32_t>(); a.out_offsets = ws->offsets.as<uint64_t>();
             a.xcd_map = knobs.xcd_map >= 0 ? (knobs.xcd_map ? 1u : 0u) : (segmented ? 1u : 0u);
             a.uniform_loop = knobs.uniform_loop >= 0 ? (knobs.uniform_loop ? 1u : 0u) : 1u;
-            a.catch_up = knobs.catch_up >= 0 ? (knobs.catch_up ? 1u : 0u) : 1u;
+            // (2: single steps on the two-step descriptors + packed half-blocks: what a lean handle has -- and GBWT_HIP_CATCH_UP=2 on any)
+            a.catch_up = knobs.catch_up >= 0 ? static_cast<uint32_t>(std::min(knobs.catch_up, 2)) : 1u;
+            if (ix->lean_extract && a.catch_up == 1u) a.catch_up = 2u;
+            if (a.catch_up == 2u && !(ix->packed_blocks && knobs.packed_blocks != 0)) a.catch_up = ix->lean_extract ? 0u : 1u;
             a.align_segments = (segmented && knobs.align_segments != 0 && !parted) ? 1u : 0u;   // (a part ends where the next rank's begins, not at the next line)
             a.all4 = knobs.all4 != 0 ? 1u : 0u;
             a.headroom = static_cast<uint32_t>(knobs.headroom);

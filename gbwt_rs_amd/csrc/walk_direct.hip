@@ -542,7 +542,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             }
             if (hi_rec - lo_rec > 64u) catch_pause = 256;
         }
-        if (!together && a.uniform_loop && a.catch_up && catch_pause == 0 && __ballot(sink.wr - drained > ring_mask + 1 - 8) == 0) {   // (its single steps stage up to eight nodes)
+        // (catch_up == 2: the single steps read the two-step descriptors and the packed half-blocks the loops read anyway -- a handle that has
+        // given its one-step descriptors and plain rank blocks back, capi.hip: open_common -- and only while the wave is on the packed blocks)
+        if (!together && a.uniform_loop && a.catch_up && !(a.catch_up == 2u && full_blocks) && catch_pause == 0 && __ballot(sink.wr - drained > ring_mask + 1 - 8) == 0) {   // (its single steps stage up to eight nodes)
             const uint64_t walking = __ballot(rec != 0);
             for (uint32_t tries = 0; tries < 4 && !together; tries++) {
                 const uint32_t any = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(rec), __builtin_ctzll(walking)));
@@ -553,7 +555,28 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 for (int d = 32; d > 0; d >>= 1) front = max(front, static_cast<uint32_t>(__shfl_xor(static_cast<int>(front), d)));
                 const bool behind = rec != 0 && key != front;
                 bool slow_here = false;
-                if (behind) {
+                if (behind && a.catch_up == 2u) {
+                    // the first step of the two-step descriptor, taken alone: E_a = {node to emit, offset base, landing record | LEAF_EMIT2 |
+                    // DESC2_SLOW, flags} (load_kernels.hip: k_link_desc2), value and rank from the packed half-block of the offset (32 offsets:
+                    // {values, ., ones before | ..}); the block base of the landing record is one more, dependent, load.  Records whose steps
+                    // run through chains, or whose counts do not fit the packed blocks, leave the attempt to the loops.
+                    const uint4 *d2 = ix.desc2 + 8 * static_cast<uint64_t>(rec);
+                    const uint4 E0 = d2[0], E1 = d2[1];
+                    const uint4 K = ix.gblocks[bb == BLOCK_NONE ? 0u : 2 * static_cast<uint64_t>(bb) + (offset >> 5)];
+                    slow_here = (E0.z & DESC2_SLOW) != 0 || (E0.w & GATHER_OK) == 0 || (E0.w & (E_CHAIN | E_ANYCHAIN)) != 0 || (E1.w & E_CHAIN) != 0;
+                    if (!slow_here) {
+                        const uint32_t bit = offset & 31u;
+                        const uint32_t value = (K.x >> bit) & 1u;
+                        const uint32_t ones = (K.z & 0x1FFFFFu) + static_cast<uint32_t>(__popc(K.x & ((1u << bit) - 1u)));
+                        const uint4 E = value ? E1 : E0;
+                        const uint32_t land = E.z & REC_MASK;
+                        rec = land; offset = E.y + (value ? ones : offset - ones);
+                        bb = land != 0 ? ix.block_base[land] : BLOCK_NONE;
+                        sink.push(E.x, E.x != 0);
+                        sink.push(rec + ix.alphabet_offset, (E.z & LEAF_EMIT2) != 0);
+                        if (sink.wr >= quota) { rec = 0; bb = BLOCK_NONE; }
+                    }
+                } else if (behind) {
                     // everything the step can need in ONE round trip: both edges, the flags and the rank block
                     const uint4 *d1 = ix.desc + 4 * static_cast<uint64_t>(rec);
                     const uint4 E0 = d1[0], E1 = d1[1], D = d1[2];

@@ -112,11 +112,13 @@ gbwt_hip_status gbwt_hip_open_records(const uint8_t *data, uint64_t data_len, co
  *                          blocks (16 B per 64 positions), LF tables of the records with outdegree > 2 (16 B per position)
  *   GBWT_HIP_OPEN_GFA      gbwt_hip_path_lines*, gbwt_hip_write_gfa* (implies EXTRACT): label lengths, translation and line header tables
  * A handle opened WITHOUT SEARCH whose walks never leave the descriptors and rank blocks (no record of outdegree > 2, no edge that failed
- * a check at open) also gives the raw descriptors back once it is open (64 B per record: 14 of config 4's 65 GB); the pool-output walk
- * modes of gbwt_hip_workspace_tune, which read them, then return GBWT_HIP_UNSUPPORTED.
+ * a check at open) also gives back, once it is open, what only the open itself, the search kernels and the non-default walk modes read: the
+ * raw descriptors, the one-step walk descriptors and the plain rank blocks (128 B per record + 16 B per 64 positions: config 4 at its
+ * stated size 65 -> 36 GB, the headline index 3.3 -> 2.2 GB); the catch-up steps of the walk then read the two-step descriptors and the
+ * packed half-blocks, and the pool-output walk modes of gbwt_hip_workspace_tune return GBWT_HIP_UNSUPPORTED.
  * Record bytes, record starts and the endmarker are always there.  An entry point outside the handle's groups returns
  * GBWT_HIP_BAD_ARGUMENT.  gbwt_hip_open_file / gbwt_hip_open_records = GBWT_HIP_OPEN_ALL.  Config 3's index (1.1 M sites x 5 008
- * haplotypes): 11.4 GB opened for everything, 3.5 GB for SEARCH; gbwt_hip_memory_usage reports what a handle holds. */
+ * haplotypes): 11.4 GB opened for everything, 3.6 GB for SEARCH; gbwt_hip_memory_usage reports what a handle holds. */
 enum { GBWT_HIP_OPEN_EXTRACT = 1, GBWT_HIP_OPEN_SEARCH = 2, GBWT_HIP_OPEN_GFA = 4, GBWT_HIP_OPEN_ALL = 7 };
 gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t flags, gbwt_hip_index **out);
 gbwt_hip_status gbwt_hip_open_records_flags(const uint8_t *data, uint64_t data_len, const uint64_t *starts,

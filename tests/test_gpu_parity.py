@@ -577,7 +577,8 @@ def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
 
 @pytest.mark.parametrize("env", [{"GBWT_HIP_WIDE_ADDRESSES": "1"}, {"GBWT_HIP_RING_SLOTS": "32"}, {"GBWT_HIP_UNIFORM_LOOP": "0"},
                                  {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_HELPER_LANES": "0"},
-                                 {"GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_GATHER_LIMIT": "0", "GBWT_HIP_WIDE_ADDRESSES": "1"}])
+                                 {"GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_GATHER_LIMIT": "0", "GBWT_HIP_WIDE_ADDRESSES": "1"},
+                                 {"GBWT_HIP_CATCH_UP": "2"}, {"GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_SAMPLE_INTERVAL": "64"}])
 def test_walk_loop_variants(monkeypatch, env):
     """The loops of k_walk_direct with 64-bit addresses, with a ring asked for that is smaller than two row pieces (the library
     raises it: a 32-slot ring never holds a 128-byte piece and the walk would not end), as the only loop, with short
@@ -667,6 +668,32 @@ def test_chained_steps_over_chopped_segments(monkeypatch, env, bidirectional):
         assert np.array_equal(offsets, o_off) and np.array_equal(nodes, o_nodes), (env, seed)
         if seed == 0:
             check_all_positions(dev, oracle)
+
+
+@pytest.mark.parametrize("extra,every", [(1, 1), (1, 37), (3, 64), (0, 1)])
+def test_lean_extract_handle_walks_like_the_full_one(extra, every):
+    """A handle opened for extraction only (gbwt_hip_open_records_flags without SEARCH) on an index none of whose records needs the generic
+    decoder gives back its raw descriptors, its one-step walk descriptors and its plain rank blocks (128 B per record + 16 B per 64
+    positions); the catch-up steps of lagging lanes then read the two-step descriptors and packed half-blocks.  Dense and sparse insertions
+    (catch-up at work) and the plain chain: every path against the generator, rows against the full handle, parts of rows too."""
+    s = S.Synth.chain(sites=20000, haplotypes=1500, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=78, extra=extra, indel_every=every)
+    full = open_synth(s)
+    lean = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, flags=G.OPEN_EXTRACT)
+    records = int(full.stats.records)
+    assert lean.memory_usage()["index_device_bytes"] <= full.memory_usage()["index_device_bytes"] - 128 * records
+    ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
+    out = lean.extract_device(ids)
+    assert int(out.total) == (s.size - s.sequences) // 2
+    sums = lean.path_sums(len(ids))
+    assert all(int(sums[h]) == s.path_checksum(h) for h in range(s.paths))
+    full.extract_device(ids)
+    assert np.array_equal(lean.path_hashes(len(ids)), full.path_hashes(len(ids)))
+    some = np.array([1, 2 * 700 + 1, 5, 2 * 1499], dtype=np.uint64)                 # reverse sequences too
+    a, b = lean.sequences_csr(some), full.sequences_csr(some)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for part in range(3):
+        x, y = lean.part_csr(ids[:200], part, 3), full.part_csr(ids[:200], part, 3)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
 @pytest.mark.parametrize("extra,every,sites", [(2, 1, 60000), (3, 64, 150000), (1, 8, 100000), (3, 4096, 150000)])
@@ -760,6 +787,14 @@ def test_headline_full_size():
         assert steps == 5000 * 2 * 333334 and np.all(at == 2 * s.sites) and np.array_equal(sums, truth), parts
         for h, got in pieces.items():
             assert np.array_equal(np.concatenate(got), s.path(h)), (parts, h)
+    # the same index opened for EXTRACT only (gbwt_hip_open_records_flags): no raw / one-step descriptors, no plain rank blocks -- two thirds of
+    # the memory, the same rows
+    lean = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, flags=G.OPEN_EXTRACT)
+    lean_bytes, all_bytes = lean.memory_usage()["index_device_bytes"], dev.memory_usage()["index_device_bytes"]
+    assert lean_bytes <= 2.4e9 and lean_bytes < 0.72 * all_bytes, (lean_bytes, all_bytes)
+    lean.extract_device(ids)
+    assert np.array_equal(lean.path_sums(s.paths), truth)
+    lean.close()
     # The 13.3 GB of rows start as one hipMalloc and are rebuilt from spread 2 GiB chunks (virtual-memory API) when the workspace
     # serves its third request of that size; every byte must come back when the workspace goes -- one hipMemUnmap per mapped chunk,
     # hipMemAddressFree, hipMemRelease (capi_internal.hpp: DeviceBuffer::release) -- and when it regrows.
@@ -1007,7 +1042,7 @@ def test_open_flags_build_what_they_name(tmp_path):
     # ... and a handle without SEARCH whose walks never need the generic decoder has given its raw descriptors back (64 bytes per record);
     # what would read them -- the pool-output walk modes -- is refused, not answered wrongly
     records = int(full.stats.records)
-    assert mem["extract"] <= mem["full"] - 64 * records, (mem, records)
+    assert mem["extract"] <= mem["full"] - 128 * records, (mem, records)
     extract.tune(walk_mode=1)
     with pytest.raises(G.GbwtHipError) as e:
         extract.sequences_csr(ids[:8])
@@ -1166,6 +1201,9 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "90", "GBWT_HIP_CHAINS": "0"},        # no chained steps: fused pairs only
                 {"GBWT_HIP_SAMPLE_INTERVAL": "19", "GBWT_HIP_CHAINS": "2", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "200", "GBWT_HIP_CATCH_UP": "0"},     # mixed waves go to the gather loop at once (no single steps of the lanes behind)
+                {"GBWT_HIP_SAMPLE_INTERVAL": "200", "GBWT_HIP_CATCH_UP": "2"},     # the single steps on the two-step descriptors + packed half-blocks (what a lean handle has, round 5)
+                {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_CHAINS": "0"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_GATHER_LIMIT": "64"},   # ... with records too long for the packed counts in the way
                 {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_ALIGN_SEGMENTS": "1"},  # line-aligned segments (round 4): walkers hand over at line boundaries of the row's memory; segments shorter than a line
                 {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "0"},   # ... with the lane-per-row writer (64-byte boundaries)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16", "GBWT_HIP_WALKER_ORDER": "1"},   # ... and walkers in the order of their start records
@@ -1358,7 +1396,7 @@ def _layered_paths(layers, haplotypes, seed):
 
 @pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "9", "GBWT_HIP_RING_SLOTS": "32", "GBWT_HIP_ROW_PIECE": "16"},
                                  {"GBWT_HIP_WALK_TABLES": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_DIRECT": "0"},
-                                 {"GBWT_HIP_SAMPLE_INTERVAL": "11", "GBWT_HIP_CATCH_UP": "0"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "11", "GBWT_HIP_CATCH_UP": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "11", "GBWT_HIP_CATCH_UP": "2"},
                                  {"GBWT_HIP_DEEP_TABLES": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "13", "GBWT_HIP_DEEP_TABLES": "0"},   # one table step per load
                                  {"GBWT_HIP_SAMPLE_INTERVAL": "10", "GBWT_HIP_RING_SLOTS": "128"}, {"GBWT_HIP_SAMPLE_INTERVAL": "21", "GBWT_HIP_ROW_PIECE": "0"},
                                  {"GBWT_HIP_SAMPLE_INTERVAL": "0"}],   # whole sequences from both ends: seven steps at a time past the middle of the row
