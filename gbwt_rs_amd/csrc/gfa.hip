@@ -535,7 +535,8 @@ void upload_label_lengths(gbwt_hip_index &ix) {
     std::vector<uint32_t> len(h.sequences_labels.size() + 1, 0);
     {   // (sixteen million nodes in a config-4-shaped GBZ: a few threads)
         const uint64_t n = h.sequences_labels.size();
-        const unsigned pieces = n >= (uint64_t(1) << 23) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned pieces = n >= (uint64_t(1) << 23) ? std::max(std::min(8u, hw), std::min(static_cast<unsigned>(std::min<uint64_t>(n >> 21, 32)), hw)) : 1u;   // (109 M nodes: 32 threads)
         auto piece = [&](unsigned p) {
             for (uint64_t s = n * p / pieces, end = n * (p + 1) / pieces; s < end; s++) {
                 const uint64_t node = 2 * s + first;              // forward GBWT node of sequence s

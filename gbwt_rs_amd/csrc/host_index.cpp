@@ -156,8 +156,13 @@ void run_pieces(unsigned pieces, Fn fn) {
 
 // (from eight million items: below that one thread is done before the copy of the record bytes to the device, which runs next to it,
 // and more threads only get in that copy's way -- parse of the headline GBZ 9.3-10.0 ms with one thread, 10.3-12.0 with eight)
+// (... and from there a thread per two million items, up to 32: the 4.4 G label characters and 218 M record starts of config 4 at its
+// stated size took 0.9 + 0.4 s of a 2 s open on eight threads -- profiles/r05_c4_open_trace.txt)
 inline unsigned pieces_for(uint64_t items) {
-    return items >= (uint64_t(1) << 23) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+    if (items < (uint64_t(1) << 23)) return 1u;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned by_size = static_cast<unsigned>(std::min<uint64_t>(items >> 21, 32));
+    return std::max(std::min(8u, hw), std::min(by_size, hw));
 }
 
 std::vector<uint64_t> decode_sparse(const SparseView &v) {
