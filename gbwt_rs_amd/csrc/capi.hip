@@ -604,11 +604,11 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
     if (!ix || !ws || ws->index != ix) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace");
     if (!(ix->caps & GBWT_HIP_OPEN_SEARCH)) return fail(GBWT_HIP_BAD_ARGUMENT, "the handle was not opened for navigation / search (GBWT_HIP_OPEN_SEARCH)");
     if (n == 0) return GBWT_HIP_OK;
-    if (!in_a || !out || !valid) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");
+    if ((!in_a && a_row != 0) || !out || !valid) return fail(GBWT_HIP_BAD_ARGUMENT, "null buffer");   // (rows of no bytes -- queries of no nodes -- have no buffer)
     ws->follow_cached = false;   // the staging buffers are shared with gbwt_hip_follow
     try {
         HIP_CHECK(hipSetDevice(ix->device));
-        ws->in_a.reserve(n * a_row);
+        ws->in_a.reserve(std::max<size_t>(n * a_row, 16));
         ws->out_a.reserve(n * out_row);
         ws->out_valid.reserve(n);
         if (in_b) ws->in_b.reserve(n * b_row);
@@ -632,12 +632,12 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
                 char *pin_in = static_cast<char *>(l.pinned[0]), *pin_out = static_cast<char *>(l.pinned[1]);
                 for (uint64_t c = next++; c < chunks && !failed; c = next++) {
                     const uint64_t lo = c * rows_per_chunk, rows = std::min(rows_per_chunk, n - lo);
-                    std::memcpy(pin_in, static_cast<const char *>(in_a) + lo * a_row, rows * a_row);
+                    if (a_row != 0) std::memcpy(pin_in, static_cast<const char *>(in_a) + lo * a_row, rows * a_row);
                     if (in_b) std::memcpy(pin_in + rows * a_row, static_cast<const char *>(in_b) + lo * b_row, rows * b_row);
                     char *d_a = ws->in_a.as<char>() + lo * a_row, *d_b = in_b ? ws->in_b.as<char>() + lo * b_row : nullptr;
                     char *d_out = ws->out_a.as<char>() + lo * out_row;
                     uint8_t *d_valid = ws->out_valid.as<uint8_t>() + lo;
-                    bool ok = hipMemcpyAsync(d_a, pin_in, rows * a_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
+                    bool ok = a_row == 0 || hipMemcpyAsync(d_a, pin_in, rows * a_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
                     if (ok && in_b) ok = hipMemcpyAsync(d_b, pin_in + rows * a_row, rows * b_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
                     if (ok) { launch(d_a, d_b, d_out, d_valid, rows, l.stream); ok = hipGetLastError() == hipSuccess; }
                     ok = ok && hipMemcpyAsync(pin_out, d_out, rows * out_row, hipMemcpyDeviceToHost, l.stream) == hipSuccess &&
@@ -667,10 +667,10 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
         const size_t piece = std::min<size_t>(HostCopier::CHUNK, std::max<size_t>(4096, ws->knobs.query_piece));
         if (lanes_in) {
             HIP_CHECK(hipStreamSynchronize(s));
-            copy_to_device(ws, ws->in_a.ptr, in_a, n * a_row, piece);
+            if (a_row != 0) copy_to_device(ws, ws->in_a.ptr, in_a, n * a_row, piece);
             if (in_b) copy_to_device(ws, ws->in_b.ptr, in_b, n * b_row, piece);
         } else {
-            HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, n * a_row, hipMemcpyHostToDevice, s));
+            if (a_row != 0) HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, n * a_row, hipMemcpyHostToDevice, s));
             if (in_b) HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, n * b_row, hipMemcpyHostToDevice, s));
         }
         HIP_CHECK(hipEventRecord(ws->qev[0], s));
