@@ -188,9 +188,17 @@ void upload_starts(gbwt_hip_index &ix) {
     const bool narrow = ix.stats.data_bytes < (uint64_t(1) << 32);
     ix.starts.reserve(std::max<size_t>(h.starts.size(), 1) * (narrow ? sizeof(uint32_t) : sizeof(uint64_t)));
     if (narrow) {
-        std::vector<uint32_t> s32(h.starts.begin(), h.starts.end());
-        if (s32.empty()) s32.push_back(0);
-        HIP_CHECK(hipMemcpy(ix.starts.ptr, s32.data(), s32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // (218 M starts of an HPRC-sized index: narrowed on a few threads, 0.2 s on one)
+        const size_t n = h.starts.size();
+        std::unique_ptr<uint32_t[]> s32(new uint32_t[std::max<size_t>(n, 1)]);
+        s32[0] = 0;
+        const unsigned pieces = n >= (size_t(1) << 23) ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
+        auto piece = [&](unsigned p) { for (size_t k = n * p / pieces, end = n * (p + 1) / pieces; k < end; k++) s32[k] = static_cast<uint32_t>(h.starts[k]); };
+        std::vector<std::thread> pool;
+        for (unsigned p = 1; p < pieces; p++) pool.emplace_back(piece, p);
+        piece(0);
+        for (auto &t : pool) t.join();
+        HIP_CHECK(hipMemcpy(ix.starts.ptr, s32.get(), std::max<size_t>(n, 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     } else if (!h.starts.empty()) {
         HIP_CHECK(hipMemcpy(ix.starts.ptr, h.starts.data(), h.starts.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
@@ -777,9 +785,24 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
         // with slices, registered pages, and -- round 4 -- four threads staging 4 MiB chunks through pinned buffers and streams of their
         // own, made once per process in the background: 16-25 ms, and a first extraction that waited 370 ms behind the pinned
         // allocations; NOTEBOOK.md, round 4)
-        early.worker = std::thread([&early, src, dst, bytes, dev]() {
+        // ... for the 60 MB of the headline index.  The 1.5 GB of an HPRC-sized one are cut into slices that several threads copy side by
+        // side (GBWT_HIP_UPLOAD_SLICES; from 256 MB: 4): profiles/r05_c4_open_trace.txt
+        unsigned slices = bytes >= (uint64_t(256) << 20) ? 4u : 1u;
+        if (const char *v = std::getenv("GBWT_HIP_UPLOAD_SLICES")) slices = static_cast<unsigned>(std::min(32, std::max(1, std::atoi(v))));
+        early.worker = std::thread([&early, src, dst, bytes, dev, slices]() {
             early.result = hipSetDevice(dev);
-            if (early.result == hipSuccess) early.result = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+            if (early.result != hipSuccess) return;
+            if (slices <= 1) { early.result = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); return; }
+            std::vector<hipError_t> results(slices, hipSuccess);
+            std::vector<std::thread> pool;
+            for (unsigned k = 0; k < slices; k++)
+                pool.emplace_back([&results, k, slices, src, dst, bytes, dev]() {
+                    const uint64_t lo = (bytes / 4096 * k / slices) * 4096, hi = k + 1 == slices ? bytes : (bytes / 4096 * (k + 1) / slices) * 4096;
+                    results[k] = hipSetDevice(dev);
+                    if (results[k] == hipSuccess && hi > lo) results[k] = hipMemcpy(static_cast<char *>(dst) + lo, src + lo, hi - lo, hipMemcpyHostToDevice);
+                });
+            for (auto &t : pool) t.join();
+            for (hipError_t r : results) if (r != hipSuccess) early.result = r;
         });
     });
     if (early.worker.joinable()) {

@@ -165,7 +165,7 @@ inline unsigned pieces_for(uint64_t items) {
     return std::max(std::min(8u, hw), std::min(by_size, hw));
 }
 
-std::vector<uint64_t> decode_sparse(const SparseView &v) {
+Words decode_sparse(const SparseView &v) {
     // A few threads, each with a stretch of the high bitvector (the rank of its first one comes from the popcounts before it): the
     // 32 million record starts of a config-4-shaped GBZ were 110 ms on one thread.  The declared number of ones must be the number of
     // set bits BEFORE it sizes an allocation (a corrupt count would ask for up to 64 times the file size and surface as "out of host
@@ -181,7 +181,7 @@ std::vector<uint64_t> decode_sparse(const SparseView &v) {
     });
     for (unsigned p = 0; p < pieces; p++) first_rank[p + 1] = first_rank[p] + count[p];
     if (first_rank[pieces] != v.ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
-    std::vector<uint64_t> values;
+    Words values;
     values.reserve(v.ones + 1);                               // the callers append a sentinel
     values.resize(v.ones);
     const uint64_t w = v.low.width;
@@ -202,7 +202,7 @@ std::vector<uint64_t> decode_sparse(const SparseView &v) {
     return values;
 }
 
-std::vector<uint64_t> read_sparse(Elements &in, uint64_t &universe) {
+Words read_sparse(Elements &in, uint64_t &universe) {
     const SparseView v = locate_sparse(in);
     universe = v.universe;
     return decode_sparse(v);
@@ -215,7 +215,7 @@ void read_bytes(Elements &in, std::vector<uint8_t> &out) {
     out.assign(p, p + len);
 }
 
-void finish_strings(Strings &s, std::vector<uint64_t> &&offsets) {
+void finish_strings(Strings &s, Words &&offsets) {
     if (!offsets.empty() && offsets[0] != 0) throw InvalidData("StringArray: First string does not start at offset 0");
     s.offsets = std::move(offsets);
     s.offsets.push_back(s.bytes.size());
@@ -230,7 +230,7 @@ void read_strings(Elements &in, Strings &s, Deferred *later = nullptr, bool back
     read_bytes(in, alphabet);
     const Packed packed = read_packed(in);
     auto decode = [view, alphabet, packed, &s]() {
-        std::vector<uint64_t> offsets = decode_sparse(view);
+        Words offsets = decode_sparse(view);
         s.bytes.resize(packed.len);
         const unsigned pieces = pieces_for(packed.len);
         run_pieces(pieces, [&](unsigned p) {
@@ -248,7 +248,7 @@ void read_strings(Elements &in, Strings &s, Deferred *later = nullptr, bool back
 // StringArray::decompress (zstd form, graph version >= 4), src/support.rs:543-571
 void read_strings_zstd(Elements &in, Strings &s) {
     uint64_t universe;
-    std::vector<uint64_t> offsets = read_sparse(in, universe);
+    Words offsets = read_sparse(in, universe);
     uint64_t total = in.word();
     std::vector<uint8_t> compressed;
     read_bytes(in, compressed);

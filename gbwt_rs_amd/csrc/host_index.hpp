@@ -25,10 +25,24 @@ struct Unsupported : std::runtime_error { using std::runtime_error::runtime_erro
 // gbwt::PathName, src/gbwt.rs:912-926
 struct PathName { uint32_t sample, contig, phase, fragment; };
 
+// An allocator whose resize() leaves new elements uninitialised: the 4.4 G label characters of an HPRC-sized GBZ are unpacked by many
+// threads into a vector that a value-initialising resize() would first zero -- and page in -- on ONE thread (a second of a two-second open,
+// profiles/r05_c4_open_trace.txt).  Every byte such a vector is resized to is written before it is read.
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+    DefaultInitAllocator() = default;
+    template <class U> DefaultInitAllocator(const DefaultInitAllocator<U> &) noexcept {}
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+using Bytes = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
+using Words = std::vector<uint64_t, DefaultInitAllocator<uint64_t>>;   // (the same for the 218 M record starts / 109 M label offsets of such a file)
+
 // support::StringArray flattened: offsets[n+1] into bytes
 struct Strings {
-    std::vector<uint64_t> offsets{0};
-    std::vector<uint8_t> bytes;
+    Words offsets{0};
+    Bytes bytes;
     size_t size() const { return offsets.size() - 1; }
     std::string str(size_t i) const { return std::string(bytes.begin() + offsets[i], bytes.begin() + offsets[i + 1]); }
     size_t len(size_t i) const { return offsets[i + 1] - offsets[i]; }
@@ -41,7 +55,7 @@ struct HostIndex {
     bool bidirectional = false;
     // BWT, src/bwt.rs:97-100: data + record starts (n_records + 1 entries, last = data.size())
     std::vector<uint8_t> data;
-    std::vector<uint64_t> starts;
+    Words starts;
     uint64_t records() const { return starts.empty() ? 0 : starts.size() - 1; }
 
     // tags of the GBWT (key -> value, lower-cased keys), src/support.rs:915-1020
@@ -66,7 +80,7 @@ struct HostIndex {
     uint64_t graph_nodes = 0;              // Header<GraphPayload>.nodes
     Strings sequences_labels;   // node labels, one per potential node
     Strings segment_names;
-    std::vector<uint64_t> segment_starts;  // node id of the first node of each segment (mapping ones)
+    Words segment_starts;  // node id of the first node of each segment (mapping ones)
     uint64_t mapping_len = 0;              // universe of the node-to-segment mapping
 
     // load_index_file_into(..., background = true): the copy of the record bytes into `data` and the decoding of the node labels --
