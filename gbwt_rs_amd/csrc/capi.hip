@@ -600,12 +600,12 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
 // Staging helper for the one-lane-per-query entry points.  A query is a ROW: a_row bytes of `in_a` (+ b_row bytes of `in_b`) in,
 // out_row bytes of `out` + one byte of `valid` out; launch(d_a, d_b, d_out, d_valid, rows, stream) runs the kernel over `rows` rows.
 //
-// Small batches: copy in, one launch, copy out, on the workspace stream.  Large ones (round 5; src/bin/benchmark.rs:161-164 times the
-// whole call, not the kernel): the rows are cut into chunks that travel through the workspace's copy lanes -- the threads, pinned buffers
-// and streams of copy_to_host -- so that one chunk's upload, another's kernel and a third's download share the time, and the host side
-// of the copies (pageable -> pinned, pinned -> pageable) runs on several cores.  A million 10-node queries: 2.95 ms per call with plain
-// hipMemcpyAsync from / to the caller's pageable memory around a 0.49 ms kernel.  The results of all chunks end up in out_a / out_valid
-// like those of a single launch.
+// Default: copy in, one launch, copy out, on the workspace stream (a million 10-node queries: 2.9-3.3 ms per call around a 0.49 ms kernel --
+// 105 MB over PCIe; src/bin/benchmark.rs:161-164 times the whole call, not the kernel).  With GBWT_HIP_QUERY_PIPELINE=1 (round 5; measured,
+// not the default: profiles/r05_query_call_sweep.txt) a large batch is cut into chunks that travel through the workspace's copy lanes -- the
+// threads, pinned buffers and streams of copy_to_host -- so that one chunk's upload, another's kernel and a third's download share the
+// time; 2 / 3 keep the one launch and move both copies / the copy back through the lanes.  The results of all chunks end up in out_a /
+// out_valid like those of a single launch.  The device-resident forms below skip the copies altogether.
 template <class Launch>
 gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *in_a, size_t a_row, const void *in_b, size_t b_row,
                           void *out, size_t out_row, uint8_t *valid, uint64_t n, Launch launch) {
