@@ -476,12 +476,15 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
         if (one_walk) {
             pool.reserve(pool_capacity * sizeof(uint4)); tags.reserve(pool_capacity * sizeof(uint2));
             HIP_CHECK(hipMemset(d_stats + 2, 0, sizeof(uint64_t)));
+            HIP_CHECK(hipMemsetAsync(d_flags + 1, 0, sizeof(uint32_t), nullptr));   // the step budget the walks of ONE pass share (walk_loops.hpp: quiet_walk)
             launch_lengths_and_samples(d, interval, ix.seq_len.as<uint32_t>(), pool.as<uint4>(), tags.as<uint2>(), d_stats + 2, pool_capacity, d_flags, nullptr);
             HIP_CHECK(hipMemcpy(&pooled, d_stats + 2, sizeof(uint64_t), hipMemcpyDeviceToHost));
             if (pooled > pool_capacity) one_walk = false;            // cannot happen (one sample per interval + one per sequence): walk twice
         }
-        if (!one_walk && !by_checkpoints)
-        launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), want_pairs ? prints.as<uint64_t>() : nullptr, d_flags, nullptr);
+        if (!one_walk && !by_checkpoints) {
+            HIP_CHECK(hipMemsetAsync(d_flags + 1, 0, sizeof(uint32_t), nullptr));
+            launch_sequence_lengths(d, ix.seq_len.as<uint32_t>(), want_pairs ? prints.as<uint64_t>() : nullptr, d_flags, nullptr);
+        }
         if (want_pairs)
             launch_check_orientation_pairs(ix.seq_len.as<uint32_t>(), prints.as<uint64_t>(), h.sequences / 2, d_flags + 2, nullptr);
         uint32_t flags[4] = {0, 0, 0, 0};

@@ -1472,6 +1472,13 @@ __device__ __forceinline__ void quiet_walk(const DeviceIndex &ix, uint64_t id, S
         // never ends -- records of a corrupt file can send a walk in circles (bit 1).  Every iteration emits a node or ends.
         if (sink.wr > 0xFFFFFFF0u) { if (overflow) atomicOr(overflow, 1u); break; }
         if (++guard > ix.max_walk) { if (overflow) atomicOr(overflow, 2u); break; }
+        // ... and ALL walks of a pass together take no more steps than there are BWT positions either: overflow[1] counts them in units of
+        // 4 096 iterations, so that the walks a corrupt record sends in circles share ONE budget and end within the time of a normal pass
+        // (round 5: two mutations of a 3 MB file each cost an open three minutes -- every circling lane ran to the bound on its own)
+        if (overflow && (guard & 4095u) == 0) {
+            const uint64_t spent = static_cast<uint64_t>(atomicAdd(overflow + 1, 1u)) + 1;
+            if (spent * 4096 > ix.max_walk || (*reinterpret_cast<volatile uint32_t *>(overflow) & 2u) != 0) { atomicOr(overflow, 2u); break; }
+        }
         two_step(ix, sink, rec, offset, bb);
         sink.checkpoint(rec, offset, bb);
     }

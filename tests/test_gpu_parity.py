@@ -1543,7 +1543,9 @@ def test_corrupt_large_files_through_the_threaded_open(tmp_path):
     """The same for a GBZ of several MiB, which takes the threaded paths of gbwt_hip_open_file: the record bytes start for the device out
     of the mapped file while the loader still decodes (a decode that throws must not unmap the file under that copy: round 3 did), the
     deferred decodes run on threads, node labels and the host copy of the record bytes in the background behind finish().  Corrupt
-    starts, labels, lengths: GBWT_HIP_INVALID_DATA (or an index that opens and answers), never a fault.  Child process with a deadline."""
+    starts, labels, lengths: GBWT_HIP_INVALID_DATA (or an index that opens and answers), never a fault -- and never a stall: records that send
+    the walks of the open in circles share one step budget (walk_loops.hpp: quiet_walk; round 5: two such mutations took three minutes each),
+    so no open takes more than ten seconds.  Child process with a deadline."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1554,12 +1556,17 @@ import numpy as np
 import gbwt_rs_amd as G
 from test_capi_cpu import mutated_large_file
 import pathlib
+import time
 opened = rejected = 0
 reasons = set()
+slowest = 0.0
 for w, value, path in mutated_large_file(pathlib.Path(TMP), per_region=60):
+    t0 = time.perf_counter()
     try:
         dev = G.GBZ.load(path)
+        slowest = max(slowest, time.perf_counter() - t0)
     except G.GbwtHipError as e:
+        slowest = max(slowest, time.perf_counter() - t0)
         assert e.status in (G._lib.INVALID_DATA, G._lib.UNSUPPORTED), (w, hex(value), str(e))
         rejected += 1
         reasons.add(str(e)[:60])
@@ -1575,6 +1582,7 @@ for w, value, path in mutated_large_file(pathlib.Path(TMP), per_region=60):
     dev.close()
 print("opened", opened, "rejected", rejected, sorted(reasons))
 assert opened > 30 and rejected > 60 and any("starts" in r or "bitvector" in r or "Elias" in r or "sparse" in r.lower() for r in reasons), reasons
+assert slowest < 30.0, f"an open of a corrupt file took {slowest:.1f} s"
 print("MUTATIONS_OK")
 '''
     out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}; TMP = {str(tmp_path)!r}\n" + code], capture_output=True, text=True, timeout=900)
