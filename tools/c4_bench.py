@@ -252,6 +252,15 @@ def run_sharded(gbz, generic, walks, rank, world, comm, barrier, device, passes=
         p_bytes = allgather(int(side.path_lines_device(my_generic, 0).total) if len(my_generic) else 0)
         w_bytes = allgather(int(lines.total))
         p_total = sum(p_bytes)
+        # (every rank must take the same way: the file system has room for the file, or nobody writes)
+        import shutil
+        room = min(allgather(int(shutil.disk_usage(os.path.dirname(file_path) or ".").free)))
+        if room < 1.1 * (p_total + sum(w_bytes)) + (1 << 30):
+            if rank == 0:
+                res["sharded_file"] = {"skipped": f"{room} bytes free under {os.path.dirname(file_path)}, the file needs {p_total + sum(w_bytes)}"}
+            side.close()
+            file_path = None
+    if file_path is not None and allgather is not None:
         if rank == 0:
             with open(file_path, "wb") as f:
                 f.truncate(p_total + sum(w_bytes))
