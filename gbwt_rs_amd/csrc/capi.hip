@@ -890,7 +890,7 @@ gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hi
         out->workspace_device_bytes = sum({&ws->seq_ids, &ws->lengths, &ws->offsets, &ws->head, &ws->pool, &ws->next, &ws->counters, &ws->nodes, &ws->scan_temp,
                                            &ws->order_keys, &ws->order_rows, &ws->order_counts, &ws->order_level, &ws->order_temp, &ws->in_a, &ws->in_b, &ws->out_a,
                                            &ws->out_valid, &ws->follow_off, &ws->gfa_a, &ws->gfa_b, &ws->gfa_c, &ws->gfa_text, &ws->gfa_text2, &ws->gfa_valid, &ws->gfa_chunk_first,
-                                           &ws->gfa_chunks});
+                                           &ws->gfa_chunks, &ws->gfa_plan});
         out->rows_bytes = ws->nodes.bytes;
         out->rows_chunks = ws->nodes.chunks.size();
         out->text_bytes = ws->gfa_text.bytes + ws->gfa_text2.bytes;

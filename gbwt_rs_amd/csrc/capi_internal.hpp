@@ -322,7 +322,7 @@ struct gbwt_hip_workspace {
     gbwt_hip::DeviceBuffer seq_ids, lengths, offsets, head, pool, next, counters, nodes, scan_temp;
     gbwt_hip::DeviceBuffer order_keys, order_rows, order_counts, order_level, order_temp;   // walker order of a segmented extraction
     gbwt_hip::DeviceBuffer in_a, in_b, out_a, out_valid, follow_off;  // search staging
-    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_text2, gfa_valid, gfa_chunk_first, gfa_chunks;  // GFA line formatting (gfa_text2: the second text buffer of a pipelined whole-file write)
+    gbwt_hip::DeviceBuffer gfa_a, gfa_b, gfa_c, gfa_text, gfa_text2, gfa_valid, gfa_chunk_first, gfa_chunks, gfa_plan;  // GFA line formatting (gfa_text2: the second text buffer of a pipelined whole-file write)
     // What the device-resident results answer.  The C idiom "size query, then the same call with a buffer" (gbwt_hip_extract,
     // _follow, _path_lines) must not compute twice: a call that repeats the request of the results still in the workspace
     // copies them out.  Keys are host copies of the ids / states of the request.

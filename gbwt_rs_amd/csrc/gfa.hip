@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "gfa_tokens.hpp"
 
 using namespace gbwt_hip;
 
@@ -203,55 +204,115 @@ __device__ __forceinline__ uint64_t line_header(const LineHeaders &hdr, uint64_t
     return plen + digits + 1;
 }
 
+// What the workgroup of a chunk starts from, put together once per request by one thread per chunk: where its node ids and its text begin, how
+// many positions it has, whether it opens / closes its line.  The workgroups used to find all that themselves -- four levels of dependent
+// loads and the decimal length of the W-line's end coordinate in every one of their 256 threads -- before they asked for their first node id.
+struct __attribute__((aligned(16))) ChunkPlan {
+    uint64_t ids_at;        // index of the chunk's first position in the rows
+    uint64_t text_at;       // byte of the text where its first token begins
+    uint32_t count, row;    // positions; the request's row (= line) it belongs to
+    uint32_t flags;         // 1: first chunk of its line (writes the header), 2: last (writes the trailer)
+    uint32_t header_len;
+};
+static_assert(sizeof(ChunkPlan) == 32, "two 16-byte loads");
+
+__global__ void __launch_bounds__(256) k_plan_chunks(const uint64_t *offsets, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path, uint64_t chunks_cap,
+                                                      const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint64_t *seq_ids, LineHeaders hdr,
+                                                      const uint64_t *line_end, LineCache cache, ChunkPlan *plans) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (c >= chunks_cap || c >= chunk_first[n]) return;
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, c);
+    const uint64_t path = seq_ids[r.path] >> 1;
+    const uint64_t header_len = line_header(hdr, path, line_end, r.path, false, nullptr, 0, 1);
+    // where the chunk's tokens start inside the line: from the scan of this request's sizing pass, or from the line cache of the index
+    const uint64_t k_chunk = c - chunk_first[r.path];
+    const uint64_t before = cache.text ? cache.text[cache.chunk_first[path] + k_chunk] + (p_lines ? cache_p_extra(k_chunk) : 0) : text_before[c] - text_before[chunk_first[r.path]];
+    ChunkPlan plan;
+    plan.ids_at = r.lo;
+    plan.text_at = line_start[r.path] + header_len + before;
+    plan.count = static_cast<uint32_t>(r.hi - r.lo);
+    plan.row = static_cast<uint32_t>(r.path);
+    plan.flags = (r.first ? 1u : 0u) | (r.last ? 2u : 0u);
+    plan.header_len = static_cast<uint32_t>(header_len);
+    plans[c] = plan;
+}
+
 // One workgroup per chunk: the header (first chunk of a line), the node tokens of the chunk, the trailer (last chunk).
 // The tokens of 1 024 positions are put together in LDS (a block scan of their widths places them) and leave as aligned 16-byte
 // stores; only the first and the last bytes of such a batch, where the text does not fill a 16-byte unit, go out one by one.
 // (With every lane storing its own six bytes one at a time the formatter wrote 330 GB/s of text.)
 constexpr uint32_t TOKEN_MAX = 12;   // ',' + ten digits + '+' (P-lines); '>' + ten digits (W-lines)
-constexpr uint32_t PER_THREAD = 4;   // consecutive positions per thread and batch (one scan and two barriers per 1 024 positions)
-__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
-                                                                   const uint64_t *text_before, int p_lines, const uint64_t *line_start, const uint64_t *seq_ids,
-                                                                   LineHeaders hdr, const uint64_t *line_end, uint8_t *out, LineCache cache) {
-    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
+// PER_THREAD: consecutive positions per thread and batch (one scan and two barriers per 256 * PER_THREAD positions)
+// WHOLE_TOKENS (GBWT_HIP_FORMAT_TOKENS, default 1): a token is put together in registers (gfa_tokens.hpp) and OR-ed into the staging buffer as
+// the three or four aligned dwords it covers -- the buffer is zero wherever no token has been placed, and whoever copies a unit out leaves it
+// zero again.  0 = the form before it: a division and a one-byte store per character (the kernel was bound by exactly those: vector ALU 83 %
+// busy, LDS 70 %, profiles/r05_format_stream.txt).
+template <bool WHOLE_TOKENS, uint32_t PER_THREAD>
+__global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const ChunkPlan *plans, int p_lines,
+                                                                   const uint64_t *seq_ids, LineHeaders hdr, const uint64_t *line_end, uint8_t *out) {
+    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS, WHOLE_TOKENS ? hipcub::BLOCK_SCAN_WARP_SCANS : hipcub::BLOCK_SCAN_RAKING>;
     __shared__ typename BlockScan::TempStorage scan_storage;
-    __shared__ __attribute__((aligned(16))) uint8_t stage[FORMAT_THREADS * PER_THREAD * TOKEN_MAX + 32];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr uint32_t BATCH = FORMAT_THREADS * PER_THREAD;
+    constexpr uint32_t STAGE_BYTES = FORMAT_THREADS * PER_THREAD * TOKEN_MAX + 48;   // a batch, the bytes in front of it in its first unit, the dwords a last token spreads over
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE_BYTES];
     if (blockIdx.x >= chunk_first[n]) return;                           // (launched for the host's upper bound of the chunk count)
-    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, blockIdx.x);
     const uint32_t t = threadIdx.x;
-    uint8_t *line = out + line_start[r.path];
-    const uint64_t path = seq_ids[r.path] >> 1;
-    const uint64_t header_len = line_header(hdr, path, line_end, r.path, r.first, line, t, FORMAT_THREADS);
-    // where the chunk's tokens start inside the line: from the scan of this request's sizing pass, or from the line cache of the index
-    const uint64_t k_chunk = blockIdx.x - chunk_first[r.path];
-    uint64_t cursor = header_len + (cache.text ? cache.text[cache.chunk_first[path] + k_chunk] + (p_lines ? cache_p_extra(k_chunk) : 0)
-                                               : text_before[blockIdx.x] - text_before[chunk_first[r.path]]);
+    const ChunkPlan plan = plans[blockIdx.x];
+    uint8_t *const text = out + plan.text_at;
+    if (plan.flags & 1u) line_header(hdr, seq_ids[plan.row] >> 1, line_end, plan.row, true, text - plan.header_len, t, FORMAT_THREADS);
+    uint64_t cursor = 0;                                                // bytes of the chunk's text written so far
+    // positions counted from the start of the chunk (32-bit arithmetic in the loop): `count` of them, the path's first one at `first_at` or nowhere
+    const uint32_t count = plan.count, first_at = (plan.flags & 1u) ? 0u : ~0u;
+    const uint32_t *const ids = nodes + plan.ids_at;
     uint32_t ahead[PER_THREAD];                                        // the node ids of the next batch are asked for before this one is put together
 #pragma unroll
-    for (uint32_t i = 0; i < PER_THREAD; i++) { const uint64_t k = r.lo + PER_THREAD * t + i; ahead[i] = k < r.hi ? nodes[k] : 0u; }
-    for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS * PER_THREAD) {
-        const uint64_t k0 = base + PER_THREAD * t;
+    for (uint32_t i = 0; i < PER_THREAD; i++) { const uint32_t k = PER_THREAD * t + i; ahead[i] = k < count ? ids[k] : 0u; }
+    if (WHOLE_TOKENS) {                                                 // (while the first node ids are on their way)
+        for (uint32_t lo = 16 * t; lo < STAGE_BYTES; lo += 16 * FORMAT_THREADS) *reinterpret_cast<u32x4 *>(stage + lo) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    for (uint32_t base = 0; base < count; base += BATCH) {
+        const uint32_t k0 = base + PER_THREAD * t;
         uint32_t node[PER_THREAD], digits[PER_THREAD], len = 0;
+        Token token[PER_THREAD];
 #pragma unroll
         for (uint32_t i = 0; i < PER_THREAD; i++) {
             node[i] = ahead[i]; digits[i] = 0;
-            const uint64_t next = k0 + FORMAT_THREADS * PER_THREAD + i;
-            ahead[i] = next < r.hi ? nodes[next] : 0u;
-            if (k0 + i < r.hi) {
+            const uint32_t next = k0 + BATCH + i;
+            ahead[i] = next < count ? ids[next] : 0u;
+            if (k0 + i >= count) continue;
+            if (WHOLE_TOKENS) {
+                token[i] = (node[i] >> 1) < 100000000u ? make_token_short(node[i], p_lines != 0, k0 + i == first_at) : make_token(node[i], p_lines != 0, k0 + i == first_at);
+                digits[i] = token[i].len;
+                len += token[i].len;
+            } else {
                 digits[i] = decimal_digits(node[i] >> 1);
                 // ',' between the tokens of a P-line and '+' / '-' behind each, '>' / '<' in front of a W-line's
-                len += digits[i] + (p_lines ? (k0 + i > r.begin ? 2u : 1u) : 1u);
+                len += digits[i] + (p_lines ? (k0 + i != first_at ? 2u : 1u) : 1u);
             }
         }
         uint32_t pos, total;
         BlockScan(scan_storage).ExclusiveSum(len, pos, total);
-        uint8_t *const to = line + cursor;
+        uint8_t *const to = text + cursor;
         const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(to) & 15u);   // the batch's text lies at stage[mis ...]: LDS and memory are aligned alike
         uint8_t *w = stage + mis + pos;
 #pragma unroll
         for (uint32_t i = 0; i < PER_THREAD; i++) {
             if (digits[i] == 0) continue;
+            if (WHOLE_TOKENS) {
+                const uint32_t at = static_cast<uint32_t>(w - stage);
+                uint32_t spread[4], *const dwords = reinterpret_cast<uint32_t *>(stage + (at & ~3u));
+                spread_token(token[i], at & 3u, spread);
+                __hip_atomic_fetch_or(dwords, spread[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(dwords + 1, spread[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(dwords + 2, spread[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (spread[3] != 0) __hip_atomic_fetch_or(dwords + 3, spread[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                w += token[i].len;
+                continue;
+            }
             if (!p_lines) *w++ = (node[i] & 1u) ? '<' : '>';
-            else if (k0 + i > r.begin) *w++ = ',';
+            else if (k0 + i != first_at) *w++ = ',';
             uint32_t v = node[i] >> 1;
             for (uint32_t d = 0; d < digits[i]; d++) { w[digits[i] - 1 - d] = static_cast<uint8_t>('0' + v % 10u); v /= 10u; }
             w += digits[i];
@@ -262,20 +323,20 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint64_t
         uint8_t *const aligned = to - mis;
         for (uint32_t lo = 16 * t; lo < end; lo += 16 * FORMAT_THREADS) {
             if (lo >= mis && lo + 16 <= end) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(stage + lo), reinterpret_cast<u32x4 *>(aligned + lo));
             } else {
                 const uint32_t from = lo < mis ? mis : lo, upto = lo + 16 < end ? lo + 16 : end;
                 for (uint32_t q = from; q < upto; q++) aligned[q] = stage[q];
             }
+            if (WHOLE_TOKENS) *reinterpret_cast<u32x4 *>(stage + lo) = u32x4{0u, 0u, 0u, 0u};
         }
         cursor += total;
         __syncthreads();
     }
     // trailer: "\t*\n" for P-lines (src/bin/gbunzip.rs:476), "\n" for W-lines (:548)
-    if (r.last && t == 0) {
-        if (p_lines) { line[cursor] = '\t'; line[cursor + 1] = '*'; line[cursor + 2] = '\n'; }
-        else line[cursor] = '\n';
+    if ((plan.flags & 2u) && t == 0) {
+        if (p_lines) { text[cursor] = '\t'; text[cursor + 1] = '*'; text[cursor + 2] = '\n'; }
+        else text[cursor] = '\n';
     }
 }
 
@@ -751,10 +812,16 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         if (translated)
             hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
                                d_chunk_first, d_chunk_path, d_text_before, segment_tables(ix), p_lines, d_valid, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
-        else
-            hipLaunchKernelGGL(k_format_chunks, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
-                               d_chunk_first, d_chunk_path, d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>(),
-                               all_cached ? cache : LineCache{nullptr, nullptr, nullptr});
+        else {
+            const char *knob = std::getenv("GBWT_HIP_FORMAT_TOKENS");                                 // read per request: an A/B inside one process
+            const int form = knob ? std::atoi(knob) : 1;
+            const auto kernel = form == 0 ? k_format_chunks<false, 4> : k_format_chunks<true, 4>;   // (eight positions per thread: five waves per SIMD, 23 % slower)
+            ws->gfa_plan.reserve(chunks_cap * sizeof(ChunkPlan));
+            hipLaunchKernelGGL(k_plan_chunks, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_first, d_chunk_path, chunks_cap,
+                               d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, all_cached ? cache : LineCache{nullptr, nullptr, nullptr}, ws->gfa_plan.as<ChunkPlan>());
+            hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_nodes, n, d_chunk_first, ws->gfa_plan.as<ChunkPlan>(), p_lines,
+                               d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
+        }
         HIP_CHECK(hipGetLastError());
         for (uint64_t k = 0; k < host_lines.size(); k++)
             if (!valid[k] && !host_lines[k].empty())

@@ -260,3 +260,33 @@ def test_product_library_holds_no_test_transport():
         assert needle not in product, needle
     test_build = open(os.path.join(csrc, "libgbwt_hip_testtransport.so"), "rb").read()
     assert b"GBWT_HIP_COMM_LOOPBACK" in test_build and b"GBWT_HIP_COMM_SELF_SEND" in test_build
+
+
+def test_gfa_tokens_against_snprintf(tmp_path):
+    """The register arithmetic that makes GFA node tokens (csrc/gfa_tokens.hpp: digits by multiplications, the token OR-ed in as aligned dwords)
+    compiled for the host under ASan + UBSan: every token length, both orientations, W-line / P-line / first-of-P-line forms, both builders,
+    every alignment, against snprintf (the reference prints ids with Rust's Display, src/bin/gbunzip.rs:462-476, 542-547)."""
+    import shutil
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "token_check"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([gxx, "-std=c++17", "-O2", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", _lib.CSRC,
+                    os.path.join(root, "tests", "cpp", "token_check.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert int(re.search(r"tokens checked: (\d+)", out.stdout).group(1)) > 1000000
+
+
+def test_format_kernel_keeps_eight_waves_per_simd():
+    """k_format_chunks hides its load -> scan -> stage -> store chain behind eight workgroups per CU (eight positions per thread = five waves
+    per SIMD measured 23 % slower, profiles/r05_format_stream.txt): at most 64 VGPRs, nothing spilled, LDS for eight workgroups."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull,
+                          os.path.join(_lib.CSRC, "gfa.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stderr.splitlines()
+    at = next(i for i, l in enumerate(lines) if "Function Name" in l and "k_format_chunksILb1ELj4E" in l)
+    block = "\n".join(lines[at:at + 14])
+    field = lambda name: int(re.search(name + r": (\d+)", block).group(1))
+    assert field("    VGPRs") <= 64 and field("VGPRs Spill") == 0 and field(r"Occupancy \[waves/SIMD\]") == 8 and field(r"LDS Size \[bytes/block\]") <= 160 * 1024 // 8, block

@@ -427,6 +427,40 @@ def test_synthetic_gfa_matches_oracle(tmp_path, alleles, sites, haps):
     assert dev.path_lines([0], 0) == oracle.path_lines([0], 0)
 
 
+def test_tokens_on_the_device(tmp_path):
+    """csrc/gfa_tokens.hpp on the GPU itself (the byte-align instruction, the 24-bit multiplications): tests/cpp/token_device_check.hip makes the
+    tokens of a million ids up to 2^31 - 1 -- ten digits: no index small enough for a test has such ids -- in every form on the device and
+    compares them with snprintf."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "token_device_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(root, "gbwt_rs_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "token_device_check.hip"), "-o", str(exe)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "device tokens checked" in out.stdout
+
+
+@pytest.mark.parametrize("chop", [1, 3])
+def test_both_token_forms_write_the_same_text(tmp_path, monkeypatch, chop):
+    """GBWT_HIP_FORMAT_TOKENS=0 (a store per character) and the default (whole tokens OR-ed into the staging buffer) against the oracle and against
+    each other: P- and W-lines of paths of several chunks, single paths, the first / last positions of chunks (node ids of 1-5 digits)."""
+    s = S.Synth.chain(sites=2600, haplotypes=40, alleles=3, model=S.MOSAIC, founders=6, switch_rate=0.01, seed=23, chop=chop)
+    path = tmp_path / "forms.gbz"
+    s.save(str(path), as_gbz=True)
+    dev, oracle = G.GBZ.load(str(path)), O.OracleGBZ(str(path))
+    paths = list(range(dev.paths()))
+    texts = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("GBWT_HIP_FORMAT_TOKENS", form)
+        ws = dev.another_workspace()
+        texts[form] = (ws.path_lines(paths, 1), ws.path_lines(paths, 0), ws.path_lines(paths[3:4], 1), ws.path_lines(paths[:1], 0))
+        ws.close()
+    assert texts["0"] == texts["1"]
+    assert texts["1"][0] == oracle.path_lines(paths, 1) and texts["1"][1] == oracle.path_lines(paths, 0)
+    dev.close()
+
+
 def test_device_resident_lines_and_rccl_gather(tmp_path):
     """gbwt_hip_path_lines_device leaves the text in HBM; dist.lines_tensors wraps it without a copy and
     dist.gather_lines moves it over RCCL (backend "nccl", world size 1 on this box: the collective and the tensor
