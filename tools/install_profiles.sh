@@ -6,6 +6,7 @@ for C in secondary high_degree search config4 config4_small; do
   cp "$(find $O/${C}_stats -name '*kernel_stats.csv' | head -1)" ${P}_${C}_kernel_stats.csv
 done
 cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" ${P}_kernel_stats.csv
+sed -i "s|profiles/$1_|profiles/$2_|g" ${P}_bench.json ${P}_bench_first.json    # (the traffic files the line cites, under the names they are committed with)
 python3 - <<P
 import json, sys
 sys.path.insert(0, '.')
