@@ -528,11 +528,16 @@ def main():
     # ---- steady state: the index resident, the same batch again and again
     for _ in range(args.warmup):
         extract()
+    # The timed region is K x 4 ms: one pause of the interpreter's cycle collector over the generator's objects would be a tenth of it
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     out, walk_ms, total_ms = timed_passes(index, ids, args.steps, rank, parts)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     assert int(out.total) == steps_done and (by_parts or steps_done == expected_steps), (int(out.total), steps_done, expected_steps)
 
     # untimed: full-size check of the last extraction against the generator's ground truth
