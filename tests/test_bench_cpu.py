@@ -1,6 +1,7 @@
 """Host logic of bench.py that needs no GPU: the fingerprint that ties a PMC profile to a build, and the rank launcher."""
 import json
 import os
+import re
 import sys
 
 import pytest
@@ -68,6 +69,10 @@ def test_round5_profiles_cover_every_config():
     assert line["parity_checked_paths"] > 1000 and line["config4"]["size"] == "full" and line["config4"]["lf_steps"] > 5e9
     for k in ("secondary", "high_degree", "search", "config4", "config4_small"):
         assert line[k]["cpu_baseline"]["kind"] == "port", k
+    # every traffic file the committed line cites is a committed file of the same build
+    cited = set(re.findall(r"profiles/[A-Za-z0-9_]+hbm_traffic\.json", open(os.path.join(ROOT, "profiles", "r05_bench.json")).read()))
+    assert len(cited) == 6 and all(os.path.exists(os.path.join(ROOT, c)) for c in cited), cited
+    assert line["roofline"]["source_fingerprint"] in prints
 
 
 def test_gpus_without_a_launcher_starts_the_ranks(monkeypatch):
