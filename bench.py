@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--model", choices=["mosaic", "iid"], default="mosaic")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the timed cpu_baseline walk (the untimed parity walk behind it takes as long again)")
     ap.add_argument("--bytes-sample", type=int, default=16, help="paths used for the reference-pattern bytes pass")
     ap.add_argument("--gather-paths", type=int, default=32, help="N > 1, weak scaling: paths per rank whose W-lines go through the final RCCL gather")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -91,13 +91,20 @@ def cpu_baseline(index_path, n_paths, target_seconds):
     per_path = steps / len(ids)
     want = int(max(len(ids), min(n_paths, target_seconds * rate / per_path)))
     ids = np.arange(0, 2 * want, 2, dtype=np.uint64)
+    # TIMED: the plain walk (SequenceIter::next and nothing else per step, src/gbwt.rs:557-568).  UNTIMED, behind it: the same paths again with
+    # a length, a node sum and an order-dependent hash kept per path -- the parity pass.  (Round 5 timed the checksum walk: a sum and a
+    # multiply-add per LF-step that the reference's iterator does not do; `checksum_walk_ratio` says what that cost.)
     t0 = time.perf_counter()
-    steps, lengths, sums, hashes = oracle.extract_checksums(ids, threads)
+    steps = oracle.extract_timed(ids, threads)
     dt = time.perf_counter() - t0
-    return ({"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port",
+    t0 = time.perf_counter()
+    c_steps, lengths, sums, hashes = oracle.extract_checksums(ids, threads)
+    dt_checks = time.perf_counter() - t0
+    assert c_steps == steps
+    return ({"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port", "checksum_walk_ratio": round(dt_checks / dt, 3),
              "sample": f"{want} of {n_paths} forward paths ({steps} LF-steps, {dt:.1f} s wall, {kind_note}, "
-                       f"pthread pool pulling path ids like gbunzip's rayon par_iter; every path's length, node sum and order-dependent hash "
-                       f"kept and compared with the GPU's)"}, ids // 2, lengths, sums, hashes)
+                       f"pthread pool pulling path ids like gbunzip's rayon par_iter); behind the timed walk the same paths are walked again, untimed "
+                       f"({dt_checks:.1f} s), keeping every path's length, node sum and order-dependent hash, which are compared with the GPU's"}, ids // 2, lengths, sums, hashes)
 
 
 def _oracle_of_synth(s):
@@ -122,8 +129,9 @@ def cpu_leg_extraction(seconds):
         want = int(max(len(ids), min(n_paths, seconds * rate / max(per_path, 1))))
         ids = np.arange(0, 2 * want, 2, dtype=np.uint64)
         t0 = time.perf_counter()
-        steps, o_lens, o_sums, o_hashes = oracle.extract_checksums(ids, threads)
+        steps = oracle.extract_timed(ids, threads)                      # timed: the plain walk; the parity pass behind it is not
         dt = time.perf_counter() - t0
+        _, o_lens, o_sums, o_hashes = oracle.extract_checksums(ids, threads)
         assert np.array_equal(lens[:want], o_lens) and np.array_equal(sums[:want], o_sums) and np.array_equal(hashes[:want], o_hashes), \
             "the extracted paths differ from the oracle's walk"
         return {"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port", "parity_checked_paths": want,
@@ -303,18 +311,38 @@ def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier
     from gbwt_rs_amd import dist as D
     box = [None]
     if rank == 0:
-        base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-        box[0] = os.path.join(tempfile.mkdtemp(prefix="gbwt_bench_c4_", dir=base), "c4.gbz")
-        g = c4_bench.generate(args.c4_size, box[0])
-        gen = {"generator_seconds": round(g.generator_seconds, 1), "save_seconds": round(g.save_seconds, 1), "paths": int(g.paths)}
-        del g
+        try:                                        # (a generator that fails on rank 0 is told to everybody: they wait in the broadcast below)
+            base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+            box[0] = os.path.join(tempfile.mkdtemp(prefix="gbwt_bench_c4_", dir=base), "c4.gbz")
+            g = c4_bench.generate(args.c4_size, box[0])
+            gen = {"generator_seconds": round(g.generator_seconds, 1), "save_seconds": round(g.save_seconds, 1), "paths": int(g.paths)}
+            del g
+        except Exception as e:  # noqa: BLE001
+            box[0] = RuntimeError(f"config 4: the generator failed on rank 0: {e!r}"[:400])
     dist.broadcast_object_list(box, src=0)
+    if isinstance(box[0], Exception):
+        raise box[0]
     path = box[0]
+
+    def agree(ok, what):
+        """Every rank learns whether EVERY rank got through a step that can fail locally, BEFORE anybody enters the next collective: a rank
+        that raised would leave its peers waiting in it (with RCCL until the watchdog aborts them, and the line with them)."""
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) != 1.0:
+            raise RuntimeError(f"config 4: {what} failed on some rank" + ("" if ok else " (this one)"))
+
+    gbz = None
     try:
-        generic = np.load(path + ".generic.npy")
-        t0 = time.perf_counter()
-        gbz = G.GBZ.load(path, device=local_rank, flags=G.OPEN_GFA)     # GFA extraction only: no search structures on any of the N replicas
-        open_ms = (time.perf_counter() - t0) * 1e3
+        failure = None
+        try:
+            generic = np.load(path + ".generic.npy")
+            t0 = time.perf_counter()
+            gbz = G.GBZ.load(path, device=local_rank, flags=G.OPEN_GFA)     # GFA extraction only: no search structures on any of the N replicas
+            open_ms = (time.perf_counter() - t0) * 1e3
+        except Exception as e:  # noqa: BLE001
+            failure = e
+        agree(failure is None, "opening the index" + (f": {failure!r}"[:300] if failure is not None else ""))
         walks = np.setdiff1d(np.arange(gbz.paths(), dtype=np.uint64), generic)
         steps = (gbz.len() - gbz.sequences()) // 2
         comm, why = None, None
@@ -356,7 +384,10 @@ def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier
                     "value": steps / (slowest * 1e-3), "value_incl_gather": steps / ((slowest + res["gather_ms"]) * 1e-3), "unit": "LF-steps/s", **gen})
         return res
     finally:
-        barrier()
+        try:
+            barrier()                              # (nobody deletes the file while a rank still reads it; a barrier that fails must not mask what was raised)
+        except Exception:  # noqa: BLE001
+            pass
         if rank == 0:
             if os.path.exists(path + ".lines.gfa"):
                 os.remove(path + ".lines.gfa")
@@ -532,12 +563,14 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    barrier()
-    t0 = time.perf_counter()
-    out, walk_ms, total_ms = timed_passes(index, ids, args.steps, rank, parts)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        out, walk_ms, total_ms = timed_passes(index, ids, args.steps, rank, parts)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     assert int(out.total) == steps_done and (by_parts or steps_done == expected_steps), (int(out.total), steps_done, expected_steps)
 
     # untimed: full-size check of the last extraction against the generator's ground truth
@@ -666,9 +699,9 @@ def main():
             import configs as K
             emitted = "emitted bytes: the u32 node id every LF-step writes (4 B per step) / kernel time; index reads show up in `traffic`"
             # every config with its own bounded CPU leg (5 s of oracle each, compared with what the GPU returned) unless --no-cpu-baseline
-            leg_x = None if args.no_cpu_baseline else cpu_leg_extraction(5.0)
-            leg_s = None if args.no_cpu_baseline else cpu_leg_search(5.0)
-            leg_l = None if args.no_cpu_baseline else cpu_leg_lines(5.0)
+            leg_x = None if args.no_cpu_baseline else cpu_leg_extraction(3.0)    # (timed plain walk + the untimed parity walk of the same paths)
+            leg_s = None if args.no_cpu_baseline else cpu_leg_search(4.0)
+            leg_l = None if args.no_cpu_baseline else cpu_leg_lines(4.0)
             extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank, cpu_leg=leg_x), "secondary", emitted)
             extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank, cpu_leg=leg_x), "high_degree", emitted)
             if not args.no_search:

@@ -41,7 +41,7 @@ class Stats(C.Structure):
 class OpenTimes(C.Structure):
     _fields_ = [("parse_ms", C.c_double), ("upload_ms", C.c_double), ("sample_ms", C.c_double), ("total_ms", C.c_double),
                 ("samples", C.c_uint64), ("checkpoint_walkers", C.c_uint64), ("checkpoint_orphans", C.c_uint64), ("checkpoint_sampling", C.c_uint32),
-                ("checkpoint_rounds", C.c_uint32)]
+                ("checkpoint_rounds", C.c_uint32), ("line_sizes_ms", C.c_double)]
 
 
 class Memory(C.Structure):
@@ -142,8 +142,8 @@ def lib():
         if "torch" not in sys.modules and not os.environ.get("GBWT_HIP_NO_TORCH_PRELOAD"):
             try:
                 import torch  # noqa: F401
-            except ImportError:
-                pass
+            except Exception:  # noqa: BLE001  (not installed, or installed and broken -- OSError / RuntimeError from its own loader: this
+                pass           # library does not need it; CPU-only callers such as gbwt_hip_parse_file must not fail because of it)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

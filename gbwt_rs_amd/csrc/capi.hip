@@ -27,7 +27,7 @@ std::string &last_error_slot() {
 }
 }  // namespace gbwt_hip
 
-namespace gbwt_hip { void upload_label_lengths(gbwt_hip_index &ix); }
+namespace gbwt_hip { void upload_label_lengths(gbwt_hip_index &ix); void fill_line_cache_at_open(gbwt_hip_index &ix); }
 
 namespace {
 
@@ -568,6 +568,11 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
         ix->host.finish();                // the loader's background work, if any: needed from here on
         if (ix->caps & GBWT_HIP_OPEN_GFA) upload_label_lengths(*ix);
     }
+    // the sizes of every path's GFA line, once (gfa.hip): needs the device passes (samples, descriptors) AND the GFA tables (label lengths)
+    if (ix->caps & GBWT_HIP_OPEN_GFA) {
+        fill_line_cache_at_open(*ix);
+        trace.mark("line sizes of every path");
+    }
     // A handle that was NOT opened for search and whose walks never leave the descriptors and rank blocks (no record takes the generic
     // decoder, lengths and samples are there, the full-width blocks are built or not needed) gives its raw descriptors back: 64 bytes per
     // record -- 14 of config 4's 65 GB.  What still needs them -- the pool-output walk modes, blocks built on first need -- is refused
@@ -1049,6 +1054,11 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             a.mode = ws->walk_mode;
             // many walkers per row when the index has sequence samples (GBWT_HIP_SEGMENTS=0: one walker per end instead)
             const bool segmented = ix->dev.samples != nullptr && max_len > 0 && n <= 0x7FFFFFFFull && ix->max_samples > 0 && knobs.segments != 0;   // (the walker order sorts 32-bit row numbers)
+            // A lean handle (open_common) has given back the raw descriptors that a walker without a sample to start from reads when it arrives
+            // on its first record (walk_loops.hpp: arrive): whole-row walkers -- GBWT_HIP_SEGMENTS=0, more than 2^31 - 1 rows -- are refused
+            // there like the pool-output modes below, before anything is launched (rows of no nodes have no walker and are served).
+            if (ix->lean_extract && !segmented && max_len > 0)
+                return fail(GBWT_HIP_UNSUPPORTED, "this handle was opened for extraction only and has given its raw descriptors back: walks that do not start from sequence samples (GBWT_HIP_SEGMENTS=0, more than 2^31 - 1 rows) need GBWT_HIP_OPEN_ALL");
             // the samples lie where the sequences pass checkpoint records, so the number of segments of a row comes from its samples, not from its length
             a.segments = segmented ? (ix->max_samples + stride - 1) / stride : 0u;
             if (parted) a.segments = a.segments / parts + 1;          // (no row has more segments in one part)

@@ -232,16 +232,14 @@ struct gbwt_hip_index {
     gbwt_hip::DeviceBuffer line_prefix[3], line_prefix_off[3], line_fragment;
     std::vector<char> host_line_prefix[3];
     std::vector<uint64_t> host_line_prefix_off[3];
-    // LINE CACHE (round 5, gfa.hip): what the GFA line of a path is made of -- the text bytes of its node tokens, chunk by chunk, and its
-    // summed label lengths (the W-line's end coordinate) -- is a property of the index, not of the request.  The first request that formats
-    // a path leaves them here; later requests of that path size and place its line without reading its node ids (the sizing pass was a
-    // fifth of a lines request: the node ids crossed HBM three times -- written by the walk, read to size the lines, read to format them).
-    // 8 bytes per 4 096 path positions + 16 per path.  Built on first use (line_cache_once); unusable (-1) without sequence lengths and
-    // for graphs with a node-to-segment translation.
-    mutable std::once_flag line_cache_once;
+    // LINE CACHE (gfa.hip): what the GFA line of a path is made of -- the text bytes of its node tokens, chunk by chunk, and its summed label
+    // lengths (the W-line's end coordinate) -- is a property of the index, not of the request.  Round 5 let the first request that formats a
+    // path leave them here; since round 6 ONE walk at open fills them for every path (fill_line_cache_at_open; kernels.hpp: LineCacheFill), so
+    // that no request sizes a line: the node ids cross HBM twice (written by the walk, read by the formatter), never three times.
+    // 8 bytes per 4 096 path positions + 16 per path.  Absent (-1) without sequence samples, for graphs with a node-to-segment translation
+    // and with GBWT_HIP_LINE_CACHE=0: requests then size their lines themselves (k_chunk_stats).
     gbwt_hip::DeviceBuffer lc_chunk_first, lc_text, lc_path;    // u64[paths + 1]: first chunk of every path; u64 per chunk: W-token bytes of the path in front of it; u64[2] per path: {W-token bytes, summed label lengths}
-    std::unique_ptr<std::atomic<uint8_t>[]> lc_ready;             // per path: its entries are there (set by the request that wrote them, after its wait)
-    std::atomic<int> lc_state{0};                                  // 0 = not looked at, 1 = usable, -1 = not for this index
+    int lc_state = 0;                                             // 1 = filled at open, -1 = not for this index (written before the handle is handed out)
     std::vector<uint32_t> host_seq_len;   // host copy of seq_len (empty when the lengths are not known): sizes byte-bounded batches of a whole-file write
     gbwt_hip::DeviceIndex dev{};
     // The full-width two-step blocks (cblocks, as large as gblocks: 1.7 GB on the headline index) are only read by the loops for records

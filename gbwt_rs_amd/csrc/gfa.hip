@@ -66,7 +66,7 @@ struct LineHeaders {
 // million nodes as it is for fifty thousand short walks (one workgroup per LINE had 0.6 G nodes/s on the former, 50 on the
 // latter).  Chunk c belongs to the path with chunk_first[path] <= c < chunk_first[path + 1] (every path has at least one
 // chunk: an empty path still has a header and a trailer).
-constexpr uint32_t LINE_CHUNK = 4096;
+constexpr uint32_t LINE_CHUNK = GFA_LINE_CHUNK;   // (kernels.hpp: the line cache is filled per chunk of this size at open)
 
 __global__ void __launch_bounds__(256) k_chunk_counts(const uint64_t *offsets, uint64_t n, uint64_t *counts) {
     const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -161,20 +161,6 @@ __global__ void __launch_bounds__(256) k_line_sizes(const uint64_t *seq_ids, con
 struct LineCache { const uint64_t *chunk_first; uint64_t *text; uint64_t *path; };
 
 __host__ __device__ __forceinline__ uint64_t cache_p_extra(uint64_t k_chunk) { return k_chunk == 0 ? 0 : k_chunk * LINE_CHUNK - 1; }
-
-// What a sizing pass has found goes into the cache (the epilogue of a request that had to size its lines): one thread per chunk.
-__global__ void __launch_bounds__(256) k_fill_line_cache(const uint64_t *offsets, const uint64_t *seq_ids, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
-                                                          uint64_t chunks_cap, const uint64_t *text_before, const uint64_t *seq_before, int p_lines, LineCache cache) {
-    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (c >= chunks_cap || c >= chunk_first[n]) return;
-    const uint64_t row = chunk_path[c], path = seq_ids[row] >> 1, a = chunk_first[row], k = c - a;
-    cache.text[cache.chunk_first[path] + k] = text_before[c] - text_before[a] - (p_lines ? cache_p_extra(k) : 0);
-    if (k == 0) {
-        const uint64_t b = chunk_first[row + 1], len = offsets[row + 1] - offsets[row];
-        cache.path[2 * path] = text_before[b] - text_before[a] - (p_lines && len != 0 ? len - 1 : 0);
-        cache.path[2 * path + 1] = seq_before[b] - seq_before[a];
-    }
-}
 
 // Line lengths and end coordinates from the cache: no node id is read.
 __global__ void __launch_bounds__(256) k_line_sizes_cached(const uint64_t *offsets, const uint64_t *seq_ids, uint64_t n, LineCache cache, LineHeaders hdr, int p_lines,
@@ -645,37 +631,58 @@ void upload_label_lengths(gbwt_hip_index &ix) {
 
 }  // namespace gbwt_hip
 
-// The line cache of a handle, made on first use (gbwt_hip_index::lc_*): usable when the sequence lengths are known (they say how many
-// chunks a path has) and the graph has no node-to-segment translation (tokens are then segment names, sized by other rules).
-static bool ensure_line_cache(const gbwt_hip_index *index) {
-    gbwt_hip_index *ix = const_cast<gbwt_hip_index *>(index);          // the lazily built part of an otherwise immutable handle
-    std::call_once(ix->line_cache_once, [ix]() {
-        const HostIndex &h = ix->host;
-        const uint64_t paths = h.path_names.size();
-        const bool translated = h.has_translation && !h.segment_starts.empty();
-        const char *off = std::getenv("GBWT_HIP_LINE_CACHE");
-        if (translated || paths == 0 || ix->host_seq_len.size() < 2 * paths || (off && std::atoi(off) == 0)) { ix->lc_state.store(-1); return; }
-        try {
-            HIP_CHECK(hipSetDevice(ix->device));
-            std::vector<uint64_t> first(paths + 1, 0);
-            for (uint64_t p = 0; p < paths; p++) {
-                const uint64_t len = ix->host_seq_len[2 * p];              // the forward sequence of path p (support::encode_path)
-                first[p + 1] = first[p] + (len == 0 ? 1 : (len + LINE_CHUNK - 1) / LINE_CHUNK);
-            }
-            ix->lc_chunk_first.reserve((paths + 1) * sizeof(uint64_t));
-            ix->lc_text.reserve(std::max<uint64_t>(first[paths], 1) * sizeof(uint64_t));
-            ix->lc_path.reserve(2 * paths * sizeof(uint64_t));
-            HIP_CHECK(hipMemcpy(ix->lc_chunk_first.ptr, first.data(), (paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-            ix->lc_ready.reset(new std::atomic<uint8_t>[paths]);
-            for (uint64_t p = 0; p < paths; p++) ix->lc_ready[p].store(0, std::memory_order_relaxed);
-            ix->lc_state.store(1, std::memory_order_release);
-        } catch (...) {
-            (void)hipGetLastError();
-            ix->lc_state.store(-1);
-        }
-    });
-    return ix->lc_state.load(std::memory_order_acquire) == 1;
+// The line cache of a handle, filled by ONE walk at open (kernels.hpp: LineCacheFill; open_walks.hip: k_segment_text): usable when the index
+// has sequence samples (the walkers start from them, as those of an extraction do) and the graph has no node-to-segment translation
+// (tokens are then segment names, sized by other rules).  Called by open_common once the device passes and the GFA tables are done, while
+// the raw descriptors are still there (slow records take the generic decoder).
+namespace gbwt_hip {
+void fill_line_cache_at_open(gbwt_hip_index &ix) {
+    const HostIndex &h = ix.host;
+    ix.lc_state = -1;
+    const uint64_t paths = h.path_names.size();
+    const bool translated = h.has_translation && !h.segment_starts.empty();
+    const char *off = std::getenv("GBWT_HIP_LINE_CACHE");
+    if (!(ix.caps & GBWT_HIP_OPEN_GFA) || !h.is_gbz || !h.has_metadata || translated || paths == 0 || (off && std::atoi(off) == 0)) return;
+    if (ix.host_seq_len.size() < 2 * paths || ix.sample_counts.size() < 2 * paths || 2 * paths > h.sequences) return;
+    const DeviceIndex &d = ix.dev;
+    if (d.samples == nullptr || d.sample_base == nullptr || d.seq_len == nullptr || d.desc2 == nullptr || (d.gblocks == nullptr && d.cblocks == nullptr)) return;
+    if (ix.label_len.ptr == nullptr) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> first(paths + 1, 0);
+    uint32_t max_samples = 0;
+    for (uint64_t p = 0; p < paths; p++) {
+        const uint64_t len = ix.host_seq_len[2 * p];                   // the forward sequence of path p (support::encode_path)
+        first[p + 1] = first[p] + (len == 0 ? 1 : (len + LINE_CHUNK - 1) / LINE_CHUNK);
+        max_samples = std::max(max_samples, ix.sample_counts[2 * p]);
+    }
+    HIP_CHECK(hipSetDevice(ix.device));
+    ix.lc_chunk_first.reserve((paths + 1) * sizeof(uint64_t));
+    ix.lc_text.reserve(std::max<uint64_t>(first[paths], 1) * sizeof(uint64_t));
+    ix.lc_path.reserve(2 * paths * sizeof(uint64_t));
+    HIP_CHECK(hipMemcpy(ix.lc_chunk_first.ptr, first.data(), (paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    DeviceBuffer chunk_seg, seg_text, flags;
+    chunk_seg.reserve(std::max<uint64_t>(first[paths], 1) * sizeof(uint32_t));
+    seg_text.reserve(std::max<uint64_t>(ix.times.samples, 1) * 2 * sizeof(uint64_t));
+    flags.reserve(sizeof(uint32_t));
+    HIP_CHECK(hipMemsetAsync(flags.ptr, 0, sizeof(uint32_t), nullptr));
+    HIP_CHECK(hipMemsetAsync(ix.lc_text.ptr, 0, std::max<uint64_t>(first[paths], 1) * sizeof(uint64_t), nullptr));
+    HIP_CHECK(hipMemsetAsync(chunk_seg.ptr, 0, std::max<uint64_t>(first[paths], 1) * sizeof(uint32_t), nullptr));
+    LineCacheFill f{};
+    f.label_len = ix.label_len.as<uint32_t>(); f.n_labels = h.sequences_labels.size(); f.paths = paths; f.max_samples = max_samples;
+    f.chunk_first = ix.lc_chunk_first.as<uint64_t>(); f.chunks = first[paths]; f.chunk_text = ix.lc_text.as<uint64_t>(); f.path_totals = ix.lc_path.as<uint64_t>();
+    f.chunk_seg = chunk_seg.as<uint32_t>(); f.seg_text = seg_text.as<uint64_t>(); f.flags = flags.as<uint32_t>();
+    launch_fill_line_cache(d, f, nullptr);
+    uint32_t bad = 0;
+    HIP_CHECK(hipMemcpy(&bad, flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    if (bad != 0) {                                                    // samples that promise more nodes than the walk delivers: requests size their lines themselves
+        ix.lc_chunk_first.release(); ix.lc_text.release(); ix.lc_path.release();
+        return;
+    }
+    ix.lc_state = 1;
+    ix.times.line_sizes_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
+}  // namespace gbwt_hip
 
 // The lines of a batch of paths, formatted ONCE into device memory (the text buffer of `slot`: ws->gfa_text or gfa_text2; line k at
 // [line_start[k], line_start[k + 1]), offsets also on the device in ws->gfa_b).  The request is remembered in the workspace: the fill call that
@@ -735,10 +742,8 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
         uint32_t *d_chunk_path = reinterpret_cast<uint32_t *>(d_bad_before + (chunks_cap + 1));
         uint8_t *d_valid = translated ? ws->gfa_valid.as<uint8_t>() : nullptr;
         const LineHeaders hdr{ix->line_prefix[mode].as<uint8_t>(), ix->line_prefix_off[mode].as<uint64_t>(), mode == 1 ? ix->line_fragment.as<uint32_t>() : nullptr};
-        // the line cache of the index: when it holds every path of the request, nothing below reads a node id before the formatter does
-        const bool have_cache = !translated && ensure_line_cache(ix);
-        bool all_cached = have_cache;
-        for (uint64_t k = 0; k < n && all_cached; k++) all_cached = ix->lc_ready[path_ids[k]].load(std::memory_order_acquire) != 0;
+        // the line cache of the index (filled at open): nothing below reads a node id before the formatter does
+        const bool all_cached = !translated && ix->lc_state == 1;
         const LineCache cache{ix->lc_chunk_first.as<uint64_t>(), ix->lc_text.as<uint64_t>(), ix->lc_path.as<uint64_t>()};
         hipLaunchKernelGGL(k_chunk_counts, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_counts);
         launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb, s);
@@ -760,9 +765,6 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
             launch_scan(d_chunk_seq, d_seq_before, chunks_cap, ws->scan_temp.ptr, tb, s);
             hipLaunchKernelGGL(k_line_sizes, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_seq_ids, d_chunk_first, n, d_text_before, d_seq_before,
                                translated ? d_bad_before : nullptr, hdr, p_lines, d_line_len, d_line_end, d_valid);
-            if (have_cache)
-                hipLaunchKernelGGL(k_fill_line_cache, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, paths.d_offsets, d_seq_ids, n, d_chunk_first, d_chunk_path,
-                                   chunks_cap, d_text_before, d_seq_before, p_lines, cache);
         }
         launch_scan(d_line_len, d_line_start, n, ws->scan_temp.ptr, tb, s);
         uint64_t total = 0;
@@ -828,8 +830,6 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
                 HIP_CHECK(hipMemcpyAsync(text.as<char>() + line_start[k], host_lines[k].data(), host_lines[k].size(), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(ws->gev[1], s));
         HIP_CHECK(hipStreamSynchronize(s));   // the text is there when the call returns (and host_lines / line_start go out of scope)
-        // what the sizing pass of this request has left in the line cache is there now: later requests of these paths skip the pass
-        if (have_cache && !all_cached) for (uint64_t k = 0; k < n; k++) ix->lc_ready[path_ids[k]].store(1, std::memory_order_release);
         ws->lines_timed = true;
         ws->lines_total = total;
         ws->lines_key.assign(path_ids, path_ids + n);

@@ -127,6 +127,28 @@ void launch_chase_counts(const DeviceIndex &ix, const uint4 *d_summaries, uint64
                          uint32_t *d_overflow, hipStream_t stream);
 void launch_chase_samples(const DeviceIndex &ix, const uint4 *d_summaries, uint64_t n_summaries, const uint4 *d_spans, const uint64_t *d_sample_base,
                           uint4 *d_samples, hipStream_t stream);
+// THE LINE CACHE, FILLED AT OPEN (round 6; gfa.hip: fill_line_cache_at_open).  What the GFA line of a path is made of -- the bytes of its
+// W-line node tokens in front of every GFA_LINE_CHUNK positions, their total, and the summed label lengths (the W-line's end coordinate,
+// src/bin/gbunzip.rs:532-540) -- is a property of the index.  Rounds 1-5 found it per request (a sizing pass over the extracted rows: 12 of
+// the 52 ms of config 4's first request) and, round 5, left it in the handle for later requests of the same path.  Now one walker per
+// SEGMENT of every forward sequence (from one sequence sample to the next: the walkers of an extraction, in plain C++) walks its segment
+// once at open, counting token bytes and label lengths instead of emitting nodes; a scan over the segments of each sequence and one
+// thread per chunk put the numbers where the requests read them.  No request sizes a line any more: the first one is like every other.
+constexpr uint32_t GFA_LINE_CHUNK = 4096;      // path positions per formatting chunk (gfa.hip)
+struct LineCacheFill {
+    const uint32_t *label_len;     // [n_labels] label length per potential node (gfa.hip: upload_label_lengths)
+    uint64_t n_labels;
+    uint64_t paths;                // path p = sequence 2p (support::encode_path)
+    uint32_t max_samples;          // the most samples a forward sequence has
+    const uint64_t *chunk_first;   // [paths + 1] first chunk of every path in chunk_text
+    uint64_t chunks;               // = chunk_first[paths] (host copy)
+    uint64_t *chunk_text;          // out, per chunk: W-token bytes of the path in front of the chunk
+    uint64_t *path_totals;         // out, [2 * paths]: {W-token bytes, summed label lengths}
+    uint32_t *chunk_seg;           // scratch, per chunk: the segment its first position lies in
+    uint64_t *seg_text;            // scratch, [2 * samples of all sequences]: {token bytes, label lengths} of every segment, then the token bytes in front of it
+    uint32_t *flags;               // [1] zeroed by the caller; bit 0: a segment did not deliver its nodes (the cache is not used)
+};
+void launch_fill_line_cache(const DeviceIndex &ix, const LineCacheFill &f, hipStream_t stream);
 // walker order of a segmented extraction: per-row segment counts -> rows sorted by count (descending, stable) and
 // level[j] = number of walkers in segments < j.  d_keys / d_rows: 2 x n scratch each (double buffers of the sort).
 size_t walker_order_temp_bytes(uint64_t n);

@@ -423,7 +423,142 @@ __global__ void __launch_bounds__(256) k_chase_samples(DeviceIndex ix, const uin
     }
 }
 
+// ---- the line cache filled at open (kernels.hpp: LineCacheFill) -------------------------------------------------------------------------
+
+// What a W-line makes of one node: '>' or '<' and the decimal digits of the node id (path_to_w_line, src/bin/gbunzip.rs:541-546); a P-line
+// token is as long (digits and '+' / '-') plus the comma in front of all but the first (gfa.hip: cache_p_extra).
+__device__ __forceinline__ uint32_t w_token_bytes(uint32_t node) {
+    const uint32_t v = node >> 1;
+    return 2u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+
+// Counts what the nodes of one segment add to their line.  Only the first `quota` nodes belong to the segment (a sample may lie between the
+// two LF steps of an iteration: the walk stages the rest like the extraction's walkers do, and nobody counts them).
+struct TextSink {
+    uint32_t wr = 0, quota = 0;
+    uint64_t text = 0, labels = 0;
+    uint64_t position = 0;           // of the next node in its path
+    const uint32_t *label_len;
+    uint64_t n_labels;
+    uint64_t *chunk_text;            // of the path: chunk k of it at [k]
+    uint32_t *chunk_seg;
+    uint32_t segment = 0, first_node = 0;
+    __device__ __forceinline__ void push(uint32_t node, bool counts) {
+        if (!counts) return;
+        if (wr < quota) {
+            // a chunk of the formatter starts here: what this segment has in front of it (the segments before it are added by k_place_chunk_text)
+            if ((position & (GFA_LINE_CHUNK - 1)) == 0 && position != 0) {
+                const uint64_t c = position / GFA_LINE_CHUNK;
+                chunk_text[c] = text; chunk_seg[c] = segment;
+            }
+            text += w_token_bytes(node);
+            const uint64_t seq = (static_cast<uint64_t>(node & ~1u) - first_node) / 2;        // GBZ::graph_node_to_sequence, src/gbz.rs:246-255
+            if ((node & ~1u) >= first_node && seq < n_labels) labels += label_len[seq];       // sequence_len(node).unwrap_or(0), src/bin/gbunzip.rs:534
+            position++;
+        }
+        wr++;
+    }
+};
+
+// One iteration of the two-step walk that hands every node to `sink` in the order the extraction emits them: on the packed half-blocks where
+// the record allows it (counting_step above, with the nodes), else on the full-width blocks / the generic decoder (two_step).
+template <class Sink>
+__device__ __forceinline__ void emitting_step(const DeviceIndex &ix, bool packed, Sink &sink, uint32_t &rec, uint32_t &offset, uint32_t &bb) {
+    const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(rec);
+    if (packed) {
+        const uint64_t idx = bb == BLOCK_NONE ? 0u : 2 * static_cast<uint64_t>(bb) + (offset >> 5);
+        const uint4 K = ix.gblocks[idx];
+        const uint32_t bit = offset & 31u, below = (1u << bit) - 1;
+        const uint32_t a = (K.x >> bit) & 1u, b = (K.y >> bit) & 1u;
+        const uint4 E = d[a];
+        if (!(E.z & DESC2_SLOW) && (E.w & GATHER_OK)) {
+            const uint32_t ones1 = K.z & 0x1FFFFFu, R0 = ((K.z >> 21) | (K.w << 11)) & 0x1FFFFFu, R1 = K.w >> 10;
+            const uint32_t m = (a ? K.x : ~K.x) & below;
+            const uint32_t p = __popc(m);
+            const uint32_t rank_a = a ? ones1 + p : (offset - bit) - ones1 + p;
+            const uint32_t ones_w = (a ? R1 : R0) + __popc(m & K.y);
+            const uint32_t j = E.y + rank_a, w = E.z & REC_MASK;
+            const uint4 leaf = d[2 + 2 * a + b];
+            rec = leaf.z & REC_MASK; offset = leaf.y + (b ? ones_w : j - ones_w); bb = leaf.w;
+            sink.push(E.x, E.x != 0);
+            if (E.w & E_CHAIN) push_chain(sink, E.x, w + ix.alphabet_offset);
+            sink.push(w + ix.alphabet_offset, (E.z & LEAF_EMIT2) != 0);
+            sink.push(leaf.x, leaf.x != 0);
+            if (leaf.z & LEAF_CHAIN) push_chain(sink, leaf.x, rec + ix.alphabet_offset);
+            sink.push(rec + ix.alphabet_offset, (leaf.z & LEAF_EMIT2) != 0);
+            return;
+        }
+    }
+    two_step(ix, sink, rec, offset, bb);
+}
+
+// Walker w = segment j of path p, j-major (w = j * paths + p): the lanes of a wave hold the same segment of neighbouring paths, as the
+// walkers of an extraction do.  Paths with fewer segments leave their lanes idle.
+__global__ void __launch_bounds__(256) k_segment_text(DeviceIndex ix, LineCacheFill f, uint32_t packed) {
+    const uint64_t w = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (w >= static_cast<uint64_t>(f.max_samples) * f.paths) return;
+    const uint64_t j = w / f.paths, p = w % f.paths, id = 2 * p;
+    const uint64_t base = ix.sample_base[id], count = ix.sample_base[id + 1] - base;
+    if (j >= count) return;
+    const uint4 here = ix.samples[base + j];
+    const uint64_t len = ix.seq_len[id];
+    const uint64_t from = j == 0 ? 0 : here.w;                     // segment 0 starts with the start node (sample 0 is the state after it)
+    const uint64_t to = j + 1 < count ? ix.samples[base + j + 1].w : len;
+    TextSink sink;
+    sink.label_len = f.label_len; sink.n_labels = f.n_labels; sink.chunk_text = f.chunk_text + f.chunk_first[p]; sink.chunk_seg = f.chunk_seg + f.chunk_first[p];
+    sink.quota = to > from ? static_cast<uint32_t>(to - from) : 0u; sink.position = from;
+    sink.segment = static_cast<uint32_t>(j); sink.first_node = ix.first_node;
+    uint32_t rec = here.x, offset = here.y, bb = here.z;
+    if (j == 0 && id < ix.n_endmarker && ix.endmarker[id].x != 0) sink.push(ix.endmarker[id].x, true);
+    while (rec != 0 && sink.wr < sink.quota) emitting_step(ix, packed != 0, sink, rec, offset, bb);   // (every iteration emits a node or ends the walk)
+    if (sink.wr < sink.quota) atomicOr(f.flags, 1u);               // the samples promise more nodes than the walk delivers: a corrupt index
+    f.seg_text[2 * (base + j)] = sink.text; f.seg_text[2 * (base + j) + 1] = sink.labels;
+}
+
+// One wave per path: the token bytes in front of every segment (exclusive scan over the segments of the forward sequence, in place) and the
+// totals of the path.
+__global__ void __launch_bounds__(256) k_path_text(DeviceIndex ix, LineCacheFill f) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (p >= f.paths) return;
+    const uint64_t base = ix.sample_base[2 * p], count = ix.sample_base[2 * p + 1] - base;
+    uint64_t text_before = 0, labels = 0;
+    for (uint64_t j0 = 0; j0 < count; j0 += WAVE) {
+        const uint64_t j = j0 + lane;
+        const uint64_t mine = j < count ? f.seg_text[2 * (base + j)] : 0u;
+        labels += j < count ? f.seg_text[2 * (base + j) + 1] : 0u;
+        uint64_t incl = mine;
+        for (int d = 1; d < WAVE; d <<= 1) { const uint64_t up = __shfl_up(incl, d, WAVE); if (static_cast<int>(lane) >= d) incl += up; }
+        if (j < count) f.seg_text[2 * (base + j)] = text_before + incl - mine;
+        text_before += __shfl(incl, WAVE - 1, WAVE);
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) labels += __shfl_down(labels, d, WAVE);
+    if (lane == 0) { f.path_totals[2 * p] = text_before; f.path_totals[2 * p + 1] = labels; }
+}
+
+// One thread per chunk: what its segment has in front of it + what the segments before that one have.
+__global__ void __launch_bounds__(256) k_place_chunk_text(DeviceIndex ix, LineCacheFill f) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (c >= f.chunks) return;
+    uint64_t lo = 0, hi = f.paths;                                  // chunk_first[lo] <= c < chunk_first[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (f.chunk_first[mid] <= c) lo = mid; else hi = mid;
+    }
+    if (c == f.chunk_first[lo]) { f.chunk_text[c] = 0; return; }   // the first chunk of a path: nothing in front of it
+    f.chunk_text[c] += f.seg_text[2 * (ix.sample_base[2 * lo] + f.chunk_seg[c])];
+}
+
 }  // namespace
+
+void launch_fill_line_cache(const DeviceIndex &ix, const LineCacheFill &f, hipStream_t stream) {
+    if (f.paths == 0) return;
+    const uint64_t walkers = static_cast<uint64_t>(f.max_samples) * f.paths;
+    const uint32_t packed = ix.gblocks != nullptr ? 1u : 0u;
+    if (walkers) hipLaunchKernelGGL(k_segment_text, dim3(grid_for(walkers, 256)), dim3(256), 0, stream, ix, f, packed);
+    hipLaunchKernelGGL(k_path_text, dim3(grid_for(f.paths, 256 / WAVE)), dim3(256), 0, stream, ix, f);
+    if (f.chunks) hipLaunchKernelGGL(k_place_chunk_text, dim3(grid_for(f.chunks, 256)), dim3(256), 0, stream, ix, f);
+}
 
 void launch_sequence_lengths(const DeviceIndex &ix, uint32_t *d_seq_len, uint64_t *d_prints, uint32_t *d_overflow, hipStream_t stream) {
     if (ix.n_sequences == 0) return;

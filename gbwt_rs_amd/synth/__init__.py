@@ -47,6 +47,8 @@ def lib():
         L.gbwt_synth_header.argtypes = [p, u64 * 8]
         L.gbwt_synth_save.restype = C.c_int
         L.gbwt_synth_save.argtypes = [p, C.c_char_p, C.c_int]
+        L.gbwt_synth_set_tag.restype = None
+        L.gbwt_synth_set_tag.argtypes = [p, C.c_char_p, C.c_char_p]
         L.gbwt_synth_path.restype = u64
         L.gbwt_synth_path.argtypes = [p, u64, p, u64]
         L.gbwt_synth_path_checksum.restype = u64
@@ -182,6 +184,10 @@ class Synth:
     def save(self, path, as_gbz=False):
         if self._L.gbwt_synth_save(self._h, os.fsencode(path), int(as_gbz)) != 0:
             raise IOError(f"cannot write {path}")
+
+    def set_tag(self, key, value):
+        """A tag of the GBWT index as save() writes it (e.g. reference_samples: gbunzip's RS:Z: header field, src/bin/gbunzip.rs:193-203)."""
+        self._L.gbwt_synth_set_tag(self._h, key.encode(), value.encode())
 
     def path(self, path_id):
         n = self._L.gbwt_synth_path(self._h, path_id, None, 0)

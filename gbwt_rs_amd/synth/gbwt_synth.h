@@ -84,6 +84,9 @@ const uint64_t *gbwt_synth_starts(const gbwt_synth *s, uint64_t *n_records);
 /* out = {sequences, size, alphabet_offset, alphabet_size, bidirectional, paths, sites, alleles} */
 void gbwt_synth_header(const gbwt_synth *s, uint64_t out[8]);
 int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz);
+/* Sets (or replaces) a tag of the GBWT index that gbwt_synth_save writes (Tags, src/support.rs:870-986) -- e.g. "reference_samples",
+ * which gbunzip's header line prints as RS:Z: (src/bin/gbunzip.rs:193-203). */
+void gbwt_synth_set_tag(gbwt_synth *s, const char *key, const char *value);
 
 /* Ground truth of chain generators: GBWT-encoded nodes of path `path_id` (forward orientation).
  * Returns the path length; writes at most `cap` nodes. */

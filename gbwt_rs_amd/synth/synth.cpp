@@ -741,6 +741,12 @@ int gbwt_synth_save(const gbwt_synth *s, const char *path, int as_gbz) {
     }
 }
 
+void gbwt_synth_set_tag(gbwt_synth *s, const char *key, const char *value) {
+    if (!s || !key || !value) return;
+    for (auto &kv : s->index.tags) if (kv.first == key) { kv.second = value; return; }
+    s->index.tags.emplace_back(key, value);
+}
+
 static bool merged_part(const gbwt_synth *s, uint64_t path_id, uint64_t &part, uint64_t &local) {
     if (s->parts.empty() || path_id >= s->haplotypes) return false;
     part = std::upper_bound(s->part_first_path.begin(), s->part_first_path.end(), path_id) - s->part_first_path.begin() - 1;

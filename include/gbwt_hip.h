@@ -144,11 +144,16 @@ gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hi
  * of it once per file): parse_ms = reading and validating the file (0 for gbwt_hip_open_records), upload_ms = host-to-device copies
  * and the per-record passes (descriptors, rank blocks, tables, endmarker), sample_ms = sequence lengths + sequence samples,
  * total_ms = the whole call.  samples = sequence samples built; checkpoint_sampling = 1 when they came from checkpoint sampling
- * (no sequence walked from end to end), with its number of launches, walkers, and hops that ended at the length cap (orphans). */
+ * (no sequence walked from end to end), with its number of launches, walkers, and hops that ended at the length cap (orphans).
+ * line_sizes_ms (inside upload_ms; handles opened for GFA lines) = the walk that sizes the GFA line of every path once, at open -- token
+ * bytes per 4 096 positions and summed label lengths, i.e. the W-line's end coordinate (src/bin/gbunzip.rs:532-540) -- so that no
+ * gbwt_hip_path_lines* request sizes a line: 0 where the handle has no such table (no GFA group, a node-to-segment translation, no
+ * sequence samples). */
 typedef struct {
     double parse_ms, upload_ms, sample_ms, total_ms;
     uint64_t samples, checkpoint_walkers, checkpoint_orphans;
     uint32_t checkpoint_sampling, checkpoint_rounds;
+    double line_sizes_ms;
 } gbwt_hip_open_times;
 gbwt_hip_status gbwt_hip_get_open_times(const gbwt_hip_index *index, gbwt_hip_open_times *out);
 

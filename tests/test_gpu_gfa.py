@@ -145,6 +145,29 @@ def test_path_modes_on_synthetic(tmp_path):
     assert dev.path_lines(ids, 2) == oracle.path_lines(ids, 2)
 
 
+def test_reference_samples_tag_in_the_header(tmp_path):
+    """write_gfa_header (src/bin/gbunzip.rs:193-203): a GBWT with the `reference_samples` tag gets "H\tVN:Z:1.1\tRS:Z:<value>" -- in every
+    path mode, the rest of the file as without the tag (this version of the reference reads the tag nowhere else on the path)."""
+    s = S.Synth.chain(sites=300, haplotypes=24, alleles=2, model=S.MOSAIC, founders=4, switch_rate=0.02, seed=23)
+    plain = tmp_path / "plain.gbz"
+    s.save(str(plain), as_gbz=True)
+    s.set_tag("reference_samples", "s0 s3")
+    tagged = tmp_path / "tagged.gbz"
+    s.save(str(tagged), as_gbz=True)
+    dev, oracle, untagged = G.GBZ.load(str(tagged)), O.OracleGBZ(str(tagged)), G.GBZ.load(str(plain))
+    for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+        out, ref = tmp_path / f"tagged{mode}.gfa", tmp_path / f"plain{mode}.gfa"
+        dev.write_gfa(str(out), mode)
+        untagged.write_gfa(str(ref), mode)
+        got = out.read_bytes()
+        assert got.startswith(b"H\tVN:Z:1.1\tRS:Z:s0 s3\nS\t"), got[:40]
+        assert got == oracle.gfa(mode), mode
+        assert got[len(b"H\tVN:Z:1.1\tRS:Z:s0 s3\n"):] == ref.read_bytes()[len(b"H\tVN:Z:1.1\n"):], mode
+    ids = list(range(dev.paths()))
+    for mode in (0, 1, 2):
+        assert dev.path_lines(ids, mode) == oracle.path_lines(ids, mode) == untagged.path_lines(ids, mode)
+
+
 def test_config_c4_shape_whole_file(tmp_path):
     """Config 4's shape: 24 contigs x 3 graph components each, ~2 300 ragged walks of 20 samples x 2 phases with non-zero
     fragment offsets, 24 generic paths -- the whole file in the three path modes and the W-lines in any order against the oracle
@@ -265,8 +288,8 @@ def test_config_c4_full_size():
     components walked by 90 haplotypes = ~42 000 ragged walks over ~109 M node ids with labels of 1 .. 1 024 bp, 5.7 G LF-steps, 51 GB of
     W-lines -- the walks of the last contig start just below 2^32, so their end coordinates (fragment + summed label lengths,
     src/bin/gbunzip.rs:532-540) need more than 32 bits.
-      * the extraction: per-path checksums of ALL forward sequences against the generator, order-dependent hashes of a seeded sample
-        against the oracle's walk;
+      * the extraction: per-path checksums of ALL forward sequences against the generator, and length / sum / order-dependent hash of
+        ALL of them against the oracle's walk (src/gbwt.rs:557-568);
       * ONE device request for all W-lines: EVERY line's length and header fields (sample, phase, contig, fragment, end) against the
         generator's ground truth (path_text_stats, itself checked against the oracle in tests/test_dist_cpu.py);
       * a seeded sample of 192 W-lines and all P-lines byte for byte against the oracle (path_to_w_line / write_p_line,
@@ -298,9 +321,10 @@ def test_config_c4_full_size():
         assert np.array_equal(dev.path_sums(len(ids)), truth)
         hashes, lens = dev.path_hashes(len(ids)), np.diff(dev.last_offsets(len(ids)))
         assert np.array_equal(lens, stats[:, 0].astype(np.uint64))
-        pick = np.sort(np.random.default_rng(4).choice(g.paths, 256, replace=False)).astype(np.uint64)
-        o_steps, o_lens, o_sums, o_hashes = oracle.gbwt().extract_checksums(2 * pick, cores)
-        assert np.array_equal(hashes[pick], o_hashes) and np.array_equal(lens[pick], o_lens) and np.array_equal(truth[pick], o_sums)
+        # (every path, not a sample -- the oracle walks all 42 016 forward sequences, 5.7 G LF-steps, about a minute on 64 threads)
+        o_steps, o_lens, o_sums, o_hashes = oracle.gbwt().extract_checksums(ids, cores)
+        assert o_steps == int(res.total)
+        assert np.array_equal(hashes, o_hashes) and np.array_equal(lens, o_lens) and np.array_equal(truth, o_sums), "a row differs from the oracle's walk"
         # one request for all W-lines: every line's length and header against the generator
         lines = dev.path_lines_device(walks, 1)
         device = torch.device("cuda", 0)
@@ -345,10 +369,12 @@ def test_config_c4_full_size():
 
 @pytest.mark.parametrize("fill_mode", [0, 1, 2])
 def test_line_cache_serves_every_mode(tmp_path, monkeypatch, fill_mode):
-    """The line cache of the index (round 5): the first request that formats a path leaves the sizes of its line there -- token bytes
-    chunk by chunk, summed label lengths -- and later requests of that path size and place its line without a sizing pass, in ANY line
-    mode (a P-line's text is the W-line's plus separators).  Lines of paths longer than one chunk, empty paths, duplicates and subsets in
-    another order: filled by one mode, asked for in all three, against the oracle and against a handle with the cache switched off."""
+    """The line cache of the index: the sizes of every path's line -- token bytes chunk by chunk, summed label lengths -- are found by ONE
+    walk at open (round 6: a walker per segment between two sequence samples; round 5 left them behind the first request of a path), and
+    every request sizes and places its lines from them without a sizing pass, in ANY line mode (a P-line's text is the W-line's plus
+    separators).  Lines of paths longer than one chunk (chunk boundaries inside and at the end of a segment), paths that visit nodes
+    again, empty paths, duplicates and subsets in another order: asked for in all three modes, whichever comes first, against the oracle
+    and against a handle with the cache switched off (GBWT_HIP_LINE_CACHE=0: every request sizes its lines itself)."""
     paths = [[2 * (1 + (7 * k + j) % 50) + ((k + j) % 3 == 0) for j in range(ln)] for k, ln in enumerate([0, 1, 9000, 4096, 4097, 12289, 5, 0, 8192, 300])]
     s = S.Synth.from_paths(paths, bidirectional=True).attach_gbz(seed=3)
     path = str(tmp_path / "cache.gbz")
@@ -360,9 +386,10 @@ def test_line_cache_serves_every_mode(tmp_path, monkeypatch, fill_mode):
     monkeypatch.delenv("GBWT_HIP_LINE_CACHE")
     everything = list(range(len(paths)))
     first = [2, 0, 5, 9]
-    assert dev.path_lines(first, fill_mode) == oracle.path_lines(first, fill_mode)               # fills the cache for these four
+    assert dev.open_times()["line_sizes_ms"] > 0 and plain.open_times()["line_sizes_ms"] == 0
+    assert dev.path_lines(first, fill_mode) == oracle.path_lines(first, fill_mode)
     for mode in (0, 1, 2):
-        for ids in (first, [5, 5, 2], everything, everything[::-1], [7], [3, 2]):                    # cached, mixed (sized again, the rest filled), cached
+        for ids in (first, [5, 5, 2], everything, everything[::-1], [7], [3, 2]):
             got = dev.path_lines(ids, mode)
             assert got == oracle.path_lines(ids, mode) == plain.path_lines(ids, mode), (fill_mode, mode, ids)
     out = tmp_path / "whole.gfa"
@@ -372,7 +399,7 @@ def test_line_cache_serves_every_mode(tmp_path, monkeypatch, fill_mode):
 
 def test_line_cache_filled_by_concurrent_requests(tmp_path):
     """Several host threads, each with a workspace of its own, format overlapping sets of paths of ONE handle at the same time, in different
-    line modes, while the handle's line cache is still empty: whichever request fills an entry first, every text equals the oracle's."""
+    line modes, all of them sizing their lines from the handle's line cache (read-only after the open): every text equals the oracle's."""
     import threading
     s = S.Synth.chain(sites=2500, haplotypes=160, alleles=2, model=S.MOSAIC, founders=8, switch_rate=0.01, seed=19, extra=1, indel_every=5)
     path = str(tmp_path / "threads.gbz")

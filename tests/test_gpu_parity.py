@@ -696,6 +696,37 @@ def test_lean_extract_handle_walks_like_the_full_one(extra, every):
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
+@pytest.mark.parametrize("flags", ["OPEN_EXTRACT", "OPEN_GFA"])
+def test_lean_handle_refuses_walks_without_samples(monkeypatch, flags):
+    """A lean handle has no raw descriptors, and a walker that does not start from a sequence sample reads them when it arrives on its
+    first record (walk_loops.hpp: arrive).  With GBWT_HIP_SEGMENTS=0 -- whole rows and, since such rows cannot be cut, the last of several
+    parts -- the request is refused with GBWT_HIP_UNSUPPORTED before anything is launched (round 5 would have read through a null device
+    pointer); earlier parts are n empty rows as the header says, rows of no nodes are served, and the same handle with a default
+    workspace still walks like the full one."""
+    s = S.Synth.chain(sites=3000, haplotypes=200, alleles=2, model=S.MOSAIC, founders=8, switch_rate=5e-3, seed=5)
+    full = open_synth(s)
+    lean = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True, flags=getattr(G, flags))
+    ids = np.arange(0, 64, 2, dtype=np.uint64)
+    want = full.sequences_csr(ids)
+    monkeypatch.setenv("GBWT_HIP_SEGMENTS", "0")
+    lean.new_workspace()
+    for call in (lambda: lean.sequences_csr(ids), lambda: lean.part_csr(ids, 2, 3)):
+        with pytest.raises(G.GbwtHipError) as e:
+            call()
+        assert e.value.status == _lib_status("UNSUPPORTED")
+    off, nodes = lean.part_csr(ids, 0, 3)
+    assert off.tolist() == [0] * (len(ids) + 1) and len(nodes) == 0
+    beyond = np.array([s.sequences, s.sequences + 7], dtype=np.uint64)          # GBWT::sequence -> None: empty rows, nothing to walk
+    assert lean.sequences_csr(beyond)[0].tolist() == [0, 0, 0]
+    monkeypatch.delenv("GBWT_HIP_SEGMENTS")
+    lean.new_workspace()
+    got = lean.sequences_csr(ids)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    for part in range(3):
+        x, y = lean.part_csr(ids, part, 3), full.part_csr(ids, part, 3)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+
+
 @pytest.mark.parametrize("extra,every,sites", [(2, 1, 60000), (3, 64, 150000), (1, 8, 100000), (3, 4096, 150000)])
 def test_indel_chain_scale_properties(extra, every, sites):
     """The same regime at a size the oracle does not finish quickly: every path against the generator's allele matrix.  Dense
@@ -738,8 +769,8 @@ def test_headline_scale_properties():
 
 def test_headline_full_size():
     """BASELINE's headline index at its full size (5 000 paths x 1 000 002 nodes, 3.33 G LF-steps per pass): every extracted path
-    against the generator's ground truth (per-path checksums reduced on the device, full rows for a few), a seeded sample of 64 paths
-    against the ORACLE's walk (whole rows + length / sum / order-dependent hash), uniform lengths, total = (size - sequences) / 2,
+    against the generator's ground truth (per-path checksums reduced on the device, full rows for a few), EVERY path against the
+    ORACLE's walk (length / sum / order-dependent hash of all 5 000 rows, whole rows for a seeded sample of 64), uniform lengths, total = (size - sequences) / 2,
     reverse sequences = flipped reversals, and the same answers from a second pass (the extraction is idempotent)."""
     s = S.Synth.chain(sites=333334, haplotypes=5000, alleles=2, model=S.MOSAIC, founders=32, switch_rate=2e-3, seed=42)
     dev = open_synth(s)
@@ -752,16 +783,18 @@ def test_headline_full_size():
     for h in (0, 1234, 4999):
         row = dev.copy_path(h)
         assert len(row) == 2 * s.sites and np.array_equal(row, s.path(h))
-    # ... and against the ORACLE at this size: a seeded sample of 64 paths walked by the CPU restatement of SequenceIter
-    # (src/gbwt.rs:557-568) -- whole rows, and the length / node sum / order-dependent hash of every sampled path as bench.py's
-    # cpu_baseline leg compares them (gbwt_hip_path_sums, gbwt_hip_path_hashes)
+    # ... and against the ORACLE at this size (every path, not a sample): ALL 5 000 forward sequences walked by the CPU
+    # restatement of SequenceIter (src/gbwt.rs:557-568) -- 3.33 G LF-steps, about half a minute on 64 host threads -- with the length, node
+    # sum and ORDER-DEPENDENT hash of every row compared (gbwt_hip_path_sums, gbwt_hip_path_hashes); whole rows for a seeded sample of 64
     oracle = oracle_of(s)
-    sample = np.sort(np.random.default_rng(64).choice(s.paths, size=64, replace=False)).astype(np.uint64)
-    o_off, o_nodes = oracle.extract(2 * sample, threads=min(os.cpu_count() or 1, 64))
-    o_steps, o_lens, o_sums, o_hashes = oracle.extract_checksums(2 * sample, threads=min(os.cpu_count() or 1, 64))
-    assert o_steps == int(o_off[-1]) == 64 * 2 * s.sites
+    threads = min(os.cpu_count() or 1, 64)
+    o_steps, o_lens, o_sums, o_hashes = oracle.extract_checksums(ids, threads=threads)
+    assert o_steps == 5000 * 2 * s.sites
     lens, sums, hashes = np.diff(dev.last_offsets(s.paths)), dev.path_sums(s.paths), dev.path_hashes(s.paths)
-    assert np.array_equal(lens[sample], o_lens) and np.array_equal(sums[sample], o_sums) and np.array_equal(hashes[sample], o_hashes)
+    assert np.array_equal(lens, o_lens) and np.array_equal(sums, o_sums) and np.array_equal(hashes, o_hashes), "a row differs from the oracle's walk"
+    sample = np.sort(np.random.default_rng(64).choice(s.paths, size=64, replace=False)).astype(np.uint64)
+    o_off, o_nodes = oracle.extract(2 * sample, threads=threads)
+    assert int(o_off[-1]) == 64 * 2 * s.sites
     for k, h in enumerate(sample):
         assert np.array_equal(dev.copy_path(int(h)), o_nodes[int(o_off[k]):int(o_off[k + 1])]), f"path {h} differs from the oracle's walk"
     rev = np.array([2 * 1234 + 1, 1, 2 * 4999 + 1], dtype=np.uint64)

@@ -182,7 +182,8 @@ def config4(passes=3, out="", device=0, size="full", cpu_leg=None):
         if out and os.path.exists(out):
             os.remove(out)
     wf = res["walk_format"]
-    res.update({"value": wf["value"], "unit": "LF-steps/s", "kernel": "k_walk_direct + k_chunk_stats + k_format_chunks", "kernel_ms": wf["ms"],
+    res.update({"value": wf["value"], "unit": "LF-steps/s", "kernel": "k_walk_direct + k_format_chunks", "kernel_ms": wf["ms"],
+                "value_first_request": wf["value_first_request"], "first_request_ms": wf["first_request_ms"],
                 "algorithmic_bytes": float(wf["bytes_moved"])})
     return res
 

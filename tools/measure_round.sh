@@ -19,7 +19,7 @@ if [ "${2:-}" != "quick" ]; then
     F=""
     case $C in
       search) K=k_search,k_bd_search; P=max; F="--fetch-factor 1";;
-      config4|config4_small) K=k_walk_direct,k_format_chunks; P=max;;   # (k_chunk_stats sizes the lines of a path ONCE: the line cache)
+      config4|config4_small) K=k_walk_direct,k_format_chunks; P=max;;   # (no request sizes a line: the line cache is filled at open, k_segment_text)
       *) K=k_walk_direct; P=last;;
     esac
     cd /tmp
