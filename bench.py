@@ -535,8 +535,12 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the one-shot flow of gbunzip (src/bin/gbunzip.rs:24-59): load, extract every path once
+    # The handle is opened for what this job calls -- extraction (gbwt_hip_open_file_flags: GBWT_HIP_OPEN_EXTRACT; weak scaling also formats a
+    # sample of W-lines for its gather) -- as a caller of the library would: the search structures and the GFA tables of a handle opened for
+    # everything (7 ms of line sizes, 1.1 GB) are built by the configs that use them (`search`, `config4`), not by this one.
+    open_flags = G.OPEN_EXTRACT if strong else G.OPEN_ALL
     t0 = time.perf_counter()
-    index = G.GBZ.load(index_path, device=local_rank)
+    index = G.GBZ.load(index_path, device=local_rank, flags=open_flags)
     open_ms = (time.perf_counter() - t0) * 1e3
     open_times = index.open_times()
     n_paths = index.paths()
@@ -772,7 +776,9 @@ def main():
                 "generator_seconds": round(gen_s, 1),
             },
             "open": {
-                "open_ms": open_ms, "parse_ms": open_times["parse_ms"], "upload_ms": open_times["upload_ms"], "sample_ms": open_times["sample_ms"],
+                "open_ms": open_ms, "flags": "GBWT_HIP_OPEN_EXTRACT" if open_flags == G.OPEN_EXTRACT else "GBWT_HIP_OPEN_ALL",
+                "parse_ms": open_times["parse_ms"], "upload_ms": open_times["upload_ms"], "sample_ms": open_times["sample_ms"],
+                "index_device_bytes": int(index.memory_usage()["index_device_bytes"]),
                 "samples": int(open_times["samples"]), "checkpoint_sampling": bool(open_times["checkpoint_sampling"]),
                 "checkpoint_walkers": int(open_times["checkpoint_walkers"]), "checkpoint_orphans": int(open_times["checkpoint_orphans"]),
                 "first_pass_ms": first_pass_ms, "first_pass_kernel_ms": first_walk_ms, "runtime_init_ms": runtime_init_ms,

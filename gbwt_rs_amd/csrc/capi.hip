@@ -800,6 +800,11 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
         early.worker = std::thread([&early, src, dst, bytes, dev, slices]() {
             early.result = hipSetDevice(dev);
             if (early.result != hipSuccess) return;
+            const bool trace = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            struct Note { bool on; std::chrono::steady_clock::time_point t0; uint64_t bytes; unsigned slices;
+                          ~Note() { if (on) std::fprintf(stderr, "[open] (record bytes to the device, %u slice(s), next to the decodes) %8.3f ms for %.1f MB\n", slices,
+                                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), bytes / 1e6); } } note{trace, t0, bytes, slices};
             if (slices <= 1) { early.result = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); return; }
             std::vector<hipError_t> results(slices, hipSuccess);
             std::vector<std::thread> pool;
@@ -816,8 +821,11 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
     if (early.worker.joinable()) {
         // the starts are decoded by now and the copy of the record bytes has a few milliseconds to go: the starts go out under them
         fill_stats(*ix);
+        OpenTrace trace;
         try { upload_starts(*ix); } catch (...) { early.worker.join(); throw; }
+        trace.mark("(record starts narrowed + sent)");
         early.worker.join();
+        trace.mark("(waited for the record bytes)");
     }
     if (early.result != hipSuccess) throw HipError{early.result, "hipMemcpy (record bytes, early)"};
     return open_common(std::move(ix), out, t_open);

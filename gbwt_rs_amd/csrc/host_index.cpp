@@ -154,13 +154,16 @@ void run_pieces(unsigned pieces, Fn fn) {
     if (failure) std::rethrow_exception(failure);
 }
 
-// (from eight million items: below that one thread is done before the copy of the record bytes to the device, which runs next to it,
-// and more threads only get in that copy's way -- parse of the headline GBZ 9.3-10.0 ms with one thread, 10.3-12.0 with eight)
-// (... and from there a thread per two million items, up to 32: the 4.4 G label characters and 218 M record starts of config 4 at its
-// stated size took 0.9 + 0.4 s of a 2 s open on eight threads -- profiles/r05_c4_open_trace.txt)
+// A thread per 256 K items up to four, and from eight million items a thread per two million up to 32.
+// (Rounds 3-5 kept ONE thread below eight million items: on those boxes the copy of the record bytes that runs next to the decodes took 9 ms
+// for the headline's 60 MB and hid a 5.7 ms decode of its two million starts.  Round 6 measured both again inside an open
+// (profiles/r06_open_probe.txt): the copy takes 1.4-1.5 ms, the one-thread decode 3.8 ms -- the decode IS the parse; four threads: 1.9 ms,
+// parse 5.1 -> 3.1 ms; eight add nothing.)
+// (... the 4.4 G label characters and 218 M record starts of config 4 at its stated size took 0.9 + 0.4 s of a 2 s open on eight threads --
+// profiles/r05_c4_open_trace.txt)
 inline unsigned pieces_for(uint64_t items) {
-    if (items < (uint64_t(1) << 23)) return 1u;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (items < (uint64_t(1) << 23)) return std::max(1u, std::min(std::min(4u, hw), static_cast<unsigned>(items >> 18)));
     const unsigned by_size = static_cast<unsigned>(std::min<uint64_t>(items >> 21, 32));
     return std::max(std::min(8u, hw), std::min(by_size, hw));
 }

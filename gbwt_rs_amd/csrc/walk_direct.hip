@@ -51,6 +51,9 @@ __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
 // do, and a batch with one long row and many short ones has as many walkers as it has segments, not rows x longest.
 struct WalkerStart { uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, first_node = 0; };
 
+// PROBE (here and in k_walk_direct): the instantiation that still looks at the measurement switches and at the frames that were measured and
+// are not the default (WalkArgs::debug, align_segments, walker_list); the product instantiation has none of them compiled in.
+template <bool PROBE>
 __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, const WalkArgs &a, uint64_t w, RowTarget &t) {
     WalkerStart s;
     // walker w -> segment j = the level it falls into, row = the (w - level[j])-th of the rows that have a segment j
@@ -60,7 +63,7 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
         if (a.level[mid] <= w) lo = mid; else hi = mid;
     }
     uint64_t j = lo, k = 0;
-    if (a.walker_list != nullptr) {                                // walkers in the order of their start records: t-th (row, segment) pair
+    if (PROBE && a.walker_list != nullptr) {                       // walkers in the order of their start records: t-th (row, segment) pair
         const uint64_t t = a.walker_list[w];
         uint64_t first = 0, last = a.n;                            // row_first[first] <= t < row_first[last]
         while (last - first > 1) {
@@ -93,15 +96,15 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     // walks on past the next sample to the end of that line (any lane may take any LF step: the nodes are the same), and the walker
     // that starts there stages the nodes in front of the boundary like all others but does not write them (`skip`).  Up to
     // piece - 1 more LF steps per segment; only the two ends of a ROW are partial lines.
-    if (a.align_segments && t.len != 0) {
+    if (PROBE && a.align_segments && t.len != 0) {
         const uint32_t piece = a.row_piece ? a.row_piece : RING_FLUSH;
         const uint64_t phase_from = (reinterpret_cast<uintptr_t>(t.row) >> 2) & (piece - 1), phase_to = (reinterpret_cast<uintptr_t>(t.row + t.len) >> 2) & (piece - 1);
         if (j > 0 && phase_from != 0) t.skip = static_cast<uint32_t>(piece - phase_from);
         if (j + 1 < count && phase_to != 0) t.len = min(t.len + (piece - phase_to), len - from);       // never past the end of the row
         if (t.skip >= t.len) { t.len = 0; t.skip = 0; }             // a segment inside one line: the walker before writes all of it
     }
-    if (a.debug & 2u) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
-    if (a.debug & 128u) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
+    if (PROBE && (a.debug & 2u)) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
+    if (PROBE && (a.debug & 128u)) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
     t.backward = false;
     t.share = static_cast<uint32_t>(t.len);
     s.rec = here.x; s.offset = here.y; s.bb = here.z;
@@ -361,7 +364,9 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
 #ifdef GBWT_HIP_WALK_WAVES
 __attribute__((amdgpu_waves_per_eu(GBWT_HIP_WALK_WAVES, GBWT_HIP_WALK_WAVES)))
 #endif
+template <bool PROBE>
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
+    const uint32_t debug = PROBE ? a.debug : 0u;             // measurement switches: none in the product instantiation
     // rows sized AFTER the launch (WalkArgs::capacity): the request did not wait for the total of its row lengths; where the rows it was
     // given are too small for it -- or there is nothing to walk -- every workgroup goes home and the host launches again
     if (a.capacity != 0) {
@@ -389,7 +394,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     // fetched into ONE L2 instead of all eight.
     uint64_t group = blockIdx.x;
     if (a.xcd_map) group = (blockIdx.x % 8u) * static_cast<uint64_t>(gridDim.x / 8u) + blockIdx.x / 8u;
-    if (a.debug & 16384u) {   // measurement switch (tools/occupancy_probe.py): the same work on XCDs 0-3 only -- the grid is twice as large, XCDs 4-7 leave at once
+    if (PROBE && (debug & 16384u)) {   // measurement switch (tools/occupancy_probe.py): the same work on XCDs 0-3 only -- the grid is twice as large, XCDs 4-7 leave at once
         if (blockIdx.x % 8u >= 4u) return;
         group = (blockIdx.x / 8u) * 4ull + blockIdx.x % 8u;
     }
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
     RowTarget target;
     WalkerStart begin;
     if (owner) {
-        if (a.segments) begin = segment_start(ix, a, w, target);
+        if (a.segments) begin = segment_start<PROBE>(ix, a, w, target);
         else target = row_target(a, w);
     }
     lds_u32_t *const my_mail = lds_ptr(&mailbox[lane]);          // word 3 = nodes staged so far
@@ -412,12 +417,12 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t serve = lane % owners;                        // the 64 lanes share the owners' look-ahead slots ...
         const uint32_t spread = (lane << 26) | (1u << 25);           // ... and spread over the target's blocks
         const uint32_t dummy = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(touch_dummy));
-        RowWriter writer{lds_ptr(ring_lds + lane), target, 0, ring_mask, (a.debug & 1u) != 0};
+        RowWriter writer{lds_ptr(ring_lds + lane), target, 0, ring_mask, (debug & 1u) != 0};
         const lds_u32_t *const served_mail = lds_ptr(&mailbox[serve]);
         const uint32_t piece = a.segments ? a.row_piece : 0u;       // rows filled back to front stay with the lane-per-row writer
         const auto lds_address = [](const void *q) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(q)); };
-        const CoopRows rows{lds_address(ring_lds), lds_address(mailbox), lds_address(row_state), ring_mask, (a.debug & 1u) != 0, (a.debug & 4u) != 0,
-                            (a.debug & 64u) != 0, (a.debug & 256u) == 0};
+        const CoopRows rows{lds_address(ring_lds), lds_address(mailbox), lds_address(row_state), ring_mask, (debug & 1u) != 0, (debug & 4u) != 0,
+                            (debug & 64u) != 0, (debug & 256u) == 0};
         uint32_t mine = lane;                                        // the row this lane watches
         uint32_t served[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // the row this lane serves in group g
         if (piece) {
@@ -436,7 +441,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
                 const uint64_t same = __ballot(phase == v);
                 rank += v < phase ? static_cast<uint32_t>(__popcll(same)) : (v == phase ? static_cast<uint32_t>(__popcll(same & lanes_below)) : 0u);
             }
-            if (a.debug & 32u) rank = lane;                          // measurement switch: groups of consecutive rows
+            if (PROBE && (debug & 32u)) rank = lane;                          // measurement switch: groups of consecutive rows
             lds_poke(lds_ptr(row_order) + rank, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             mine = lds_peek(lds_ptr(row_order) + lane);
@@ -905,7 +910,10 @@ void launch_walk_direct(const DeviceIndex &ix, const WalkArgs &args, hipStream_t
     unsigned groups = grid_for(walkers, p);
     if (args.xcd_map) groups = (groups + 7u) / 8u * 8u;   // whole eighths; the workgroups past the end own nothing
     if (args.debug & 16384u) groups = grid_for(walkers, p) * 2u + 8u;
-    hipLaunchKernelGGL(k_walk_direct, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
+    // the product kernel, or -- for a workspace whose knobs ask for a measurement switch or one of the frames that are not the default -- the probe one
+    const bool probe = args.debug != 0 || args.align_segments != 0 || args.walker_list != nullptr;
+    if (probe) hipLaunchKernelGGL(k_walk_direct<true>, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
+    else hipLaunchKernelGGL(k_walk_direct<false>, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
 }
 
 }  // namespace gbwt_hip

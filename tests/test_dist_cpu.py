@@ -271,3 +271,64 @@ def test_config4_partition_over_gloo(tmp_path, world):
     port = _free_port()
     mp.spawn(_c4_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _rehearse_bench(world, extra_env=None, timeout=420):
+    """tests/bench_rehearsal.py under torch.distributed.run, `world` gloo ranks on CPU: (exit code, the JSON lines on stdout, stderr)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "tests", "bench_rehearsal.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--sites", "300", "--haplotypes", "24", "--c4-size", "tiny"]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(x) for x in done.stdout.splitlines() if x.startswith("{")]
+    return done.returncode, lines, done.stderr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_n_gpus_over_gloo(world):
+    """bench.py --gpus N END TO END without a GPU: N gloo ranks run bench.main() unchanged over a stand-in for the handle
+    classes that answers every extraction and every GFA line with the oracle (tests/bench_rehearsal.py).  Every collective of the N > 1 flow
+    is entered by every rank (the run ends), rank 0 prints exactly ONE line, and the line has the shape the driver and the judge read:
+    the headline under both cuts, the final gather, config 4 sharded with per-rank numbers, the gather and the per-rank file writes."""
+    rc, lines, err = _rehearse_bench(world)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, (len(lines), err[-2000:])
+    line = lines[0]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "value_cold", "kernel_ms_per_rank", "value_incl_gather", "open", "shard", "other_cut", "config4"):
+        assert key in line, key
+    assert line["n_gpus"] == world and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "strong" and line["vs_baseline"] is None
+    assert line["unit"] == "LF-steps/s" and line["higher_is_better"] is True and line["dtype"] == "u32" and "cpu_baseline" not in line   # (N = 1 only)
+    assert line["shard"] == "parts" and line["other_cut"]["shard"] == "paths" and line["other_cut"]["value"] > 0
+    assert len(line["kernel_ms_per_rank"]) == world
+    assert line["config"]["lf_steps_per_gpu"] * world >= 24 * 2 * 300            # every rank its stretch of every row: together all LF-steps
+    gather = line["config"]["final_gather"]
+    assert "error" not in gather and gather["ms"] > 0 and gather["bytes"] == 4 * 24 * 2 * 300 + 8 * 24, gather
+    assert line["value_incl_gather"] is not None and 0 < line["value_incl_gather"] < line["value"]
+    c4 = line["config4"]
+    assert "error" not in c4, c4
+    assert c4["n_gpus"] == world and len(c4["ranks"]) == world and sorted(r["rank"] for r in c4["ranks"]) == list(range(world))
+    assert sum(r["walks"] for r in c4["ranks"]) + sum(r["p_lines"] for r in c4["ranks"]) == c4["paths"]
+    assert c4["gather_ms"] > 0 and c4["value"] > 0 and c4["value_incl_gather"] < c4["value"] and c4["text_bytes"] == sum(r["text_bytes"] for r in c4["ranks"]) - c4["p_text_bytes"]
+    assert c4["sharded_file"]["bytes"] == c4["text_bytes"] + c4["p_text_bytes"] and "gathered W-lines == rank 0" in c4["check"]
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["traffic"] is None                     # (no PMC profile at N > 1)
+
+
+@pytest.mark.parametrize("failure", ["c4_open:1", "c4_open:0", "c4_generate"])
+def test_bench_survives_a_rank_that_fails_in_config4(failure):
+    """A rank that cannot open config 4's index (or rank 0 whose generator fails) must not leave its peers waiting in the next collective
+    until the process group's timeout -- with RCCL the watchdog would abort them and the headline's line would be lost with them (ADVICE
+    r05): the ranks AGREE on the failure before anybody enters a collective (bench.py: config4_sharded.agree), all of them leave the
+    object, and rank 0 still prints the line, with the error in `config4`, within seconds."""
+    import time
+    t0 = time.perf_counter()
+    rc, lines, err = _rehearse_bench(2, {"REHEARSAL_FAIL": failure}, timeout=240)
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    assert time.perf_counter() - t0 < 200
+    line = lines[0]
+    assert "error" in line["config4"] and line["value"] > 0 and line["other_cut"]["value"] > 0 and "ms" in line["config"]["final_gather"]
