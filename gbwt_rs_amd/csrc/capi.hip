@@ -1077,29 +1077,8 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
                 if (parted) a.segments = static_cast<uint32_t>(uint64_t(a.segments) * (part + 1) / parts - uint64_t(a.segments) * part / parts);   // (device_index.hpp: row_segments)
                 walkers = static_cast<uint64_t>(a.segments) * n;   // every row has every segment: no order to compute
                 a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
-            } else if (segmented && knobs.walker_order != 0 && n <= 0x7FFFFFFFull) {
-                // (GBWT_HIP_WALKER_ORDER=1; measured in round 4 and NOT the default: profiles/r04_walk_experiments.txt)  Rows with different numbers of
-                // segments (ragged walks, a subset of the paths): walkers in the order of the RECORD their segment starts on.  The samples lie where sequences pass checkpoint records (open_walks.hip), so the walkers that start on
-                // one record are the rows that travel together there -- whichever rows they are: a batch of 32 000 walks over 480 graph
-                // components, sorted by row length until round 4, had every wave on 64 different records (201 G LF-steps/s in the gather
-                // loop; profiles/r04_walk_experiments.txt).
-                ws->order_counts.reserve(n * sizeof(uint64_t)); ws->order_level.reserve((n + 1) * sizeof(uint64_t));
-                launch_walker_counts(strided, ws->seq_ids.as<uint64_t>(), n, ws->order_counts.as<uint64_t>(), s);
-                launch_scan(ws->order_counts.as<uint64_t>(), ws->order_level.as<uint64_t>(), n, ws->scan_temp.ptr, temp_bytes, s);
-                HIP_CHECK(hipMemcpyAsync(&walkers, ws->order_level.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                if (walkers >= 0xFFFFFFF0ull) return fail(GBWT_HIP_UNSUPPORTED, "more than 2^32 walkers in one extraction: extract fewer sequences per call");
-                const size_t ob = walker_list_temp_bytes(std::max<uint64_t>(walkers, 1));
-                ws->order_keys.reserve(2 * std::max<uint64_t>(walkers, 1) * sizeof(uint32_t)); ws->order_rows.reserve(2 * std::max<uint64_t>(walkers, 1) * sizeof(uint32_t));
-                ws->order_temp.reserve(std::max<size_t>(ob, 16));
-                const uint32_t *sorted = nullptr;
-                if (walkers) launch_walker_list(strided, ws->seq_ids.as<uint64_t>(), n, ws->order_level.as<uint64_t>(), walkers, ws->order_keys.as<uint32_t>(),
-                                                ws->order_rows.as<uint32_t>(), ws->order_temp.ptr, ob, &sorted, s);
-                a.sorted_rows = nullptr; a.level = nullptr; a.walkers = walkers;
-                a.walker_list = walkers ? sorted : nullptr; a.row_first = ws->order_level.as<uint64_t>();
-                if (walkers == 0) { a.segments = 0; walkers = ix->orientation_pairs ? 2 * n : n; }      // (nothing but empty rows)
             } else if (segmented) {
-                // (GBWT_HIP_WALKER_ORDER=0, rounds 1-3) walker order: segment by segment over the rows that have the segment (rows sorted by their segment count)
+                // rows with different numbers of segments: walkers segment by segment over the rows that have the segment (rows sorted by their segment count)
                 const size_t ob = walker_order_temp_bytes(n), sb = scan_temp_bytes(a.segments);
                 ws->order_keys.reserve(2 * n * sizeof(uint32_t)); ws->order_rows.reserve(2 * n * sizeof(uint32_t));
                 ws->order_counts.reserve(a.segments * sizeof(uint64_t)); ws->order_level.reserve((a.segments + 1ull) * sizeof(uint64_t));
@@ -1129,7 +1108,10 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             a.catch_up = knobs.catch_up >= 0 ? static_cast<uint32_t>(std::min(knobs.catch_up, 2)) : 1u;
             if (ix->lean_extract && a.catch_up == 1u) a.catch_up = 2u;
             if (a.catch_up == 2u && !(ix->packed_blocks && knobs.packed_blocks != 0)) a.catch_up = ix->lean_extract ? 0u : 1u;
-            a.align_segments = (segmented && knobs.align_segments != 0 && !parted) ? 1u : 0u;   // (a part ends where the next rank's begins, not at the next line)
+            // look-ahead in mixed waves where few rows pass a record (fewer than 512 BWT positions per record on average: config 4 has 52, the
+            // headline 3 300 -- there seventy waves share every line and the extra load of the gather loop costs what it saves, round 2)
+            a.gather_reach = knobs.gather_reach >= 0 ? static_cast<uint32_t>(knobs.gather_reach)
+                                                     : (ix->stats.records != 0 && ix->host.size / ix->stats.records < 512 ? 1u : 0u);
             a.all4 = knobs.all4 != 0 ? 1u : 0u;
             a.headroom = static_cast<uint32_t>(knobs.headroom);
             // without packed half-blocks every wave starts on the full-width loops (the packed ones load before they look at GATHER_OK)

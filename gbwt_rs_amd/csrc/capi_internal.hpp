@@ -265,12 +265,11 @@ struct gbwt_hip_index {
 // index at the same time, each with its own workspace -- include/gbwt_hip.h).  -1 = not set: the library's default for the batch.
 struct ExtractKnobs {
     int direct = 1, segments = 1, both_ends = 1;             // GBWT_HIP_DIRECT / _SEGMENTS / _BOTH_ENDS (0 switches the feature off)
-    int align_segments = 0;                                   // GBWT_HIP_ALIGN_SEGMENTS: 1 = the boundary between two walkers of a row is a line boundary of the row's memory (round 4: measured, 2.4 % slower on the headline: not the default)
     int all4 = 1;                                             // GBWT_HIP_ALL4: 0 = the uniform loop counts every node it stages (rounds 1-3)
     int sample_stride = -1;                                   // GBWT_HIP_SAMPLE_STRIDE: a walker per this many samples of a row; -1 = by the size of the batch (gbwt_hip_extract_device)
     int defer_total = 1;                                      // GBWT_HIP_DEFER_TOTAL: 0 = every request waits for the total of its row lengths before it launches the walk (rounds 1-3)
-    int walker_order = 0;                                     // GBWT_HIP_WALKER_ORDER: 1 = ragged batches in the order of the walkers' start records (round 4: measured, not the default), 0 = by number of segments
     int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
+    int gather_reach = -1;                                    // GBWT_HIP_GATHER_REACH: look-ahead of mixed waves (WalkArgs::gather_reach); -1 = by the index (rows per record), 0 = none
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
     uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
     unsigned copy_threads = 8;                                // GBWT_HIP_COPY_THREADS
@@ -290,10 +289,9 @@ struct ExtractKnobs {
         k.helper_naps = std::max(-1, num("GBWT_HIP_HELPER_NAPS", -1));
         k.xcd_map = num("GBWT_HIP_XCD_MAP", -1); k.uniform_loop = num("GBWT_HIP_UNIFORM_LOOP", -1); k.packed_blocks = num("GBWT_HIP_PACKED_BLOCKS", -1);
         k.catch_up = num("GBWT_HIP_CATCH_UP", -1);
-        k.walker_order = num("GBWT_HIP_WALKER_ORDER", 0);
+        k.gather_reach = std::min(64, std::max(-1, num("GBWT_HIP_GATHER_REACH", -1)));
         k.sample_stride = num("GBWT_HIP_SAMPLE_STRIDE", -1);
         k.defer_total = num("GBWT_HIP_DEFER_TOTAL", 1);
-        k.align_segments = num("GBWT_HIP_ALIGN_SEGMENTS", 0);
         k.all4 = num("GBWT_HIP_ALL4", 1);
         k.headroom = std::min(32, std::max(0, num("GBWT_HIP_HEADROOM", 0)));
         k.row_piece = num("GBWT_HIP_ROW_PIECE", -1); if (k.row_piece != 0 && k.row_piece != 16 && k.row_piece != 32) k.row_piece = -1;

@@ -69,8 +69,9 @@ struct WalkArgs {
     uint32_t uniform_loop;     // k_walk_direct: try the wave-uniform loop (scalar descriptor fetch) first
     uint32_t headroom;         // k_walk_direct: ring slots a loop keeps free (0 = by the index: 8, or the longest chained iteration; measurements)
     uint32_t all4;             // k_walk_direct: the uniform loop stages the four nodes of an iteration in a row on E_ALL4 records (0: counts every node; measurements)
-    uint32_t align_segments;   // k_walk_direct, segmented: the boundary between two walkers of a row is a piece boundary of the row's memory (walk_direct.hip: LINE-ALIGNED SEGMENTS)
     uint32_t catch_up;         // k_walk_direct: a mixed wave first lets the lanes that are behind take single steps (walk_direct.hip: CATCH-UP)
+    uint32_t gather_reach;     // k_walk_direct: > 0 = the gather loop posts the look-ahead target of every record it leaves and the helper touches the descriptors
+                               // and blocks of this many consecutive records from it (round 6: indexes with few rows per record); 0 = no look-ahead in mixed waves
     uint32_t packed_blocks;    // k_walk_direct: the uniform loop starts on the packed half-blocks (0: on the full-width blocks at once; measurements)
     uint32_t debug;            // measurement switches of k_walk_direct (GBWT_HIP_DEBUG_DRY_ROWS; never set by the library itself; the output is
                                // wrong with 1, 2 and 128): 1 = no row stores, 2 = all rows written into one 64 MB window, 128 = into 1 MB, 4 = plain
@@ -80,12 +81,6 @@ struct WalkArgs {
     const uint32_t *sorted_rows;   // [n]
     const uint64_t *level;         // [segments + 1]; level[segments] = number of walkers; null = every row has every segment (w = j * n + k)
     uint64_t walkers;              // = level[segments] (host copy)
-    // ... or (round 4) walkers in the order of the RECORD their segment starts on: walker w fills the segment walker_list[w] = t, the
-    // (t - row_first[k])-th of row k, where row_first = exclusive scan of the rows' segment counts.  Sequence samples lie where
-    // sequences pass checkpoint records, so the walkers that start on one record are the ones that travel together -- whatever row
-    // they belong to: the waves of a batch of ragged walks over hundreds of graph components are uniform again (launch_walker_list).
-    const uint32_t *walker_list;   // [walkers], or null
-    const uint64_t *row_first;     // [n + 1]
     uint64_t capacity;         // > 0: the rows hold this many nodes and out_offsets[n] may say that more are needed: then nobody walks (gbwt_hip_extract_part_device launches again)
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
 };
@@ -160,12 +155,6 @@ bool launch_row_offsets(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n
 void launch_part_lengths(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_lengths, uint32_t *d_max_len, hipStream_t stream);
 void launch_walker_order(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint32_t segments, uint32_t *d_keys, uint32_t *d_rows,
                          uint64_t *d_level_counts, uint64_t *d_level, void *d_temp, size_t temp_bytes, const uint32_t **d_sorted_rows, hipStream_t stream);
-// the record-ordered walker list: counts[k] = segments of row k (launch_scan turns them into row_first); then keys = start record of every
-// (row, segment), values = its number t, sorted by key.  d_keys / d_vals: 2 x walkers scratch each (double buffers of the sort).
-void launch_walker_counts(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_counts, hipStream_t stream);
-size_t walker_list_temp_bytes(uint64_t walkers);
-void launch_walker_list(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, const uint64_t *d_row_first, uint64_t walkers, uint32_t *d_keys, uint32_t *d_vals,
-                        void *d_temp, size_t temp_bytes, const uint32_t **d_sorted, hipStream_t stream);
 void launch_compact(const WalkArgs &args, const uint64_t *d_offsets, uint32_t *d_nodes, hipStream_t stream);
 
 // per-path sum of node ids over CSR rows (checking hook)

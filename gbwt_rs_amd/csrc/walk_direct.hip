@@ -30,7 +30,6 @@ struct RowTarget {
     uint64_t len = 0;            // nodes in the row
     bool backward = false;       // this walker comes from the other end: node k goes to row[len - 1 - k], flipped
     uint32_t share = 0;          // nodes this walker has to deliver
-    uint32_t skip = 0;           // line-aligned segments: the first `skip` of them lie in front of this walker's first piece boundary and are written by the walker before
 };
 
 __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
@@ -51,8 +50,9 @@ __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
 // do, and a batch with one long row and many short ones has as many walkers as it has segments, not rows x longest.
 struct WalkerStart { uint32_t rec = 0, offset = 0, bb = BLOCK_NONE, first_node = 0; };
 
-// PROBE (here and in k_walk_direct): the instantiation that still looks at the measurement switches and at the frames that were measured and
-// are not the default (WalkArgs::debug, align_segments, walker_list); the product instantiation has none of them compiled in.
+// PROBE (here and in k_walk_direct): the instantiation that still looks at the measurement switches (WalkArgs::debug); the product
+// instantiation has none of them compiled in.  (Two frames that round 4 measured and did not keep -- segment boundaries aligned to the lines
+// of the row's memory, walkers ordered by their start record -- lived here as knobs until round 6: NOTEBOOK.md, round 4.)
 template <bool PROBE>
 __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, const WalkArgs &a, uint64_t w, RowTarget &t) {
     WalkerStart s;
@@ -63,16 +63,7 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
         if (a.level[mid] <= w) lo = mid; else hi = mid;
     }
     uint64_t j = lo, k = 0;
-    if (PROBE && a.walker_list != nullptr) {                       // walkers in the order of their start records: t-th (row, segment) pair
-        const uint64_t t = a.walker_list[w];
-        uint64_t first = 0, last = a.n;                            // row_first[first] <= t < row_first[last]
-        while (last - first > 1) {
-            const uint64_t mid = (first + last) / 2;
-            if (a.row_first[mid] <= t) first = mid; else last = mid;
-        }
-        k = first; j = t - a.row_first[first];
-    }
-    else if (a.level == nullptr) { j = w / a.n; k = w % a.n; }      // every row has every segment: w = j * n + k
+    if (a.level == nullptr) { j = w / a.n; k = w % a.n; }           // every row has every segment: w = j * n + k
     else k = a.sorted_rows[w - a.level[lo]];
     const uint64_t id = a.seq_ids[k];
     if (id >= ix.n_sequences) return s;                      // GBWT::sequence: no such sequence -> an empty row
@@ -89,20 +80,6 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     const uint64_t to = j + 1 < count ? ix.samples[base + (j + 1) * stride].w : len;
     t.row = a.out_nodes + a.out_offsets[k] + (from - (parted ? segment_position(ix, rs, id, rs.lo) : 0u));
     t.len = to > from ? to - from : 0;
-    // LINE-ALIGNED SEGMENTS (round 4).  Samples lie where sequences pass checkpoint records, rows start wherever the rows before them
-    // end: a segment begins and ends anywhere in a 128-byte line of the row's memory, and both ends used to go out as partial lines --
-    // single stores, five times as expensive per byte as whole lines under `nt` (NOTEBOOK.md, r02 #4), two of the nine lines of a
-    // 256-node segment.  Now the boundary between two walkers of a row is the first piece boundary AT OR BEHIND the sample: a walker
-    // walks on past the next sample to the end of that line (any lane may take any LF step: the nodes are the same), and the walker
-    // that starts there stages the nodes in front of the boundary like all others but does not write them (`skip`).  Up to
-    // piece - 1 more LF steps per segment; only the two ends of a ROW are partial lines.
-    if (PROBE && a.align_segments && t.len != 0) {
-        const uint32_t piece = a.row_piece ? a.row_piece : RING_FLUSH;
-        const uint64_t phase_from = (reinterpret_cast<uintptr_t>(t.row) >> 2) & (piece - 1), phase_to = (reinterpret_cast<uintptr_t>(t.row + t.len) >> 2) & (piece - 1);
-        if (j > 0 && phase_from != 0) t.skip = static_cast<uint32_t>(piece - phase_from);
-        if (j + 1 < count && phase_to != 0) t.len = min(t.len + (piece - phase_to), len - from);       // never past the end of the row
-        if (t.skip >= t.len) { t.len = 0; t.skip = 0; }             // a segment inside one line: the walker before writes all of it
-    }
     if (PROBE && (a.debug & 2u)) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
     if (PROBE && (a.debug & 128u)) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
     t.backward = false;
@@ -152,7 +129,7 @@ struct RowWriter {
     bool dry = false;            // measurement switch (GBWT_HIP_DEBUG_DRY_ROWS): read the ring, store nothing
     __device__ __forceinline__ uint32_t slot(uint32_t k) const { return stage[(k & mask) * RING_PITCH]; }
     __device__ __forceinline__ void put(uint32_t k) {
-        if (k >= t.len || k < t.skip || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row (or in front of this walker's part of it)
+        if (k >= t.len || dry) return;   // k >= len cannot happen in a consistent index; never write outside the row
         if (t.backward) t.row[t.len - 1 - k] = slot(k) ^ 1u; else t.row[k] = slot(k);
     }
     __device__ __forceinline__ void chunk() {   // 16 nodes = 64 bytes
@@ -192,10 +169,6 @@ struct RowWriter {
     // piece is one aligned cache-line half (unaligned pieces would go out as sixteen 4-byte stores each and reach HBM as
     // partial lines: 22.7 GB written for 13.3 GB of node ids before this).
     __device__ __forceinline__ void drain(uint32_t staged) {
-        if (drained < t.skip) {                                   // (line-aligned segments: t.skip = the nodes up to the first 64-byte boundary)
-            if (staged < t.skip) return;
-            drained = t.skip;
-        }
         if (!t.backward) {
             const uint32_t mis = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(t.row + drained) >> 2) & (RING_FLUSH - 1));
             if (mis != 0) {
@@ -237,13 +210,12 @@ __device__ __forceinline__ void coop_visit(const CoopRows &c, uint32_t r, uint32
     constexpr uint32_t PIECE = 4 * LPR;
     const uint32_t staged = lds_word(c.mail + 16 * r + 12);
     const u32x4_t st = lds_peek4((const lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r));   // waits for both
-    const uint32_t drained = st.w, len = st.z & 0x7FFFFFFFu;
+    const uint32_t drained = st.w, len = st.z;
     const uint32_t pend = staged - drained;
     const uint32_t mis = ((st.x >> 2) + drained) & (PIECE - 1);      // nodes past the last piece boundary of the row's memory
     uint32_t n = PIECE - mis;                                        // nodes up to the next boundary
     if (pend < n) { if (!done || pend == 0) return; n = pend; }      // short pieces only once the walk is over
     volatile lds_u32_t *const publish = (volatile lds_u32_t *)static_cast<uintptr_t>(c.state + 16 * r + 12);   // only after the nodes have left the ring
-    if (drained == 0 && (st.z & 0x80000000u)) { if (p == 0) *publish = n; return; }   // line-aligned segments: the nodes in front of the first boundary are the previous walker's
     if (c.skip_reads) { if (p == 0) *publish = drained + n; return; }   // measurement switch: the ring is emptied unread
     // a pointer rebuilt from integers is a generic one: say that it is global memory, or the stores become flat_store
     // (which also count in lgkmcnt, so that every LDS wait of the helper would wait for its row writes as well)
@@ -322,7 +294,7 @@ __device__ __forceinline__ uint64_t coop_drain(const CoopRows &c, uint32_t lane,
             const uint32_t drained = st.w, waiting = staged - drained;
             const uint32_t off = ((st.x >> 2) + drained) & (PIECE - 1);
             const bool ready = waiting >= PIECE - off;
-            const bool fast = ready && off == 0 && drained + PIECE <= (st.z & 0x7FFFFFFFu);
+            const bool fast = ready && off == 0 && drained + PIECE <= st.z;
             if (fast) {
                 const uint32_t col = c.ring + 4 * rows[g], k = drained + 4 * p;
                 u32x4_t out;
@@ -361,10 +333,10 @@ __device__ __forceinline__ void touch_line(const void *p, uint32_t lds_dummy) {
 // VGPRs = four waves per SIMD = eight workgroups per CU, which is also what the LDS allows (64 ring slots x 65 lanes x 4 bytes + 2.5
 // KB per workgroup).  -DGBWT_HIP_WALK_WAVES=5 fits the kernel into 96 VGPRs (3 spilled outside the loops); it changes nothing while
 // the rings are this size, and smaller rings cannot hold a 128-byte row piece (profiles/r02_walk_bounds.txt #17).
+template <bool PROBE>
 #ifdef GBWT_HIP_WALK_WAVES
 __attribute__((amdgpu_waves_per_eu(GBWT_HIP_WALK_WAVES, GBWT_HIP_WALK_WAVES)))
 #endif
-template <bool PROBE>
 __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkArgs a) {
     const uint32_t debug = PROBE ? a.debug : 0u;             // measurement switches: none in the product instantiation
     // rows sized AFTER the launch (WalkArgs::capacity): the request did not wait for the total of its row lengths; where the rows it was
@@ -429,7 +401,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             const uint64_t at = reinterpret_cast<uintptr_t>(target.row);
             lds_poke(lds_ptr(&row_state[lane].x), static_cast<uint32_t>(at));
             lds_poke(lds_ptr(&row_state[lane].y), static_cast<uint32_t>(at >> 32));
-            lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0x7FFFFFF0u)) | (target.skip ? 0x80000000u : 0u));
+            lds_poke(lds_ptr(&row_state[lane].z), static_cast<uint32_t>(std::min<uint64_t>(target.len, 0x7FFFFFF0u)));
             // order = the rows sorted by (address phase within a piece, row): rank by counting, once per workgroup
             // (by ballots over the 16 / 32 possible phases: the loop over the 64 rows' LDS entries this replaces was a quarter of what a
             // workgroup spends outside its walk -- short segments, i.e. small batches and the per-rank shards of a multi-GPU run, pay that
@@ -455,7 +427,27 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             const uint32_t done = lds_peek(done_flag);               // read before the counts: the final count is then complete
             const u32x4_t mail = lds_peek4(served_mail);
             const uint32_t look_rec = mail.x, look_base = mail.y, look_count = mail.z, stamp = mail.w;
-            if (lane < a.helper_lanes && look_rec != 0 && stamp != seen) {
+            // MIXED WAVES ON RECORDS THAT FEW ROWS PASS (WalkArgs::gather_reach, round 6).  The helper looks at a lane's mailbox once per
+            // four or five iterations of its walker, so a touch of the target alone covers a quarter of the records the lane will visit --
+            // enough where seventy other waves pass the same records, nothing where one or two do (config 4: ~50 positions per record).
+            // There ONE lane per distinct target (neighbouring lanes hold rows of the same graph component: a touch per lane was 64 address
+            // passes for two lines) touches the descriptor lines of the target and of the records BEHIND it (ids along a walk are close
+            // to consecutive in a graph whose ids are sorted topologically, as vg's are) and the block lines behind its first block:
+            // what the walkers need until the helper looks again.
+            const uint32_t before = static_cast<uint32_t>(__shfl_up(static_cast<int>(look_rec), 1));
+            const bool mixed_targets = a.gather_reach != 0 && __ballot(look_rec != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(look_rec)))) != 0;
+            if (mixed_targets) {
+                if (look_rec != 0 && stamp != seen && (lane == 0 || look_rec != before)) {
+                    const uint4 *const blocks = (look_count & 0x80000000u) ? ix.cblocks : ix.gblocks;
+                    for (uint32_t r = 0; r < a.gather_reach; r++) {
+                        const uint64_t next = min(static_cast<uint64_t>(look_rec) + r, ix.n_records - 1);
+                        touch_line(ix.desc2 + 8 * next, dummy);
+                        touch_line(ix.desc2 + 8 * next + 4, dummy);
+                        if ((r & 1u) == 0 && (look_count & 0x7FFFFFFFu) != 0)
+                            touch_line(blocks + min(2 * static_cast<uint64_t>(look_base) + 2 * r, 2 * ix.n_blocks - 1), dummy);   // (64-byte lines: two blocks of 64 offsets each)
+                    }
+                }
+            } else if (lane < a.helper_lanes && look_rec != 0 && stamp != seen) {
                 const uint4 *d = ix.desc2 + 8 * static_cast<uint64_t>(look_rec);
                 touch_line(d, dummy);
                 touch_line(d + 4, dummy);
@@ -646,7 +638,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint32_t patience = (a.catch_up && a.uniform_loop) ? 8u * catch_pause : 0x7FFFFFFFu;
         if (mixed && patience != 0 && catch_pause != 0) catch_pause = 1;      // (the stay replaces the pause: one more outer round, then a new attempt)
         if (mixed) slow_exit = full_blocks ? walk2_gather_loop_full(ix.desc2, ix.cblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), patience)
-                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), patience);
+                                           : walk2_gather_loop(ix.desc2, ix.gblocks, ix.alphabet_offset, ring_base, mail_slot, drained, narrow, quota, ring_mask, RING_PITCH, rec, offset, bb, sink.wr, headroom, static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&row_state[lane].w)), patience, a.gather_reach);
 #ifdef GBWT_HIP_PROBE_LOOP_SHARE
         probe_vector += sink.wr - wr1;
 #endif
@@ -840,52 +832,6 @@ __global__ void __launch_bounds__(256) k_level_counts(const uint32_t *sorted_key
     counts[j] = lo;
 }
 
-// counts[k] = segments of row k = samples of its sequence
-__global__ void __launch_bounds__(256) k_walker_counts(DeviceIndex ix, const uint64_t *ids, uint64_t n, uint64_t *counts) {
-    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (k >= n) return;
-    const uint64_t id = ids[k];
-    uint64_t segments = 0;
-    if (id < ix.n_sequences) { const RowSegments rs = row_segments(ix, id); segments = rs.hi - rs.lo; }
-    counts[k] = segments;
-}
-
-// keys[t] = the record the t-th (row, segment) pair starts on, vals[t] = t
-__global__ void __launch_bounds__(256) k_walker_keys(DeviceIndex ix, const uint64_t *ids, uint64_t n, const uint64_t *row_first,
-                                                      uint64_t walkers, uint32_t *keys, uint32_t *vals) {
-    const uint64_t t = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
-    if (t >= walkers) return;
-    uint64_t first = 0, last = n;
-    while (last - first > 1) {
-        const uint64_t mid = (first + last) / 2;
-        if (row_first[mid] <= t) first = mid; else last = mid;
-    }
-    const RowSegments rs = row_segments(ix, ids[first]);          // (rows of ids >= n_sequences have no walkers)
-    keys[t] = ix.samples[rs.base + (rs.lo + t - row_first[first]) * rs.stride].x;
-    vals[t] = static_cast<uint32_t>(t);
-}
-
-void launch_walker_counts(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, uint64_t *d_counts, hipStream_t stream) {
-    hipLaunchKernelGGL(k_walker_counts, dim3(grid_for(n, 256)), dim3(256), 0, stream, ix, d_ids, n, d_counts);
-}
-
-size_t walker_list_temp_bytes(uint64_t walkers) {
-    size_t bytes = 0;
-    hipcub::DoubleBuffer<uint32_t> keys(nullptr, nullptr), vals(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, vals, static_cast<int>(walkers));
-    return bytes;
-}
-
-void launch_walker_list(const DeviceIndex &ix, const uint64_t *d_ids, uint64_t n, const uint64_t *d_row_first, uint64_t walkers, uint32_t *d_keys, uint32_t *d_vals,
-                        void *d_temp, size_t temp_bytes, const uint32_t **d_sorted, hipStream_t stream) {
-    hipLaunchKernelGGL(k_walker_keys, dim3(grid_for(walkers, 256)), dim3(256), 0, stream, ix, d_ids, n, d_row_first, walkers, d_keys, d_vals);
-    int bits = 1;
-    while (bits < 32 && (ix.n_records >> bits) != 0) bits++;       // record indices have this many bits
-    hipcub::DoubleBuffer<uint32_t> keys(d_keys, d_keys + walkers), vals(d_vals, d_vals + walkers);
-    (void)hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, keys, vals, static_cast<int>(walkers), 0, bits, stream);   // stable: walkers on one record stay in (row, segment) order
-    *d_sorted = vals.Current();
-}
-
 size_t walker_order_temp_bytes(uint64_t n) {
     size_t bytes = 0;
     hipcub::DoubleBuffer<uint32_t> keys(nullptr, nullptr), rows(nullptr, nullptr);
@@ -910,8 +856,8 @@ void launch_walk_direct(const DeviceIndex &ix, const WalkArgs &args, hipStream_t
     unsigned groups = grid_for(walkers, p);
     if (args.xcd_map) groups = (groups + 7u) / 8u * 8u;   // whole eighths; the workgroups past the end own nothing
     if (args.debug & 16384u) groups = grid_for(walkers, p) * 2u + 8u;
-    // the product kernel, or -- for a workspace whose knobs ask for a measurement switch or one of the frames that are not the default -- the probe one
-    const bool probe = args.debug != 0 || args.align_segments != 0 || args.walker_list != nullptr;
+    // the product kernel, or -- for a workspace whose knobs ask for a measurement switch (GBWT_HIP_DEBUG_DRY_ROWS) -- the probe one
+    const bool probe = args.debug != 0;
     if (probe) hipLaunchKernelGGL(k_walk_direct<true>, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
     else hipLaunchKernelGGL(k_walk_direct<false>, dim3(groups), dim3(2 * WAVE), args.ring_slots * RING_PITCH * sizeof(uint32_t), stream, ix, args);
 }

@@ -1237,13 +1237,11 @@ SEGMENT_ENVS = [{},                                                             
                 {"GBWT_HIP_SAMPLE_INTERVAL": "200", "GBWT_HIP_CATCH_UP": "2"},     # the single steps on the two-step descriptors + packed half-blocks (what a lean handle has, round 5)
                 {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_CHAINS": "0"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_GATHER_LIMIT": "64"},   # ... with records too long for the packed counts in the way
-                {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_ALIGN_SEGMENTS": "1"},  # line-aligned segments (round 4): walkers hand over at line boundaries of the row's memory; segments shorter than a line
-                {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "0"},   # ... with the lane-per-row writer (64-byte boundaries)
-                {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16", "GBWT_HIP_WALKER_ORDER": "1"},   # ... and walkers in the order of their start records
-                {"GBWT_HIP_SAMPLE_INTERVAL": "2048", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
-                {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_SAMPLE_STRIDE": "2"},   # strided walkers (round 4): a walker per 2 / 3 / 5 samples of a row, in every walker order
-                {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3", "GBWT_HIP_WALKER_ORDER": "1"},
-                {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_SAMPLE_STRIDE": "5", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "100", "GBWT_HIP_ROW_PIECE": "0"},    # the lane-per-row writer (no cooperative row pieces)
+                {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_ROW_PIECE": "16"},    # 64-byte row pieces
+                {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_SAMPLE_STRIDE": "2"},   # strided walkers (round 4): a walker per 2 / 3 / 5 samples of a row
+                {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3"},
+                {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_SAMPLE_STRIDE": "5"},
                 {"GBWT_HIP_SAMPLE_INTERVAL": "64", "GBWT_HIP_SAMPLE_STRIDE": "1000"},   # ... more than any row has: one walker per row
                 {"GBWT_HIP_SEGMENTS": "0"}]                                      # samples present but unused: one walker per end
 
@@ -1293,8 +1291,7 @@ def test_segmented_extraction(monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "50", "GBWT_HIP_XCD_MAP": "0"},
-                                 {"GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1", "GBWT_HIP_ALIGN_SEGMENTS": "1"},
-                                 {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_SAMPLE_STRIDE": "3"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "2", "GBWT_HIP_WALKER_ORDER": "1"}],
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_SAMPLE_STRIDE": "3"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "2", "GBWT_HIP_ROW_PIECE": "16"}],
                          ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
 def test_walker_order_with_ragged_rows(monkeypatch, env):
     """A few long haplotypes and thousands of short walks (a fragmented assembly): the walkers of a segmented extraction
@@ -1324,7 +1321,7 @@ def test_walker_order_with_ragged_rows(monkeypatch, env):
 
 
 PART_ENVS = [{}, {"GBWT_HIP_SAMPLE_INTERVAL": "8"}, {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3"},
-             {"GBWT_HIP_SAMPLE_INTERVAL": "8", "GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_ALIGN_SEGMENTS": "1", "GBWT_HIP_ROW_PIECE": "16"},
+             {"GBWT_HIP_SAMPLE_INTERVAL": "24", "GBWT_HIP_ROW_PIECE": "16"},
              {"GBWT_HIP_SAMPLE_INTERVAL": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "32", "GBWT_HIP_DEFER_TOTAL": "0"},
              # the pool-output fallbacks cannot cut rows: the whole row is the LAST part, every earlier part is empty (never the row from every part)
              {"GBWT_HIP_DIRECT": "0"}, {"GBWT_HIP_WALK_MODE": "1"}, {"GBWT_HIP_SEQ_LEN": "0"}]

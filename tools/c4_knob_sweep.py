@@ -13,9 +13,9 @@ generic = np.load(path + ".generic.npy")
 walks = np.setdiff1d(np.arange(g.paths, dtype=np.uint64), generic)
 ids = 2 * walks
 gbz = G.GBZ.load(path, flags=G.OPEN_EXTRACT)
-knobs = ["GBWT_HIP_UNIFORM_LOOP", "GBWT_HIP_CATCH_UP", "GBWT_HIP_HELPER_NAPS", "GBWT_HIP_WALKER_ORDER", "GBWT_HIP_RING_SLOTS", "GBWT_HIP_XCD_MAP", "GBWT_HIP_ALL4", "GBWT_HIP_VMM"]
+knobs = ["GBWT_HIP_UNIFORM_LOOP", "GBWT_HIP_CATCH_UP", "GBWT_HIP_HELPER_NAPS", "GBWT_HIP_RING_SLOTS", "GBWT_HIP_XCD_MAP", "GBWT_HIP_ALL4", "GBWT_HIP_VMM"]
 settings = [{}, {"GBWT_HIP_UNIFORM_LOOP": "0"}, {"GBWT_HIP_CATCH_UP": "0"}, {"GBWT_HIP_UNIFORM_LOOP": "0", "GBWT_HIP_CATCH_UP": "0"}, {"GBWT_HIP_HELPER_NAPS": "2"}, {"GBWT_HIP_HELPER_NAPS": "8"},
-            {"GBWT_HIP_WALKER_ORDER": "1"}, {"GBWT_HIP_WALKER_ORDER": "1", "GBWT_HIP_UNIFORM_LOOP": "0"}, {"GBWT_HIP_XCD_MAP": "0"}, {"GBWT_HIP_RING_SLOTS": "128"}, {"GBWT_HIP_VMM": "0"}, {}]
+            {"GBWT_HIP_XCD_MAP": "0"}, {"GBWT_HIP_RING_SLOTS": "128"}, {"GBWT_HIP_VMM": "0"}, {}]
 for env in settings:
     for k in knobs:
         os.environ.pop(k, None)
