@@ -205,6 +205,42 @@ void upload_starts(gbwt_hip_index &ix) {
     ix.starts_uploaded = true;
 }
 
+// The record starts decoded on the device from the Elias-Fano words in the mapped file (HostIndex::starts_view; kernels.hpp: launch_ef_*).
+// Round 5 decoded them on the host, narrowed them to u32 and sent them: 0.35 s of config 4's open for its 218 M starts (0.19 s of decode on up
+// to 32 threads in front of it), 2.5 ms of the headline's -- all of it in front of the first device pass.  The words are a sixth of the table
+// (137 of 872 MB for config 4) and the decode is three launches; the host's own decode (for the GFA tables and the graph lines) runs in the
+// loader's background thread meanwhile and reports what is wrong with the words as it always did (HostIndex::finish).
+void decode_starts_on_device(gbwt_hip_index &ix) {
+    const HostIndex::StartsView v = ix.host.starts_view;
+    const uint64_t data_len = ix.stats.data_bytes, ones = v.ones;
+    const bool narrow = data_len < (uint64_t(1) << 32);
+    ix.starts.reserve((ones + 1) * (narrow ? sizeof(uint32_t) : sizeof(uint64_t)));
+    DeviceBuffer words, ranks, scan_tmp, flags;
+    words.reserve(std::max<uint64_t>(v.high_words + v.low_words, 1) * sizeof(uint64_t));
+    ranks.reserve(2 * (v.high_words + 1) * sizeof(uint64_t));
+    const size_t tb = scan_temp_bytes(std::max<uint64_t>(v.high_words, 1));
+    scan_tmp.reserve(std::max<size_t>(tb, 16));
+    flags.reserve(sizeof(uint32_t));
+    HIP_CHECK(hipMemsetAsync(flags.ptr, 0, sizeof(uint32_t), nullptr));
+    uint64_t *d_high = words.as<uint64_t>(), *d_low = d_high + v.high_words, *d_counts = ranks.as<uint64_t>(), *d_rank = d_counts + (v.high_words + 1);
+    if (v.high_words) HIP_CHECK(hipMemcpy(d_high, v.high, v.high_words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (v.low_words) HIP_CHECK(hipMemcpy(d_low, v.low, v.low_words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    launch_ef_counts(d_high, v.high_words, d_counts, nullptr);
+    if (v.high_words) launch_scan(d_counts, d_rank, v.high_words, scan_tmp.ptr, tb, nullptr);
+    else HIP_CHECK(hipMemsetAsync(d_rank, 0, sizeof(uint64_t), nullptr));
+    launch_ef_values(d_high, v.high_words, d_rank, d_low, v.low_words, static_cast<uint32_t>(v.low_width), ones, data_len,
+                     narrow ? ix.starts.as<uint32_t>() : nullptr, narrow ? nullptr : ix.starts.as<uint64_t>(), nullptr);
+    launch_starts_check(narrow ? ix.starts.as<uint32_t>() : nullptr, narrow ? nullptr : ix.starts.as<uint64_t>(), ones, flags.as<uint32_t>(), nullptr);
+    uint64_t total = 0;
+    uint32_t bad = 0;
+    HIP_CHECK(hipMemcpy(&total, d_rank + v.high_words, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&bad, flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipGetLastError());
+    if (total != ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
+    if (bad != 0) throw InvalidData("BWT: record starts are not sorted offsets into the data");
+    ix.starts_uploaded = true;
+}
+
 // Uploads the host image and runs the load-time device passes.  `endmarker`: record 0 already decompressed by the caller (who is then free
 // to let another thread finish the loader's background work meanwhile: nothing below touches the record bytes of the host image), or null.
 void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>> *early_endmarker) {
@@ -212,8 +248,8 @@ void upload(gbwt_hip_index &ix, const std::vector<std::pair<uint32_t, uint32_t>>
     HostIndex &h = ix.host;
     if (h.alphabet_size > (uint64_t(1) << 32)) throw Unsupported("alphabet_size > 2^32 is not supported (u32 node ids on device)");
     HIP_CHECK(hipSetDevice(ix.device));
-    const uint64_t n_records = h.records();
-    const uint64_t data_bytes = ix.stats.data_bytes;       // (fill_stats; the host image's own copy may still be on its way: HostIndex::pending)
+    const uint64_t n_records = ix.stats.records;           // (fill_stats; the host image's own starts and record bytes may still be on their way: HostIndex::pending)
+    const uint64_t data_bytes = ix.stats.data_bytes;
     if (!ix.record_bytes_uploaded) {
         ix.data.reserve(data_bytes + DATA_PAD);
         HIP_CHECK(hipMemset(ix.data.ptr, 0, data_bytes + DATA_PAD));
@@ -786,6 +822,7 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
         raw->data.reserve(bytes + DATA_PAD);
         HIP_CHECK(hipMemset(raw->data.ptr, 0, bytes + DATA_PAD));
         raw->record_bytes_uploaded = true;
+        h.starts_on_device = true;                            // ... and the record starts are decoded there, from the words of the file (decode_starts_on_device)
         const uint8_t *src = h.record_bytes();
         void *dst = raw->data.ptr;
         const int dev = raw->device;
@@ -822,8 +859,8 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
         // the starts are decoded by now and the copy of the record bytes has a few milliseconds to go: the starts go out under them
         fill_stats(*ix);
         OpenTrace trace;
-        try { upload_starts(*ix); } catch (...) { early.worker.join(); throw; }
-        trace.mark("(record starts narrowed + sent)");
+        try { if (ix->host.starts_on_device) decode_starts_on_device(*ix); else upload_starts(*ix); } catch (...) { early.worker.join(); throw; }
+        trace.mark("(record starts on the device)");
         early.worker.join();
         trace.mark("(waited for the record bytes)");
     }

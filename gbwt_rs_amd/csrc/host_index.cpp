@@ -101,6 +101,7 @@ void skip_option(Elements &in) {
 // the copy of the record bytes and the unpacking of a million labels were three quarters of the 36 ms the headline GBZ took to parse.
 struct Deferred {
     std::vector<std::function<void()>> tasks, background;      // background: may still be running when the loader returns (HostIndex::pending)
+    std::function<void()> starts_task;                         // the decode of the record starts: foreground, or background when the caller decodes them on the device
     bool small = false;                                        // a file of a few megabytes: threads would cost more than they save
     void run() {
         if (tasks.empty()) return;
@@ -391,13 +392,14 @@ void read_gbwt(Elements &in, HostIndex &h, Deferred &later) {
     if (index.universe != data_len) throw InvalidData("BWT: Index / data length mismatch");
     h.file_data = data; h.file_data_len = data_len;
     later.background.push_back([&h, data, data_len]() { h.data.assign(data, data + data_len); });
-    later.tasks.push_back([&h, index, data_len]() {
+    h.starts_view = HostIndex::StartsView{index.ones, index.universe, index.high.n_words, index.low.width, index.low.n_words, index.high.words, index.low.words};
+    later.starts_task = [&h, index, data_len]() {
         h.starts = decode_sparse(index);
         for (size_t i = 0; i < h.starts.size(); i++)
             if (h.starts[i] > data_len || (i > 0 && h.starts[i] < h.starts[i - 1]))
                 throw InvalidData("BWT: record starts are not sorted offsets into the data");
         h.starts.push_back(data_len);
-    });
+    };
 
     uint64_t da_len = in.word();  // document array samples: opaque pass-through in the reference (417)
     const uint64_t *da = in.words(da_len);
@@ -512,6 +514,7 @@ void HostIndex::finish() {
     pending.reset();
     if (p->worker.joinable()) p->worker.join();
     file_data = nullptr; file_data_len = 0;
+    starts_on_device = false; starts_view = StartsView{};         // `starts` is there (or the decode has thrown, below): the mapping goes
     if (p->failure) std::rethrow_exception(p->failure);
     if (is_gbz) check_graph(*this);
 }
@@ -566,11 +569,17 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
         h.pending = pending;
         on_located(h);
     }
+    // the record starts: decoded here, or -- when the caller has taken the located index to the device -- behind the caller's back
+    if (later.starts_task) {
+        if (h.starts_on_device && background && !later.small) later.background.push_back(std::move(later.starts_task));
+        else { h.starts_on_device = false; later.tasks.push_back(std::move(later.starts_task)); }
+    }
     later.run();
     trace.mark("foreground decodes");
     if (!background) {
         h.pending.reset();
         h.file_data = nullptr; h.file_data_len = 0;
+        h.starts_view = HostIndex::StartsView{};
         if (h.is_gbz) check_graph(h);
         return;
     }
@@ -591,10 +600,31 @@ HostIndex load_index_file(const std::string &path) {
     return h;
 }
 
+uint64_t HostIndex::record_start(uint64_t k) const {
+    if (!starts_on_device) return k < starts.size() ? starts[k] : record_bytes_len();
+    const StartsView &v = starts_view;
+    if (k >= v.ones) return record_bytes_len();
+    uint64_t seen = 0;
+    for (uint64_t wi = 0; wi < v.high_words; wi++) {
+        uint64_t word = v.high[wi];
+        const uint64_t c = static_cast<uint64_t>(__builtin_popcountll(word));
+        if (seen + c <= k) { seen += c; continue; }
+        for (; seen < k; seen++) word &= word - 1;
+        const uint64_t pos = wi * 64 + static_cast<uint64_t>(__builtin_ctzll(word)), upper = pos - k, w = v.low_width;
+        const uint64_t bit = k * w, lw = bit >> 6, off = bit & 63;
+        uint64_t low = lw < v.low_words ? v.low[lw] >> off : 0;
+        if (off + w > 64 && lw + 1 < v.low_words) low |= v.low[lw + 1] << (64 - off);
+        if (w < 64) low &= (uint64_t(1) << w) - 1;
+        return std::min(record_bytes_len(), (w >= 64 ? 0 : upper << w) | low);
+    }
+    return record_bytes_len();
+}
+
 std::vector<std::pair<uint32_t, uint32_t>> decompress_endmarker(const HostIndex &h, uint64_t limit) {
     std::vector<std::pair<uint32_t, uint32_t>> out;
-    if (h.records() == 0 || h.starts[1] <= h.starts[0]) return out;
-    const uint8_t *p = h.record_bytes() + h.starts[0], *end = h.record_bytes() + h.starts[1];
+    const uint64_t first = h.record_start(0), second = h.record_start(1);
+    if (h.records() == 0 || second <= first) return out;
+    const uint8_t *p = h.record_bytes() + first, *end = h.record_bytes() + second;
     auto varint = [&](uint64_t &v) -> bool {                  // ByteCodeIter::next, src/support.rs:1151-1164
         v = 0;
         unsigned shift = 0;

@@ -56,7 +56,15 @@ struct HostIndex {
     // BWT, src/bwt.rs:97-100: data + record starts (n_records + 1 entries, last = data.size())
     std::vector<uint8_t> data;
     Words starts;
-    uint64_t records() const { return starts.empty() ? 0 : starts.size() - 1; }
+    // The Elias-Fano index of the record starts as it lies in the mapped file (SparseVector, Appendix A: value_k = ((pos_k - k) << w) | low[k]).
+    // An open that decodes the starts ON THE DEVICE (starts_on_device, set by its on_located callback) uploads these words and lets the host
+    // decode into `starts` -- which the GFA tables and the graph lines read, nothing the device passes need -- run in the background: until
+    // finish() has returned `starts` must not be touched; records() and record_start() answer from the located index.
+    struct StartsView { uint64_t ones = 0, universe = 0, high_words = 0, low_width = 1, low_words = 0; const uint64_t *high = nullptr, *low = nullptr; };
+    StartsView starts_view;
+    bool starts_on_device = false;
+    uint64_t records() const { return starts_on_device ? starts_view.ones : (starts.empty() ? 0 : starts.size() - 1); }
+    uint64_t record_start(uint64_t k) const;      // starts[k]; while the host decode is in the background: select(k) on the located index (k of a few: a scan from the front)
 
     // tags of the GBWT (key -> value, lower-cased keys), src/support.rs:915-1020
     std::vector<std::pair<std::string, std::string>> tags;

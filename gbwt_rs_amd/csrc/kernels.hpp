@@ -181,6 +181,16 @@ void launch_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, u
 void launch_bd_search(const DeviceIndex &ix, const uint64_t *queries, uint64_t n, uint64_t len, uint64_t first,
                       gbwt_hip_bd_state *out, uint8_t *valid, hipStream_t s);
 
+// The record starts decoded ON THE DEVICE from the Elias-Fano words of the file (round 6; SparseVector, SURVEY Appendix A: value_k =
+// ((pos_k - k) << w) | low[k], pos_k = k-th set bit of `high`): d_counts[i] = popcount(high[i]) (launch_scan turns them into the rank of
+// every word's first one), then every word writes the values of its ones -- clamped to data_len, at most `ones` of them -- narrowed to
+// u32 where d_starts32 is given; entry `ones` = data_len (the sentinel).  launch_starts_check: flags[0] |= 1 where two neighbours are out
+// of order (BWT::load's callers rely on sorted starts, src/bwt.rs:116-121).
+void launch_ef_counts(const uint64_t *d_high, uint64_t high_words, uint64_t *d_counts, hipStream_t s);
+void launch_ef_values(const uint64_t *d_high, uint64_t high_words, const uint64_t *d_rank, const uint64_t *d_low, uint64_t low_words, uint32_t width, uint64_t ones,
+                      uint64_t data_len, uint32_t *d_starts32, uint64_t *d_starts64, hipStream_t s);
+void launch_starts_check(const uint32_t *d_starts32, const uint64_t *d_starts64, uint64_t ones, uint32_t *d_flags, hipStream_t s);
+
 // inclusive scan of lengths[n] into offsets[1..n], offsets[0] = 0 (hipcub); temp storage managed by caller
 size_t scan_temp_bytes(uint64_t n);
 void launch_scan(const uint64_t *d_lengths, uint64_t *d_offsets, uint64_t n, void *d_temp, size_t temp_bytes, hipStream_t s);

@@ -761,6 +761,53 @@ void launch_finish_block_base(const uint32_t *d_counts, uint32_t *d_block_base, 
     if (n) hipLaunchKernelGGL(k_finish_block_base, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_counts, d_block_base, n, d_desc_raw);
 }
 
+// ---- the record starts from the Elias-Fano words of the file (kernels.hpp) ---------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ef_counts(const uint64_t *high, uint64_t n, uint64_t *counts) {
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i < n) counts[i] = static_cast<uint64_t>(__popcll(high[i]));
+}
+
+__global__ void __launch_bounds__(256) k_ef_values(const uint64_t *high, uint64_t n, const uint64_t *rank, const uint64_t *low, uint64_t low_words, uint32_t w, uint64_t ones,
+                                                    uint64_t data_len, uint32_t *out32, uint64_t *out64) {
+    const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (i == 0) { if (out32) out32[ones] = static_cast<uint32_t>(data_len); else out64[ones] = data_len; }   // the sentinel
+    if (i >= n) return;
+    uint64_t word = high[i], k = rank[i];
+    while (word != 0 && k < ones) {                                 // (a word count that disagrees with `ones` is the caller's to report: nothing is written past the table)
+        const uint64_t pos = i * 64 + static_cast<uint64_t>(__ffsll(static_cast<unsigned long long>(word)) - 1);
+        word &= word - 1;
+        const uint64_t upper = pos - k, bit = k * w, lw = bit >> 6, off = bit & 63;
+        uint64_t lo = lw < low_words ? low[lw] >> off : 0;
+        if (off + w > 64 && lw + 1 < low_words) lo |= low[lw + 1] << (64 - off);
+        if (w < 64) lo &= (uint64_t(1) << w) - 1;
+        uint64_t value = (w >= 64 ? 0 : upper << w) | lo;
+        if ((w < 64 && upper != 0 && (upper >> (64 - w)) != 0) || value > data_len) value = data_len;       // a value outside the data: the host's decode of the same words reports it (InvalidData)
+        if (out32) out32[k] = static_cast<uint32_t>(value); else out64[k] = value;
+        k++;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_starts_check(const uint32_t *s32, const uint64_t *s64, uint64_t ones, uint32_t *flags) {
+    const uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (k >= ones) return;
+    const uint64_t a = s32 ? s32[k] : s64[k], b = s32 ? s32[k + 1] : s64[k + 1];
+    if (a > b) atomicOr(flags, 1u);
+}
+
+void launch_ef_counts(const uint64_t *d_high, uint64_t high_words, uint64_t *d_counts, hipStream_t s) {
+    if (high_words) hipLaunchKernelGGL(k_ef_counts, dim3(grid_for(high_words, 256)), dim3(256), 0, s, d_high, high_words, d_counts);
+}
+
+void launch_ef_values(const uint64_t *d_high, uint64_t high_words, const uint64_t *d_rank, const uint64_t *d_low, uint64_t low_words, uint32_t width, uint64_t ones,
+                      uint64_t data_len, uint32_t *d_starts32, uint64_t *d_starts64, hipStream_t s) {
+    hipLaunchKernelGGL(k_ef_values, dim3(grid_for(std::max<uint64_t>(high_words, 1), 256)), dim3(256), 0, s, d_high, high_words, d_rank, d_low, low_words, width, ones, data_len,
+                       d_starts32, d_starts64);
+}
+
+void launch_starts_check(const uint32_t *d_starts32, const uint64_t *d_starts64, uint64_t ones, uint32_t *d_flags, hipStream_t s) {
+    if (ones) hipLaunchKernelGGL(k_starts_check, dim3(grid_for(ones, 256)), dim3(256), 0, s, d_starts32, d_starts64, ones, d_flags);
+}
+
 size_t scan_temp_bytes(uint64_t n) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, static_cast<const uint64_t *>(nullptr), static_cast<uint64_t *>(nullptr),
