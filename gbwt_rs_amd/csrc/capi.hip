@@ -591,8 +591,13 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
         std::thread tail([raw, &tail_failure]() {
             try {
                 HIP_CHECK(hipSetDevice(raw->device));
+                const bool trace_tail = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
+                const auto t0 = std::chrono::steady_clock::now();
                 raw->host.finish();
+                const auto t1 = std::chrono::steady_clock::now();
                 if (raw->caps & GBWT_HIP_OPEN_GFA) upload_label_lengths(*raw);
+                if (trace_tail) std::fprintf(stderr, "[open] (next to the device passes: the loader's background decodes %8.3f ms, GFA tables %8.3f ms)\n",
+                                             std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
             } catch (...) { tail_failure = std::current_exception(); }
         });
         try { upload(*ix, &endmarker); } catch (...) { tail.join(); throw; }

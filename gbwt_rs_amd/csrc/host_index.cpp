@@ -391,7 +391,16 @@ void read_gbwt(Elements &in, HostIndex &h, Deferred &later) {
     const uint8_t *data = reinterpret_cast<const uint8_t *>(in.words(data_len / 8 + (data_len % 8 != 0 ? 1 : 0)));
     if (index.universe != data_len) throw InvalidData("BWT: Index / data length mismatch");
     h.file_data = data; h.file_data_len = data_len;
-    later.background.push_back([&h, data, data_len]() { h.data.assign(data, data + data_len); });
+    // (the host's copy of the record bytes: 1.8 GB for config 4 at its stated size -- 0.9 s as ONE assign() that pages its target in on one thread,
+    // the longest thing in that open; in pieces on a few threads into a vector whose resize() does not touch it: profiles/r06_c4_open.txt)
+    later.background.push_back([&h, data, data_len]() {
+        h.data.resize(data_len);
+        const unsigned pieces = data_len >= (uint64_t(64) << 20) ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
+        run_pieces(pieces, [&](unsigned p) {
+            const uint64_t lo = data_len / pieces * p, hi = p + 1 == pieces ? data_len : data_len / pieces * (p + 1);
+            if (hi > lo) std::memcpy(h.data.data() + lo, data + lo, hi - lo);
+        });
+    });
     h.starts_view = HostIndex::StartsView{index.ones, index.universe, index.high.n_words, index.low.width, index.low.n_words, index.high.words, index.low.words};
     later.starts_task = [&h, index, data_len]() {
         h.starts = decode_sparse(index);
@@ -588,7 +597,12 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
     std::vector<std::function<void()>> jobs = std::move(later.background);
     if (!jobs.empty())
         raw->worker = std::thread([raw, jobs]() {
-            try { run_pieces(static_cast<unsigned>(jobs.size()), [&](unsigned p) { jobs[p](); }); }   // the record bytes and the labels side by side
+            const bool trace_jobs = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
+            try { run_pieces(static_cast<unsigned>(jobs.size()), [&](unsigned p) {        // the record bytes, the record starts and the labels side by side
+                const auto t0 = std::chrono::steady_clock::now();
+                jobs[p]();
+                if (trace_jobs) std::fprintf(stderr, "[load] (background job %u of %zu)     %8.3f ms\n", p, jobs.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }); }
             catch (...) { raw->failure = std::current_exception(); }
         });
     h.pending = std::move(pending);

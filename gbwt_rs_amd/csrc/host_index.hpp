@@ -54,7 +54,7 @@ struct HostIndex {
     uint64_t sequences = 0, size = 0, alphabet_offset = 0, alphabet_size = 0;
     bool bidirectional = false;
     // BWT, src/bwt.rs:97-100: data + record starts (n_records + 1 entries, last = data.size())
-    std::vector<uint8_t> data;
+    Bytes data;
     Words starts;
     // The Elias-Fano index of the record starts as it lies in the mapped file (SparseVector, Appendix A: value_k = ((pos_k - k) << w) | low[k]).
     // An open that decodes the starts ON THE DEVICE (starts_on_device, set by its on_located callback) uploads these words and lets the host

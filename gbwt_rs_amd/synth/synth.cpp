@@ -25,12 +25,12 @@ using gbwt_hip::PathName;
 namespace {
 
 // ---- codecs (encoder side) ------------------------------------------------------------------
-inline void put_varint(std::vector<uint8_t> &out, uint64_t v) {
+template <class Out> inline void put_varint(Out &out, uint64_t v) {
     while (v > 0x7F) { out.push_back(static_cast<uint8_t>((v & 0x7F) | 0x80)); v >>= 7; }
     out.push_back(static_cast<uint8_t>(v));
 }
 
-inline void put_run(std::vector<uint8_t> &out, uint64_t sigma, uint64_t value, uint64_t len) {
+template <class Out> inline void put_run(Out &out, uint64_t sigma, uint64_t value, uint64_t len) {
     if (sigma >= 255) { put_varint(out, value); put_varint(out, len - 1); return; }
     uint64_t threshold = 256 / sigma;
     if (len < threshold) out.push_back(static_cast<uint8_t>(value + sigma * (len - 1)));
@@ -38,10 +38,11 @@ inline void put_run(std::vector<uint8_t> &out, uint64_t sigma, uint64_t value, u
 }
 
 // Appends one record: edges (node ascending) + body given as successor ranks with run merging.
-struct RecordWriter {
-    std::vector<uint8_t> &out;
+template <class Out>
+struct RecordWriterT {
+    Out &out;
     uint64_t sigma = 0, run_value = 0, run_len = 0;
-    explicit RecordWriter(std::vector<uint8_t> &o) : out(o) {}
+    explicit RecordWriterT(Out &o) : out(o) {}
     void begin(const std::vector<std::pair<uint64_t, uint64_t>> &edges) {
         sigma = edges.size();
         put_varint(out, sigma);
@@ -56,6 +57,7 @@ struct RecordWriter {
     }
     void end() { if (run_len) put_run(out, sigma, run_value, run_len); run_len = 0; }
 };
+template <class Out> RecordWriterT<Out> make_record_writer(Out &o) { return RecordWriterT<Out>(o); }
 
 // ---- deterministic RNG (xoshiro256** seeded by splitmix64) -------------------------------------
 struct Rng {
@@ -217,7 +219,7 @@ void forward_sweep(const gbwt_synth &g, Pool &pool) {
     SiteStats st;
     std::vector<std::pair<uint64_t, uint64_t>> edges;
     std::vector<uint64_t> before(A);
-    RecordWriter rw(pool.bytes);
+    auto rw = make_record_writer(pool.bytes);
     auto unary = [&](uint64_t slot, uint64_t to, uint64_t offset, uint64_t visits) {   // every visit comes from the one predecessor and goes on to `to`
         pool.begin(slot);
         edges.clear();
@@ -269,7 +271,7 @@ void reverse_sweep(const gbwt_synth &g, Pool &pool) {
     for (uint64_t h = 0; h < n; h++) ord[h] = static_cast<uint32_t>(h);
     SiteStats st, prev;
     std::vector<std::pair<uint64_t, uint64_t>> edges;
-    RecordWriter rw(pool.bytes);
+    auto rw = make_record_writer(pool.bytes);
     auto unary = [&](uint64_t slot, uint64_t to, uint64_t offset, uint64_t visits) {
         pool.begin(slot);
         edges.clear();
@@ -340,7 +342,7 @@ void build_chain(gbwt_synth &g, uint64_t seed) {
     ix.starts.reserve(2 * S * W + 2);
     ix.starts.push_back(0);
     {
-        RecordWriter rw(ix.data);
+        auto rw = make_record_writer(ix.data);
         rw.begin(edges);
         for (uint64_t h = 0; h < n; h++) { rw.push(0); rw.push(1 + last.rank[g.allele(S - 1, h)]); }
         rw.end();
@@ -482,7 +484,7 @@ void build_from_paths(gbwt_synth &g, const uint64_t *offsets, const uint64_t *no
         return c;
     };
     ix.data.clear(); ix.starts.clear();
-    RecordWriter rw(ix.data);
+    auto rw = make_record_writer(ix.data);
     for (uint64_t r = 0; r < n_records; r++) {
         ix.starts.push_back(ix.data.size());
         std::vector<uint64_t> succ;
@@ -688,7 +690,7 @@ gbwt_synth *gbwt_synth_merge(const gbwt_synth *const *parts, uint64_t n_parts, c
     ix.data.clear();
     ix.starts.assign(1, 0);
     {
-        RecordWriter rw(ix.data);
+        auto rw = make_record_writer(ix.data);
         rw.begin(end_edges);
         for (auto &r : end_run_list) rw.push(r.first, r.second);
         rw.end();
