@@ -342,12 +342,22 @@ class GBWT:
         check(self._L.gbwt_hip_follow(self._h, self._ws, _ptr(st), st.size, int(backward), _ptr(offsets), _ptr(out), out.size, C.byref(total), _ptr(valid)))
         return offsets, out[:total.value], valid.astype(bool)
 
-    def search(self, queries):
-        """find(q[0]) + extend over q[1:] for every row of the (n, len) query matrix (src/bin/benchmark.rs:155-169)."""
+    @staticmethod
+    def _results(n, dtype, out):
+        """Result arrays of a host-pointer query call: fresh ones, or the caller's `out` = (states, valid uint8) of the right shape -- a caller
+        that asks again and again keeps its arrays: the device-to-host copy into pages that have been touched takes half the time of the copy
+        into fresh ones (profiles/r06_download_probe.txt)."""
+        if out is None:
+            return np.zeros(n, dtype=dtype), np.zeros(n, dtype=np.uint8)
+        states, valid = out
+        assert states.dtype == dtype and states.shape == (n,) and states.flags.c_contiguous and valid.dtype == np.uint8 and valid.shape == (n,) and valid.flags.c_contiguous
+        return states, valid
+
+    def search(self, queries, out=None):
+        """find(q[0]) + extend over q[1:] for every row of the (n, len) query matrix (src/bin/benchmark.rs:155-169).  `out`: see _results."""
         q = np.ascontiguousarray(queries, dtype=np.uint64)
         assert q.ndim == 2
-        out = np.zeros(q.shape[0], dtype=STATE_DTYPE)
-        valid = np.zeros(q.shape[0], dtype=np.uint8)
+        out, valid = self._results(q.shape[0], STATE_DTYPE, out)
         check(self._L.gbwt_hip_search(self._h, self._ws, _ptr(q), q.shape[0], q.shape[1], _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 
@@ -373,12 +383,11 @@ class GBWT:
         check(self._L.gbwt_hip_bd_search_device(self._h, self._ws, C.c_void_p(int(d_queries)), n, length, first, C.byref(out)))
         return out
 
-    def bd_search(self, queries, first):
-        """bd_find(q[first]) then alternating extend_forward / extend_backward over every row of the query matrix."""
+    def bd_search(self, queries, first, out=None):
+        """bd_find(q[first]) then alternating extend_forward / extend_backward over every row of the query matrix.  `out`: see _results."""
         q = np.ascontiguousarray(queries, dtype=np.uint64)
         assert q.ndim == 2
-        out = np.zeros(q.shape[0], dtype=BD_DTYPE)
-        valid = np.zeros(q.shape[0], dtype=np.uint8)
+        out, valid = self._results(q.shape[0], BD_DTYPE, out)
         check(self._L.gbwt_hip_bd_search(self._h, self._ws, _ptr(q), q.shape[0], q.shape[1], first, _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 

@@ -620,9 +620,8 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
     // on such a handle with GBWT_HIP_UNSUPPORTED (gbwt_hip_extract_part_device, ensure_cblocks).
     {
         gbwt_hip_index &x = *ix;
-        const char *keep = std::getenv("GBWT_HIP_KEEP_RAW");
         if (!(x.caps & GBWT_HIP_OPEN_SEARCH) && x.slow_records == 0 && x.dev.seq_len != nullptr && x.dev.samples != nullptr && x.max_samples > 0 &&
-            x.dev.tables == nullptr && (x.dev.cblocks != nullptr || x.packed_blocks) && !(keep && std::atoi(keep) != 0)) {
+            x.dev.tables == nullptr && (x.dev.cblocks != nullptr || x.packed_blocks)) {
             HIP_CHECK(hipDeviceSynchronize());
             x.desc_raw.release();
             x.dev.desc_raw = nullptr;
@@ -630,8 +629,7 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
             // ... and with them the one-step walk descriptors and the plain rank blocks (64 B per record + 16 B per 64 positions): all that read
             // them after the open were the catch-up steps of k_walk_direct, which on such a handle step on the two-step descriptors and the
             // packed half-blocks instead (WalkArgs::catch_up == 2), and the walk modes that are refused here anyway
-            const char *keep_steps = std::getenv("GBWT_HIP_KEEP_ONE_STEP");
-            if (x.packed_blocks && x.dev.gblocks != nullptr && !(keep_steps && std::atoi(keep_steps) != 0)) {
+            if (x.packed_blocks && x.dev.gblocks != nullptr) {
                 x.desc.release(); x.blocks.release();
                 x.dev.desc = nullptr; x.dev.blocks = nullptr;
             }
@@ -648,13 +646,11 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
 
 // Staging helper for the one-lane-per-query entry points.  A query is a ROW: a_row bytes of `in_a` (+ b_row bytes of `in_b`) in,
 // out_row bytes of `out` + one byte of `valid` out; launch(d_a, d_b, d_out, d_valid, rows, stream) runs the kernel over `rows` rows.
-//
-// Default: copy in, one launch, copy out, on the workspace stream (a million 10-node queries: 2.9-3.3 ms per call around a 0.49 ms kernel --
-// 105 MB over PCIe; src/bin/benchmark.rs:161-164 times the whole call, not the kernel).  With GBWT_HIP_QUERY_PIPELINE=1 (round 5; measured,
-// not the default: profiles/r05_query_call_sweep.txt) a large batch is cut into chunks that travel through the workspace's copy lanes -- the
-// threads, pinned buffers and streams of copy_to_host -- so that one chunk's upload, another's kernel and a third's download share the
-// time; 2 / 3 keep the one launch and move both copies / the copy back through the lanes.  The results of all chunks end up in out_a /
-// out_valid like those of a single launch.  The device-resident forms below skip the copies altogether.
+// Copy in, one launch, copy out, on the workspace stream (a million 10-node queries: 2.9-3.3 ms per call around a 0.49 ms kernel -- 105 MB over
+// PCIe; src/bin/benchmark.rs:161-164 times the whole call, not the kernel).  The pageable copies are the fastest way this driver offers between
+// caller-owned host memory and the device (profiles/r06_download_probe.txt: 1 ms per 48 MB into touched memory, 2.4 ms into fresh pages; staging
+// through pinned buffers on several threads -- round 5's GBWT_HIP_QUERY_PIPELINE, removed -- 4-6 ms).  The device-resident forms below skip the
+// copies altogether.
 template <class Launch>
 gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const void *in_a, size_t a_row, const void *in_b, size_t b_row,
                           void *out, size_t out_row, uint8_t *valid, uint64_t n, Launch launch) {
@@ -670,80 +666,17 @@ gbwt_hip_status run_query(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, cons
         ws->out_valid.reserve(n);
         if (in_b) ws->in_b.reserve(n * b_row);
         for (auto &e : ws->qev) if (!e) HIP_CHECK(hipEventCreate(&e));
-        const size_t in_row = a_row + (in_b ? b_row : 0), back_row = out_row + 1;
-        const unsigned threads = ws->knobs.copy_threads;
-        const size_t PIECE = std::min<size_t>(HostCopier::CHUNK, std::max<size_t>(4096, ws->knobs.query_piece));   // bytes of a chunk in either direction
-        const size_t widest = std::max(in_row, back_row);
-        const uint64_t rows_per_chunk = std::max<uint64_t>(1, PIECE / widest);                  // (rows wider than a piece take the plain way below)
-        const uint64_t chunks = widest <= PIECE ? (n + rows_per_chunk - 1) / rows_per_chunk : 0;
-        std::unique_lock<std::mutex> lanes_lock(ws->copier.busy, std::defer_lock);
-        if (chunks >= 4 && threads >= 2 && ws->knobs.query_pipeline == 1 && (lanes_lock.lock(), ws->copier.ensure(ix->device, threads))) {
-            hipStream_t s = ws->stream;
-            HIP_CHECK(hipEventRecord(ws->qev[0], s));
-            std::atomic<uint64_t> next{0};
-            std::atomic<int> failed{0};
-            const unsigned lanes = static_cast<unsigned>(std::min<uint64_t>(threads, chunks));
-            auto work = [&](unsigned t) {
-                HostCopier::Lane &l = ws->copier.lanes[t];
-                if (hipSetDevice(ix->device) != hipSuccess || hipStreamWaitEvent(l.stream, ws->qev[0], 0) != hipSuccess) { failed = 1; return; }
-                char *pin_in = static_cast<char *>(l.pinned[0]), *pin_out = static_cast<char *>(l.pinned[1]);
-                for (uint64_t c = next++; c < chunks && !failed; c = next++) {
-                    const uint64_t lo = c * rows_per_chunk, rows = std::min(rows_per_chunk, n - lo);
-                    if (a_row != 0) std::memcpy(pin_in, static_cast<const char *>(in_a) + lo * a_row, rows * a_row);
-                    if (in_b) std::memcpy(pin_in + rows * a_row, static_cast<const char *>(in_b) + lo * b_row, rows * b_row);
-                    char *d_a = ws->in_a.as<char>() + lo * a_row, *d_b = in_b ? ws->in_b.as<char>() + lo * b_row : nullptr;
-                    char *d_out = ws->out_a.as<char>() + lo * out_row;
-                    uint8_t *d_valid = ws->out_valid.as<uint8_t>() + lo;
-                    bool ok = a_row == 0 || hipMemcpyAsync(d_a, pin_in, rows * a_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
-                    if (ok && in_b) ok = hipMemcpyAsync(d_b, pin_in + rows * a_row, rows * b_row, hipMemcpyHostToDevice, l.stream) == hipSuccess;
-                    if (ok) { launch(d_a, d_b, d_out, d_valid, rows, l.stream); ok = hipGetLastError() == hipSuccess; }
-                    ok = ok && hipMemcpyAsync(pin_out, d_out, rows * out_row, hipMemcpyDeviceToHost, l.stream) == hipSuccess &&
-                         hipMemcpyAsync(pin_out + rows * out_row, d_valid, rows, hipMemcpyDeviceToHost, l.stream) == hipSuccess &&
-                         hipStreamSynchronize(l.stream) == hipSuccess;
-                    if (!ok) { failed = 1; break; }
-                    std::memcpy(static_cast<char *>(out) + lo * out_row, pin_out, rows * out_row);
-                    std::memcpy(valid + lo, pin_out + rows * out_row, rows);
-                }
-                if (hipEventRecord(l.landed[0], l.stream) != hipSuccess) failed = 1;
-            };
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < lanes; t++) pool.emplace_back(work, t);
-            work(0);
-            for (auto &t : pool) t.join();
-            if (failed) { (void)hipGetLastError(); return fail(GBWT_HIP_DEVICE_ERROR, "a chunk of the query pipeline failed"); }
-            for (unsigned t = 0; t < lanes; t++) HIP_CHECK(hipStreamWaitEvent(s, ws->copier.lanes[t].landed[0], 0));
-            HIP_CHECK(hipEventRecord(ws->qev[1], s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            ws->query_timed = true;
-            return GBWT_HIP_OK;
-        }
-        if (lanes_lock.owns_lock()) lanes_lock.unlock();
         hipStream_t s = ws->stream;
-        // mode 2: ONE launch, the copies around it through the lanes (several threads, pinned pieces); mode 3: only the copy back
-        const bool lanes_in = ws->knobs.query_pipeline == 2, lanes_out = ws->knobs.query_pipeline == 2 || ws->knobs.query_pipeline == 3;
-        const size_t piece = std::min<size_t>(HostCopier::CHUNK, std::max<size_t>(4096, ws->knobs.query_piece));
-        if (lanes_in) {
-            HIP_CHECK(hipStreamSynchronize(s));
-            if (a_row != 0) copy_to_device(ws, ws->in_a.ptr, in_a, n * a_row, piece);
-            if (in_b) copy_to_device(ws, ws->in_b.ptr, in_b, n * b_row, piece);
-        } else {
-            if (a_row != 0) HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, n * a_row, hipMemcpyHostToDevice, s));
-            if (in_b) HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, n * b_row, hipMemcpyHostToDevice, s));
-        }
+        if (a_row != 0) HIP_CHECK(hipMemcpyAsync(ws->in_a.ptr, in_a, n * a_row, hipMemcpyHostToDevice, s));
+        if (in_b) HIP_CHECK(hipMemcpyAsync(ws->in_b.ptr, in_b, n * b_row, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipEventRecord(ws->qev[0], s));
         launch(ws->in_a.as<char>(), in_b ? ws->in_b.as<char>() : nullptr, ws->out_a.as<char>(), ws->out_valid.as<uint8_t>(), n, s);
         HIP_CHECK(hipEventRecord(ws->qev[1], s));
         ws->query_timed = true;
         HIP_CHECK(hipGetLastError());
-        if (lanes_out) {
-            HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            copy_to_host(ws, out, ws->out_a.ptr, n * out_row, piece);
-        } else {
-            HIP_CHECK(hipMemcpyAsync(out, ws->out_a.ptr, n * out_row, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-        }
+        HIP_CHECK(hipMemcpyAsync(out, ws->out_a.ptr, n * out_row, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(valid, ws->out_valid.ptr, n, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
         return GBWT_HIP_OK;
     } catch (const HipError &e) {
         return status_of(e);
@@ -836,9 +769,8 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
         // own, made once per process in the background: 16-25 ms, and a first extraction that waited 370 ms behind the pinned
         // allocations; NOTEBOOK.md, round 4)
         // ... for the 60 MB of the headline index.  The 1.5 GB of an HPRC-sized one are cut into slices that several threads copy side by
-        // side (GBWT_HIP_UPLOAD_SLICES; from 256 MB: 4): profiles/r05_c4_open_trace.txt
+        // side (from 256 MB: 4): profiles/r05_c4_open_trace.txt
         unsigned slices = bytes >= (uint64_t(256) << 20) ? 4u : 1u;
-        if (const char *v = std::getenv("GBWT_HIP_UPLOAD_SLICES")) slices = static_cast<unsigned>(std::min(32, std::max(1, std::atoi(v))));
         early.worker = std::thread([&early, src, dst, bytes, dev, slices]() {
             early.result = hipSetDevice(dev);
             if (early.result != hipSuccess) return;
@@ -1137,7 +1069,7 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             // about one workgroup per four SIMDs keeps every workgroup resident (32 KB of LDS each)
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                : segmented ? 64u : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(16, (walkers + 1023) / 1024)));
-            a.helper_lanes = knobs.helper_lanes >= 0 ? static_cast<uint32_t>(knobs.helper_lanes) : 64u;
+            a.helper_lanes = 64u;
             a.wide_addresses = knobs.wide_addresses ? 1u : 0u;
             a.ring_slots = knobs.ring_slots > 0 ? static_cast<uint32_t>(knobs.ring_slots) : (segmented ? 64u : 128u);   // many walkers: smaller rings, more workgroups per CU (7.4 vs 8.1 ms on the headline)
             // many walkers per CU: a helper that polls less leaves more issue slots and LDS cycles to them (6 until the packed half-blocks
@@ -1233,7 +1165,7 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             a.paths_per_wave = ws->paths_per_wave ? ws->paths_per_wave
                                                    : static_cast<uint32_t>(std::min<uint64_t>(64, std::max<uint64_t>(32, (n + 1023) / 1024)));
             a.pack16 = ix->stats.max_record_len < 65536 ? 1u : 0u;
-            a.helper_lanes = knobs.helper_lanes >= 0 ? static_cast<uint32_t>(knobs.helper_lanes) : 64u;
+            a.helper_lanes = 64u;
             a.wide_addresses = knobs.wide_addresses ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
@@ -1339,40 +1271,6 @@ void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t byt
     if (failed) { (void)hipGetLastError(); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }   // whatever went wrong: the plain way, which reports it
 }
 
-// The other direction (round 5: the queries of a large search batch): every thread copies its pieces of the caller's pageable memory into
-// its pinned buffers and sends them on; returns when everything has landed.
-void copy_to_device(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece) {
-    const size_t CHUNK = std::min(std::max<size_t>(piece, 4096), HostCopier::CHUNK);
-    const int device = ws->index->device;
-    const unsigned threads = ws->knobs.copy_threads;
-    if (bytes < 4 * CHUNK || threads < 2) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
-    std::lock_guard<std::mutex> guard(ws->copier.busy);
-    if (!ws->copier.ensure(device, threads)) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
-    const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
-    std::atomic<size_t> next{0};
-    std::atomic<int> failed{0};
-    auto work = [&](unsigned t) {
-        HostCopier::Lane &l = ws->copier.lanes[t];
-        if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
-        bool used_buffer[2] = {false, false};
-        int b = 0;
-        for (size_t c = next++; c < chunks && !failed; c = next++, b ^= 1) {
-            const size_t at = c * CHUNK, len = std::min(CHUNK, bytes - at);
-            if (used_buffer[b] && hipEventSynchronize(l.landed[b]) != hipSuccess) { failed = 1; break; }      // the copy out of this buffer two pieces ago
-            std::memcpy(l.pinned[b], static_cast<const char *>(src) + at, len);
-            if (hipMemcpyAsync(static_cast<char *>(dst) + at, l.pinned[b], len, hipMemcpyHostToDevice, l.stream) != hipSuccess ||
-                hipEventRecord(l.landed[b], l.stream) != hipSuccess) { failed = 1; break; }
-            used_buffer[b] = true;
-        }
-        if (hipStreamSynchronize(l.stream) != hipSuccess) failed = 1;
-    };
-    const unsigned used = static_cast<unsigned>(std::min<size_t>(threads, chunks));
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < used; t++) pool.emplace_back(work, t);
-    work(0);
-    for (auto &t : pool) t.join();
-    if (failed) { (void)hipGetLastError(); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
-}
 
 }  // namespace gbwt_hip
 

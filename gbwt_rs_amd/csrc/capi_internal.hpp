@@ -268,23 +268,15 @@ struct ExtractKnobs {
     int all4 = 1;                                             // GBWT_HIP_ALL4: 0 = the uniform loop counts every node it stages (rounds 1-3)
     int sample_stride = -1;                                   // GBWT_HIP_SAMPLE_STRIDE: a walker per this many samples of a row; -1 = by the size of the batch (gbwt_hip_extract_device)
     int defer_total = 1;                                      // GBWT_HIP_DEFER_TOTAL: 0 = every request waits for the total of its row lengths before it launches the walk (rounds 1-3)
-    int helper_lanes = -1, ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
+    int ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     int gather_reach = -1;                                    // GBWT_HIP_GATHER_REACH: look-ahead of mixed waves (WalkArgs::gather_reach); -1 = by the index (rows per record), 0 = none
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
     uint32_t debug = 0;                                       // GBWT_HIP_DEBUG_DRY_ROWS (measurement switches, WalkArgs::debug)
     unsigned copy_threads = 8;                                // GBWT_HIP_COPY_THREADS
-    int query_pipeline = 0;                                   // GBWT_HIP_QUERY_PIPELINE: 0 = query batches in one piece over the workspace stream (default); 1 = large batches in chunks through the
-                                                              // copy lanes (upload / kernel / download of different chunks at once), 2 = one launch with both copies through the lanes,
-                                                              // 3 = only the copy back through them.  Measured (profiles/r05_query_call_sweep.txt, a million 10-node queries = 105 / 129 MB over
-                                                              // PCIe per call): alone in a process the chunks win on the bidirectional form (7.2 -> 3.0 ms) and tie on the other (3.1 ms),
-                                                              // inside bench.py's process they lose on both (3.1 -> 4.1, 5.8 -> 10.6 ms): the call is bound by PCIe and by the host's
-                                                              // memcpy threads, not by the 0.5 ms kernel -- so one piece stays the default and the device-resident forms are the fast path
-    size_t query_piece = size_t(2) << 20;                     // GBWT_HIP_QUERY_PIECE_KIB: bytes of a piece of the copy lanes in a query call
     static ExtractKnobs from_env() {
         ExtractKnobs k;
         const auto num = [](const char *name, int unset) { const char *v = std::getenv(name); return v ? std::atoi(v) : unset; };
         k.direct = num("GBWT_HIP_DIRECT", 1); k.segments = num("GBWT_HIP_SEGMENTS", 1); k.both_ends = num("GBWT_HIP_BOTH_ENDS", 1);
-        k.helper_lanes = std::max(-1, num("GBWT_HIP_HELPER_LANES", -1));
         k.ring_slots = num("GBWT_HIP_RING_SLOTS", -1); if (k.ring_slots != 32 && k.ring_slots != 64 && k.ring_slots != 128) k.ring_slots = -1;
         k.helper_naps = std::max(-1, num("GBWT_HIP_HELPER_NAPS", -1));
         k.xcd_map = num("GBWT_HIP_XCD_MAP", -1); k.uniform_loop = num("GBWT_HIP_UNIFORM_LOOP", -1); k.packed_blocks = num("GBWT_HIP_PACKED_BLOCKS", -1);
@@ -298,8 +290,6 @@ struct ExtractKnobs {
         k.wide_addresses = std::getenv("GBWT_HIP_WIDE_ADDRESSES") != nullptr;
         k.debug = static_cast<uint32_t>(num("GBWT_HIP_DEBUG_DRY_ROWS", 0));
         k.copy_threads = static_cast<unsigned>(std::min(64, std::max(1, num("GBWT_HIP_COPY_THREADS", 8))));
-        k.query_pipeline = num("GBWT_HIP_QUERY_PIPELINE", 0);
-        k.query_piece = static_cast<size_t>(std::max(4, num("GBWT_HIP_QUERY_PIECE_KIB", 2048))) << 10;
         return k;
     }
 };
@@ -341,5 +331,4 @@ namespace gbwt_hip {
 // Device -> pageable host memory over the workspace's copy threads (GBWT_HIP_COPY_THREADS, default 8), each with two pinned staging
 // buffers and a stream of its own (capi.hip)
 void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece = HostCopier::CHUNK);
-void copy_to_device(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece = HostCopier::CHUNK);
 }

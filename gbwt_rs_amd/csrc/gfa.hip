@@ -229,14 +229,14 @@ __global__ void __launch_bounds__(256) k_plan_chunks(const uint64_t *offsets, ui
 // (With every lane storing its own six bytes one at a time the formatter wrote 330 GB/s of text.)
 constexpr uint32_t TOKEN_MAX = 12;   // ',' + ten digits + '+' (P-lines); '>' + ten digits (W-lines)
 // PER_THREAD: consecutive positions per thread and batch (one scan and two barriers per 256 * PER_THREAD positions)
-// WHOLE_TOKENS (GBWT_HIP_FORMAT_TOKENS, default 1): a token is put together in registers (gfa_tokens.hpp) and OR-ed into the staging buffer as
-// the three or four aligned dwords it covers -- the buffer is zero wherever no token has been placed, and whoever copies a unit out leaves it
-// zero again.  0 = the form before it: a division and a one-byte store per character (the kernel was bound by exactly those: vector ALU 83 %
-// busy, LDS 70 %, profiles/r05_format_stream.txt).
-template <bool WHOLE_TOKENS, uint32_t PER_THREAD>
+// A token is put together in registers (gfa_tokens.hpp) and OR-ed into the staging buffer as the three or four aligned dwords it covers -- the
+// buffer is zero wherever no token has been placed, and whoever copies a unit out leaves it zero again.  (Rounds 1-4 made a token with a
+// division and a one-byte store per character; that form was bound by exactly those -- vector ALU 83 % busy, LDS 70 %,
+// profiles/r05_format_stream.txt -- and lived on behind GBWT_HIP_FORMAT_TOKENS=0 until round 6.)
+template <uint32_t PER_THREAD>
 __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const ChunkPlan *plans, int p_lines,
                                                                    const uint64_t *seq_ids, LineHeaders hdr, const uint64_t *line_end, uint8_t *out) {
-    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS, WHOLE_TOKENS ? hipcub::BLOCK_SCAN_WARP_SCANS : hipcub::BLOCK_SCAN_RAKING>;
+    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS, hipcub::BLOCK_SCAN_WARP_SCANS>;
     __shared__ typename BlockScan::TempStorage scan_storage;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr uint32_t BATCH = FORMAT_THREADS * PER_THREAD;
@@ -254,10 +254,8 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint32_t
     uint32_t ahead[PER_THREAD];                                        // the node ids of the next batch are asked for before this one is put together
 #pragma unroll
     for (uint32_t i = 0; i < PER_THREAD; i++) { const uint32_t k = PER_THREAD * t + i; ahead[i] = k < count ? ids[k] : 0u; }
-    if (WHOLE_TOKENS) {                                                 // (while the first node ids are on their way)
-        for (uint32_t lo = 16 * t; lo < STAGE_BYTES; lo += 16 * FORMAT_THREADS) *reinterpret_cast<u32x4 *>(stage + lo) = u32x4{0u, 0u, 0u, 0u};
-        __syncthreads();
-    }
+    for (uint32_t lo = 16 * t; lo < STAGE_BYTES; lo += 16 * FORMAT_THREADS) *reinterpret_cast<u32x4 *>(stage + lo) = u32x4{0u, 0u, 0u, 0u};   // (while the first node ids are on their way)
+    __syncthreads();
     for (uint32_t base = 0; base < count; base += BATCH) {
         const uint32_t k0 = base + PER_THREAD * t;
         uint32_t node[PER_THREAD], digits[PER_THREAD], len = 0;
@@ -268,15 +266,10 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint32_t
             const uint32_t next = k0 + BATCH + i;
             ahead[i] = next < count ? ids[next] : 0u;
             if (k0 + i >= count) continue;
-            if (WHOLE_TOKENS) {
-                token[i] = (node[i] >> 1) < 100000000u ? make_token_short(node[i], p_lines != 0, k0 + i == first_at) : make_token(node[i], p_lines != 0, k0 + i == first_at);
-                digits[i] = token[i].len;
-                len += token[i].len;
-            } else {
-                digits[i] = decimal_digits(node[i] >> 1);
-                // ',' between the tokens of a P-line and '+' / '-' behind each, '>' / '<' in front of a W-line's
-                len += digits[i] + (p_lines ? (k0 + i != first_at ? 2u : 1u) : 1u);
-            }
+            // ',' between the tokens of a P-line and '+' / '-' behind each, '>' / '<' in front of a W-line's
+            token[i] = (node[i] >> 1) < 100000000u ? make_token_short(node[i], p_lines != 0, k0 + i == first_at) : make_token(node[i], p_lines != 0, k0 + i == first_at);
+            digits[i] = token[i].len;
+            len += token[i].len;
         }
         uint32_t pos, total;
         BlockScan(scan_storage).ExclusiveSum(len, pos, total);
@@ -286,23 +279,14 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint32_t
 #pragma unroll
         for (uint32_t i = 0; i < PER_THREAD; i++) {
             if (digits[i] == 0) continue;
-            if (WHOLE_TOKENS) {
-                const uint32_t at = static_cast<uint32_t>(w - stage);
-                uint32_t spread[4], *const dwords = reinterpret_cast<uint32_t *>(stage + (at & ~3u));
-                spread_token(token[i], at & 3u, spread);
-                __hip_atomic_fetch_or(dwords, spread[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_or(dwords + 1, spread[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_or(dwords + 2, spread[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (spread[3] != 0) __hip_atomic_fetch_or(dwords + 3, spread[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                w += token[i].len;
-                continue;
-            }
-            if (!p_lines) *w++ = (node[i] & 1u) ? '<' : '>';
-            else if (k0 + i != first_at) *w++ = ',';
-            uint32_t v = node[i] >> 1;
-            for (uint32_t d = 0; d < digits[i]; d++) { w[digits[i] - 1 - d] = static_cast<uint8_t>('0' + v % 10u); v /= 10u; }
-            w += digits[i];
-            if (p_lines) *w++ = (node[i] & 1u) ? '-' : '+';
+            const uint32_t at = static_cast<uint32_t>(w - stage);
+            uint32_t spread[4], *const dwords = reinterpret_cast<uint32_t *>(stage + (at & ~3u));
+            spread_token(token[i], at & 3u, spread);
+            __hip_atomic_fetch_or(dwords, spread[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(dwords + 1, spread[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(dwords + 2, spread[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (spread[3] != 0) __hip_atomic_fetch_or(dwords + 3, spread[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            w += token[i].len;
         }
         __syncthreads();
         const uint32_t end = mis + total;
@@ -314,7 +298,7 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks(const uint32_t
                 const uint32_t from = lo < mis ? mis : lo, upto = lo + 16 < end ? lo + 16 : end;
                 for (uint32_t q = from; q < upto; q++) aligned[q] = stage[q];
             }
-            if (WHOLE_TOKENS) *reinterpret_cast<u32x4 *>(stage + lo) = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(stage + lo) = u32x4{0u, 0u, 0u, 0u};
         }
         cursor += total;
         __syncthreads();
@@ -815,9 +799,7 @@ static gbwt_hip_status path_lines_compute(const gbwt_hip_index *ix, gbwt_hip_wor
             hipLaunchKernelGGL(k_format_chunks_segments, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n,
                                d_chunk_first, d_chunk_path, d_text_before, segment_tables(ix), p_lines, d_valid, d_line_start, d_seq_ids, hdr, d_line_end, text.as<uint8_t>());
         else {
-            const char *knob = std::getenv("GBWT_HIP_FORMAT_TOKENS");                                 // read per request: an A/B inside one process
-            const int form = knob ? std::atoi(knob) : 1;
-            const auto kernel = form == 0 ? k_format_chunks<false, 4> : k_format_chunks<true, 4>;   // (eight positions per thread: five waves per SIMD, 23 % slower)
+            const auto kernel = k_format_chunks<4>;   // (eight positions per thread: five waves per SIMD, 23 % slower)
             ws->gfa_plan.reserve(chunks_cap * sizeof(ChunkPlan));
             hipLaunchKernelGGL(k_plan_chunks, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_first, d_chunk_path, chunks_cap,
                                d_text_before, p_lines, d_line_start, d_seq_ids, hdr, d_line_end, all_cached ? cache : LineCache{nullptr, nullptr, nullptr}, ws->gfa_plan.as<ChunkPlan>());

@@ -286,7 +286,7 @@ def test_format_kernel_keeps_eight_waves_per_simd():
                           os.path.join(_lib.CSRC, "gfa.hip")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stderr.splitlines()
-    at = next(i for i, l in enumerate(lines) if "Function Name" in l and "k_format_chunksILb1ELj4E" in l)
+    at = next(i for i, l in enumerate(lines) if "Function Name" in l and "k_format_chunksILj4E" in l)
     block = "\n".join(lines[at:at + 14])
     field = lambda name: int(re.search(name + r": (\d+)", block).group(1))
     assert field("    VGPRs") <= 64 and field("VGPRs Spill") == 0 and field(r"Occupancy \[waves/SIMD\]") == 8 and field(r"LDS Size \[bytes/block\]") <= 160 * 1024 // 8, block

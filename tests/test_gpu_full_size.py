@@ -56,14 +56,10 @@ def test_config_c3_full_size():
     assert np.array_equal((st["end"] - st["start"])[ok], (bd["forward"]["end"] - bd["forward"]["start"])[ok])
     assert np.array_equal((bd["forward"]["end"] - bd["forward"]["start"])[ok], (bd["reverse"]["end"] - bd["reverse"]["start"])[ok])
     assert np.array_equal(bd["reverse"]["node"][ok], queries[ok][:, 0] ^ np.uint64(1))
-    # the same queries through the other ways in: in chunks through the pinned copy lanes (the host forms above moved them in one piece),
-    # and the device-resident forms (queries in HBM, states left in the workspace)
+    # the same queries through the other ways in: a second workspace of the handle, and the device-resident forms (queries in HBM, states
+    # left in the workspace)
     import torch
-    os.environ["GBWT_HIP_QUERY_PIPELINE"] = "1"          # in chunks through the pinned copy lanes (the calls above: in one piece)
-    try:
-        plain = dev.another_workspace()
-    finally:
-        del os.environ["GBWT_HIP_QUERY_PIPELINE"]
+    plain = dev.another_workspace()
     st1, ok1 = plain.search(queries)
     bd1, bok1 = plain.bd_search(queries, 4)
     assert np.array_equal(ok, ok1) and np.array_equal(st, st1) and np.array_equal(bok, bok1) and np.array_equal(bd, bd1)

@@ -469,22 +469,22 @@ def test_tokens_on_the_device(tmp_path):
 
 
 @pytest.mark.parametrize("chop", [1, 3])
-def test_both_token_forms_write_the_same_text(tmp_path, monkeypatch, chop):
-    """GBWT_HIP_FORMAT_TOKENS=0 (a store per character) and the default (whole tokens OR-ed into the staging buffer) against the oracle and against
-    each other: P- and W-lines of paths of several chunks, single paths, the first / last positions of chunks (node ids of 1-5 digits)."""
+def test_token_text_at_chunk_and_digit_boundaries(tmp_path, chop):
+    """The formatter's whole-token form (tokens made in registers, OR-ed into a zeroed staging buffer) against the oracle: P- and W-lines of paths
+    of several chunks, single paths, the first / last positions of chunks, node ids of 1-5 digits, from two workspaces of one handle."""
     s = S.Synth.chain(sites=2600, haplotypes=40, alleles=3, model=S.MOSAIC, founders=6, switch_rate=0.01, seed=23, chop=chop)
     path = tmp_path / "forms.gbz"
     s.save(str(path), as_gbz=True)
     dev, oracle = G.GBZ.load(str(path)), O.OracleGBZ(str(path))
     paths = list(range(dev.paths()))
-    texts = {}
-    for form in ("0", "1"):
-        monkeypatch.setenv("GBWT_HIP_FORMAT_TOKENS", form)
+    texts = []
+    for _ in range(2):
         ws = dev.another_workspace()
-        texts[form] = (ws.path_lines(paths, 1), ws.path_lines(paths, 0), ws.path_lines(paths[3:4], 1), ws.path_lines(paths[:1], 0))
+        texts.append((ws.path_lines(paths, 1), ws.path_lines(paths, 0), ws.path_lines(paths[3:4], 1), ws.path_lines(paths[:1], 0)))
         ws.close()
-    assert texts["0"] == texts["1"]
-    assert texts["1"][0] == oracle.path_lines(paths, 1) and texts["1"][1] == oracle.path_lines(paths, 0)
+    assert texts[0] == texts[1]
+    assert texts[0][0] == oracle.path_lines(paths, 1) and texts[0][1] == oracle.path_lines(paths, 0)
+    assert texts[0][2] == oracle.path_lines(paths[3:4], 1) and texts[0][3] == oracle.path_lines(paths[:1], 0)
     dev.close()
 
 

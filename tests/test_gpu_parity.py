@@ -576,7 +576,7 @@ def test_indel_chain_bit_exact(tmp_path, alleles, extra, model):
 
 
 @pytest.mark.parametrize("env", [{"GBWT_HIP_WIDE_ADDRESSES": "1"}, {"GBWT_HIP_RING_SLOTS": "32"}, {"GBWT_HIP_UNIFORM_LOOP": "0"},
-                                 {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_HELPER_LANES": "0"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "256", "GBWT_HIP_LOOKAHEAD_HOPS": "0"},
                                  {"GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_GATHER_LIMIT": "0", "GBWT_HIP_WIDE_ADDRESSES": "1"},
                                  {"GBWT_HIP_CATCH_UP": "2"}, {"GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_GATHER_LIMIT": "300"}, {"GBWT_HIP_CATCH_UP": "2", "GBWT_HIP_SAMPLE_INTERVAL": "64"}])
 def test_walk_loop_variants(monkeypatch, env):
@@ -956,17 +956,14 @@ def test_config_c3_search_bit_exact(model, haplotypes):
 
 
 def test_large_query_batches_travel_in_chunks(monkeypatch):
-    """Host-pointer query calls large enough for the chunk pipeline (round 5: chunks of ~2 MiB through the workspace's pinned copy lanes,
-    upload / kernel / download of different chunks at once) -- every entry point of the navigation / search group, with a row count that
-    is not a multiple of the chunk: (GBWT_HIP_QUERY_PIPELINE=1) the same answers as one piece over the workspace stream (the default), as the
-    device-resident forms, and (a seeded sample) as the oracle."""
+    """Large host-pointer query calls (1.3 M rows, tens of MB each way) -- every entry point of the navigation / search group: the same
+    answers from two workspaces of one handle, from the device-resident forms, and (a seeded sample) from the oracle.  (Round 5 moved such
+    batches in chunks through pinned copy lanes behind GBWT_HIP_QUERY_PIPELINE; measured slower than the one pageable copy each way and
+    removed in round 6: profiles/r06_download_probe.txt.)"""
     import torch
     s = S.Synth.chain(sites=2000, haplotypes=600, alleles=2, model=S.MOSAIC, founders=16, switch_rate=5e-3, seed=29)
     dev, oracle = open_synth(s), oracle_of(s)
-    plain = dev.another_workspace()                        # (in one piece over the workspace stream: the default)
-    monkeypatch.setenv("GBWT_HIP_QUERY_PIPELINE", "1")
-    dev.new_workspace()                                    # chunks through the copy lanes
-    monkeypatch.delenv("GBWT_HIP_QUERY_PIPELINE")
+    plain = dev.another_workspace()
     gen = np.random.default_rng(12)
     n = 1300003
     nodes = gen.integers(0, s.alphabet_size + 3, n, dtype=np.uint64)

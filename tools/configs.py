@@ -113,33 +113,29 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
                        f"src/bin/benchmark.rs:124-153 does (seed {seed}); find + {length - 1} x extend per query in one launch, and bd_find + alternating "
                        "extend_forward / extend_backward",
            "queries": int(n), "unit": "queries/s"}
-    # the kernel alone: queries resident in HBM, states left in the workspace (gbwt_hip_search_device); the call as src/bin/benchmark.rs:161-164
-    # times it: host pointers in and out (gbwt_hip_search: one piece over the workspace stream), and the same in chunks through the pinned
-    # copy lanes (GBWT_HIP_QUERY_PIPELINE=1: measured, not the default -- profiles/r05_query_call_sweep.txt)
+    # the kernel alone: queries resident in HBM, states left in the workspace (gbwt_hip_search_device); and the call as src/bin/benchmark.rs:161-164
+    # times it: host pointers in and out (gbwt_hip_search: one pageable copy each way over the workspace stream), into FRESH result arrays and
+    # into result arrays the caller has used before (profiles/r06_download_probe.txt: the kernel faults fresh pages in under the copy)
     import torch
     d_q = torch.from_numpy(queries.view(np.int64)).cuda(device)
-    os.environ["GBWT_HIP_QUERY_PIPELINE"] = "1"
-    try:
-        chunked = dev.another_workspace()
-    finally:
-        del os.environ["GBWT_HIP_QUERY_PIPELINE"]
-    forms = (("unidirectional", "k_search", lambda w: w.search(queries), lambda: dev.states_to_host(dev.search_device(d_q.data_ptr(), n, length))),
-             ("bidirectional", "k_bd_search", lambda w: w.bd_search(queries, length // 2),
+    forms = (("unidirectional", "k_search", G.STATE_DTYPE, lambda w, o: w.search(queries, out=o), lambda: dev.states_to_host(dev.search_device(d_q.data_ptr(), n, length))),
+             ("bidirectional", "k_bd_search", G.BD_DTYPE, lambda w, o: w.bd_search(queries, length // 2, out=o),
               lambda: dev.states_to_host(dev.bd_search_device(d_q.data_ptr(), n, length, length // 2), bidirectional=True)))
-    for name, kernel, host_form, device_form in forms:
-        host_form(dev), host_form(chunked), device_form()
-        ks, ws, ws1 = [], [], []
+    for name, kernel, dtype, host_form, device_form in forms:
+        kept = (np.zeros(n, dtype=dtype), np.zeros(n, dtype=np.uint8))
+        host_form(dev, None), host_form(dev, kept), device_form()
+        ks, ws, ws_kept = [], [], []
         for _ in range(passes):
             t1 = time.perf_counter()
-            out, ok = host_form(dev)
+            out, ok = host_form(dev, None)
             ws.append((time.perf_counter() - t1) * 1e3)
             t1 = time.perf_counter()
-            out1, ok1 = host_form(chunked)
-            ws1.append((time.perf_counter() - t1) * 1e3)
+            out1, ok1 = host_form(dev, kept)
+            ws_kept.append((time.perf_counter() - t1) * 1e3)
             out2, ok2 = device_form()
             ks.append(dev.last_query_ms())
         assert ok.all(), "a query cut out of the index itself was not found"
-        assert np.array_equal(out, out1) and np.array_equal(out, out2) and ok1.all() and ok2.all(), "the three ways into the kernel disagree"
+        assert np.array_equal(out, out2) and ok2.all() and np.array_equal(out, out1) and ok1.all(), "the ways into the kernel disagree"
         fwd = out if name == "unidirectional" else out["forward"]
         assert ((fwd["end"] > fwd["start"]) & (fwd["node"] == queries[:, -1 if name == "unidirectional" else length - 1])).all()
         k = float(np.mean(ks))
@@ -147,13 +143,12 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
         # the record + two 16-byte rank blocks (range start and end)
         bytes_q = 8 * length + (24 if name == "unidirectional" else 48) + 1 + length * (64 + 2 * 16)
         pcie = n * (8 * length + (24 if name == "unidirectional" else 48) + 1)
-        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.median(ws)), "wall_ms_chunked": float(np.median(ws1)), "value": n / (k * 1e-3),
-                     "value_call": n / (float(np.median(ws)) * 1e-3), "steps_per_s": n * length / (k * 1e-3), "ns_per_node_call": float(np.median(ws)) * 1e6 / (n * length),
+        res[name] = {"kernel": kernel, "kernel_ms": k, "wall_ms": float(np.median(ws)), "wall_ms_reused_results": float(np.median(ws_kept)), "value": n / (k * 1e-3),
+                     "value_call": n / (float(np.median(ws)) * 1e-3), "value_call_reused_results": n / (float(np.median(ws_kept)) * 1e-3), "steps_per_s": n * length / (k * 1e-3), "ns_per_node_call": float(np.median(ws)) * 1e6 / (n * length),
                      "pcie_bytes_per_call": int(pcie), "pcie_GB_per_s": pcie / (float(np.median(ws)) * 1e-3) / 1e9,
                      "algorithmic_bytes": float(bytes_q * n), "found": int(ok.sum())}
         if name == "unidirectional":
             final_states, final_ok = out, ok
-    chunked.close()
     del d_q
     res["value_call"] = res["unidirectional"]["value_call"]
     res["value_note"] = ("value = queries / kernel time with the queries resident in HBM (gbwt_hip_search_device); value_call = queries / wall time of "

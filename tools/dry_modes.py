@@ -9,9 +9,9 @@ s = S.Synth.chain(sites=333334, haplotypes=5000, alleles=2, model=S.MOSAIC, foun
 ids = np.arange(0, s.sequences, 2, dtype=np.uint64)
 dev = G.GBWT.from_records(s.data(), s.starts(), s.alphabet_offset, s.alphabet_size, s.sequences, s.size, True)
 for label, env in (("default", {}), ("rows not stored (1)", {"GBWT_HIP_DEBUG_DRY_ROWS": "1"}), ("ring emptied unread (64)", {"GBWT_HIP_DEBUG_DRY_ROWS": "64"}),
-                   ("rows into 1 MB (128)", {"GBWT_HIP_DEBUG_DRY_ROWS": "128"}), ("no look-ahead touches", {"GBWT_HIP_HELPER_LANES": "0"}),
+                   ("rows into 1 MB (128)", {"GBWT_HIP_DEBUG_DRY_ROWS": "128"}), ("no look-ahead targets", {"GBWT_HIP_LOOKAHEAD_HOPS": "0"}),
                    ("plain stores (4)", {"GBWT_HIP_DEBUG_DRY_ROWS": "4"}), ("default again", {})):
-    for k in ("GBWT_HIP_DEBUG_DRY_ROWS", "GBWT_HIP_HELPER_LANES"):
+    for k in ("GBWT_HIP_DEBUG_DRY_ROWS", "GBWT_HIP_LOOKAHEAD_HOPS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     os.environ["GBWT_HIP_VMM"] = "0"
