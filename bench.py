@@ -526,6 +526,12 @@ def main():
     tiny_dev = G.GBWT.from_records(tiny.data(), tiny.starts(), tiny.alphabet_offset, tiny.alphabet_size, tiny.sequences, tiny.size, True, device=local_rank)
     tiny_dev.sequences_csr(np.arange(tiny.sequences, dtype=np.uint64))
     tiny_dev.close()
+    # ... and the runtime's path for LARGE pageable copies, which it sets up on first use (the first 60 MB host-to-device copy of a process
+    # takes 31 ms, every later one 1.1 ms: profiles/r06_upload_probe.txt; the first open of a file in a process paid 8-10 ms of it in its
+    # parse, profiles/r06_open_probe.txt): one 64 MB round trip of a throw-away buffer, counted with the runtime's start like the rest
+    scratch = torch.empty(64 << 20, dtype=torch.uint8)
+    scratch.cuda(local_rank).cpu()
+    del scratch
     torch.cuda.synchronize()
     runtime_init_ms = (time.perf_counter() - t0) * 1e3
 
@@ -783,7 +789,8 @@ def main():
                 "checkpoint_walkers": int(open_times["checkpoint_walkers"]), "checkpoint_orphans": int(open_times["checkpoint_orphans"]),
                 "first_pass_ms": first_pass_ms, "first_pass_kernel_ms": first_walk_ms, "runtime_init_ms": runtime_init_ms,
                 "note": "open_ms = GBZ.load of the .gbz (file read + parse, upload, rank blocks and descriptors, sequence samples) with the HIP "
-                        "runtime already started (runtime_init_ms: what starting it cost, once per process); first_pass_ms includes the "
+                        "runtime already started (runtime_init_ms: what starting it cost, once per process -- context, code objects, a tiny open, and "
+                        "one 64 MB pageable copy each way, which sets up the runtime's staging for large copies); first_pass_ms includes the "
                         "allocation of the rows; value_cold = LF-steps / (open_ms + first_pass_ms)",
             },
             "roofline": {

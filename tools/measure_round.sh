@@ -2,7 +2,7 @@
 # of the bench, and the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of the headline kernel and of every other config.
 # usage: measure_round.sh TAG [quick]
 set -x
-R=$GRAFT_REPO_ROOT; T=${1:-r05}; O=$R/gpurun_out/$T; mkdir -p $O
+R=$GRAFT_REPO_ROOT; T=${1:-r06}; O=$R/gpurun_out/$T; mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err
