@@ -75,6 +75,34 @@ def test_round5_profiles_cover_every_config():
     assert line["roofline"]["source_fingerprint"] in prints
 
 
+def test_round6_profiles_cover_every_config():
+    """Round 6: the same set of PMC traffic files, of ONE build; the committed bench line has the shape this round's changes give it -- the
+    headline handle opened for extraction only, the cpu_baseline timed on the plain walk (checksum walk untimed: its ratio on the line),
+    config 4's first request next to its steady passes with the line sizes found at open, search calls into kept result arrays."""
+    keys = {"r06_hbm_traffic.json": "sites=333334 haplotypes=5000 model=mosaic seed=42", "r06_secondary_hbm_traffic.json": "secondary",
+            "r06_high_degree_hbm_traffic.json": "high_degree", "r06_search_hbm_traffic.json": "search", "r06_config4_hbm_traffic.json": "config4",
+            "r06_config4_small_hbm_traffic.json": "config4_small"}
+    prints = set()
+    for name, key in keys.items():
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        factor = t.get("fetch_factor", 2.0)
+        assert t["workload_key"] == key and len(t["source_fingerprint"]) == 16 and factor == (1.0 if key == "search" else 2.0), name
+        assert t["traffic_bytes_per_launch"] == factor * t["fetch_bytes_raw"] + t["write_bytes"] and t["kernels"], name
+        prints.add(t["source_fingerprint"])
+    assert len(prints) == 1
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    assert line["open"]["flags"] == "GBWT_HIP_OPEN_EXTRACT" and line["open"]["open_ms"] < 30 and line["parity_checked_paths"] > 1000
+    assert 0.8 < line["cpu_baseline"]["checksum_walk_ratio"] < 2.0 and line["cpu_baseline"]["kind"] == "port"
+    c4 = line["config4"]
+    assert c4["size"] == "full" and c4["line_sizes_ms"] > 0 and c4["walk_format"]["first_request_ms"] < 1.25 * c4["walk_format"]["ms"] + 10
+    assert c4["kernel"] == "k_walk_direct + k_format_chunks" and c4["value_first_request"] > 0
+    for form in ("unidirectional", "bidirectional"):
+        assert line["search"][form]["wall_ms_reused_results"] <= line["search"][form]["wall_ms"] * 1.2
+    cited = set(re.findall(r"profiles/[A-Za-z0-9_]+hbm_traffic\.json", open(os.path.join(ROOT, "profiles", "r06_bench.json")).read()))
+    assert len(cited) == 6 and all(os.path.exists(os.path.join(ROOT, c)) for c in cited), cited
+    assert line["roofline"]["source_fingerprint"] in prints
+
+
 def test_gpus_without_a_launcher_starts_the_ranks(monkeypatch):
     """--gpus N > 1 outside torchrun: the ranks are children of this (GPU-free) process, started over 127.0.0.1."""
     calls = []

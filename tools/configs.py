@@ -44,7 +44,9 @@ def _extraction(s, passes, warm, device, cpu_leg=None):
     out, walk, _ = _timed_passes(dev, ids, passes)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
-    truth = np.array([s.path_checksum(h) for h in range(s.paths)], dtype=np.uint64)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:      # (the generator's walk of every path: C code that runs without the interpreter lock)
+        truth = np.array(list(pool.map(s.path_checksum, range(s.paths))), dtype=np.uint64)
     assert np.array_equal(dev.path_sums(len(ids)), truth), "extracted paths differ from the generator's ground truth"
     steps = int(out.total)
     res = {"value": steps * passes / elapsed, "unit": "LF-steps/s", "kernel": "k_walk_direct", "kernel_ms": float(np.mean(walk)),
