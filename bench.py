@@ -300,6 +300,9 @@ def final_gather(args, index, out, s, rank, world, local_rank, backend, comm_dev
     return info
 
 
+_C4_FILES = []          # what config4_sharded has put under /dev/shm (rank 0): removed by main() when the step is abandoned and its own `finally` never runs
+
+
 def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch):
     """BASELINE config 4 as it is named: full GFA extraction sharded over the N GPUs with the RCCL gather (tools/c4_bench.py: run_sharded).
     Rank 0 generates the GBZ once (/dev/shm), every rank opens it (the index is replicated), formats the lines of its block of path ids
@@ -314,6 +317,7 @@ def config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier
         try:                                        # (a generator that fails on rank 0 is told to everybody: they wait in the broadcast below)
             base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
             box[0] = os.path.join(tempfile.mkdtemp(prefix="gbwt_bench_c4_", dir=base), "c4.gbz")
+            _C4_FILES.append(box[0])
             g = c4_bench.generate(args.c4_size, box[0])
             gen = {"generator_seconds": round(g.generator_seconds, 1), "save_seconds": round(g.save_seconds, 1), "paths": int(g.paths)}
             del g
@@ -497,7 +501,9 @@ def main():
         dist = dist_mod
         torch.cuda.set_device(local_rank)
         import datetime
-        patience = datetime.timedelta(minutes=5)        # (rank 0 generates config 4's GBZ for half a minute while the others wait for its path)
+        # (rank 0 generates config 4's GBZ for half a minute while the others wait for its path.  Longer than the guards below: with RCCL the process
+        # group's watchdog ABORTS a process whose collective times out -- the guarded steps must be abandoned by their guard first, so that the line survives)
+        patience = datetime.timedelta(minutes=45)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=patience)
         else:
@@ -615,6 +621,7 @@ def main():
     gather_info = None
     other_cut = None
     c4_sharded = None
+    abandoned = []                                 # guarded steps of the N > 1 flow that did not come back (below)
     cold_ms = open_ms + first_pass_ms              # the one-shot flow of the slowest rank
     rank_kernel_ms = [float(np.mean(walk_ms))]
     if dist is not None:
@@ -627,13 +634,6 @@ def main():
         per_rank = torch.zeros(world, dtype=torch.float64, device=comm_device)
         dist.all_gather_into_tensor(per_rank, torch.tensor([float(np.mean(walk_ms))], dtype=torch.float64, device=comm_device))
         rank_kernel_ms = [float(x) for x in per_rank.cpu().tolist()]
-        # The one exchange of the job (outside the timed region, src/bin/gbunzip.rs:421-434: the writer's mutex)
-        try:
-            gather_info = final_gather(args, index, out, s, rank, world, local_rank, backend, comm_device, by_parts, strong, n_paths, all_steps, my_paths, barrier, dist, torch)
-        except AssertionError:
-            raise                                  # wrong rows are an error of the run, not of the transport
-        except Exception as e:  # noqa: BLE001    (a transport that fails -- RCCL, the process group -- must not take the measurement with it)
-            gather_info = {"error": repr(e)[:500], "rank": rank}
         if strong:
             # ... and the SAME batch under the other cut (north_star: "the path set shards ... across the 8 GPUs" = --shard paths; the default
             # is --shard parts, every rank its stretch of every row): the same K timed passes between the same barriers
@@ -657,13 +657,46 @@ def main():
                          "slowest_kernel_ms": float(t[1].item()),
                          "sharding": ("path p walked whole by rank p mod G (SURVEY 8e; north_star's partition)" if by_parts else
                                       "every rank walks stretch r of EVERY path (gbwt_hip_extract_part_device)")}
+        # FROM HERE ON NOTHING MAY TAKE THE LINE WITH IT.  What follows -- the gather of the rows through the library's own RCCL communicator, config 4
+        # sharded over the ranks -- has run between loopback ranks, over gloo and at world size 1, never between GPUs: each step runs in a thread
+        # that the main thread waits for a bounded time (BENCH_GUARD_SECONDS, default 600 per step).  A step that does not come back is
+        # ABANDONED: its object says so, the steps behind it are skipped (the collectives are in an unknown state), rank 0 prints the line
+        # with everything measured above, and the ranks leave without another barrier.  Wrong rows stay an error of the run (AssertionError).
+        guard_s = float(os.environ.get("BENCH_GUARD_SECONDS", "600"))
+
+        def bounded(what, fn):
+            import threading
+            box = {}
+
+            def run():
+                try:
+                    torch.cuda.set_device(local_rank)
+                    box["value"] = fn()
+                except AssertionError as e:
+                    box["assertion"] = e
+                except Exception as e:  # noqa: BLE001    (a transport that fails -- RCCL, the process group -- must not take the measurement with it)
+                    box["error"] = e
+
+            t = threading.Thread(target=run, daemon=True, name=what)
+            t.start()
+            t.join(guard_s)
+            if t.is_alive():
+                abandoned.append(what)
+                return {"error": f"{what}: no answer within {guard_s:.0f} s on rank {rank}: abandoned (the ranks leave without a barrier)", "rank": rank}
+            if "assertion" in box:
+                raise box["assertion"]
+            if "error" in box:
+                return {"error": repr(box["error"])[:500], "rank": rank}
+            return box["value"]
+
+        # The one exchange of the job (outside the timed region, src/bin/gbunzip.rs:421-434: the writer's mutex)
+        gather_info = bounded("final_gather", lambda: final_gather(args, index, out, s, rank, world, local_rank, backend, comm_device, by_parts, strong, n_paths, all_steps,
+                                                                      my_paths, barrier, dist, torch))
         if not (args.no_extras or args.no_config4):
-            # (the headline's numbers above must not be lost to this object: whatever a rank throws in here ends up in the object, and a rank
-            # that waits for one that threw is released by the process group's timeout)
-            try:
-                c4_sharded = config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch)
-            except Exception as e:  # noqa: BLE001
-                c4_sharded = {"error": repr(e)[:500], "rank": rank}
+            if abandoned:
+                c4_sharded = {"error": "skipped: " + abandoned[0] + " was abandoned on this rank", "rank": rank}
+            else:
+                c4_sharded = bounded("config4_sharded", lambda: config4_sharded(args, rank, world, local_rank, backend, comm_device, barrier, dist, torch))
     else:
         all_steps = float(steps_done)
 
@@ -841,7 +874,20 @@ def main():
             result["cpu_baseline"] = cpu
         if gather_info is not None:
             result["config"]["final_gather"] = gather_info
+        if abandoned:
+            result["abandoned"] = abandoned
         print(json.dumps(result), flush=True)
+    if abandoned:
+        # a thread of this process still sits in a collective that will not complete: no barrier, no teardown of communicators it holds --
+        # the line is out (rank 0), the files go, the process ends here
+        for f in [index_path] + [x + tail for x in _C4_FILES for tail in ("", ".generic.npy", ".tmp", ".lines.gfa")]:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if dist is not None:
         try:
             dist.barrier()

@@ -9,7 +9,9 @@ Nothing here is a product path and nothing of it is measured: the line it prints
 what needs hardware: the HIP kernels (pytest -m gpu) and RCCL itself.
 
 REHEARSAL_FAIL=c4_open:<rank> makes that rank's open of config 4's index raise (the ranks must agree on the failure and the headline's
-line must still come out); REHEARSAL_FAIL=c4_generate makes rank 0's generator raise."""
+line must still come out); REHEARSAL_FAIL=c4_generate makes rank 0's generator raise; REHEARSAL_FAIL=gather_hang:<rank> makes that rank never
+come back from the exchange of the final gather (what a transport that hangs between GPUs would look like: every rank's guard must abandon
+the step -- BENCH_GUARD_SECONDS -- and rank 0 must still print the line)."""
 import os
 import sys
 import time
@@ -165,7 +167,12 @@ def main():
     torch.cuda.is_available = lambda: True
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.set_device = lambda *a, **k: None
+    torch.Tensor.cuda = lambda self, *a, **k: self
     os.environ.setdefault("BENCH_DIST_BACKEND", "gloo")
+    if FAIL.startswith("gather_hang:") and int(FAIL.split(":")[1]) == RANK:
+        def hang(*a, **k):
+            time.sleep(3600)
+        D.gather_parts = hang
     if FAIL == "c4_generate" and RANK == 0:
         import c4_bench
         def broken(*a, **k):

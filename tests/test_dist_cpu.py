@@ -332,3 +332,18 @@ def test_bench_survives_a_rank_that_fails_in_config4(failure):
     assert time.perf_counter() - t0 < 200
     line = lines[0]
     assert "error" in line["config4"] and line["value"] > 0 and line["other_cut"]["value"] > 0 and "ms" in line["config"]["final_gather"]
+
+
+def test_bench_abandons_a_step_that_hangs():
+    """A transport that HANGS (not fails) in the final gather -- rank 1 never comes back from the exchange, rank 0 waits for its rows: what a first
+    run between GPUs could look like.  Every rank's guard abandons the step after BENCH_GUARD_SECONDS, config 4 behind it is skipped, rank 0
+    prints the line with everything measured before (the headline under both cuts), the ranks exit 0 without another barrier, and the whole
+    run is bounded."""
+    import time
+    t0 = time.perf_counter()
+    rc, lines, err = _rehearse_bench(2, {"REHEARSAL_FAIL": "gather_hang:1", "BENCH_GUARD_SECONDS": "6"}, timeout=240)
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    assert time.perf_counter() - t0 < 120
+    line = lines[0]
+    assert line["abandoned"] == ["final_gather"] and "abandoned" in line["config"]["final_gather"]["error"] and "skipped" in line["config4"]["error"]
+    assert line["value"] > 0 and line["other_cut"]["value"] > 0 and line["n_gpus"] == 2 and line["value_incl_gather"] is None
