@@ -751,7 +751,6 @@ def main():
             # every config with its own bounded CPU leg (5 s of oracle each, compared with what the GPU returned) unless --no-cpu-baseline
             leg_x = None if args.no_cpu_baseline else cpu_leg_extraction(3.0)    # (timed plain walk + the untimed parity walk of the same paths)
             leg_s = None if args.no_cpu_baseline else cpu_leg_search(4.0)
-            leg_l = None if args.no_cpu_baseline else cpu_leg_lines(4.0)
             extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank, cpu_leg=leg_x), "secondary", emitted)
             extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank, cpu_leg=leg_x), "high_degree", emitted)
             if not args.no_search:
@@ -761,9 +760,29 @@ def main():
             if not args.no_config4:
                 c4_definition = ("bytes moved by walk + format: node ids written by the walk and read by the formatter + the text written "
                                  "/ wall time of the two requests (P-lines, W-lines), host side included")
-                extras["config4"] = config_roofline(K.config4(device=local_rank, size=args.c4_size, cpu_leg=leg_l), "config4", c4_definition)
-                if args.c4_size == "full":
-                    extras["config4_small"] = config_roofline(K.config4_small(device=local_rank, cpu_leg=leg_l), "config4_small", c4_definition)
+                # Config 4 runs in a PROCESS OF ITS OWN (a child: tools/configs.py; this process keeps its GPU state and waits).  Its
+                # `first_request_ms` -- the one request gbunzip's flow makes -- includes the allocation of 73 GB of rows and text, and memory a
+                # process has given back is paid for by that process's next large allocation (profiles/r05_alloc_microbench.txt: 2.5 s after
+                # a release of 48 GiB): behind the configs above, in this process, the first request once took 1.8 s instead of 36 ms.
+                import subprocess
+                names = ["config4"] + (["config4_small"] if args.c4_size == "full" else [])
+                cmd = [sys.executable, os.path.join(ROOT, "tools", "configs.py")] + names + ["--device", str(local_rank), "--c4-size", args.c4_size]
+                if not args.no_cpu_baseline:
+                    cmd += ["--cpu-leg", "4"]
+                child = subprocess.run(cmd, capture_output=True, text=True)
+                sys.stderr.write(child.stderr[-4000:])
+                got = None
+                for text in reversed(child.stdout.splitlines()):
+                    if text.startswith("{"):
+                        got = json.loads(text)
+                        break
+                if child.returncode != 0 or got is None:
+                    extras["config4"] = {"error": f"tools/configs.py {' '.join(names)} exited with {child.returncode}: {child.stderr[-400:]}"}
+                else:
+                    if len(names) == 1:
+                        got = {"config4": got}
+                    for name in names:
+                        extras[name] = config_roofline(got[name], name, c4_definition)
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/measure_round.sh -> profiles/*_hbm_traffic.json).  It is quoted only when those passes ran THIS build with
         # THESE knobs on THIS workload (fingerprint of the kernel sources + GBWT_HIP_* environment); a profile of another

@@ -190,7 +190,27 @@ def config4_small(passes=5, out="/dev/shm/gbwt_bench_c4.gfa", device=0, cpu_leg=
 
 
 if __name__ == "__main__":
+    # usage: configs.py NAME [NAME ...] [--device D] [--c4-size SIZE] [--cpu-leg SECONDS]
+    # one name: its object as one JSON line (tools/measure_round.sh); several: {name: object}.  --cpu-leg: with bench.py's CPU leg of the config
+    # (the oracle over a bounded sample, results compared) -- bench.py starts config 4 this way, in a process of its own.
+    import argparse
     import json
-    name = sys.argv[1]
-    fn = {"secondary": secondary, "high_degree": high_degree, "search": search, "config4": config4, "config4_small": config4_small}[name]
-    print(json.dumps(fn()), flush=True)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="+", choices=["secondary", "high_degree", "search", "config4", "config4_small"])
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--c4-size", default="full")
+    ap.add_argument("--cpu-leg", type=float, default=0.0)
+    a = ap.parse_args()
+    legs = {}
+    if a.cpu_leg > 0:
+        import bench
+        legs = {"secondary": bench.cpu_leg_extraction(a.cpu_leg), "high_degree": bench.cpu_leg_extraction(a.cpu_leg), "search": bench.cpu_leg_search(a.cpu_leg),
+                "config4": bench.cpu_leg_lines(a.cpu_leg), "config4_small": bench.cpu_leg_lines(a.cpu_leg)}
+    out = {}
+    for name in a.names:
+        if name == "config4":
+            out[name] = config4(device=a.device, size=a.c4_size, cpu_leg=legs.get(name))
+        else:
+            fn = {"secondary": secondary, "high_degree": high_degree, "search": search, "config4_small": config4_small}[name]
+            out[name] = fn(device=a.device, cpu_leg=legs.get(name))
+    print(json.dumps(out[a.names[0]] if len(a.names) == 1 else out), flush=True)
