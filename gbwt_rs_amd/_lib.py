@@ -108,6 +108,7 @@ SIGNATURES = {
     "gbwt_hip_bd_search_device": (_int, [_p, _p, _p, _u64, _u64, _u64, C.POINTER(States)]),
     "gbwt_hip_path_lines": (_int, [_p, _p, _p, _u64, _int, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_path_lines_device": (_int, [_p, _p, _p, _u64, _int, C.POINTER(Lines)]),
+    "gbwt_hip_segment_paths": (_int, [_p, _p, _p, _u64, _p, _p, _u64, C.POINTER(_u64)]),
     "gbwt_hip_write_gfa": (_int, [_p, _p, C.c_char_p]),
     "gbwt_hip_write_gfa_mode": (_int, [_p, _p, C.c_char_p, _int]),
     "gbwt_hip_path_sums": (_int, [_p, _p, _p, _u64]),

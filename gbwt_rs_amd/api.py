@@ -439,6 +439,23 @@ class GBZ(GBWT):
         ids = np.ascontiguousarray(path_ids, dtype=np.uint64)
         return self.sequences_csr(2 * ids + np.uint64(1 if orientation else 0))
 
+    def segment_paths(self, seq_ids):
+        """GBZ::segment_path (src/gbz.rs:477-489) for a batch of SEQUENCE ids (2 * path + orientation): (offsets[n + 1], tokens) with token =
+        (segment id << 1) | orientation -- the (Segment, Orientation) pairs SegmentPathIter yields, up to the place where it stops for a path
+        that is not a concatenation of whole segments.  GbwtHipError(BAD_ARGUMENT) without a node-to-segment translation (the reference: None)."""
+        ids = np.ascontiguousarray(seq_ids, dtype=np.uint64)
+        offsets = np.zeros(ids.size + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(self._L.gbwt_hip_segment_paths(self._h, self._ws, _ptr(ids), ids.size, _ptr(offsets), None, 0, C.byref(total)))
+        tokens = np.zeros(max(total.value, 1), dtype=np.uint64)
+        check(self._L.gbwt_hip_segment_paths(self._h, self._ws, _ptr(ids), ids.size, _ptr(offsets), _ptr(tokens), tokens.size, C.byref(total)))
+        return offsets, tokens[:total.value]
+
+    def segment_path(self, path_id, orientation=FORWARD):
+        """[(segment id, orientation), ...] of one path (GBZ::segment_path(path_id, orientation))."""
+        _, tokens = self.segment_paths([2 * path_id + (1 if orientation else 0)])
+        return [(int(t) >> 1, int(t) & 1) for t in tokens]
+
     def path_lines_device(self, path_ids, mode):
         """The same lines left in HBM: a Lines struct (device pointers to the text and to the n + 1 line offsets)."""
         ids = np.ascontiguousarray(path_ids, dtype=np.uint64)

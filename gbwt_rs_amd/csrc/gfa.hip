@@ -412,6 +412,58 @@ __global__ void __launch_bounds__(FORMAT_THREADS) k_format_chunks_segments(const
     }
 }
 
+// ---- GBZ::segment_path as data (src/gbz.rs:477-489; SegmentPathIter 1098-1169) ------------------------------------------------------------
+// One wave per chunk: the segment tokens of the chunk (positions that are the first node of a segment in the direction of travel) and
+// whether some position fits no segment.
+__global__ void __launch_bounds__(256) k_segment_chunk_tokens(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
+                                                               uint64_t chunks_cap, SegmentTables t, uint64_t *chunk_tokens, uint64_t *chunk_bad) {
+    const uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (c >= chunks_cap) return;
+    if (c >= chunk_first[n]) { if (lane == 0) { chunk_tokens[c] = 0; chunk_bad[c] = 0; } return; }
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, c);
+    uint64_t tokens = 0;
+    uint32_t bad = 0;
+    for (uint64_t k = r.lo + lane; k < r.hi; k += WAVE) {
+        uint32_t s;
+        const uint32_t kind = classify_position(t, nodes, r.begin, k, s);
+        if (kind == 2) bad = 1;
+        if (kind == 1) tokens++;
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) { tokens += __shfl_down(tokens, d, WAVE); bad |= __shfl_down(bad, d, WAVE); }
+    if (lane == 0) { chunk_tokens[c] = tokens; chunk_bad[c] = bad; }
+}
+
+// per row: its tokens, and whether every position fitted a whole segment (else the host replays the reference's iterator on the row)
+__global__ void __launch_bounds__(256) k_segment_row_tokens(const uint64_t *chunk_first, uint64_t n, const uint64_t *tokens_before, const uint64_t *bad_before, uint64_t *row_tokens, uint8_t *valid) {
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t a = chunk_first[p], b = chunk_first[p + 1];
+    row_tokens[p] = tokens_before[b] - tokens_before[a];
+    valid[p] = bad_before[b] == bad_before[a] ? 1 : 0;
+}
+
+// One workgroup per chunk: token k of a valid row = (segment << 1) | orientation, at row_start[row] + tokens of the row in front of the chunk + its rank in the chunk
+__global__ void __launch_bounds__(FORMAT_THREADS) k_segment_fill_tokens(const uint64_t *offsets, const uint32_t *nodes, uint64_t n, const uint64_t *chunk_first, const uint32_t *chunk_path,
+                                                                         const uint64_t *tokens_before, SegmentTables t, const uint8_t *valid, const uint64_t *row_start, uint64_t *out) {
+    using BlockScan = hipcub::BlockScan<uint32_t, FORMAT_THREADS>;
+    __shared__ typename BlockScan::TempStorage scan_storage;
+    if (blockIdx.x >= chunk_first[n]) return;
+    const ChunkRange r = chunk_range(chunk_first, chunk_path, offsets, blockIdx.x);
+    if (!valid[r.path]) return;
+    uint64_t cursor = row_start[r.path] + (tokens_before[blockIdx.x] - tokens_before[chunk_first[r.path]]);
+    for (uint64_t base = r.lo; base < r.hi; base += FORMAT_THREADS) {
+        const uint64_t k = base + threadIdx.x;
+        uint32_t s = 0, is_token = 0;
+        if (k < r.hi) is_token = classify_position(t, nodes, r.begin, k, s) == 1 ? 1u : 0u;
+        uint32_t pos, total;
+        BlockScan(scan_storage).ExclusiveSum(is_token, pos, total);
+        if (is_token) out[cursor + pos] = (static_cast<uint64_t>(s) << 1) | (nodes[k] & 1u);
+        cursor += total;
+        __syncthreads();
+    }
+}
+
 void require_gfa_capable(const gbwt_hip_index *ix) {
     if (!(ix->caps & GBWT_HIP_OPEN_GFA)) throw InvalidData("the handle was not opened for GFA lines (GBWT_HIP_OPEN_GFA)");
     if (!ix->host.is_gbz) throw InvalidData("GFA lines need a GBZ (graph + metadata), this handle holds a bare GBWT");
@@ -1147,6 +1199,87 @@ gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *ix, gbwt_hip_wo
     out->total = ws->lines_total;
     out->n = n;
     return GBWT_HIP_OK;
+    GBWT_HIP_GUARD_END
+}
+
+gbwt_hip_status gbwt_hip_segment_paths(const gbwt_hip_index *ix, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n, uint64_t *out_offsets, uint64_t *out_tokens,
+                                       uint64_t capacity, uint64_t *total) {
+    GBWT_HIP_GUARD_BEGIN
+    if (!ix || !ws || ws->index != ix || !total) return fail(GBWT_HIP_BAD_ARGUMENT, "null or mismatched index / workspace / total");
+    if (n && (!seq_ids || !out_offsets)) return fail(GBWT_HIP_BAD_ARGUMENT, "null seq_ids / out_offsets");
+    *total = 0;
+    const HostIndex &h = ix->host;
+    if (!(ix->caps & GBWT_HIP_OPEN_GFA)) return fail(GBWT_HIP_BAD_ARGUMENT, "the handle was not opened for GFA lines (GBWT_HIP_OPEN_GFA): the node-to-segment tables belong to that group");
+    if (!h.is_gbz || !h.has_translation || h.segment_starts.empty())
+        return fail(GBWT_HIP_BAD_ARGUMENT, "no node-to-segment translation (GBZ::segment_path returns None, src/gbz.rs:477-480)");
+    if (out_offsets) out_offsets[0] = 0;
+    if (n == 0) return GBWT_HIP_OK;
+    try {
+        gbwt_hip_paths paths{};
+        const gbwt_hip_status st = gbwt_hip_extract_device(ix, ws, seq_ids, n, &paths);
+        if (st != GBWT_HIP_OK) return st;
+        ws->lines_cached = false;                                        // (the line buffers of the workspace are used below)
+        HIP_CHECK(hipSetDevice(ix->device));
+        hipStream_t s = ws->stream;
+        const uint64_t chunks_cap = paths.total / LINE_CHUNK + n;
+        if (chunks_cap > 0x7FFFFFFFull) return fail(GBWT_HIP_UNSUPPORTED, "too many chunks in one batch: ask for fewer paths per call");
+        const size_t tb = scan_temp_bytes(std::max(n, chunks_cap));
+        ws->gfa_a.reserve(2 * (n + 1) * sizeof(uint64_t));
+        ws->gfa_chunk_first.reserve(2 * (n + 1) * sizeof(uint64_t));
+        ws->gfa_chunks.reserve((2 * chunks_cap + 2 * (chunks_cap + 1)) * sizeof(uint64_t) + (chunks_cap + 1) * sizeof(uint32_t));
+        ws->scan_temp.reserve(std::max<size_t>(tb, 16));
+        ws->gfa_valid.reserve(std::max<uint64_t>(n, 16));
+        uint64_t *d_row_tokens = ws->gfa_a.as<uint64_t>(), *d_row_start = d_row_tokens + (n + 1);
+        uint64_t *d_chunk_first = ws->gfa_chunk_first.as<uint64_t>(), *d_chunk_counts = d_chunk_first + (n + 1);
+        uint64_t *d_chunk_tokens = ws->gfa_chunks.as<uint64_t>(), *d_chunk_bad = d_chunk_tokens + chunks_cap, *d_tokens_before = d_chunk_bad + chunks_cap,
+                 *d_bad_before = d_tokens_before + (chunks_cap + 1);
+        uint32_t *d_chunk_path = reinterpret_cast<uint32_t *>(d_bad_before + (chunks_cap + 1));
+        uint8_t *d_valid = ws->gfa_valid.as<uint8_t>();
+        const SegmentTables tables = segment_tables(ix);
+        hipLaunchKernelGGL(k_chunk_counts, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, paths.d_offsets, n, d_chunk_counts);
+        launch_scan(d_chunk_counts, d_chunk_first, n, ws->scan_temp.ptr, tb, s);
+        hipLaunchKernelGGL(k_chunk_paths, dim3(static_cast<unsigned>((chunks_cap + 255) / 256)), dim3(256), 0, s, d_chunk_first, n, chunks_cap, d_chunk_path);
+        hipLaunchKernelGGL(k_segment_chunk_tokens, dim3(static_cast<unsigned>((chunks_cap + 3) / 4)), dim3(256), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path, chunks_cap,
+                           tables, d_chunk_tokens, d_chunk_bad);
+        launch_scan(d_chunk_tokens, d_tokens_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+        launch_scan(d_chunk_bad, d_bad_before, chunks_cap, ws->scan_temp.ptr, tb, s);
+        hipLaunchKernelGGL(k_segment_row_tokens, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, d_chunk_first, n, d_tokens_before, d_bad_before, d_row_tokens, d_valid);
+        std::vector<uint64_t> counts(n), offs(n + 1);
+        std::vector<uint8_t> valid(n);
+        HIP_CHECK(hipMemcpyAsync(counts.data(), d_row_tokens, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(valid.data(), d_valid, n, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(offs.data(), paths.d_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipGetLastError());
+        // rows that are not concatenations of whole segments: the reference's iterator stops somewhere inside them; replayed on the host
+        std::vector<std::vector<std::pair<uint64_t, bool>>> replayed(n);
+        std::vector<uint32_t> row;
+        for (uint64_t k = 0; k < n; k++) {
+            if (valid[k]) continue;
+            row.resize(offs[k + 1] - offs[k]);
+            if (!row.empty()) HIP_CHECK(hipMemcpy(row.data(), paths.d_nodes + offs[k], row.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint64_t seq_len = 0;
+            host_segment_path(h, row.data(), row.size(), replayed[k], seq_len);
+            counts[k] = replayed[k].size();
+        }
+        out_offsets[0] = 0;
+        for (uint64_t k = 0; k < n; k++) out_offsets[k + 1] = out_offsets[k] + counts[k];
+        *total = out_offsets[n];
+        if (!out_tokens || *total == 0) return GBWT_HIP_OK;               // the size query
+        if (capacity < *total) return fail(GBWT_HIP_CAPACITY, "output capacity too small for the segment tokens");
+        ws->gfa_text.reserve(std::max<uint64_t>(*total, 1) * sizeof(uint64_t));
+        HIP_CHECK(hipMemcpyAsync(d_row_start, out_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_segment_fill_tokens, dim3(static_cast<unsigned>(chunks_cap)), dim3(FORMAT_THREADS), 0, s, paths.d_offsets, paths.d_nodes, n, d_chunk_first, d_chunk_path,
+                           d_tokens_before, tables, d_valid, d_row_start, ws->gfa_text.as<uint64_t>());
+        HIP_CHECK(hipMemcpyAsync(out_tokens, ws->gfa_text.ptr, *total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipGetLastError());
+        for (uint64_t k = 0; k < n; k++)
+            for (size_t j = 0; j < replayed[k].size(); j++) out_tokens[out_offsets[k] + j] = (replayed[k][j].first << 1) | (replayed[k][j].second ? 1u : 0u);
+        return GBWT_HIP_OK;
+    } catch (const HipError &e) {
+        return status_of(e);
+    }
     GBWT_HIP_GUARD_END
 }
 

@@ -294,6 +294,14 @@ gbwt_hip_status gbwt_hip_path_lines(const gbwt_hip_index *index, gbwt_hip_worksp
 typedef struct { const char *d_text; const uint64_t *d_line_offsets; uint64_t total; uint64_t n; } gbwt_hip_lines;
 gbwt_hip_status gbwt_hip_path_lines_device(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *path_ids,
                                            uint64_t n, int mode, gbwt_hip_lines *out);
+/* GBZ::segment_path(path, orientation) for a batch of SEQUENCE ids (2 * path + orientation; src/gbz.rs:477-489, SegmentPathIter 1098-1169):
+ * a CSR of tokens, token = (segment id << 1) | orientation (0 forward, 1 reverse) -- the (Segment, Orientation) pairs the iterator yields, the
+ * segment as its index in the translation (GBZ::segment_iter order; names and sequences belong to the host's Graph).  A path that is not a
+ * concatenation of whole segments yields the tokens up to the place where the reference's iterator stops.  GBWT_HIP_BAD_ARGUMENT for a graph
+ * without a node-to-segment translation (the reference returns None) and for a handle that was not opened for GFA lines.  out_offsets has n + 1
+ * entries; out_tokens NULL = size query (*total = tokens of all rows; the rows are walked again by the fill call). */
+gbwt_hip_status gbwt_hip_segment_paths(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const uint64_t *seq_ids, uint64_t n, uint64_t *out_offsets,
+                                       uint64_t *out_tokens, uint64_t capacity, uint64_t *total);
 /* gbwt_hip_write_gfa: the whole file `gbunzip -t 1` writes (write_gfa_impl, src/bin/gbunzip.rs:205-226, default
  * path mode): H, S and L lines from the host copy of the graph, then P-lines and W-lines in ascending path id. */
 gbwt_hip_status gbwt_hip_write_gfa(const gbwt_hip_index *index, gbwt_hip_workspace *ws, const char *path);

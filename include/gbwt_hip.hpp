@@ -221,6 +221,19 @@ public:
         for (uint32_t v : r.nodes) out.emplace_back(node_id(v), node_orientation(v));
         return out;
     }
+    // GBZ::segment_path(path_id, orientation).collect(): (segment id, orientation) pairs -- the segment as its index in the node-to-segment
+    // translation --, or nullopt: no such path, or no translation (src/gbz.rs:477-489; SegmentPathIter 1098-1169)
+    std::optional<std::vector<std::pair<uint64_t, Orientation>>> segment_path(uint64_t path_id, Orientation orientation) const {
+        if (path_id >= paths() || !stats().has_translation) return std::nullopt;
+        const uint64_t id = encode_path(path_id, orientation);
+        uint64_t offsets[2] = {0, 0}, total = 0;
+        check(gbwt_hip_segment_paths(index_.get(), ws_.get(), &id, 1, offsets, nullptr, 0, &total));
+        std::vector<uint64_t> tokens(total);
+        if (total) check(gbwt_hip_segment_paths(index_.get(), ws_.get(), &id, 1, offsets, tokens.data(), total, &total));
+        std::vector<std::pair<uint64_t, Orientation>> out;
+        for (uint64_t t : tokens) out.emplace_back(t >> 1, (t & 1) ? Orientation::Reverse : Orientation::Forward);
+        return out;
+    }
     // GBZ::search_state, src/gbz.rs:508-510
     std::optional<BidirectionalState> search_state(uint64_t id, Orientation orientation) const { return bd_find(encode_node(id, orientation)); }
     // GBZ::follow_forward / follow_backward collected (StateIter, src/gbz.rs:519-544, 1211-1251); nullopt = no iterator

@@ -159,6 +159,8 @@ char *go_gbz_write_gfa_mode(const go_gbz *z, int path_mode, size_t *len);   /* 0
 char *go_metadata_pan_sn_path(const go_gbwt *g, uint64_t path_id, size_t *len);   /* Metadata::pan_sn_path; NULL = None */
 /* only the lines for the given path ids: mode 0 = P (path_to_p_line), 1 = W (path_to_w_line), 2 = P with PanSN names (path_to_pan_sn) */
 char *go_gbz_path_lines(const go_gbz *z, const uint64_t *path_ids, uint64_t n, int mode, size_t *len);
+/* GBZ::segment_path collected for sequence seq_id = 2 * path + orientation (src/gbz.rs:477-489, 1098-1169): (segment id << 1) | orientation per pair */
+int64_t go_gbz_segment_path(const go_gbz *z, uint64_t seq_id, uint64_t *out, uint64_t cap);
 void go_free(void *p);
 /* metadata peek for tests */
 uint64_t go_gbz_paths(const go_gbz *z);

@@ -609,6 +609,37 @@ static path_item *collect_path(const go_gbz *z, uint64_t path_id, uint64_t *n_it
     return items;
 }
 
+/* GBZ::segment_path(path, orientation) collected (src/gbz.rs:477-489; SegmentPathIter::next 1146-1169, visit / advance 1110-1141): the
+ * (segment, orientation) pairs the iterator yields for SEQUENCE seq_id = 2 * path + orientation, as (segment id << 1) | orientation; the
+ * iterator stops for good where a node is not the one the current segment expects, or maps to no segment.  Returns the number of pairs
+ * (at most `cap` are written), -1 without a node-to-segment translation or for a sequence that does not exist (None). */
+int64_t go_gbz_segment_path(const go_gbz *z, uint64_t seq_id, uint64_t *out, uint64_t cap) {
+    if (!(z->graph.flags & 1)) return -1;                                       /* has_translation */
+    int64_t len = go_gbwt_sequence(z->index, seq_id, NULL, 0);
+    if (len < 0) return -1;
+    uint64_t *nodes = (uint64_t *)malloc(((size_t)len + 1) * sizeof(uint64_t));
+    go_gbwt_sequence(z->index, seq_id, nodes, (uint64_t)len);
+    int have_next = 0, next_rev = 0;
+    uint64_t next_node = 0, seg_start = 0, seg_end = 0, cnt = 0;
+    for (int64_t k = 0; k < len; k++) {
+        uint64_t node_id = nodes[k] / 2; int rev = (int)(nodes[k] & 1);          /* support::decode_node */
+        if (have_next) {
+            if (node_id != next_node || rev != next_rev) break;                 /* fail = true */
+        } else {
+            if (!z_has_node(z, node_id)) break;                                 /* node_to_segment -> None: fail */
+            segment s = graph_node_to_segment(z, node_id);
+            if (cnt < cap && out) out[cnt] = (s.id << 1) | (uint64_t)rev;
+            cnt++;
+            seg_start = s.nodes_start; seg_end = s.nodes_end;
+            next_node = rev ? seg_end - 1 : seg_start; next_rev = rev; have_next = 1;    /* visit() */
+        }
+        if (!next_rev) { if (next_node + 1 < seg_end) next_node += 1; else have_next = 0; }     /* advance() */
+        else { if (next_node > seg_start) next_node -= 1; else have_next = 0; }
+    }
+    free(nodes);
+    return (int64_t)cnt;
+}
+
 static void sb_item_name(sbuf *b, const path_item *it) {
     if (it->name) sb_write(b, it->name, it->name_len); else sb_u64(b, it->node_id);
 }

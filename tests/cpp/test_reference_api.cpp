@@ -126,6 +126,23 @@ int main(int argc, char **argv) {
     // Metadata::pan_sn_path, doc-test src/gbwt.rs:596-598
     REQUIRE(gbz.pan_sn_path(3) == "sample#2#A");
     REQUIRE(gbz.path_lines({3}, 2) == "P\tsample#2#A\t11+,13+,14+,16+,17+\t*\n");
+    // GBZ::segment_path, src/gbz/tests.rs:466-497 (three paths of translation.gbz as segment identifiers; reverse = reversed and flipped; past the
+    // end and without a translation: None) and the doc-test src/gbz.rs:1080-1092 (path 2 reversed starts with s17-, s16-)
+    {
+        GBZ translated(dir + "/translation.gbz");
+        const std::vector<std::vector<uint64_t>> truth = {{0, 1, 3, 5, 7}, {0, 1, 3, 5, 7}, {0, 2, 3, 6, 7}};
+        REQUIRE(translated.paths() == truth.size());
+        for (uint64_t p = 0; p < truth.size(); p++) {
+            const auto f = translated.segment_path(p, Orientation::Forward), r = translated.segment_path(p, Orientation::Reverse);
+            REQUIRE(f && r && f->size() == truth[p].size() && r->size() == truth[p].size());
+            for (size_t k = 0; k < truth[p].size(); k++) {
+                REQUIRE((*f)[k] == std::make_pair(truth[p][k], Orientation::Forward));
+                REQUIRE((*r)[k] == std::make_pair(truth[p][truth[p].size() - 1 - k], Orientation::Reverse));
+            }
+        }
+        REQUIRE(!translated.segment_path(truth.size(), Orientation::Forward) && !translated.segment_path(truth.size(), Orientation::Reverse));
+        REQUIRE(!gbz.segment_path(0, Orientation::Forward));                 // example.gbz has no node-to-segment translation
+    }
     // a unidirectional index refuses what the reference asserts on (src/gbwt.rs:237,312)
     try {
         GBWT bad(dir + "/does-not-exist.gbwt");

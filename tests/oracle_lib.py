@@ -143,6 +143,7 @@ def lib():
         "go_gbz_write_gfa_mode": (p, [p, C.c_int, C.POINTER(C.c_size_t)]),
         "go_metadata_pan_sn_path": (p, [p, u64, C.POINTER(C.c_size_t)]),
         "go_gbz_path_lines": (p, [p, p, u64, C.c_int, C.POINTER(C.c_size_t)]),
+        "go_gbz_segment_path": (C.c_int64, [p, u64, p, u64]),
         "go_free": (None, [p]),
         "go_gbz_paths": (u64, [p]),
         "go_gbwt_has_metadata": (C.c_int, [p]),
@@ -542,6 +543,16 @@ class OracleGBZ:
         out = C.string_at(p, n.value).decode()
         self.L.go_free(p)
         return out
+
+    def segment_path(self, seq_id):
+        """GBZ::segment_path(path, orientation) collected for sequence 2 * path + orientation: [(segment id, orientation), ...], or None
+        (no translation / no such sequence); src/gbz.rs:477-489, SegmentPathIter 1098-1169."""
+        n = self.L.go_gbz_segment_path(self.h, seq_id, None, 0)
+        if n < 0:
+            return None
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self.L.go_gbz_segment_path(self.h, seq_id, out.ctypes.data, n)
+        return [(int(t) >> 1, int(t) & 1) for t in out[:n]]
 
     def path_lines(self, path_ids, mode):
         ids = np.ascontiguousarray(path_ids, dtype=np.uint64)

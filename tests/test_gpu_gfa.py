@@ -145,6 +145,39 @@ def test_path_modes_on_synthetic(tmp_path):
     assert dev.path_lines(ids, 2) == oracle.path_lines(ids, 2)
 
 
+def test_segment_paths_as_data(tmp_path):
+    """gbwt_hip_segment_paths = GBZ::segment_path for a batch of sequence ids (src/gbz.rs:477-489; SegmentPathIter 1098-1169): the reference's own
+    known answers on translation.gbz (src/gbz/tests.rs:466-497: three paths as segment ids, reverse = reversed and flipped; past-the-end ids are
+    empty rows), valid paths of several chunks and broken paths (the iterator stops inside them) against the oracle in both orientations, in one
+    batch and one by one; a graph without a translation: BAD_ARGUMENT (the reference returns None)."""
+    dev, oracle = G.GBZ.load(os.path.join(O.GOLDEN, "translation.gbz")), O.OracleGBZ(os.path.join(O.GOLDEN, "translation.gbz"))
+    truth = [[0, 1, 3, 5, 7], [0, 1, 3, 5, 7], [0, 2, 3, 6, 7]]
+    for p, segments in enumerate(truth):
+        assert dev.segment_path(p, G.FORWARD) == [(s, 0) for s in segments] == oracle.segment_path(2 * p)
+        assert dev.segment_path(p, G.REVERSE) == [(s, 1) for s in reversed(segments)] == oracle.segment_path(2 * p + 1)
+    off, tokens = dev.segment_paths([5, 0, 6, 7, 3])                     # ids 6, 7: past the end -> no iterator, an empty row
+    assert off.tolist() == [0, 5, 10, 10, 10, 15] and [(int(t) >> 1, int(t) & 1) for t in tokens[:5]] == [(7, 1), (6, 1), (3, 1), (2, 1), (0, 1)]
+    starts = [1, 4, 5, 7, 8, 12]
+    fwd = lambda a, b: [2 * v for v in range(a, b + 1)]
+    rev = lambda a, b: [2 * v + 1 for v in range(b, a - 1, -1)]
+    unit = fwd(1, 3) + fwd(4, 4) + rev(5, 6) + fwd(7, 7) + fwd(8, 11) + rev(12, 12)
+    paths = [unit, fwd(2, 3) + fwd(4, 4), fwd(1, 2) + fwd(4, 4), fwd(1, 3) + rev(5, 5) + fwd(7, 7), fwd(4, 4) + fwd(9, 9), fwd(8, 9) + rev(9, 9), fwd(1, 3) + fwd(1, 3),
+             unit * 800, [], fwd(12, 12), (fwd(1, 3) + rev(5, 6)) * 2000 + fwd(2, 2)]                # valid, broken in six ways, three chunks long, empty, long and broken at its very end
+    dev, oracle = translated_graph(tmp_path, paths, starts, "segment_paths.gbz")
+    ids = np.arange(2 * len(paths), dtype=np.uint64)
+    off, tokens = dev.segment_paths(ids)
+    for k, seq in enumerate(ids):
+        want = oracle.segment_path(int(seq))
+        got = [(int(t) >> 1, int(t) & 1) for t in tokens[int(off[k]):int(off[k + 1])]]
+        assert got == want, (int(seq), got[:8], want[:8])
+        assert dev.segment_path(int(seq) // 2, int(seq) & 1) == want
+    assert len(oracle.segment_path(2 * 7)) == 6 * 800 and len(oracle.segment_path(2 * 1)) == 1                # (the long valid path; the path that enters a segment in its middle)
+    plain = G.GBZ.load(os.path.join(O.GOLDEN, "example.gbz"))
+    with pytest.raises(G.GbwtHipError) as e:
+        plain.segment_paths([0])
+    assert e.value.status == G._lib.BAD_ARGUMENT
+
+
 def test_reference_samples_tag_in_the_header(tmp_path):
     """write_gfa_header (src/bin/gbunzip.rs:193-203): a GBWT with the `reference_samples` tag gets "H\tVN:Z:1.1\tRS:Z:<value>" -- in every
     path mode, the rest of the file as without the tag (this version of the reference reads the tag nowhere else on the path)."""

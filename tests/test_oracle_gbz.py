@@ -95,3 +95,17 @@ def test_path_modes(name):
         assert q[1] == z.pan_sn_path(i).encode() and p[0] == q[0] == b"P" and p[2:] == q[2:]
     if name == "example.gbz":
         assert z.path_lines([3], 2) == b"P\tsample#2#A\t11+,13+,14+,16+,17+\t*\n"
+
+
+def test_segment_paths_known_answers():
+    """src/gbz/tests.rs:466-497 (segment_paths): translation.gbz has three paths as sequences of segment identifiers; the reverse orientation is
+    the reversed list with every orientation flipped; a past-the-end path and a graph without a translation give None.  The doc-test of
+    SegmentPathIter (src/gbz.rs:1080-1092): path 2 reversed = s17-, s16-, s14-, s13-, s11- (segment ids 7, 6, 3, 2, 0)."""
+    z = O.OracleGBZ(os.path.join(O.GOLDEN, "translation.gbz"))
+    truth = [[0, 1, 3, 5, 7], [0, 1, 3, 5, 7], [0, 2, 3, 6, 7]]
+    for p, segments in enumerate(truth):
+        assert z.segment_path(2 * p) == [(s, 0) for s in segments]
+        assert z.segment_path(2 * p + 1) == [(s, 1) for s in reversed(segments)]
+    assert z.segment_path(2 * 2 + 1) == [(7, 1), (6, 1), (3, 1), (2, 1), (0, 1)]
+    assert z.segment_path(2 * len(truth)) is None and z.segment_path(2 * len(truth) + 1) is None
+    assert O.OracleGBZ(os.path.join(O.GOLDEN, "example.gbz")).segment_path(0) is None            # no translation
