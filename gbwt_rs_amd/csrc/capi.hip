@@ -214,7 +214,6 @@ void decode_starts_on_device(gbwt_hip_index &ix) {
     const HostIndex::StartsView v = ix.host.starts_view;
     const uint64_t data_len = ix.stats.data_bytes, ones = v.ones;
     const bool narrow = data_len < (uint64_t(1) << 32);
-    ix.starts.reserve((ones + 1) * (narrow ? sizeof(uint32_t) : sizeof(uint64_t)));
     DeviceBuffer words, ranks, scan_tmp, flags;
     words.reserve(std::max<uint64_t>(v.high_words + v.low_words, 1) * sizeof(uint64_t));
     ranks.reserve(2 * (v.high_words + 1) * sizeof(uint64_t));
@@ -228,15 +227,18 @@ void decode_starts_on_device(gbwt_hip_index &ix) {
     launch_ef_counts(d_high, v.high_words, d_counts, nullptr);
     if (v.high_words) launch_scan(d_counts, d_rank, v.high_words, scan_tmp.ptr, tb, nullptr);
     else HIP_CHECK(hipMemsetAsync(d_rank, 0, sizeof(uint64_t), nullptr));
+    // the declared number of ones must be the number of set bits BEFORE it sizes the table (a corrupt count could ask for 32 times the file
+    // size of device memory and surface as a device error instead of InvalidData: the host decode checks in the same order)
+    uint64_t total = 0;
+    HIP_CHECK(hipMemcpy(&total, d_rank + v.high_words, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (total != ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
+    ix.starts.reserve((ones + 1) * (narrow ? sizeof(uint32_t) : sizeof(uint64_t)));
     launch_ef_values(d_high, v.high_words, d_rank, d_low, v.low_words, static_cast<uint32_t>(v.low_width), ones, data_len,
                      narrow ? ix.starts.as<uint32_t>() : nullptr, narrow ? nullptr : ix.starts.as<uint64_t>(), nullptr);
     launch_starts_check(narrow ? ix.starts.as<uint32_t>() : nullptr, narrow ? nullptr : ix.starts.as<uint64_t>(), ones, flags.as<uint32_t>(), nullptr);
-    uint64_t total = 0;
     uint32_t bad = 0;
-    HIP_CHECK(hipMemcpy(&total, d_rank + v.high_words, sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(&bad, flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipGetLastError());
-    if (total != ones) throw InvalidData("SparseVector: high bitvector does not have the declared number of ones");
     if (bad != 0) throw InvalidData("BWT: record starts are not sorted offsets into the data");
     ix.starts_uploaded = true;
 }

@@ -691,6 +691,7 @@ void fill_line_cache_at_open(gbwt_hip_index &ix) {
         first[p + 1] = first[p] + (len == 0 ? 1 : (len + LINE_CHUNK - 1) / LINE_CHUNK);
         max_samples = std::max(max_samples, ix.sample_counts[2 * p]);
     }
+    if (static_cast<uint64_t>(max_samples) * paths > (uint64_t(1) << 36)) return;      // (walkers = most samples of a path x paths: beyond any launch; such a handle sizes per request)
     HIP_CHECK(hipSetDevice(ix.device));
     ix.lc_chunk_first.reserve((paths + 1) * sizeof(uint64_t));
     ix.lc_text.reserve(std::max<uint64_t>(first[paths], 1) * sizeof(uint64_t));
