@@ -27,7 +27,7 @@ std::string &last_error_slot() {
 }
 }  // namespace gbwt_hip
 
-namespace gbwt_hip { void upload_label_lengths(gbwt_hip_index &ix); void fill_line_cache_at_open(gbwt_hip_index &ix); }
+namespace gbwt_hip { void upload_label_lengths(gbwt_hip_index &ix); void mask_label_lengths(gbwt_hip_index &ix); void fill_line_cache_at_open(gbwt_hip_index &ix); }
 
 namespace {
 
@@ -613,6 +613,7 @@ gbwt_hip_status open_common(std::unique_ptr<gbwt_hip_index> ix, gbwt_hip_index *
     }
     // the sizes of every path's GFA line, once (gfa.hip): needs the device passes (samples, descriptors) AND the GFA tables (label lengths)
     if (ix->caps & GBWT_HIP_OPEN_GFA) {
+        mask_label_lengths(*ix);          // (needs both as well: the label lengths from that thread, the record bytes and starts from this one)
         fill_line_cache_at_open(*ix);
         trace.mark("line sizes of every path");
     }
@@ -754,6 +755,7 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
         ~EarlyCopy() { if (worker.joinable()) worker.join(); }
     } early;
     gbwt_hip_index *raw = ix.get();
+    static const bool lazy_host_records = [] { const char *e = std::getenv("GBWT_HIP_LAZY_HOST_RECORDS"); return !(e && e[0] == '0'); }();
     load_index_file_into(path, ix->host, true, [raw, &early](HostIndex &h) {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0 || hipSetDevice(raw->device) != hipSuccess) { (void)hipGetLastError(); return; }   // open_common says so
@@ -793,7 +795,7 @@ gbwt_hip_status gbwt_hip_open_file_flags(const char *path, int device, uint32_t 
             for (auto &t : pool) t.join();
             for (hipError_t r : results) if (r != hipSuccess) early.result = r;
         });
-    });
+    }, lazy_host_records);
     if (early.worker.joinable()) {
         // the starts are decoded by now and the copy of the record bytes has a few milliseconds to go: the starts go out under them
         fill_stats(*ix);
@@ -871,7 +873,7 @@ gbwt_hip_status gbwt_hip_memory_usage(const gbwt_hip_index *index, const gbwt_hi
     // (the full-width two-step blocks: at open, or by the first request that needs them -- the atomic says when they are there)
     if (ix.dev.cblocks != nullptr || ix.lazy_cblocks.load(std::memory_order_acquire) != nullptr) out->index_device_bytes += ix.cblocks.bytes;
     const HostIndex &h = ix.host;
-    out->index_host_bytes = h.data.size() + h.starts.size() * sizeof(uint64_t) + h.da_samples.size() * sizeof(uint64_t) + h.path_names.size() * sizeof(PathName) +
+    out->index_host_bytes = (h.records_made() ? h.data.size() + h.starts.size() * sizeof(uint64_t) : 0) + h.da_samples.size() * sizeof(uint64_t) + h.path_names.size() * sizeof(PathName) +
                             h.sample_names.bytes.size() + h.contig_names.bytes.size() + h.sequences_labels.bytes.size() + h.sequences_labels.offsets.size() * sizeof(uint64_t) +
                             h.segment_names.bytes.size() + h.segment_names.offsets.size() * sizeof(uint64_t) + h.segment_starts.size() * sizeof(uint64_t) +
                             ix.sample_counts.size() * sizeof(uint32_t);

@@ -474,6 +474,7 @@ void require_gfa_capable(const gbwt_hip_index *ix) {
 bool host_edges(const HostIndex &h, uint64_t rec, std::vector<std::pair<uint64_t, uint64_t>> &edges) {
     edges.clear();
     if (rec >= h.records()) return false;
+    h.ensure_records();
     const uint8_t *p = h.data.data() + h.starts[rec], *end = h.data.data() + h.starts[rec + 1];
     auto varint = [&](uint64_t &v) -> bool {
         v = 0;
@@ -502,6 +503,7 @@ bool host_has_node(const HostIndex &h, uint64_t node_id) {
     const uint64_t node = 2 * node_id, first = h.alphabet_offset + 1;
     if (node < first || node >= h.alphabet_size) return false;
     const uint64_t rec = node - h.alphabet_offset;
+    h.ensure_records();
     return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;
 }
 
@@ -610,23 +612,20 @@ static void upload_line_headers(gbwt_hip_index &ix) {
     HIP_CHECK(hipMemcpy(ix.line_fragment.ptr, fragment.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 }
 
-// Uploads the label length of every potential node (0 where GBZ::has_node is false, src/gbz.rs:286-289).
+// Uploads the label length of every potential node; mask_label_lengths below then zeroes those of the nodes that do not exist (GBZ::has_node,
+// src/gbz.rs:286-289) ON THE DEVICE, from the record bytes and starts there -- the host's image of them is not made by an open
+// (HostIndex::ensure_records), and the device passes that put them there may still be running on another thread when this one is.
 void upload_label_lengths(gbwt_hip_index &ix) {
     const HostIndex &h = ix.host;
     if (!h.is_gbz) return;
-    const uint64_t first = h.alphabet_offset + 1;
-    std::vector<uint32_t> len(h.sequences_labels.size() + 1, 0);
+    std::vector<uint32_t, DefaultInitAllocator<uint32_t>> len(h.sequences_labels.size() + 1);
+    len.back() = 0;
     {   // (sixteen million nodes in a config-4-shaped GBZ: a few threads)
         const uint64_t n = h.sequences_labels.size();
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const unsigned pieces = n >= (uint64_t(1) << 23) ? std::max(std::min(8u, hw), std::min(static_cast<unsigned>(std::min<uint64_t>(n >> 21, 32)), hw)) : 1u;   // (109 M nodes: 32 threads)
         auto piece = [&](unsigned p) {
-            for (uint64_t s = n * p / pieces, end = n * (p + 1) / pieces; s < end; s++) {
-                const uint64_t node = 2 * s + first;              // forward GBWT node of sequence s
-                const uint64_t rec = node - h.alphabet_offset;
-                const bool real = rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;   // BWT::id_iter
-                len[s] = real ? static_cast<uint32_t>(h.sequences_labels.len(s)) : 0u;
-            }
+            for (uint64_t s = n * p / pieces, end = n * (p + 1) / pieces; s < end; s++) len[s] = static_cast<uint32_t>(h.sequences_labels.len(s));
         };
         std::vector<std::thread> pool;
         for (unsigned p = 1; p < pieces; p++) pool.emplace_back(piece, p);
@@ -665,6 +664,15 @@ void upload_label_lengths(gbwt_hip_index &ix) {
     put(ix.node_real, node_real.data(), node_real.size());
 }
 
+}  // namespace gbwt_hip
+
+namespace gbwt_hip {
+void mask_label_lengths(gbwt_hip_index &ix) {
+    if (!ix.host.is_gbz || ix.label_len.ptr == nullptr) return;
+    launch_mask_label_lengths(ix.dev, ix.label_len.as<uint32_t>(), ix.host.sequences_labels.size(), nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+}
 }  // namespace gbwt_hip
 
 // The line cache of a handle, filled by ONE walk at open (kernels.hpp: LineCacheFill; open_walks.hip: k_segment_text): usable when the index
@@ -977,6 +985,7 @@ uint64_t host_graph_lines(const HostIndex &h, bool translated, PositionalFile &f
     }
     // segments + links over the real nodes (write_segments / write_links, src/bin/gbunzip.rs:230-317)
     const uint64_t first = h.alphabet_offset + 1, potential = h.sequences_labels.size();
+    h.ensure_records();                                            // the graph lines read the host's image of the records (made now if this is its first use)
     auto real = [&](uint64_t seq) {
         const uint64_t rec = 2 * seq + first - h.alphabet_offset;
         return rec < h.records() && h.starts[rec + 1] > h.starts[rec] && h.data[h.starts[rec]] != 0;

@@ -18,6 +18,7 @@
 #include <exception>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 namespace gbwt_hip {
@@ -102,6 +103,7 @@ void skip_option(Elements &in) {
 struct Deferred {
     std::vector<std::function<void()>> tasks, background;      // background: may still be running when the loader returns (HostIndex::pending)
     std::function<void()> starts_task;                         // the decode of the record starts: foreground, or background when the caller decodes them on the device
+    std::function<void()> records_copy;                        // the host's copy of the record bytes: background -- or, with the starts, on first use (HostIndex::ensure_records)
     bool small = false;                                        // a file of a few megabytes: threads would cost more than they save
     void run() {
         if (tasks.empty()) return;
@@ -393,14 +395,14 @@ void read_gbwt(Elements &in, HostIndex &h, Deferred &later) {
     h.file_data = data; h.file_data_len = data_len;
     // (the host's copy of the record bytes: 1.8 GB for config 4 at its stated size -- 0.9 s as ONE assign() that pages its target in on one thread,
     // the longest thing in that open; in pieces on a few threads into a vector whose resize() does not touch it: profiles/r06_c4_open.txt)
-    later.background.push_back([&h, data, data_len]() {
+    later.records_copy = [&h, data, data_len]() {
         h.data.resize(data_len);
         const unsigned pieces = data_len >= (uint64_t(64) << 20) ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
         run_pieces(pieces, [&](unsigned p) {
             const uint64_t lo = data_len / pieces * p, hi = p + 1 == pieces ? data_len : data_len / pieces * (p + 1);
             if (hi > lo) std::memcpy(h.data.data() + lo, data + lo, hi - lo);
         });
-    });
+    };
     h.starts_view = HostIndex::StartsView{index.ones, index.universe, index.high.n_words, index.low.width, index.low.n_words, index.high.words, index.low.words};
     later.starts_task = [&h, index, data_len]() {
         h.starts = decode_sparse(index);
@@ -517,15 +519,32 @@ struct HostIndex::Pending {
     ~Pending() { if (worker.joinable()) worker.join(); }
 };
 
+struct HostIndex::LazyRecords {
+    std::shared_ptr<Pending> image;                            // the mapping `make` reads -- and record_bytes() / starts_view point into: lives as long as the index
+    std::function<void()> make;
+    std::once_flag once;
+    std::atomic<bool> made{false};
+};
+
 void HostIndex::finish() {
     if (!pending) return;
-    std::shared_ptr<Pending> p = std::move(pending);          // record_bytes() now answers from `data`
+    std::shared_ptr<Pending> p = std::move(pending);
     pending.reset();
     if (p->worker.joinable()) p->worker.join();
-    file_data = nullptr; file_data_len = 0;
-    starts_on_device = false; starts_view = StartsView{};         // `starts` is there (or the decode has thrown, below): the mapping goes
+    if (!lazy_records) {                                           // record_bytes() now answers from `data`, `starts` is there (or the decode has
+        file_data = nullptr; file_data_len = 0;                    // thrown, below): the mapping goes
+        starts_on_device = false; starts_view = StartsView{};
+    }
     if (p->failure) std::rethrow_exception(p->failure);
     if (is_gbz) check_graph(*this);
+}
+
+bool HostIndex::records_made() const { return !lazy_records || lazy_records->made.load(std::memory_order_acquire); }
+
+void HostIndex::ensure_records() const {
+    if (!lazy_records) return;
+    LazyRecords &lazy = *lazy_records;
+    std::call_once(lazy.once, [&lazy]() { lazy.make(); lazy.made.store(true, std::memory_order_release); });   // (a throw leaves the flag unset: the next caller tries again)
 }
 
 namespace {
@@ -542,7 +561,7 @@ struct LoadTrace {
 };
 }  // namespace
 
-void load_index_file_into(const std::string &path, HostIndex &h, bool background, const std::function<void(HostIndex &)> &on_located) {
+void load_index_file_into(const std::string &path, HostIndex &h, bool background, const std::function<void(HostIndex &)> &on_located, bool lazy_records) {
     LoadTrace trace;
     h = HostIndex();
     std::shared_ptr<HostIndex::Pending> pending = std::make_shared<HostIndex::Pending>();
@@ -569,6 +588,7 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
         for (auto &t : later.background) later.tasks.push_back(std::move(t));
         later.background.clear();
     }
+    const bool in_background = background && !later.small;
     trace.mark("sections located");
     if (on_located) {
         // record_bytes() answers from the mapping from here on.  `h` keeps its share of the mapping across the decodes below as well:
@@ -579,10 +599,22 @@ void load_index_file_into(const std::string &path, HostIndex &h, bool background
         on_located(h);
     }
     // the record starts: decoded here, or -- when the caller has taken the located index to the device -- behind the caller's back
+    // ... and with them the host's copy of the record bytes: behind the caller's back as well, or -- lazy_records -- when somebody asks
+    if (h.starts_on_device && in_background && lazy_records && later.starts_task && later.records_copy) {
+        h.lazy_records = std::make_shared<HostIndex::LazyRecords>();
+        h.lazy_records->image = pending;
+        HostIndex *target = &h;                                    // (the index stays where it is: it is a member of the handle)
+        h.lazy_records->make = [target, copy = std::move(later.records_copy), decode = std::move(later.starts_task)]() {
+            try { run_pieces(2, [&](unsigned p) { if (p == 0) copy(); else decode(); }); }
+            catch (...) { target->data = Bytes(); target->starts = Words(); throw; }
+        };
+        later.records_copy = nullptr; later.starts_task = nullptr;
+    }
     if (later.starts_task) {
-        if (h.starts_on_device && background && !later.small) later.background.push_back(std::move(later.starts_task));
+        if (h.starts_on_device && in_background) later.background.push_back(std::move(later.starts_task));
         else { h.starts_on_device = false; later.tasks.push_back(std::move(later.starts_task)); }
     }
+    if (later.records_copy) (in_background ? later.background : later.tasks).push_back(std::move(later.records_copy));
     later.run();
     trace.mark("foreground decodes");
     if (!background) {

@@ -99,9 +99,21 @@ struct HostIndex {
     std::shared_ptr<Pending> pending;
     const uint8_t *file_data = nullptr;
     uint64_t file_data_len = 0;
-    const uint8_t *record_bytes() const { return pending ? file_data : data.data(); }
-    uint64_t record_bytes_len() const { return pending ? file_data_len : data.size(); }
+    const uint8_t *record_bytes() const { return file_data ? file_data : data.data(); }
+    uint64_t record_bytes_len() const { return file_data ? file_data_len : data.size(); }
     void finish();
+
+    // THE HOST'S OWN IMAGE OF THE RECORDS, MADE ON FIRST USE (round 6).  `data` and `starts` are read by the graph lines of the whole-file
+    // writer (S / L lines: GBZ::has_node, Record::decompress_edges), by the tables of a node-to-segment translation and by save_index_file --
+    // by nothing an open, an extraction, a search or a lines request does.  For an HPRC-sized file they are 3.5 GB of freshly faulted pages
+    // (0.6-0.9 s on sixteen threads next to the device passes, which take 0.4: the longest thing in that open, profiles/r06_c4_open.txt).  A
+    // load with `lazy_records` whose caller decodes the starts on the device therefore leaves them unmade and keeps the file mapped for as
+    // long as the index lives; ensure_records() -- idempotent, safe from several threads -- makes them when somebody asks.  Everything
+    // else answers from the mapping: record_bytes(), records(), record_start().
+    struct LazyRecords;
+    std::shared_ptr<LazyRecords> lazy_records;
+    void ensure_records() const;
+    bool records_made() const;
 };
 
 // Parses a .gbwt or .gbz (detected by the header tag).  Throws InvalidData / IoError.
@@ -109,7 +121,8 @@ HostIndex load_index_file(const std::string &path);
 // The same into `out`, which must stay where it is until out.finish() has returned when `background` is set (see HostIndex::pending).
 // `on_located` (optional) runs once the file has been walked -- header fields set, record_bytes() valid -- and before anything is decoded:
 // an open starts the host-to-device copy of the record bytes there, next to the Elias-Fano decode of the starts.
-void load_index_file_into(const std::string &path, HostIndex &out, bool background, const std::function<void(HostIndex &)> &on_located = nullptr);
+// `lazy_records`: see HostIndex::ensure_records (only with `background`, a file of 4 MB or more, and an on_located that has set starts_on_device).
+void load_index_file_into(const std::string &path, HostIndex &out, bool background, const std::function<void(HostIndex &)> &on_located = nullptr, bool lazy_records = false);
 
 // Writes the index back in the simple-sds format (GBWT v5; GBZ v1 container with an uncompressed
 // graph, version 3), following the Serialize impls src/gbwt.rs:389-400, src/gbz.rs:662-672,

@@ -190,6 +190,9 @@ void launch_ef_counts(const uint64_t *d_high, uint64_t high_words, uint64_t *d_c
 void launch_ef_values(const uint64_t *d_high, uint64_t high_words, const uint64_t *d_rank, const uint64_t *d_low, uint64_t low_words, uint32_t width, uint64_t ones,
                       uint64_t data_len, uint32_t *d_starts32, uint64_t *d_starts64, hipStream_t s);
 void launch_starts_check(const uint32_t *d_starts32, const uint64_t *d_starts64, uint64_t ones, uint32_t *d_flags, hipStream_t s);
+// label_len[s] = 0 for every potential node s < n whose forward record (2 s + 1) is empty or has no edge (GBZ::has_node); reads the record bytes
+// and starts on the device -- the host's image of them may not exist (HostIndex::ensure_records)
+void launch_mask_label_lengths(const DeviceIndex &ix, uint32_t *d_label_len, uint64_t n, hipStream_t s);
 
 // inclusive scan of lengths[n] into offsets[1..n], offsets[0] = 0 (hipcub); temp storage managed by caller
 size_t scan_temp_bytes(uint64_t n);

@@ -794,6 +794,24 @@ __global__ void __launch_bounds__(256) k_starts_check(const uint32_t *s32, const
     if (a > b) atomicOr(flags, 1u);
 }
 
+// GBZ::has_node (src/gbz.rs:286-289) for every potential node s (forward GBWT node 2 s + first, record 2 s + 1): where the record is empty or
+// holds no edge the node does not exist and its label length becomes 0 (BWT::id_iter skips such records, src/bwt.rs:341-351)
+__global__ void __launch_bounds__(256) k_mask_label_lengths(DeviceIndex ix, uint32_t *label_len, uint64_t n) {
+    const uint64_t s = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t rec = 2 * s + 1;
+    bool real = false;
+    if (rec < ix.n_records) {
+        const uint64_t a = ix.starts32 ? ix.starts32[rec] : ix.starts64[rec], b = ix.starts32 ? ix.starts32[rec + 1] : ix.starts64[rec + 1];
+        real = b > a && b <= ix.data_len && ix.data[a] != 0;
+    }
+    if (!real) label_len[s] = 0;
+}
+
+void launch_mask_label_lengths(const DeviceIndex &ix, uint32_t *d_label_len, uint64_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_mask_label_lengths, dim3(grid_for(n, 256)), dim3(256), 0, s, ix, d_label_len, n);
+}
+
 void launch_ef_counts(const uint64_t *d_high, uint64_t high_words, uint64_t *d_counts, hipStream_t s) {
     if (high_words) hipLaunchKernelGGL(k_ef_counts, dim3(grid_for(high_words, 256)), dim3(256), 0, s, d_high, high_words, d_counts);
 }

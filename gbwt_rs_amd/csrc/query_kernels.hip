@@ -93,7 +93,18 @@ __device__ __forceinline__ bool block_follow(const DeviceIndex &ix, const RawDes
     else return false;
     const uint32_t len = d.B.w;
     const uint32_t ps = start < len ? static_cast<uint32_t>(start) : len, pe = end < len ? static_cast<uint32_t>(end) : len;
-    const uint32_t z0 = count0_before(ix, d, rec, ps), z1 = count0_before(ix, d, rec, pe);
+    // two rank-block lookups -- or fewer: nothing lies before position 0 (the first extension of every find), and a range that ends in the
+    // block it starts in (most ranges after a few extensions) reads that block once: one 16-byte load instead of two per lane
+    uint32_t z0, z1;
+    if (two && ps != 0 && pe < len && (ps >> RANK_BLOCK_SHIFT) == (pe >> RANK_BLOCK_SHIFT)) {
+        const uint4 K = ix.blocks[d.C.z + (ps >> RANK_BLOCK_SHIFT)];
+        const uint64_t bits = (static_cast<uint64_t>(K.y) << 32) | K.x;
+        z0 = ps - (K.z + __popcll(bits & ((uint64_t(1) << (ps & 63u)) - 1)));
+        z1 = pe - (K.z + __popcll(bits & ((uint64_t(1) << (pe & 63u)) - 1)));
+    } else {
+        z0 = ps == 0 ? 0u : count0_before(ix, d, rec, ps);
+        z1 = count0_before(ix, d, rec, pe);
+    }
     const uint32_t before_s = rank ? ps - z0 : z0, before_e = rank ? pe - z1 : z1;
     const uint64_t base = rank ? d.A.w : d.A.y;
     rstart = base + before_s; rend = base + before_e;

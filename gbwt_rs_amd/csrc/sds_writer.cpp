@@ -148,6 +148,7 @@ void write_gbwt(Out &out, const HostIndex &h) {
     out.word(h.sequences); out.word(h.size); out.word(h.alphabet_offset); out.word(h.alphabet_size);
     out.word((h.bidirectional ? 1u : 0u) | (h.has_metadata ? 2u : 0u) | 4u);
     write_tags(out, h.tags);
+    h.ensure_records();
     write_sparse(out, h.data.size(), h.starts.data(), h.records());
     out.bytes(h.data.data(), h.data.size());
     out.word(h.da_samples.size());

@@ -89,7 +89,11 @@ int gbwt_hip_device_count(void);
  * Detects GBWT vs GBZ by the header tag, rejects what the reference rejects (src/headers.rs:101-115,
  * 229-231; src/bwt.rs:179-181; src/gbz.rs:684-692) and uploads the record stream, the dense record
  * start array (decoded from the Elias-Fano index) and the decompressed endmarker (src/gbwt.rs:413-414)
- * to `device`. */
+ * to `device`.
+ * THE FILE STAYS MAPPED while the handle is open (files of 4 MB or more): the host's own copy of the record bytes and starts -- read by the
+ * S / L lines of gbwt_hip_write_gfa* and by a node-to-segment translation, by nothing else -- is made from the mapping when it is first
+ * needed, not by the open (3.5 GB and 0.4 s of a 1.0 s open for an HPRC-sized GBZ).  Replace such a file by rename, never truncate or
+ * rewrite it in place under an open handle.  GBWT_HIP_LAZY_HOST_RECORDS=0 in the environment: the copy is made by the open, as until round 5. */
 gbwt_hip_status gbwt_hip_open_file(const char *path, int device, gbwt_hip_index **out);
 
 /* Host-only parse + validation of a .gbwt/.gbz (no device needed): what load_from would accept. */

@@ -256,6 +256,42 @@ def test_whole_file_in_many_batches(tmp_path):
         assert out.read_bytes() == exp, mode
 
 
+def test_host_records_are_made_on_first_use(tmp_path):
+    """An open from a file decodes the record starts on the device and leaves the HOST's image of the records (bytes + starts: what the S / L
+    lines of the whole-file writer read, nothing an open or a lines request does) unmade (HostIndex::ensure_records; files of 4 MB or more with
+    1 MB or more of record bytes -- smaller ones are decoded in the foreground as before).  The label lengths of the nodes that do not exist
+    are zeroed on the device instead (k_mask_label_lengths).  Lines before and after, the whole file in the three modes, and the same from a
+    process with GBWT_HIP_LAZY_HOST_RECORDS=0 -- all equal to the oracle's."""
+    import subprocess
+    import sys
+    g = S.Synth.genome(contigs=8, fragments=4, haplotypes=48, sites=4000, seed=9)
+    path = tmp_path / "lazy.gbz"
+    g.save(str(path), as_gbz=True)
+    assert os.path.getsize(path) >= (4 << 20) and len(g.data()) >= (1 << 20)
+    oracle = O.OracleGBZ(str(path))
+    ids = np.arange(g.paths, dtype=np.uint64)
+    for flags in (G.OPEN_GFA, G.OPEN_ALL):
+        dev = G.GBZ.load(str(path), flags=flags)
+        before = dev.memory_usage()["index_host_bytes"]
+        for mode in (0, 1, 2):
+            assert dev.path_lines(ids, mode) == oracle.path_lines(ids, mode)
+        assert dev.memory_usage()["index_host_bytes"] == before           # (a lines request reads none of it)
+        for mode in (G.PATHS_DEFAULT, G.PATHS_PAN_SN, G.PATHS_REF_ONLY):
+            out = tmp_path / f"lazy_{flags}_{mode}.gfa"
+            dev.write_gfa(str(out), mode)
+            assert out.read_bytes() == oracle.gfa(mode), (flags, mode)
+        after = dev.memory_usage()["index_host_bytes"]
+        assert after >= before + len(g.data()) + 8 * len(g.starts()), (before, after)    # made by the graph lines, once
+        dev.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import gbwt_rs_amd as G\n"
+            f"dev = G.GBZ.load({str(path)!r})\n"
+            f"assert dev.memory_usage()['index_host_bytes'] >= {len(g.data())}\n"
+            f"dev.write_gfa({str(tmp_path)!r} + '/eager.gfa', 0)\n")
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, GBWT_HIP_LAZY_HOST_RECORDS="0"), timeout=600)
+    assert (tmp_path / "eager.gfa").read_bytes() == oracle.gfa(0)
+
+
 def test_config_c4_small_whole_file():
     """Config 4's stand-in of rounds 3-4 (bench.py's `config4_small`): Synth.genome 24 contigs x 20 components, 90 haplotypes -- 32 286
     ragged walks over one-base nodes, 0.50 G LF-steps, 4.5 GB of GFA.  The whole file through the pipelined writer (1 GiB batches, 64 MiB pieces), checked
