@@ -225,8 +225,12 @@ void finish_strings(Strings &s, Words &&offsets) {
     if (!offsets.empty() && offsets[0] != 0) throw InvalidData("StringArray: First string does not start at offset 0");
     s.offsets = std::move(offsets);
     s.offsets.push_back(s.bytes.size());
-    for (size_t i = 1; i < s.offsets.size(); i++)
-        if (s.offsets[i] < s.offsets[i - 1]) throw InvalidData("StringArray: offsets are not sorted");
+    const size_t n = s.offsets.size();
+    const unsigned pieces = pieces_for(n);
+    run_pieces(pieces, [&](unsigned p) {
+        for (size_t i = std::max<size_t>(1, n * p / pieces), end = n * (p + 1) / pieces; i < end; i++)
+            if (s.offsets[i] < s.offsets[i - 1]) throw InvalidData("StringArray: offsets are not sorted");
+    });
 }
 
 // StringArray::load (packed form), src/support.rs:601-647; with `later` the decoding is a deferred task
@@ -236,16 +240,22 @@ void read_strings(Elements &in, Strings &s, Deferred *later = nullptr, bool back
     read_bytes(in, alphabet);
     const Packed packed = read_packed(in);
     auto decode = [view, alphabet, packed, &s]() {
-        Words offsets = decode_sparse(view);
+        // the offsets and the characters side by side (one after the other until round 6: 109 M offsets, then a gigabyte of characters --
+        // the longest thing left on the host side of an HPRC-sized open once the record image became lazy)
+        Words offsets;
         s.bytes.resize(packed.len);
         const unsigned pieces = pieces_for(packed.len);
-        run_pieces(pieces, [&](unsigned p) {
-            for (uint64_t i = packed.len * p / pieces, end = packed.len * (p + 1) / pieces; i < end; i++) {
-                uint64_t x = packed.get(i);
-                if (x >= alphabet.size()) throw InvalidData("StringArray: packed character outside the alphabet");
-                s.bytes[i] = alphabet[x];
-            }
-        });
+        auto characters = [&]() {
+            run_pieces(pieces, [&](unsigned p) {
+                for (uint64_t i = packed.len * p / pieces, end = packed.len * (p + 1) / pieces; i < end; i++) {
+                    uint64_t x = packed.get(i);
+                    if (x >= alphabet.size()) throw InvalidData("StringArray: packed character outside the alphabet");
+                    s.bytes[i] = alphabet[x];
+                }
+            });
+        };
+        if (view.ones >= (uint64_t(1) << 18)) run_pieces(2, [&](unsigned p) { if (p == 0) offsets = decode_sparse(view); else characters(); });
+        else { offsets = decode_sparse(view); characters(); }
         finish_strings(s, std::move(offsets));
     };
     if (later) (background ? later->background : later->tasks).push_back(decode); else decode();

@@ -108,9 +108,17 @@ __global__ void __launch_bounds__(256) k_build_desc(DeviceIndex ix, uint4 *desc,
         sum += __shfl_down(static_cast<unsigned long long>(sum), d);
         bad += __shfl_down(static_cast<unsigned long long>(bad), d);
     }
-    if (threadIdx.x % WAVE != 0) return;
-    if (max_len) atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(max_len));
-    if (max_sigma) atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(max_sigma));
+    // ... and over the workgroup, and a maximum is only sent where it would change what is there (it only grows: a stale read sends one
+    // atomic too many, never one too few): 218 M records were 10 M atomics on three addresses
+    __shared__ uint64_t part[4][4];
+    const uint32_t wave = threadIdx.x / WAVE;
+    if (threadIdx.x % WAVE == 0) { part[wave][0] = max_len; part[wave][1] = max_sigma; part[wave][2] = sum; part[wave][3] = bad; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (uint32_t w = 1; w < 4; w++) { max_len = max(max_len, part[w][0]); max_sigma = max(max_sigma, part[w][1]); sum += part[w][2]; bad += part[w][3]; }
+    const volatile uint64_t *seen = stats;
+    if (max_len > seen[0]) atomicMax(reinterpret_cast<unsigned long long *>(stats + 0), static_cast<unsigned long long>(max_len));
+    if (max_sigma > seen[1]) atomicMax(reinterpret_cast<unsigned long long *>(stats + 1), static_cast<unsigned long long>(max_sigma));
     if (bad & 0xFFFFFFFFull) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 2), static_cast<unsigned long long>(bad & 0xFFFFFFFFull));
     if (bad >> 32) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 4), static_cast<unsigned long long>(bad >> 32));
     if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), static_cast<unsigned long long>(sum));
@@ -518,7 +526,10 @@ __global__ void __launch_bounds__(256) k_link_desc2(DeviceIndex ix, uint4 *out, 
             }
         }
         if (*chained < most) atomicMax(chained, most);
-        atomicAdd(chained + 1, 1u);                                            // records with a chained step
+    }
+    {   // records with a chained step, counted per wave (ten million of config 4's records have one: as many atomics on one address before)
+        const uint64_t lanes = __ballot(any_chain && chained != nullptr);
+        if (lanes != 0 && (threadIdx.x % WAVE) == static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(lanes)) - 1)) atomicAdd(chained + 1, static_cast<uint32_t>(__popcll(lanes)));
     }
     o[2] = leaf[0]; o[3] = leaf[1]; o[4] = leaf[2]; o[5] = leaf[3];
     o[6] = make_uint4(0u, 0u, 0u, 0u);
