@@ -1,4 +1,4 @@
-// capi_internal.hpp -- handle / workspace structures shared by the C-ABI translation units (capi.hip, gfa.hip).
+// capi_internal.hpp -- handle / workspace structures shared by the C-ABI translation units (capi_open.hip, capi_extract.hip, capi_query.hip, gfa.hip, comm.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -191,7 +191,7 @@ inline gbwt_hip_status status_of_current_exception() noexcept {
         return fail(GBWT_HIP_DEVICE_ERROR, "unexpected exception");
     }
 }
-// The pinned staging buffers and streams of a workspace's device-to-host copies (capi.hip: copy_to_host), made on first use.
+// The pinned staging buffers and streams of a workspace's device-to-host copies (capi_extract.hip: copy_to_host), made on first use.
 struct HostCopier {
     static constexpr size_t CHUNK = size_t(16) << 20;
     struct Lane { void *pinned[2] = {nullptr, nullptr}; hipEvent_t landed[2] = {nullptr, nullptr}; hipStream_t stream = nullptr; };
@@ -207,12 +207,16 @@ struct HostCopier {
 #define GBWT_HIP_GUARD_BEGIN try {
 #define GBWT_HIP_GUARD_END } catch (...) { return gbwt_hip::status_of_current_exception(); }
 
+// The full-width two-step blocks of a handle, built on first need, and a copy of its DeviceIndex with them put in (capi_open.hip)
+const uint4 *ensure_cblocks(const gbwt_hip_index *index);
+DeviceIndex with_cblocks(const gbwt_hip_index *ix);
+
 }  // namespace gbwt_hip
 
 struct gbwt_hip_index {
     gbwt_hip::HostIndex host;
     int device = 0;
-    bool lean_extract = false;           // opened without SEARCH and no record needs the generic decoder: desc_raw was given back after the open (capi.hip: open_common)
+    bool lean_extract = false;           // opened without SEARCH and no record needs the generic decoder: desc_raw was given back after the open (capi_open.hip: open_common)
     uint64_t slow_records = ~uint64_t(0); // non-empty records whose walk descriptor says "generic decoder" (k_link_desc2's count; ~0 = not counted)
     uint32_t caps = GBWT_HIP_OPEN_ALL;   // what the handle was opened for (gbwt_hip_open_*_flags): which arrays exist, which entry points answer
     uint64_t table_positions = 0;     // BWT positions in records with LF tables (outdegree > 2)
@@ -249,7 +253,7 @@ struct gbwt_hip_index {
     std::atomic<const uint4 *> lazy_cblocks{nullptr};
     bool packed_blocks = true;        // gblocks was built (false: the index is too large for 32-bit half-block indices, or GBWT_HIP_GATHER_LIMIT=0)
     uint32_t max_samples = 0;         // the largest number of samples of a sequence
-    uint32_t sample_coarse = 1;       // the samples are this many times finer than a batch of the whole index wants: extractions stride over them (capi.hip)
+    uint32_t sample_coarse = 1;       // the samples are this many times finer than a batch of the whole index wants: extractions stride over them (capi_extract.hip)
     std::vector<uint32_t> sample_counts;   // samples of every sequence (host copy: an extraction looks whether its rows all have the same number)
     uint32_t uniform_samples = 0;     // every sequence has this many samples (0: they differ): the walkers of an extraction are then w = segment * n + row
     bool starts_uploaded = false;         // ... and the record starts
@@ -298,7 +302,7 @@ struct gbwt_hip_workspace {
     const gbwt_hip_index *index = nullptr;
     ExtractKnobs knobs;
     hipStream_t stream = nullptr;
-    uint64_t *pinned_words = nullptr;         // four words of pinned host memory: the total and extremes of a request whose rows are sized after its launch (capi.hip)
+    uint64_t *pinned_words = nullptr;         // four words of pinned host memory: the total and extremes of a request whose rows are sized after its launch (capi_extract.hip)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t qev[2] = {nullptr, nullptr};   // around the kernel(s) of the last navigation / search call
     hipEvent_t gev[2] = {nullptr, nullptr};   // around the formatting of the last GFA lines request (behind its walk)
@@ -329,6 +333,6 @@ struct gbwt_hip_workspace {
 
 namespace gbwt_hip {
 // Device -> pageable host memory over the workspace's copy threads (GBWT_HIP_COPY_THREADS, default 8), each with two pinned staging
-// buffers and a stream of its own (capi.hip)
+// buffers and a stream of its own (capi_extract.hip)
 void copy_to_host(gbwt_hip_workspace *ws, void *dst, const void *src, size_t bytes, size_t piece = HostCopier::CHUNK);
 }

@@ -558,7 +558,7 @@ void HostIndex::ensure_records() const {
 }
 
 namespace {
-// GBWT_HIP_TRACE_OPEN=1: the loader's phases on stderr, like the device side of an open (capi.hip: OpenTrace)
+// GBWT_HIP_TRACE_OPEN=1: the loader's phases on stderr, like the device side of an open (capi_open.hip: OpenTrace)
 struct LoadTrace {
     bool on = std::getenv("GBWT_HIP_TRACE_OPEN") != nullptr;
     std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();

@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
             if (hi_rec - lo_rec > 64u) catch_pause = 256;
         }
         // (catch_up == 2: the single steps read the two-step descriptors and the packed half-blocks the loops read anyway -- a handle that has
-        // given its one-step descriptors and plain rank blocks back, capi.hip: open_common -- and only while the wave is on the packed blocks)
+        // given its one-step descriptors and plain rank blocks back, capi_open.hip: open_common -- and only while the wave is on the packed blocks)
         if (!together && a.uniform_loop && a.catch_up && !(a.catch_up == 2u && full_blocks) && catch_pause == 0 && __ballot(sink.wr - drained > ring_mask + 1 - 8) == 0) {   // (its single steps stage up to eight nodes)
             const uint64_t walking = __ballot(rec != 0);
             for (uint32_t tries = 0; tries < 4 && !together; tries++) {
