@@ -28,6 +28,8 @@ import time
 
 import numpy as np
 
+_PROCESS_START = time.perf_counter()
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -902,6 +904,7 @@ def main():
             result["abandoned"] = abandoned
         if failed_checks:
             result["errors"] = [f"{w}: the step's result failed its check (see its object)" for w in failed_checks]
+        result["bench_seconds"] = round(time.perf_counter() - _PROCESS_START, 1)   # this process, imports to line (generators, CPU legs and the other configs included)
         print(json.dumps(result), flush=True)
     if abandoned:
         # a thread of this process still sits in a collective that will not complete: no barrier, no teardown of communicators it holds --

@@ -119,8 +119,12 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             }
             DeviceIndex strided = ix->dev; strided.sample_stride = stride;
             if (parted) { strided.sample_part = part; strided.sample_parts = parts; }
+            // every row of one, known length (the headline's shape, config 5): no table of offsets is needed to walk, and the walk kernel
+            // writes the one the caller gets (WalkArgs::uniform_len) -- nothing is launched in front of it
+            const bool all_valid = ids_valid && ix->uniform_len != 0 && !parted;
+            const bool fused_offsets = all_valid && knobs.fused_offsets != 0;
             // lengths, offsets and extremes: one launch for the batch sizes there are, else a memset and three
-            if (!launch_row_offsets(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), ws->counters.as<uint32_t>(), s)) {
+            if (!fused_offsets && !launch_row_offsets(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->offsets.as<uint64_t>(), ws->counters.as<uint32_t>(), s)) {
                 HIP_CHECK(hipMemsetAsync(ws->counters.ptr, 0, 4 * sizeof(uint32_t), s));
                 if (parted) launch_part_lengths(strided, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
                 else launch_gather_lengths(ix->dev.seq_len, ix->dev.n_sequences, ws->seq_ids.as<uint64_t>(), n, ws->lengths.as<uint64_t>(), ws->counters.as<uint32_t>(), s);
@@ -128,7 +132,6 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             }
             uint64_t total = 0;
             uint32_t extremes[2] = {0, 0};   // the longest row, ~(the shortest)
-            const bool all_valid = ids_valid && ix->uniform_len != 0 && !parted;
             // every row of the batch with the same number of samples (the forward sequences of haplotypes over one reference frame: the
             // headline's shape): walker w = segment * n + row, no order to compute -- and nothing the host has to ask the device for
             uint32_t common = ix->uniform_samples;
@@ -228,6 +231,7 @@ gbwt_hip_status gbwt_hip_extract_part_device(const gbwt_hip_index *ix, gbwt_hip_
             a.debug = knobs.debug;                               // timing experiments only, see WalkArgs::debug
             a.both_ends = (ix->orientation_pairs && knobs.both_ends != 0) ? 1u : 0u;
             a.capacity = defer ? capacity : 0;
+            if (fused_offsets) { a.uniform_len = ix->uniform_len; a.fill_offsets = ws->offsets.as<uint64_t>(); }
             HIP_CHECK(hipEventRecord(ws->ev[0], s));
             if (!parted || (total != 0 && walkers != 0)) launch_walk(dev, a, s);   // (a part of nothing but empty stretches: no walkers)
             HIP_CHECK(hipEventRecord(ws->ev[1], s));

@@ -272,6 +272,7 @@ struct ExtractKnobs {
     int all4 = 1;                                             // GBWT_HIP_ALL4: 0 = the uniform loop counts every node it stages (rounds 1-3)
     int sample_stride = -1;                                   // GBWT_HIP_SAMPLE_STRIDE: a walker per this many samples of a row; -1 = by the size of the batch (gbwt_hip_extract_device)
     int defer_total = 1;                                      // GBWT_HIP_DEFER_TOTAL: 0 = every request waits for the total of its row lengths before it launches the walk (rounds 1-3)
+    int fused_offsets = 1;                                    // GBWT_HIP_FUSED_OFFSETS: 0 = the offsets of a batch of equally long rows come from k_row_offsets in front of the walk, as every batch's did until round 6 (WalkArgs::uniform_len)
     int ring_slots = -1, helper_naps = -1, xcd_map = -1, uniform_loop = -1, packed_blocks = -1, row_piece = -1, catch_up = -1, headroom = 0;
     int gather_reach = -1;                                    // GBWT_HIP_GATHER_REACH: look-ahead of mixed waves (WalkArgs::gather_reach); -1 = by the index (rows per record), 0 = none
     bool wide_addresses = false;                              // GBWT_HIP_WIDE_ADDRESSES set (any value)
@@ -288,6 +289,7 @@ struct ExtractKnobs {
         k.gather_reach = std::min(64, std::max(-1, num("GBWT_HIP_GATHER_REACH", -1)));
         k.sample_stride = num("GBWT_HIP_SAMPLE_STRIDE", -1);
         k.defer_total = num("GBWT_HIP_DEFER_TOTAL", 1);
+        k.fused_offsets = num("GBWT_HIP_FUSED_OFFSETS", 1);
         k.all4 = num("GBWT_HIP_ALL4", 1);
         k.headroom = std::min(32, std::max(0, num("GBWT_HIP_HEADROOM", 0)));
         k.row_piece = num("GBWT_HIP_ROW_PIECE", -1); if (k.row_piece != 0 && k.row_piece != 16 && k.row_piece != 32) k.row_piece = -1;

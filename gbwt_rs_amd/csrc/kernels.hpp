@@ -83,6 +83,11 @@ struct WalkArgs {
     uint64_t walkers;              // = level[segments] (host copy)
     uint64_t capacity;         // > 0: the rows hold this many nodes and out_offsets[n] may say that more are needed: then nobody walks (gbwt_hip_extract_part_device launches again)
     uint32_t segments;         // > 0: walker w fills segment w / n of row w % n, starting at that sequence sample (DeviceIndex::samples)
+    // ROWS OF ONE LENGTH (round 6): every row of the batch has uniform_len nodes (all ids valid, whole rows): row k starts at k * uniform_len --
+    // the walkers compute it, and the kernel itself writes the n + 1 offsets the caller gets to fill_offsets (= out_offsets): the launch that
+    // computed them in front of the walk (k_row_offsets: 11 us + a launch gap, a sixth of config 5's 80 us walk) is gone for such batches
+    uint32_t uniform_len;      // 0: read out_offsets
+    uint64_t *fill_offsets;
 };
 constexpr uint32_t WALK_TWO_STEP = 0, WALK_LANE_SERIAL = 1, WALK_COOP = 2, WALK_ONE_STEP = 3;
 void launch_walk(const DeviceIndex &ix, const WalkArgs &args, hipStream_t stream);

@@ -32,12 +32,15 @@ struct RowTarget {
     uint32_t share = 0;          // nodes this walker has to deliver
 };
 
+// first node of row k in out_nodes (WalkArgs::uniform_len: rows of one length need no table)
+__device__ __forceinline__ uint64_t row_offset(const WalkArgs &a, uint64_t k) { return a.uniform_len != 0 ? k * a.uniform_len : a.out_offsets[k]; }
+
 __device__ __forceinline__ RowTarget row_target(const WalkArgs &a, uint64_t w) {
     RowTarget t;
     const uint64_t k = w < a.n ? w : w - a.n;
     t.backward = w >= a.n;
-    t.len = a.out_offsets[k + 1] - a.out_offsets[k];
-    t.row = a.out_nodes + a.out_offsets[k];
+    t.len = row_offset(a, k + 1) - row_offset(a, k);
+    t.row = a.out_nodes + row_offset(a, k);
     const uint64_t share = !a.both_ends ? t.len : (t.backward ? t.len / 2 : t.len - t.len / 2);
     t.share = static_cast<uint32_t>(share);
     return t;
@@ -73,12 +76,12 @@ __device__ __forceinline__ WalkerStart segment_start(const DeviceIndex &ix, cons
     const uint64_t base = rs.base, stride = rs.stride, count = rs.count;
     j += rs.lo;
     const bool parted = ix.sample_parts > 1;
-    const uint64_t len = parted ? ix.seq_len[id] : a.out_offsets[k + 1] - a.out_offsets[k];
+    const uint64_t len = parted ? ix.seq_len[id] : row_offset(a, k + 1) - row_offset(a, k);
     if (j >= rs.hi) return s;                                 // this row has fewer segments: nothing to do
     const uint4 here = ix.samples[base + j * stride];
     const uint64_t from = j == 0 ? 0 : here.w;                // segment 0 starts with the start node (sample 0 is the state after it)
     const uint64_t to = j + 1 < count ? ix.samples[base + (j + 1) * stride].w : len;
-    t.row = a.out_nodes + a.out_offsets[k] + (from - (parted ? segment_position(ix, rs, id, rs.lo) : 0u));
+    t.row = a.out_nodes + row_offset(a, k) + (from - (parted ? segment_position(ix, rs, id, rs.lo) : 0u));
     t.len = to > from ? to - from : 0;
     if (PROBE && (a.debug & 2u)) t.row = a.out_nodes + (w % 4096u) * 4096u;   // measurement switch: all rows land in one 64 MB window (wrong output)
     if (PROBE && (a.debug & 128u)) t.row = a.out_nodes + (w % 64u) * 4096u;   //                     ... in 1 MB (stays in every L2)
@@ -345,6 +348,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_walk_direct(DeviceIndex ix, WalkAr
         const uint64_t total = a.out_offsets[a.n];
         if (total == 0 || total > a.capacity) return;
     }
+    if (a.fill_offsets != nullptr)            // rows of one length: the offsets the caller reads, written here (WalkArgs::uniform_len)
+        for (uint64_t k = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; k <= a.n; k += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+            a.fill_offsets[k] = k * a.uniform_len;
     extern __shared__ uint32_t ring_lds[];   // a.ring_slots * RING_PITCH entries (dynamic: the ring size sets how many workgroups fit a CU)
     __shared__ uint4 mailbox[WAVE];          // per walking lane: {look-ahead record, first block, blocks, nodes staged so far}
     __shared__ uint4 row_state[WAVE];        // per walking lane: {row address low, high, length (cooperative row writes), nodes the helper has moved to the row}

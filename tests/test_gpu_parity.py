@@ -696,6 +696,30 @@ def test_lean_extract_handle_walks_like_the_full_one(extra, every):
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
+@pytest.mark.parametrize("env", [{}, {"GBWT_HIP_FUSED_OFFSETS": "0"}, {"GBWT_HIP_SEGMENTS": "0"}, {"GBWT_HIP_SAMPLE_INTERVAL": "0"},
+                                 {"GBWT_HIP_SAMPLE_INTERVAL": "16", "GBWT_HIP_SAMPLE_STRIDE": "3"}],
+                         ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()) or "defaults")
+def test_rows_of_one_length_need_no_offsets_launch(monkeypatch, env):
+    """Where every sequence of the index has the same number of nodes (the headline's shape, config 5) a batch of valid ids knows its row
+    offsets without a table: the walkers compute them and k_walk_direct writes the n + 1 offsets the caller reads (WalkArgs::uniform_len;
+    GBWT_HIP_FUSED_OFFSETS=0: k_row_offsets in front of the walk, as before round 6).  Shuffled ids with repeats, both orientations, one row,
+    7 000 rows, and a batch with an id that does not exist (not uniform: the table path) -- offsets and nodes against the oracle's walk."""
+    s = S.Synth.chain(sites=700, haplotypes=160, alleles=2, model=S.MOSAIC, founders=8, switch_rate=1e-2, seed=21)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = open_synth(s)
+    gbwt = oracle_of(s)
+    rng = np.random.default_rng(3)
+    batches = [rng.integers(0, s.sequences, size=500).astype(np.uint64), np.array([s.sequences - 1], dtype=np.uint64),
+               rng.integers(0, s.sequences, size=7000).astype(np.uint64), np.array([3, s.sequences + 5, 0, 1], dtype=np.uint64)]
+    for ids in batches:
+        off, nodes = dev.sequences_csr(ids)
+        o_off, o_nodes = gbwt.extract(ids, threads=4)
+        assert np.array_equal(off, o_off) and np.array_equal(nodes, o_nodes), (env, len(ids))
+        out = dev.extract_device(ids)
+        assert np.array_equal(dev.last_offsets(len(ids)), o_off) and int(out.total) == int(o_off[-1])
+
+
 @pytest.mark.parametrize("flags", ["OPEN_EXTRACT", "OPEN_GFA"])
 def test_lean_handle_refuses_walks_without_samples(monkeypatch, flags):
     """A lean handle has no raw descriptors, and a walker that does not start from a sequence sample reads them when it arrives on its
