@@ -1095,12 +1095,17 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
     REFRESH
 // K0 = {bits1, bits2}, K1 = {ones1, R0, R1} of the lane's two-step block: SGPR base + 32-bit byte offset while the block
 // array is below 4 GiB, a 64-bit address per lane above
-#define GBWT_WALK2U_LEAF(MASK, X, Y, Z, W)                                                                 \
+// A leaf {node to emit, offset base, landing record | flags, its block base} lies in four consecutive SGPRs: two 64-bit moves per leaf
+// (v_mov_b64 from an SGPR pair runs at the rate of v_mov_b32, tools/microbench_mov64.hip) instead of three moves and an add -- the offset
+// base lands in v81 and the landing word in v42 (the old offset is dead by now), GBWT_WALK2U_LEAVES_DONE puts them where the rest of the loop
+// expects them with the add done once for all four leaves: 10 VALU instructions for the selection instead of 16 (round 6).
+#define GBWT_WALK2U_LEAF(MASK, XY, ZW)                                                                     \
     MASK "\n\t"                                                                                           \
-    "v_mov_b32_e32 v80, " X "\n\t"                       /* node to emit */                              \
-    "v_add_u32_e32 v42, " Y ", v75\n\t"                  /* the new offset = offset base + rank_b */     \
-    "v_mov_b32_e32 v81, " Z "\n\t"                       /* landing record | flags */                    \
-    "v_mov_b32_e32 v43, " W "\n\t"                        /* its block base */
+    "v_mov_b64 v[80:81], " XY "\n\t"                     /* node to emit, offset base */                 \
+    "v_mov_b64 v[42:43], " ZW "\n\t"                     /* landing record | flags, its block base */
+#define GBWT_WALK2U_LEAVES_DONE                                                                           \
+    "v_mov_b32_e32 v87, v42\n\t"                         /* landing record | flags */                    \
+    "v_add_u32_e32 v42, v81, v75\n\t"                    /* the new offset = offset base + rank_b */
 // The up to four nodes of an iteration into the ring (v72 / v78 first step, v80 / v40 second step); CHAIN_E / CHAIN_L = the nodes between them
 // where a step is chained (GBWT_CHAIN_BLOCK), or nothing.
 #define GBWT_WALK2U_STAGE(CHAIN_E, CHAIN_L) \
@@ -1123,7 +1128,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "ds_write_b32 v47, v80\n\t"                        /* node of the leaf */ \
         "v_addc_co_u32_e32 v44, vcc, 0, v44, vcc\n\t" \
         CHAIN_L \
-        "v_cmp_gt_i32_e32 vcc, 0, v81\n\t"                 /* second step fused? */ \
+        "v_cmp_gt_i32_e32 vcc, 0, v87\n\t"                 /* second step fused? */ \
         "v_and_b32_e32 v47, %[ringmask], v44\n\t" \
         "v_mad_u32_u24 v47, v47, %[stride], %[ring]\n\t" \
         "ds_write_b32 v47, v79\n\t" \
@@ -1161,14 +1166,14 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "v_sub_u32_e32 v75, v71, v74\n\t"                /* j - ones */ \
         "v_and_b32_e32 v78, 0x3fffffff, v73\n\t"          /* w_a */ \
         "v_cndmask_b32_e64 v75, v75, v74, s[46:47]\n\t"  /* rank_b */ \
-        GBWT_WALK2U_LEAF("s_nor_b64 exec, s[44:45], s[46:47]", "s56", "s57", "s58", "s59")     /* lanes of leaf (0, 0) */ \
-        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[46:47], s[44:45]", "s60", "s61", "s62", "s63")   /*          leaf (0, 1) */ \
-        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[44:45], s[46:47]", "s64", "s65", "s66", "s67")   /*          leaf (1, 0) */ \
-        GBWT_WALK2U_LEAF("s_and_b64 exec, s[44:45], s[46:47]", "s68", "s69", "s70", "s71")     /*          leaf (1, 1) */ \
+        GBWT_WALK2U_LEAF("s_nor_b64 exec, s[44:45], s[46:47]", "s[56:57]", "s[58:59]")     /* lanes of leaf (0, 0) */ \
+        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[46:47], s[44:45]", "s[60:61]", "s[62:63]")   /*          leaf (0, 1) */ \
+        GBWT_WALK2U_LEAF("s_andn2_b64 exec, s[44:45], s[46:47]", "s[64:65]", "s[66:67]")   /*          leaf (1, 0) */ \
+        GBWT_WALK2U_LEAF("s_and_b64 exec, s[44:45], s[46:47]", "s[68:69]", "s[70:71]")     /*          leaf (1, 1) */ \
         "s_mov_b64 exec, -1\n\t" \
-        "v_and_b32_e32 v40, 0x3fffffff, v81\n\t"           /* the new record */ \
-        "v_mov_b32_e32 v48, s72\n\t"                        /* mailbox: look-ahead target of the record just left (before its SGPRs are reloaded) ... */ \
-        "v_mov_b32_e32 v49, s73\n\t" \
+        GBWT_WALK2U_LEAVES_DONE \
+        "v_and_b32_e32 v40, 0x3fffffff, v87\n\t"           /* the new record */ \
+        "v_mov_b64 v[48:49], s[72:73]\n\t"                  /* mailbox: look-ahead target of the record just left (before its SGPRs are reloaded) ... */ \
         "v_mov_b32_e32 v50, s74\n\t" \
         GBWT_WALK2U_MAIL_FLAG \
         GBWT_WALK2U_ISSUE(KLOAD, "")                        /* the loads of the next position go out now; staging the nodes runs underneath them */ \
@@ -1230,7 +1235,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         "v_cmp_eq_u32_e32 vcc, 1, v62\n\t" \
         "v_cndmask_b32_e32 v82, v82, v86, vcc\n\t"          /* E_a.w of the lane's edge */ \
         GBWT_WALK2U_STAGE(GBWT_CHAIN_BLOCK("e", "", "v_and_b32_e32 v86, 2, v82\n\t" "v_cmp_ne_u32_e32 vcc, 0, v86\n\t", "v72", "v78", "v83", "v84", "v85", "v86"), \
-                          GBWT_CHAIN_BLOCK("l", "", "v_and_b32_e32 v86, 0x40000000, v81\n\t" "v_cmp_ne_u32_e32 vcc, 0, v86\n\t", "v80", "v40", "v83", "v84", "v85", "v86")) \
+                          GBWT_CHAIN_BLOCK("l", "", "v_and_b32_e32 v86, 0x40000000, v87\n\t" "v_cmp_ne_u32_e32 vcc, 0, v86\n\t", "v80", "v40", "v83", "v84", "v85", "v86")) \
         "s_branch .Lgbwt_walk2u_staged_%=\n\t" \
         ".Lgbwt_walk2u_slow_%=:\n\t" \
         "s_mov_b32 %[reason], 1\n\t" \
@@ -1252,7 +1257,7 @@ __device__ __forceinline__ uint32_t walk2_gather_loop_full(const uint4 *desc2, c
         : "memory", "vcc", "scc", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
           "v40", "v42", "v43", "v44", "v45", "v46", "v61", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v60", "v47", "v62", "v63", \
-          "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", \
+          "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", \
           "s80", "s81", "s82", "s83", "s84");
 #define GBWT_WALK2U_BODY \
     uint32_t reason; \
