@@ -739,16 +739,14 @@ __device__ __forceinline__ uint32_t walk2_gather_loop(const uint4 *desc2, const 
         "v_add_u32_e32 v76, -1, v72\n\t"                    /* a ? 0 : ~0 */ \
         "v_cmp_eq_u32_e32 vcc, 1, v72\n\t"                  /* vcc = a */ \
         "v_cmp_eq_u32_e64 s[46:47], 1, v84\n\t"             /* s[46:47] = b */ \
-        "v_xor_b32_e32 v78, v60, v76\n\t"                   /* a ? bits1 : ~bits1 */ \
         "v_and_b32_e32 v79, 0x1fffff, v62\n\t"              /* ones1 */ \
-        "v_and_b32_e32 v78, v78, v74\n\t"                   /* m: the equal values of v below `bit` */ \
+        "v_bitop3_b32 v78, v60, v76, v74 bitop3:0x28\n\t"   /* m: the equal values of v below `bit` = (bits1 ^ (a ? 0 : ~0)) & below, one three-input operation (gfx950) */ \
         "v_alignbit_b32 v82, v63, v62, 21\n\t" \
         "v_sub_u32_e32 v77, v77, v79\n\t"                   /* (offset - bit) - ones1 */ \
-        "v_bcnt_u32_b32 v80, v78, 0\n\t"                    /* p */ \
         "v_cndmask_b32_e32 v77, v77, v79, vcc\n\t"          /* a ? ones1 : that */ \
         "v_and_b32_e32 v82, 0x1fffff, v82\n\t"              /* R_0 */ \
         "v_lshrrev_b32_e32 v81, 10, v63\n\t"                /* R_1 */ \
-        "v_add_u32_e32 v77, v77, v80\n\t"                   /* rank_a */ \
+        "v_bcnt_u32_b32 v77, v78, v77\n\t"                  /* rank_a = that + popcount(m) (the count accumulates) */ \
         "v_and_b32_e32 v78, v78, v61\n\t"                   /* a-paths below `bit` with value 1 in w_a */ \
         "v_cndmask_b32_e32 v82, v82, v81, vcc\n\t"          /* R_a */ \
         "v_bcnt_u32_b32 v82, v78, v82\n\t"                  /* ones of w_a before j */ \
@@ -1392,6 +1390,7 @@ __device__ __forceinline__ uint32_t walk2_uniform_loop_full(const uint4 *desc2, 
 #undef GBWT_WALK2U_KLOAD_NARROW
 #undef GBWT_WALK2U_ISSUE
 #undef GBWT_WALK2U_FLAG_CHECK
+#undef GBWT_WALK2U_LEAVES_DONE
 #undef GBWT_WALK2U_MAIL_FLAG
 #endif
 
