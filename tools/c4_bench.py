@@ -62,11 +62,33 @@ def generate(size, path, threads=None):
     return g
 
 
-def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
-    import gbwt_rs_amd as G
-    tmpdir = tempfile.mkdtemp(prefix="gbwt_c4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    path = os.path.join(tmpdir, "c4.gbz")
+def prepare(size, path):
+    """generate() for a run() in ANOTHER process (bench.py: the generator works next to bench.py's own configs and the measuring process starts
+    fresh): the .gbz, the generic path ids and, in `path`.meta.json, what run() reads off the Synth."""
     g = generate(size, path)
+    with open(path + ".meta.json.tmp", "w") as f:
+        json.dump({"size": size, "paths": int(g.paths), "alphabet_size": int(g.alphabet_size), "generator_seconds": g.generator_seconds, "save_seconds": g.save_seconds}, f)
+    os.replace(path + ".meta.json.tmp", path + ".meta.json")
+
+
+class _Prepared:
+    def __init__(self, meta):
+        self.paths, self.alphabet_size = meta["paths"], meta["alphabet_size"]
+        self.generator_seconds, self.save_seconds = meta["generator_seconds"], meta["save_seconds"]
+
+
+def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None, prepared=None):
+    import gbwt_rs_amd as G
+    g = None
+    if prepared and os.path.exists(prepared) and os.path.exists(prepared + ".meta.json"):
+        with open(prepared + ".meta.json") as f:
+            meta = json.load(f)
+        if meta.get("size") == size:
+            path, tmpdir, g = prepared, os.path.dirname(prepared), _Prepared(meta)
+    if g is None:
+        tmpdir = tempfile.mkdtemp(prefix="gbwt_c4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        path = os.path.join(tmpdir, "c4.gbz")
+        g = generate(size, path)
     generic = np.load(path + ".generic.npy")
     # The HIP runtime is started before the open is timed, as bench.py does for the headline (context, code objects, a tiny open, one 64 MB
     # pageable copy each way: what a process pays once) -- this function runs in a process of its own when bench.py calls it.
@@ -156,7 +178,7 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
 
 
 def cleanup(path):
-    for f in (path, path + ".generic.npy", path + ".tmp"):
+    for f in (path, path + ".generic.npy", path + ".tmp", path + ".meta.json", path + ".meta.json.tmp"):
         if os.path.exists(f):
             os.remove(f)
     try:
@@ -334,5 +356,9 @@ if __name__ == "__main__":
     ap.add_argument("--size", choices=sorted(SIZES), default="small")
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--prepare", default="", help="only generate: the .gbz at this path (+ .generic.npy, .meta.json) for a run(prepared=...) in another process")
     a = ap.parse_args()
-    print(json.dumps(run(a.size, a.passes, a.out)), flush=True)
+    if a.prepare:
+        prepare(a.size, a.prepare)
+    else:
+        print(json.dumps(run(a.size, a.passes, a.out)), flush=True)
