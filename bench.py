@@ -92,7 +92,7 @@ def cpu_baseline(index_path, n_paths, target_seconds):
     rate = steps / dt
     per_path = steps / len(ids)
     # (one path per thread walks a third faster per step than a sample that keeps every thread busy for seconds: 0.7 of the calibrated
-    # rate puts the timed walk at its target instead of 1.4-1.5 times over it)
+    # rate puts the timed walk near its target instead of 1.4-1.5 times over it)
     want = int(max(len(ids), min(n_paths, 0.7 * target_seconds * rate / per_path)))
     ids = np.arange(0, 2 * want, 2, dtype=np.uint64)
     # TIMED: the plain walk (SequenceIter::next and nothing else per step, src/gbwt.rs:557-568).  UNTIMED, behind it: the same paths again with
@@ -101,15 +101,14 @@ def cpu_baseline(index_path, n_paths, target_seconds):
     t0 = time.perf_counter()
     steps = oracle.extract_timed(ids, threads)
     dt = time.perf_counter() - t0
-    checked = ids[::2]                             # (every second path of the sample: tests/test_gpu_full_size.py walks ALL of them against the oracle)
     t0 = time.perf_counter()
-    c_steps, lengths, sums, hashes = oracle.extract_checksums(checked, threads)
+    c_steps, lengths, sums, hashes = oracle.extract_checksums(ids, threads)
     dt_checks = time.perf_counter() - t0
-    assert 0 < c_steps <= steps
-    return ({"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port", "checksum_walk_ratio": round((dt_checks / c_steps) / (dt / steps), 3),
+    assert c_steps == steps
+    return ({"value": steps / dt, "unit": "LF-steps/s", "cores": threads, "kind": "port", "checksum_walk_ratio": round(dt_checks / dt, 3),
              "sample": f"{want} of {n_paths} forward paths ({steps} LF-steps, {dt:.1f} s wall, {kind_note}, "
-                       f"pthread pool pulling path ids like gbunzip's rayon par_iter); behind the timed walk every second path of the sample is walked again, untimed "
-                       f"({dt_checks:.1f} s), keeping its length, node sum and order-dependent hash, which are compared with the GPU's"}, checked // 2, lengths, sums, hashes)
+                       f"pthread pool pulling path ids like gbunzip's rayon par_iter); behind the timed walk the same paths are walked again, untimed "
+                       f"({dt_checks:.1f} s), keeping every path's length, node sum and order-dependent hash, which are compared with the GPU's"}, ids // 2, lengths, sums, hashes)
 
 
 def _oracle_of_synth(s):
@@ -752,36 +751,16 @@ def main():
             # (b)-(e) the other BASELINE configs, each with a roofline object of its own (tools/configs.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import configs as K
-            # Config 4's GENERATOR (20 s of host work, no GPU) runs next to the configs of this process, in a process of its own that writes
-            # the .gbz and exits; the process that MEASURES config 4 is started afterwards, fresh, as before (below).  (One process for both
-            # -- generate early, wait for a go, then measure -- was tried: its first request took 1.8 s instead of 36 ms, like a request made
-            # in this process, whatever lay between this process's last GPU work and the go.)
-            c4_prep = c4_prepared = None
-            if not args.no_config4 and args.c4_size == "full":
-                import subprocess
-                c4_dir = tempfile.mkdtemp(prefix="gbwt_c4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-                c4_prepared = os.path.join(c4_dir, "c4.gbz")
-                _C4_FILES.append(c4_prepared)
-                c4_prep = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "c4_bench.py"), "--size", args.c4_size, "--prepare", c4_prepared],
-                                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             emitted = "emitted bytes: the u32 node id every LF-step writes (4 B per step) / kernel time; index reads show up in `traffic`"
             # every config with its own bounded CPU leg (5 s of oracle each, compared with what the GPU returned) unless --no-cpu-baseline
             leg_x = None if args.no_cpu_baseline else cpu_leg_extraction(3.0)    # (timed plain walk + the untimed parity walk of the same paths)
             leg_s = None if args.no_cpu_baseline else cpu_leg_search(4.0)
-            try:
-                extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank, cpu_leg=leg_x), "secondary", emitted)
-                extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank, cpu_leg=leg_x), "high_degree", emitted)
-                if not args.no_search:
-                    extras["search"] = config_roofline(K.search(device=local_rank, cpu_leg=leg_s), "search",
-                                                       "bytes a query must move in this layout: its nodes in, its state out, and per step one 64-byte record descriptor + "
-                                                       "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)", kernel="k_search")
-            except BaseException:
-                if c4_prep is not None:                              # the generator does not outlive a parent that fails, nor do its files
-                    c4_prep.kill()
-                    c4_prep.wait()
-                    import c4_bench
-                    c4_bench.cleanup(c4_prepared)
-                raise
+            extras["secondary"] = config_roofline(K.secondary(args.sites, args.haplotypes, model, args.seed, device=local_rank, cpu_leg=leg_x), "secondary", emitted)
+            extras["high_degree"] = config_roofline(K.high_degree(args.haplotypes, args.seed, device=local_rank, cpu_leg=leg_x), "high_degree", emitted)
+            if not args.no_search:
+                extras["search"] = config_roofline(K.search(device=local_rank, cpu_leg=leg_s), "search",
+                                                   "bytes a query must move in this layout: its nodes in, its state out, and per step one 64-byte record descriptor + "
+                                                   "two 16-byte rank blocks / kernel time (find + 9 x extend, unidirectional)", kernel="k_search")
             if not args.no_config4:
                 c4_definition = ("bytes moved by walk + format: node ids written by the walk and read by the formatter + the text written "
                                  "/ wall time of the two requests (P-lines, W-lines), host side included")
@@ -789,11 +768,13 @@ def main():
                 # `first_request_ms` -- the one request gbunzip's flow makes -- includes the allocation of 73 GB of rows and text, and memory a
                 # process has given back is paid for by that process's next large allocation (profiles/r05_alloc_microbench.txt: 2.5 s after
                 # a release of 48 GiB): behind the configs above, in this process, the first request once took 1.8 s instead of 36 ms.
+                # (Round 6 also ran the generator next to this process's configs -- 107 s instead of 140 for the whole line -- and saw first
+                # requests of 1.8-2.4 s in those runs; the same then showed up in this order as well: it is the driver clearing released
+                # memory under a 73 GB allocation, by the state other processes left the device in, not the order of the processes
+                # (tools/vram_first_touch_probe.py).  config4.first_request_host_ms / _device_ms say which part a run's first request was.)
                 import subprocess
                 names = ["config4"] + (["config4_small"] if args.c4_size == "full" else [])
                 cmd = [sys.executable, os.path.join(ROOT, "tools", "configs.py")] + names + ["--device", str(local_rank), "--c4-size", args.c4_size]
-                if c4_prep is not None and c4_prep.wait() == 0:      # (else: the measuring process generates for itself, as it did until round 6)
-                    cmd += ["--c4-prepared", c4_prepared]
                 if not args.no_cpu_baseline:
                     cmd += ["--cpu-leg", "4"]
                 child = subprocess.run(cmd, capture_output=True, text=True)

@@ -62,33 +62,11 @@ def generate(size, path, threads=None):
     return g
 
 
-def prepare(size, path):
-    """generate() for a run() in ANOTHER process (bench.py: the generator works next to bench.py's own configs and the measuring process starts
-    fresh): the .gbz, the generic path ids and, in `path`.meta.json, what run() reads off the Synth."""
-    g = generate(size, path)
-    with open(path + ".meta.json.tmp", "w") as f:
-        json.dump({"size": size, "paths": int(g.paths), "alphabet_size": int(g.alphabet_size), "generator_seconds": g.generator_seconds, "save_seconds": g.save_seconds}, f)
-    os.replace(path + ".meta.json.tmp", path + ".meta.json")
-
-
-class _Prepared:
-    def __init__(self, meta):
-        self.paths, self.alphabet_size = meta["paths"], meta["alphabet_size"]
-        self.generator_seconds, self.save_seconds = meta["generator_seconds"], meta["save_seconds"]
-
-
-def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None, prepared=None):
+def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
     import gbwt_rs_amd as G
-    g = None
-    if prepared and os.path.exists(prepared) and os.path.exists(prepared + ".meta.json"):
-        with open(prepared + ".meta.json") as f:
-            meta = json.load(f)
-        if meta.get("size") == size:
-            path, tmpdir, g = prepared, os.path.dirname(prepared), _Prepared(meta)
-    if g is None:
-        tmpdir = tempfile.mkdtemp(prefix="gbwt_c4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        path = os.path.join(tmpdir, "c4.gbz")
-        g = generate(size, path)
+    tmpdir = tempfile.mkdtemp(prefix="gbwt_c4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(tmpdir, "c4.gbz")
+    g = generate(size, path)
     generic = np.load(path + ".generic.npy")
     # The HIP runtime is started before the open is timed, as bench.py does for the headline (context, code objects, a tiny open, one 64 MB
     # pageable copy each way: what a process pays once) -- this function runs in a process of its own when bench.py calls it.
@@ -139,10 +117,17 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None, prepa
                           "value": steps / (wall_ms * 1e-3), "bytes_moved": moved, "achieved_GB_per_s": moved / wall_ms / 1e6,
                           "frac": moved / wall_ms / 1e6 / 8000.0, "first_request_ms": first[0], "second_request_ms": second[0],
                           "value_first_request": steps / (first[0] * 1e-3), "line_sizes_at_open_ms": times.get("line_sizes_ms", 0.0),
+                          # the first request, split: what the GPU did (walk kernel + format stream, HIP events) and the rest -- the host side, which is
+                          # the allocation of the rows and the text (73 GB at the stated size).  hipMalloc hands out clean memory in ~ 3 ms; when what the
+                          # driver has at hand was released by another process (or by this one) a moment ago it clears it first, at ~ 30-40 GB/s
+                          # (tools/vram_first_touch_probe.py, profiles/r06_vram_first_touch.txt: 100 GB in 0.4 ms or in 0.5 / 2.2 / 3.3 / 5.2 s by what
+                          # ran before): 1.8-2.4 s of a first request on a box in that state, none of it this library's work
+                          "first_request_device_ms": first[2] + first[3], "first_request_host_ms": first[0] - first[2] - first[3],
                           "note": "bytes_moved = node ids written once by the walk (4 B/step) and read once by the formatter + the text written; no request sizes "
                                   "its lines (the index knows them since its open: line_sizes_at_open_ms, inside open_ms), so every pass formats every path "
                                   "as gbunzip does -- once, from nothing but the index; first_request_ms also holds the allocation of the workspace's rows and "
-                                  "text buffers; frac = bytes_moved / wall time / 8 TB/s"}
+                                  "text buffers (first_request_host_ms: milliseconds, or seconds when the driver first has to clear memory that another "
+                                  "process released just before); frac = bytes_moved / wall time / 8 TB/s"}
     # walk only: all forward sequences of the walks -> device CSR (the ragged batch: walker order computed per request).  Behind the lines
     # passes: its third request rebuilds the rows from spread chunks (GBWT_HIP_VMM), and memory a process gives back is paid for by its NEXT
     # large allocation (profiles/r05_alloc_microbench.txt: hipMalloc of 16 GiB 0.2 ms, 2.5 s right after a hipFree of 48 GiB) -- medians
@@ -178,7 +163,7 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None, prepa
 
 
 def cleanup(path):
-    for f in (path, path + ".generic.npy", path + ".tmp", path + ".meta.json", path + ".meta.json.tmp"):
+    for f in (path, path + ".generic.npy", path + ".tmp"):
         if os.path.exists(f):
             os.remove(f)
     try:
@@ -356,9 +341,5 @@ if __name__ == "__main__":
     ap.add_argument("--size", choices=sorted(SIZES), default="small")
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--out", default="")
-    ap.add_argument("--prepare", default="", help="only generate: the .gbz at this path (+ .generic.npy, .meta.json) for a run(prepared=...) in another process")
     a = ap.parse_args()
-    if a.prepare:
-        prepare(a.size, a.prepare)
-    else:
-        print(json.dumps(run(a.size, a.passes, a.out)), flush=True)
+    print(json.dumps(run(a.size, a.passes, a.out)), flush=True)

@@ -168,19 +168,20 @@ def search(sites=1100000, haplotypes=5008, n_queries=1000000, length=10, seed=7,
     return res
 
 
-def config4(passes=3, out="", device=0, size="full", cpu_leg=None, prepared=None):
+def config4(passes=3, out="", device=0, size="full", cpu_leg=None):
     """BASELINE config 4 on one GPU at the size SURVEY 8(d) states (tools/c4_bench.py: SIZES["full"]); size="small" is the stand-in of rounds
     3-4 (bench.py's `config4_small`, with the whole file written to /dev/shm)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import c4_bench
     try:
-        res = c4_bench.run(size=size, passes=passes, out=out, device=device, cpu_leg=cpu_leg, prepared=prepared)
+        res = c4_bench.run(size=size, passes=passes, out=out, device=device, cpu_leg=cpu_leg)
     finally:
         if out and os.path.exists(out):
             os.remove(out)
     wf = res["walk_format"]
     res.update({"value": wf["value"], "unit": "LF-steps/s", "kernel": "k_walk_direct + k_format_chunks", "kernel_ms": wf["ms"],
                 "value_first_request": wf["value_first_request"], "first_request_ms": wf["first_request_ms"],
+                "first_request_device_ms": wf["first_request_device_ms"], "first_request_host_ms": wf["first_request_host_ms"],
                 "algorithmic_bytes": float(wf["bytes_moved"])})
     return res
 
@@ -200,7 +201,6 @@ if __name__ == "__main__":
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--c4-size", default="full")
     ap.add_argument("--cpu-leg", type=float, default=0.0)
-    ap.add_argument("--c4-prepared", default="", help="config4: the .gbz another process has generated (tools/c4_bench.py --prepare)")
     a = ap.parse_args()
     legs = {}
     if a.cpu_leg > 0:
@@ -210,7 +210,7 @@ if __name__ == "__main__":
     out = {}
     for name in a.names:
         if name == "config4":
-            out[name] = config4(device=a.device, size=a.c4_size, cpu_leg=legs.get(name), prepared=a.c4_prepared or None)
+            out[name] = config4(device=a.device, size=a.c4_size, cpu_leg=legs.get(name))
         else:
             fn = {"secondary": secondary, "high_degree": high_degree, "search": search, "config4_small": config4_small}[name]
             out[name] = fn(device=a.device, cpu_leg=legs.get(name))
