@@ -771,7 +771,7 @@ def main():
                 # (Round 6 also ran the generator next to this process's configs -- 107 s instead of 140 for the whole line -- and saw first
                 # requests of 1.8-2.4 s in those runs; the same then showed up in this order as well: it is the driver clearing released
                 # memory under a 73 GB allocation, by the state other processes left the device in, not the order of the processes
-                # (tools/vram_first_touch_probe.py).  config4.first_request_host_ms / _device_ms say which part a run's first request was.)
+                # (tools/vram_first_touch_probe.py).  config4.first_request_device_ms holds it: the clearing runs on the device, in front of the first kernel that touches the allocation.)
                 import subprocess
                 names = ["config4"] + (["config4_small"] if args.c4_size == "full" else [])
                 cmd = [sys.executable, os.path.join(ROOT, "tools", "configs.py")] + names + ["--device", str(local_rank), "--c4-size", args.c4_size]

@@ -117,17 +117,18 @@ def run(size="small", passes=5, out="", device=0, keep=None, cpu_leg=None):
                           "value": steps / (wall_ms * 1e-3), "bytes_moved": moved, "achieved_GB_per_s": moved / wall_ms / 1e6,
                           "frac": moved / wall_ms / 1e6 / 8000.0, "first_request_ms": first[0], "second_request_ms": second[0],
                           "value_first_request": steps / (first[0] * 1e-3), "line_sizes_at_open_ms": times.get("line_sizes_ms", 0.0),
-                          # the first request, split: what the GPU did (walk kernel + format stream, HIP events) and the rest -- the host side, which is
-                          # the allocation of the rows and the text (73 GB at the stated size).  hipMalloc hands out clean memory in ~ 3 ms; when what the
-                          # driver has at hand was released by another process (or by this one) a moment ago it clears it first, at ~ 30-40 GB/s
-                          # (tools/vram_first_touch_probe.py, profiles/r06_vram_first_touch.txt: 100 GB in 0.4 ms or in 0.5 / 2.2 / 3.3 / 5.2 s by what
-                          # ran before): 1.8-2.4 s of a first request on a box in that state, none of it this library's work
+                          # the first request, split: the time between the HIP events around the walk and around the format on the stream, and the rest
+                          # (the host: hipMalloc of the rows and the text, 73 GB at the stated size, launches).  The host's part is 1-3 ms.  The device's
+                          # is the two kernels (33 ms) -- or seconds: memory that a process has released is cleared by the driver ON THE DEVICE before
+                          # the first kernel may touch the allocation it went into, at 30-40 GB/s (tools/vram_first_touch_probe.py,
+                          # profiles/r06_vram_first_touch.txt: 100 GB usable after 0.4 ms or after 0.5 / 2.2 / 3.3 / 5.2 s by what ran before): 1.8-2.4 s of
+                          # a first request on a box in that state, none of it this library's work, all of it inside the events
                           "first_request_device_ms": first[2] + first[3], "first_request_host_ms": first[0] - first[2] - first[3],
                           "note": "bytes_moved = node ids written once by the walk (4 B/step) and read once by the formatter + the text written; no request sizes "
                                   "its lines (the index knows them since its open: line_sizes_at_open_ms, inside open_ms), so every pass formats every path "
                                   "as gbunzip does -- once, from nothing but the index; first_request_ms also holds the allocation of the workspace's rows and "
-                                  "text buffers (first_request_host_ms: milliseconds, or seconds when the driver first has to clear memory that another "
-                                  "process released just before); frac = bytes_moved / wall time / 8 TB/s"}
+                                  "text buffers, and on the device whatever the driver runs before fresh memory may be touched (first_request_device_ms: 33 ms of "
+                                  "kernels, or seconds when it first clears memory that a process released just before); frac = bytes_moved / wall time / 8 TB/s"}
     # walk only: all forward sequences of the walks -> device CSR (the ragged batch: walker order computed per request).  Behind the lines
     # passes: its third request rebuilds the rows from spread chunks (GBWT_HIP_VMM), and memory a process gives back is paid for by its NEXT
     # large allocation (profiles/r05_alloc_microbench.txt: hipMalloc of 16 GiB 0.2 ms, 2.5 s right after a hipFree of 48 GiB) -- medians
